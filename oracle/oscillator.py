@@ -1,0 +1,70 @@
+"""Oracle restatement of the damped-oscillator bank (TEST INFRASTRUCTURE ONLY).
+
+Follows /root/reference/src/ddsp/oscillator.py:
+  TraditionalDampedOscillator.forward :282-310
+  DampedOscillator.forward            :113-141
+  WeightedSum / DirectValue           :23-46   and  src/ddsp/utils.py:6-9
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+
+def modified_sigmoid(x):
+    """2*sigmoid(x)^2.3 + 1e-6 (ddsp/utils.py:6-9)."""
+    return 2 * (torch.sigmoid(x) ** 2.3) + 1e-6
+
+
+def weighted_sum(values, params):
+    """softplus-normalised combination along the last axis (oscillator.py:31-35)."""
+    x = F.softplus(params)
+    x = x / x.sum(dim=-1).unsqueeze(-1)
+    return (values * x).sum(dim=-1)
+
+
+def bank(freq, forces, sample_num, sr, alpha, beta, amp=None):
+    """Reference signal path, fp32 torch, autograd-capable.
+
+    freq (m,1) ; forces (A,F) un-flipped ; alpha, beta scalars or (1,m,1) ; amp None or (A,m,1).
+    Phase and decay are accumulated with fp32 cumsum exactly like the reference (:297-298),
+    then the mode sum is FIR-filtered with the force by a grouped conv1d (:306-309).
+    Returns (signal (A,S), damped_freq (A,m,S))."""
+    A, nF = forces.shape
+    m = freq.shape[0]
+    f = torch.reshape(freq, (1, m, 1)).repeat((A, 1, sample_num))
+    lbd = (f * 2 * np.pi) ** 2
+    damp = 0.5 * (alpha + beta * lbd)
+    fd = (lbd - damp ** 2) ** 0.5 / (2 * np.pi)
+    damped_freq = fd
+    damp = torch.cumsum(damp / sr, dim=2)
+    ph = torch.cumsum(fd / sr, dim=2)
+    sig = torch.exp(-damp) * torch.sin(2 * np.pi * ph)
+    if amp is not None:
+        sig = amp * sig
+    sig = sig.sum(1).unsqueeze(0)
+    w = torch.flip(forces.reshape(A, 1, -1), [-1])
+    sig = F.conv1d(sig, w, groups=A, padding=nF - 1).squeeze(0)
+    return sig[:, :sample_num], damped_freq
+
+
+def bank_closed_form_f64(freq, forces, sample_num, sr, alpha, beta, amp=None):
+    """fp64 closed form  s[t] = sum_m a_m exp(-d_m tau) sin(w_m tau), tau=(t+1)/sr, then causal FIR.
+    The limit the fp32 cumsum path approximates; used to state tolerances."""
+    f = np.asarray(freq, dtype=np.float64).reshape(-1)
+    forces = np.asarray(forces, dtype=np.float64)
+    A = forces.shape[0]
+    al = np.broadcast_to(np.asarray(alpha, dtype=np.float64).reshape(-1), f.shape) if np.ndim(alpha) else alpha
+    be = np.broadcast_to(np.asarray(beta, dtype=np.float64).reshape(-1), f.shape) if np.ndim(beta) else beta
+    lbd = (2 * np.pi * f) ** 2
+    d = 0.5 * (al + be * lbd)
+    wd = np.sqrt(lbd - d * d)
+    tau = (np.arange(sample_num) + 1.0) / sr
+    modes = np.exp(-d[:, None] * tau[None]) * np.sin(wd[:, None] * tau[None])  # (m,S)
+    if amp is None:
+        s = np.broadcast_to(modes.sum(0), (A, sample_num))
+    else:
+        s = (np.asarray(amp, dtype=np.float64).reshape(A, -1, 1) * modes[None]).sum(1)
+    out = np.zeros((A, sample_num))
+    for a in range(A):
+        out[a] = np.convolve(s[a], forces[a])[:sample_num]
+    return out

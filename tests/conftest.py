@@ -1,0 +1,27 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def load_golden(name):
+    path = os.path.join(GOLDEN, name)
+    if not os.path.exists(path):
+        pytest.skip(f"fixture {name} missing")
+    return np.load(path, allow_pickle=False)
+
+
+@pytest.fixture(scope="session")
+def golden():
+    return load_golden
