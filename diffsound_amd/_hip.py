@@ -1,0 +1,108 @@
+"""ctypes binding of libdiffsound_hip.so (the C ABI declared in include/diffsound_hip.h).
+
+There is NO fallback: if the library is missing or a call fails, a RuntimeError is raised
+(the reference's native op surfaces errors the same way, as RuntimeError through pybind:
+reference src/include/macro.h:75-83).  Tensors are passed as raw ``data_ptr()`` values and the
+kernels are enqueued on torch's current HIP stream.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libdiffsound_hip.so")
+
+c_i32p = ctypes.POINTER(ctypes.c_int32)
+_P = ctypes.c_void_p
+_I64 = ctypes.c_int64
+_I = ctypes.c_int
+_D = ctypes.c_double
+_F = ctypes.c_float
+
+_SIGNATURES = {
+    "ds_last_error": (ctypes.c_char_p, []),
+    "ds_abi_version": (_I, []),
+    "ds_pattern_build": (_I, [_P, _I64, _I, _I64, _I, ctypes.POINTER(_P)]),
+    "ds_pattern_sizes": (_I, [_P, ctypes.POINTER(_I64), ctypes.POINTER(_I64), ctypes.POINTER(_I64)]),
+    "ds_pattern_export": (_I, [_P, _P, _P, _P, _P, _P]),
+    "ds_pattern_free": (None, [_P]),
+    "ds_assemble_kml": (_I, [_P, _P, _I64, _I, _I64, _P, _P, _I64, _P, _P, _P, _P, _P, _P, _P]),
+    "ds_combine_material": (_I, [_P, _P, _P, _I64, _P, _I64, _D, _D, _P, _P, _P, _P]),
+    "ds_spmm_bsr3": (_I, [_I, _P, _P, _P, _I64, _P, _I64, _P, _I64, _I, _P]),
+    "ds_gram_workspace_bytes": (_I64, [_I64, _I, _I]),
+    "ds_gram": (_I, [_P, _I64, _I, _P, _I, _I64, _I, _I64, _P, _P, _I64, _P]),
+    "ds_residual": (_I, [_P, _I64, _P, _I64, _P, _I64, _P, _I64, _I, _P, _P, _P]),
+    "ds_cheb_init": (_I, [_P, _I64, _P, _I64, _P, _I64, _P, _I64, _I, _F, _P]),
+    "ds_cheb_step": (_I, [_P, _I64, _P, _I64, _P, _I64, _P, _I64, _P, _I64, _I, _F, _F, _P]),
+    "ds_mix": (_I, [_P, _I64, _I, _P, _I, _P, _I64, _I64, _F, _F, _P]),
+    "ds_osc_bank_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _D, _P, _P]),
+    "ds_osc_bank_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _D, _P, _P, _P, _P, _P]),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+_lib = None
+
+
+def lib():
+    """Load (once) and return the ctypes handle; RuntimeError if the HIP extension is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"diffsound_amd: HIP extension {LIB_PATH} is missing - build it with "
+                "`python -c 'import __graft_entry__ as g; g.build()'` or `make -C diffsound_amd/csrc`. "
+                "There is no CPU fallback.")
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(status, what):
+    if status != 0:
+        msg = lib().ds_last_error()
+        raise RuntimeError(f"{what} failed (status {status}): {msg.decode() if msg else ''}")
+
+
+def stream_ptr():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    return ctypes.c_void_p(0 if t is None else t.data_ptr())
+
+
+def require_gpu(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("diffsound_amd: tensors must live on the HIP device (no CPU fallback)")
+
+
+class Pattern:
+    """Host-side symbolic BSR-3 pattern (see ds_pattern_build in include/diffsound_hip.h)."""
+
+    def __init__(self, tets_cpu_i32, nv, nthreads=0):
+        t = tets_cpu_i32
+        if t.device.type != "cpu" or t.dtype != torch.int32 or not t.is_contiguous() or t.dim() != 2:
+            raise ValueError("Pattern: tets must be a contiguous (T, N) int32 CPU tensor")
+        handle = ctypes.c_void_p()
+        check(lib().ds_pattern_build(ptr(t), t.shape[0], t.shape[1], nv, nthreads, ctypes.byref(handle)),
+              "ds_pattern_build")
+        try:
+            a, b, c = _I64(), _I64(), _I64()
+            check(lib().ds_pattern_sizes(handle, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)),
+                  "ds_pattern_sizes")
+            self.nv, self.nnzb, self.ncontrib = a.value, b.value, c.value
+            self.rowptr = torch.empty(self.nv + 1, dtype=torch.int32)
+            self.colidx = torch.empty(self.nnzb, dtype=torch.int32)
+            self.diagidx = torch.empty(self.nv, dtype=torch.int32)
+            self.cptr = torch.empty(self.nnzb + 1, dtype=torch.int32)
+            self.clist = torch.empty(self.ncontrib, dtype=torch.int32)
+            check(lib().ds_pattern_export(handle, ptr(self.rowptr), ptr(self.colidx), ptr(self.diagidx),
+                                          ptr(self.cptr), ptr(self.clist)), "ds_pattern_export")
+        finally:
+            lib().ds_pattern_free(handle)

@@ -1,0 +1,278 @@
+// Fused block-vector updates of the eigensolver - gfx950.
+//
+//  ds_residual   R <- K X - (M X) diag(lam) and the column norms the convergence test needs
+//                (reference update_residual / update_converged_count, src/lobpcg/_lobpcg.py:301-333:
+//                 three torch ops + two torch.norm + a Python loop over a device tensor)
+//  ds_cheb_init / ds_cheb_step   one fused pass per term of the Chebyshev block-Jacobi polynomial
+//                preconditioner (the reference has no preconditioner: iK=None, _linalg_utils.py:32-33)
+//  ds_mix        Out <- alpha A C + beta Out, the "tall-skinny times small" update GEMM
+//                (reference X <- S Z, P <- S Z_p, U <- U - V (V^T B U): _lobpcg.py:463-466, 629)
+//
+// All blocks are row-major (n x ncols) f32 with explicit leading dimensions; one lane owns 4
+// consecutive columns of the 3 rows of one node (16-byte accesses), which is also the natural unit
+// of the 3x3 block-Jacobi solve.
+#include <algorithm>
+
+#include "ds_common.h"
+
+namespace {
+
+using f4 = __attribute__((ext_vector_type(4))) float;
+
+__device__ __forceinline__ f4 ld4(const float* p) { return *reinterpret_cast<const f4*>(p); }
+__device__ __forceinline__ void st4(float* p, f4 v) { *reinterpret_cast<f4*>(p) = v; }
+
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+    residual_kernel(float* __restrict__ R, int64_t ldr, const float* __restrict__ MX, int64_t ldm,
+                    const float* __restrict__ X, int64_t ldx, const double* __restrict__ lam, int64_t n, int ncols,
+                    int cgroups, double* __restrict__ rn2, double* __restrict__ xn2) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];  // [2][ncols]
+    for (int i = threadIdx.x; i < 2 * ncols; i += blockDim.x) sm[i] = 0.0;
+    __syncthreads();
+    const int cg = threadIdx.x % cgroups;
+    const int rl = threadIdx.x / cgroups;
+    const int rows_per_block = blockDim.x / cgroups;
+    const int c0 = cg * 4;
+    double pr[4] = {0, 0, 0, 0}, px[4] = {0, 0, 0, 0};
+    if (rl < rows_per_block) {
+        float l4[4];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) l4[v] = (float)lam[c0 + v];
+        for (int64_t r = (int64_t)blockIdx.x * rows_per_block + rl; r < n; r += (int64_t)gridDim.x * rows_per_block) {
+            f4 rv = ld4(R + r * ldr + c0);
+            const f4 mv = ld4(MX + r * ldm + c0);
+            const f4 xv = ld4(X + r * ldx + c0);
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                rv[v] = fmaf(-mv[v], l4[v], rv[v]);
+                pr[v] += (double)rv[v] * (double)rv[v];
+                px[v] += (double)xv[v] * (double)xv[v];
+            }
+            st4(R + r * ldr + c0, rv);
+        }
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            atomicAdd(&sm[c0 + v], pr[v]);
+            atomicAdd(&sm[ncols + c0 + v], px[v]);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < ncols; i += blockDim.x) {
+        atomicAdd(&rn2[i], sm[i]);
+        atomicAdd(&xn2[i], sm[ncols + i]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// T r for one node: 3x3 block (row-major dinv) times the 3 rows r0,r1,r2 (4 columns each)
+__device__ __forceinline__ void bj_apply(const float* __restrict__ d, const f4& r0, const f4& r1, const f4& r2, f4& t0,
+                                         f4& t1, f4& t2) {
+    t0 = d[0] * r0 + d[1] * r1 + d[2] * r2;
+    t1 = d[3] * r0 + d[4] * r1 + d[5] * r2;
+    t2 = d[6] * r0 + d[7] * r1 + d[8] * r2;
+}
+
+template <bool STEP>
+__global__ void __launch_bounds__(256)
+    cheb_kernel(const float* __restrict__ AD, int64_t lda, float* __restrict__ R, int64_t ldr, float* __restrict__ D,
+                int64_t ldd, float* __restrict__ W, int64_t ldw, const float* __restrict__ dinv, int64_t nv,
+                int cgroups, float c1, float c2) {
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t node = tid / cgroups;
+    const int c0 = (int)(tid - node * cgroups) * 4;
+    if (node >= nv) return;
+    float d[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) d[k] = dinv[node * 9 + k];
+    const int64_t r = node * 3;
+    f4 r0 = ld4(R + r * ldr + c0), r1 = ld4(R + (r + 1) * ldr + c0), r2 = ld4(R + (r + 2) * ldr + c0);
+    f4 t0, t1, t2;
+    if (STEP) {
+        r0 -= ld4(AD + r * lda + c0);
+        r1 -= ld4(AD + (r + 1) * lda + c0);
+        r2 -= ld4(AD + (r + 2) * lda + c0);
+        st4(R + r * ldr + c0, r0);
+        st4(R + (r + 1) * ldr + c0, r1);
+        st4(R + (r + 2) * ldr + c0, r2);
+        bj_apply(d, r0, r1, r2, t0, t1, t2);
+        const f4 d0 = c1 * ld4(D + r * ldd + c0) + c2 * t0;
+        const f4 d1 = c1 * ld4(D + (r + 1) * ldd + c0) + c2 * t1;
+        const f4 d2 = c1 * ld4(D + (r + 2) * ldd + c0) + c2 * t2;
+        st4(D + r * ldd + c0, d0);
+        st4(D + (r + 1) * ldd + c0, d1);
+        st4(D + (r + 2) * ldd + c0, d2);
+        st4(W + r * ldw + c0, ld4(W + r * ldw + c0) + d0);
+        st4(W + (r + 1) * ldw + c0, ld4(W + (r + 1) * ldw + c0) + d1);
+        st4(W + (r + 2) * ldw + c0, ld4(W + (r + 2) * ldw + c0) + d2);
+    } else {
+        bj_apply(d, r0, r1, r2, t0, t1, t2);
+        t0 *= c2;
+        t1 *= c2;
+        t2 *= c2;
+        st4(D + r * ldd + c0, t0);
+        st4(D + (r + 1) * ldd + c0, t1);
+        st4(D + (r + 2) * ldd + c0, t2);
+        st4(W + r * ldw + c0, t0);
+        st4(W + (r + 1) * ldw + c0, t1);
+        st4(W + (r + 2) * ldw + c0, t2);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Out <- alpha A C + beta Out with v_mfma_f32_16x16x4_f32 (exact f32 FMA chain).
+// A wave owns RT*16 rows x JT*16 columns of Out.  One 16-byte load gives lane (i = l&15, kq = l>>4)
+// the four values A[row i][k0 + 4 kq + s], s = 0..3; MFMA step s therefore reduces over the index set
+// {k0 + 4 kq + s}, and the C operand for that step is row k0 + 4 (l>>4) + s of C (L1/L2 resident).
+using f4acc = __attribute__((ext_vector_type(4))) float;
+constexpr int RT = 2;
+
+template <int JT, bool VECA>
+__global__ void __launch_bounds__(256)
+    mix_kernel(const float* __restrict__ A, int64_t lda, int p, const float* __restrict__ C, int q,
+               float* __restrict__ Out, int64_t ldo, int64_t n, int j_base, float alpha, float beta) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int li = lane & 15, lq = lane >> 4;
+    const int64_t row0 = ((int64_t)blockIdx.x * 4 + wave) * (RT * 16);
+    if (row0 >= n) return;  // wave-uniform
+    f4acc acc[RT][JT];
+#pragma unroll
+    for (int t = 0; t < RT; ++t)
+#pragma unroll
+        for (int j = 0; j < JT; ++j) acc[t][j] = f4acc{0.f, 0.f, 0.f, 0.f};
+    bool jv[JT];
+#pragma unroll
+    for (int j = 0; j < JT; ++j) jv[j] = (j_base + j * 16 + li) < q;
+
+    for (int k0 = 0; k0 < p; k0 += 16) {
+        f4 a[RT];
+        const int kk = k0 + 4 * lq;
+#pragma unroll
+        for (int t = 0; t < RT; ++t) {
+            const int64_t r = row0 + t * 16 + li;
+            if (VECA) {
+                a[t] = (r < n && kk < p) ? ld4(A + r * lda + kk) : f4{0.f, 0.f, 0.f, 0.f};  // p % 4 == 0 here
+            } else {
+#pragma unroll
+                for (int s = 0; s < 4; ++s) a[t][s] = (r < n && kk + s < p) ? A[r * lda + kk + s] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int kr = kk + s;
+            const float* cp = C + (int64_t)kr * q + j_base + li;
+#pragma unroll
+            for (int j = 0; j < JT; ++j) {
+                const float b = (kr < p && jv[j]) ? cp[j * 16] : 0.f;
+#pragma unroll
+                for (int t = 0; t < RT; ++t) acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t][s], b, acc[t][j], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < RT; ++t)
+#pragma unroll
+        for (int j = 0; j < JT; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int64_t r = row0 + t * 16 + lq * 4 + g;
+                const int col = j_base + j * 16 + li;
+                if (r < n && col < q) {
+                    float* o = Out + r * ldo + col;
+                    const float v = alpha * acc[t][j][g];
+                    *o = (beta == 0.f) ? v : fmaf(beta, *o, v);
+                }
+            }
+}
+
+template <int JT>
+int launch_mix(const float* A, int64_t lda, int p, const float* C, int q, float* Out, int64_t ldo, int64_t n,
+               int j_base, float alpha, float beta, bool veca, hipStream_t st) {
+    const unsigned grid = (unsigned)ds::ceil_div(n, 4 * RT * 16);
+    if (veca)
+        mix_kernel<JT, true><<<grid, 256, 0, st>>>(A, lda, p, C, q, Out, ldo, n, j_base, alpha, beta);
+    else
+        mix_kernel<JT, false><<<grid, 256, 0, st>>>(A, lda, p, C, q, Out, ldo, n, j_base, alpha, beta);
+    DS_LAUNCH_CHECK("mix_kernel");
+    return DS_OK;
+}
+
+bool aligned16(const void* p, int64_t ld_elems) {
+    return ((reinterpret_cast<uintptr_t>(p) | (uintptr_t)(ld_elems * 4)) & 15) == 0;
+}
+
+}  // namespace
+
+extern "C" int ds_residual(float* R, int64_t ldr, const float* MX, int64_t ldm, const float* X, int64_t ldx,
+                           const double* lam, int64_t n, int ncols, double* rn2, double* xn2, ds_stream_t stream) {
+    DS_REQUIRE(R && MX && X && lam && rn2 && xn2, "ds_residual: null pointer");
+    DS_REQUIRE(n > 0 && ncols > 0 && ncols % 4 == 0 && ncols <= 1024, "ds_residual: ncols must be a multiple of 4 <= 1024");
+    DS_REQUIRE(aligned16(R, ldr) && aligned16(MX, ldm) && aligned16(X, ldx), "ds_residual: rows must be 16-byte aligned");
+    hipStream_t st = ds::as_stream(stream);
+    int rc = ds::check_hip(hipMemsetAsync(rn2, 0, sizeof(double) * ncols, st), "ds_residual memset");
+    if (rc) return rc;
+    rc = ds::check_hip(hipMemsetAsync(xn2, 0, sizeof(double) * ncols, st), "ds_residual memset");
+    if (rc) return rc;
+    const int cgroups = ncols / 4;
+    const int rows_per_block = 256 / cgroups;
+    const int64_t nblk = std::min<int64_t>(1024, ds::ceil_div(n, rows_per_block));
+    residual_kernel<<<(unsigned)nblk, 256, 2 * ncols * sizeof(double), st>>>(R, ldr, MX, ldm, X, ldx, lam, n, ncols,
+                                                                             cgroups, rn2, xn2);
+    DS_LAUNCH_CHECK("residual_kernel");
+    return DS_OK;
+}
+
+extern "C" int ds_cheb_init(const float* R, int64_t ldr, float* D, int64_t ldd, float* W, int64_t ldw,
+                            const float* dinv, int64_t nv, int ncols, float c, ds_stream_t stream) {
+    DS_REQUIRE(R && D && W && dinv, "ds_cheb_init: null pointer");
+    DS_REQUIRE(nv > 0 && ncols > 0 && ncols % 4 == 0, "ds_cheb_init: ncols must be a multiple of 4");
+    DS_REQUIRE(aligned16(R, ldr) && aligned16(D, ldd) && aligned16(W, ldw), "ds_cheb_init: rows must be 16-byte aligned");
+    const int cgroups = ncols / 4;
+    const int64_t nthreads = nv * cgroups;
+    cheb_kernel<false><<<(unsigned)ds::ceil_div(nthreads, 256), 256, 0, ds::as_stream(stream)>>>(
+        nullptr, 0, const_cast<float*>(R), ldr, D, ldd, W, ldw, dinv, nv, cgroups, 0.f, c);
+    DS_LAUNCH_CHECK("cheb_kernel<init>");
+    return DS_OK;
+}
+
+extern "C" int ds_cheb_step(const float* AD, int64_t lda, float* R, int64_t ldr, float* D, int64_t ldd, float* W,
+                            int64_t ldw, const float* dinv, int64_t nv, int ncols, float c1, float c2,
+                            ds_stream_t stream) {
+    DS_REQUIRE(AD && R && D && W && dinv, "ds_cheb_step: null pointer");
+    DS_REQUIRE(nv > 0 && ncols > 0 && ncols % 4 == 0, "ds_cheb_step: ncols must be a multiple of 4");
+    DS_REQUIRE(aligned16(AD, lda) && aligned16(R, ldr) && aligned16(D, ldd) && aligned16(W, ldw),
+               "ds_cheb_step: rows must be 16-byte aligned");
+    const int cgroups = ncols / 4;
+    const int64_t nthreads = nv * cgroups;
+    cheb_kernel<true><<<(unsigned)ds::ceil_div(nthreads, 256), 256, 0, ds::as_stream(stream)>>>(
+        AD, lda, R, ldr, D, ldd, W, ldw, dinv, nv, cgroups, c1, c2);
+    DS_LAUNCH_CHECK("cheb_kernel<step>");
+    return DS_OK;
+}
+
+extern "C" int ds_mix(const float* A, int64_t lda, int p, const float* C, int q, float* Out, int64_t ldo, int64_t n,
+                      float alpha, float beta, ds_stream_t stream) {
+    DS_REQUIRE(A && C && Out, "ds_mix: null pointer");
+    DS_REQUIRE(n > 0 && p > 0 && q > 0, "ds_mix: empty problem");
+    DS_REQUIRE(lda >= p && ldo >= q, "ds_mix: leading dimension smaller than the block width");
+    hipStream_t st = ds::as_stream(stream);
+    const bool veca = aligned16(A, lda) && (p % 4 == 0);
+    int rc = DS_OK;
+    // column chunks of at most 10 MFMA tiles (160 columns) so the accumulators stay in registers
+    for (int j_base = 0; j_base < q && rc == DS_OK; j_base += 160) {
+        const int tiles = (int)ds::ceil_div(std::min(q - j_base, 160), 16);
+        switch (tiles) {
+            case 1: rc = launch_mix<1>(A, lda, p, C, q, Out, ldo, n, j_base, alpha, beta, veca, st); break;
+            case 2: rc = launch_mix<2>(A, lda, p, C, q, Out, ldo, n, j_base, alpha, beta, veca, st); break;
+            case 3: rc = launch_mix<3>(A, lda, p, C, q, Out, ldo, n, j_base, alpha, beta, veca, st); break;
+            case 4: rc = launch_mix<4>(A, lda, p, C, q, Out, ldo, n, j_base, alpha, beta, veca, st); break;
+            case 5: rc = launch_mix<5>(A, lda, p, C, q, Out, ldo, n, j_base, alpha, beta, veca, st); break;
+            case 6: rc = launch_mix<6>(A, lda, p, C, q, Out, ldo, n, j_base, alpha, beta, veca, st); break;
+            case 7:
+            case 8: rc = launch_mix<8>(A, lda, p, C, q, Out, ldo, n, j_base, alpha, beta, veca, st); break;
+            default: rc = launch_mix<10>(A, lda, p, C, q, Out, ldo, n, j_base, alpha, beta, veca, st); break;
+        }
+    }
+    return rc;
+}

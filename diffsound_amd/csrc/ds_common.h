@@ -1,0 +1,48 @@
+// Internal helpers shared by the translation units of libdiffsound_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+
+#include "diffsound_hip.h"
+
+namespace ds {
+
+void set_error(const char* fmt, ...);
+
+inline int check_hip(hipError_t e, const char* what) {
+    if (e == hipSuccess) return DS_OK;
+    set_error("%s: %s", what, hipGetErrorString(e));
+    return DS_ERR_HIP;
+}
+
+inline hipStream_t as_stream(ds_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// Workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8 share one L2).  Give each
+// XCD a contiguous slice of the logical work list so neighbouring rows share an L2 (bijective for
+// any grid size).  Speed only, never correctness.
+__device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nblk) {
+    const unsigned q = nblk >> 3, r = nblk & 7u;
+    const unsigned xcd = bid & 7u, idx = bid >> 3;
+    const unsigned base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + idx;
+}
+
+}  // namespace ds
+
+#define DS_REQUIRE(cond, ...)            \
+    do {                                 \
+        if (!(cond)) {                   \
+            ds::set_error(__VA_ARGS__);  \
+            return DS_ERR_ARG;           \
+        }                                \
+    } while (0)
+
+#define DS_LAUNCH_CHECK(name)                                         \
+    do {                                                              \
+        int _rc = ds::check_hip(hipGetLastError(), name " launch");   \
+        if (_rc != DS_OK) return _rc;                                 \
+    } while (0)

@@ -1,0 +1,247 @@
+"""Device-resident block eigensolver for  K u = lambda M u  (lowest elastic modes of a free body).
+
+This is the engine behind ``lobpcg_func`` / ``DiffSoundObj.eigen_decomposition``.  It is the
+"ortho" LOBPCG of Duersch et al. 2018 that the reference's ``src/lobpcg/_lobpcg.py:433-477``
+implements, re-designed for MI355X:
+
+  * the search basis  S = [X | P | W]  lives in ONE row-major (n x 3b) fp32 buffer so that the
+    stiffness product  K S  is a single BSR-3 block-SpMM launch (the HBM-roofline kernel) and
+    the Rayleigh-Ritz matrix  S^T (K S)  is a single tall-skinny MFMA Gram launch with fp64
+    accumulation;
+  * the six rigid-body modes are deflated analytically (the reference instead asks for k+6
+    pairs and drops six, src/utils/utils.py:80-90, and does not converge - SURVEY.md 0.4);
+  * the preconditioner is a Chebyshev polynomial in (block-Jacobi)^-1 K, i.e. only more SpMMs;
+  * all large operations go through an ``ops`` object (HIP kernels in the product); the small
+    (<= 3b x 3b) dense algebra is fp64 ``torch.linalg`` on the same device;
+  * a final fp64 Rayleigh-Ritz "polish" on the converged block returns eigenvalues accurate to
+    second order in the fp32 iteration error together with the quadratic forms
+    u^T K_lambda u, u^T K_mu u needed by the differentiable read-out.
+
+The ``ops`` protocol (see ``diffsound_amd/modal_ops.py`` for the HIP implementation):
+  n, device, dtype, rigid (n x 6, M-orthonormal), apply_K, apply_M, gram, mix, residual,
+  precond, polish_products.
+"""
+from dataclasses import dataclass, field
+from typing import Callable, Optional
+
+import torch
+
+
+@dataclass
+class SolverConfig:
+    block: int = 0  # search block width b (0 -> k rounded up to a multiple of 8, plus guards)
+    guard: int = 8
+    # backward-stable criterion of the reference (_lobpcg.py:307-333):
+    #   ||K x - lambda M x|| / (||x|| (||K|| + lambda ||M||)) < tol   per wanted pair.
+    # fp32 iterates stored in HBM carry rounding noise that K amplifies to ~3 eps32 = 3.5e-7 on this
+    # scale, so 2e-6 is ~6x above the floor; the fp64 polish then yields eigenvalues good to ~1e-8.
+    tol: float = 0.0  # 0 -> 2e-6 for fp32 iterates, 1e-10 for fp64
+    maxit: int = 400
+    ortho_passes: int = 2
+    check_every: int = 1
+    seed: int = 0
+    cheb_degree: int = 8  # terms of the Chebyshev polynomial preconditioner (1 = plain block-Jacobi)
+    cheb_ratio: float = 100.0  # the polynomial targets the interval [lmax/ratio, lmax] of T K
+    power_iters: int = 30
+    lmax_safety: float = 1.2
+    lmax_cap: float = 0.0  # rigorous bound lambda_max(T K) <= nodes per element (4 / 10); 0 = none
+
+
+@dataclass
+class ModalResult:
+    eigenvalues: torch.Tensor  # (k,) fp64, ascending
+    vectors: torch.Tensor  # (n, k) M-orthonormal
+    a_lambda: torch.Tensor  # (k,) u^T K_lambda u   fp64
+    b_mu: torch.Tensor  # (k,) u^T K_mu u       fp64
+    m_diag: torch.Tensor  # (k,) u^T M u          fp64 (== 1 up to rounding)
+    iterations: int = 0
+    rerr: Optional[torch.Tensor] = None  # (k,) last relative residuals
+    history: list = field(default_factory=list)
+    block_vectors: Optional[torch.Tensor] = None  # (n, b) whole converged block (warm start)
+
+
+def _sym(G):
+    return 0.5 * (G + G.transpose(0, 1))
+
+
+def _svqb_transform(G, tau=1e-12):
+    """T such that (W T)^T M (W T) = I given G = W^T M W  (reference _get_svqb, _lobpcg.py:527-585,
+    non-dropping branch: tiny eigenvalues are clamped, not removed)."""
+    d = torch.rsqrt(torch.clamp(G.diagonal(), min=1e-300))
+    E, Z = torch.linalg.eigh(_sym(G) * d[:, None] * d[None, :])
+    E = torch.clamp(E, min=tau * E.abs().max())
+    return (d[:, None] * Z) * torch.rsqrt(E)[None, :]
+
+
+class ChebyshevBlockJacobi:
+    """W = p(T K) T R with T = inverse 3x3 diagonal blocks of K and p the degree-(d-1) Chebyshev
+    polynomial that approximates 1/x on [lmax/ratio, lmax] (Saad, Iterative Methods, Alg. 12.1).
+    Costs d-1 block-SpMMs with K per application; symmetric and fixed, as LOBPCG requires."""
+
+    def __init__(self, ops, degree, ratio, power_iters=30, seed=0, safety=1.2, cap=0.0):
+        self.ops = ops
+        self.degree = max(1, int(degree))
+        n, dev, dt = ops.n, ops.device, ops.dtype
+        g = torch.Generator(device="cpu").manual_seed(seed + 17)
+        x = torch.randn((n, 8), generator=g, dtype=torch.float32).to(device=dev, dtype=dt)
+        y = torch.empty_like(x)
+        z = torch.empty_like(x)
+        lm = None
+        for _ in range(power_iters):  # largest eigenvalue of T K by block power iteration
+            ops.apply_K(x, y)
+            ops.cheb_init(y, z, x, 1.0)  # x = T y
+            nrm = torch.linalg.vector_norm(x.double(), dim=0)
+            lm = nrm.max()
+            x = (x / nrm.to(dt)[None, :]).contiguous()
+        # power iteration under-estimates; an under-estimated lmax makes the polynomial blow up on
+        # the top of the spectrum (measured: 2% low -> no convergence), an over-estimate costs little
+        self.lmax = safety * float(lm)
+        if cap > 0.0:
+            self.lmax = min(self.lmax, cap)
+        self.lmin = self.lmax / float(ratio)
+        self._D = None
+        self._AD = None
+
+    def apply(self, R, W):
+        """Destroys R.  W <- preconditioned residual."""
+        ops = self.ops
+        theta = 0.5 * (self.lmax + self.lmin)
+        delta = 0.5 * (self.lmax - self.lmin)
+        if self._D is None or self._D.shape != R.shape:
+            self._D = torch.empty_like(R)
+            self._AD = torch.empty_like(R)
+        D, AD = self._D, self._AD
+        ops.cheb_init(R, D, W, 1.0 / theta)  # D = T R / theta ; W = D
+        sigma1 = theta / delta
+        rho = 1.0 / sigma1
+        for _ in range(self.degree - 1):
+            ops.apply_K(D, AD)
+            rho_new = 1.0 / (2.0 * sigma1 - rho)
+            ops.cheb_step(AD, R, D, W, rho_new * rho, 2.0 * rho_new / delta)  # R-=AD; D=c1 D+c2 T R; W+=D
+            rho = rho_new
+
+
+class ModalSolver:
+    def __init__(self, ops, cfg: Optional[SolverConfig] = None):
+        self.ops = ops
+        self.cfg = cfg or SolverConfig()
+        self.precond = ChebyshevBlockJacobi(ops, self.cfg.cheb_degree, self.cfg.cheb_ratio,
+                                            self.cfg.power_iters, self.cfg.seed, self.cfg.lmax_safety,
+                                            self.cfg.lmax_cap)
+
+    # ------------------------------------------------------------------ helpers
+    def _orthonormalize(self, W, V_blocks, MW):
+        """Make W M-orthogonal to every block in V_blocks and M-orthonormal (reference _get_ortho,
+        _lobpcg.py:587-679, with a fixed number of passes instead of host-synchronising norms)."""
+        ops = self.ops
+        for _ in range(self.cfg.ortho_passes):
+            ops.apply_M(W, MW)
+            for V in V_blocks:
+                C = ops.gram(V, MW)
+                ops.mix(V, C, W, alpha=-1.0, beta=1.0)
+            ops.apply_M(W, MW)
+            T = _svqb_transform(ops.gram(W, MW))
+            ops.mix_inplace(W, T)
+
+    # ------------------------------------------------------------------ main entry
+    def solve(self, k: int, X0: Optional[torch.Tensor] = None,
+              tracker: Optional[Callable] = None) -> ModalResult:
+        ops, cfg = self.ops, self.cfg
+        n, dev, dt = ops.n, ops.device, ops.dtype
+        b = cfg.block or ((k + cfg.guard + 7) // 8) * 8
+        if X0 is not None and X0.shape[1] > b:
+            b = X0.shape[1]
+        if n < 3 * b + 6:
+            raise ValueError(
+                "LOBPCG is not applicable when the number of rows (={}) is smaller than 3 x the block size"
+                " (={}) plus the 6 rigid modes".format(n, b))
+        Y = ops.rigid
+        S = torch.empty((n, 3 * b), dtype=dt, device=dev)
+        S2 = torch.empty((n, 3 * b), dtype=dt, device=dev)
+        KS = torch.empty((n, 3 * b), dtype=dt, device=dev)
+        R = torch.empty((n, b), dtype=dt, device=dev)
+        MX = torch.empty((n, b), dtype=dt, device=dev)
+        MW = torch.empty((n, b), dtype=dt, device=dev)
+
+        X = S[:, :b]
+        if X0 is None:
+            g = torch.Generator(device="cpu").manual_seed(cfg.seed)
+            X.copy_(torch.randn((n, b), generator=g, dtype=torch.float32).to(device=dev, dtype=dt))
+        else:
+            X[:, : X0.shape[1]].copy_(X0.to(dt))
+            if X0.shape[1] < b:
+                g = torch.Generator(device="cpu").manual_seed(cfg.seed)
+                X[:, X0.shape[1]:].copy_(
+                    torch.randn((n, b - X0.shape[1]), generator=g, dtype=torch.float32).to(device=dev, dtype=dt))
+        # operator norm estimates with a random block, as the reference does (_lobpcg.py:280-285)
+        ops.apply_K(X, KS[:, :b])
+        ops.apply_M(X, MW)
+        xn = torch.linalg.vector_norm(X.double())
+        A_norm = torch.linalg.vector_norm(KS[:, :b].double()) / xn
+        B_norm = torch.linalg.vector_norm(MW.double()) / xn
+        tol = cfg.tol or (2e-6 if dt == torch.float32 else 1e-10)
+        self._orthonormalize(X, [Y], MW)
+        ops.apply_K(X, KS[:, :b])
+        lam, Z = torch.linalg.eigh(_sym(ops.gram(X, KS[:, :b])))
+        ops.mix(S[:, :b], Z, S2[:, :b])
+        S, S2 = S2, S
+        ops.mix(KS[:, :b], Z, R)  # R holds K X for the first residual
+        have_p = False
+        history = []
+        rel = None
+        it = 0
+        for it in range(cfg.maxit + 1):
+            X = S[:, :b]
+            ops.apply_M(X, MX)
+            rn2, xn2 = ops.residual(R, MX, X, lam)  # R <- R - MX*lam in place; ||R_j||^2, ||X_j||^2 (fp64)
+            rel = torch.sqrt(rn2 / xn2) / (A_norm + lam.abs() * B_norm)
+            if it % cfg.check_every == 0 or it == cfg.maxit:
+                relk = rel[:k]
+                nconv = int((relk < tol).sum())
+                history.append((it, float(relk.max())))
+                if tracker is not None:
+                    tracker(dict(istep=it, converged_count=nconv, rerr=relk, E=lam[:k], X=X))
+                if nconv >= k or it == cfg.maxit:
+                    break
+            w0 = 2 * b if have_p else b
+            W = S[:, w0:w0 + b]
+            self.precond.apply(R, W)
+            self._orthonormalize(W, [Y, S[:, :w0]], MW)
+            sz = w0 + b
+            ops.apply_K(S[:, :sz], KS[:, :sz])
+            E_, Z = torch.linalg.eigh(_sym(ops.gram(S[:, :sz], KS[:, :sz])))
+            lam = E_[:b].clone()
+            Z1 = Z[:, :b]
+            # P = S Z2 basis((Z[:b, b:])^T): the part of the discarded Ritz space that overlaps old X
+            Q = torch.linalg.qr(Z[:b, b:].transpose(0, 1).contiguous()).Q
+            Zp = Z[:, b:] @ Q
+            ops.mix(S[:, :sz], Z1, S2[:, :b])
+            ops.mix(S[:, :sz], Zp, S2[:, b:2 * b])
+            ops.mix(KS[:, :sz], Z1, R)  # K X_new for the next residual
+            S, S2 = S2, S
+            have_p = True
+
+        X = S[:, :b]
+        return self._polish(X, k, it, rel[:k] if rel is not None else None, history)
+
+    # ------------------------------------------------------------------ fp64 Rayleigh-Ritz polish
+    def _polish(self, X, k, it, rerr, history):
+        ops = self.ops
+        Gl, Gm, GM = ops.polish_products(X)  # fp64 (b x b): X^T K_lambda X, X^T K_mu X, X^T M X
+        lamL, mu = ops.lame
+        GA = _sym(lamL * Gl + mu * Gm)
+        GB = _sym(GM)
+        L = torch.linalg.cholesky(GB)
+        Li = torch.linalg.solve_triangular(L, torch.eye(L.shape[0], dtype=L.dtype, device=L.device), upper=False)
+        E, Zt = torch.linalg.eigh(_sym(Li @ GA @ Li.transpose(0, 1)))
+        C = Li.transpose(0, 1) @ Zt  # generalized eigenvectors, C^T GB C = I
+        Ck = C[:, :k].contiguous()
+        U = torch.empty((ops.n, k), dtype=ops.dtype, device=ops.device)
+        ops.mix(X, Ck, U)
+        a = ((Ck.transpose(0, 1) @ _sym(Gl)) * Ck.transpose(0, 1)).sum(1)
+        bq = ((Ck.transpose(0, 1) @ _sym(Gm)) * Ck.transpose(0, 1)).sum(1)
+        m = ((Ck.transpose(0, 1) @ GB) * Ck.transpose(0, 1)).sum(1)
+        Xb = torch.empty_like(X)
+        ops.mix(X, C.contiguous(), Xb)
+        return ModalResult(E[:k].clone(), U, a, bq, m, iterations=it, rerr=rerr, history=history,
+                           block_vectors=Xb)

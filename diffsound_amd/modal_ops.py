@@ -1,0 +1,220 @@
+"""Device-side FEM system and the HIP implementation of the eigensolver's ``ops`` protocol.
+
+``TetSystem``   one mesh (topology + geometry): symbolic BSR-3 pattern, then K_lambda, K_mu, M_s
+                assembled on the GPU in fp64 (reference DiffSoundObj.update_stiff_matrix /
+                update_mass_matrix, src/diffelastic/diff_model.py:184-312).
+``HipModalOps`` one material hypothesis (lam, mu) on a TetSystem: fp32 K = lam K_lambda + mu K_mu,
+                block-Jacobi blocks, rigid-body basis, and every large operation the solver
+                needs, each one a call into libdiffsound_hip.so.
+No operation here has a CPU implementation; tensors must be HIP tensors.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _hip, fem_tables
+
+DS_F32, DS_F64 = 0, 1
+
+
+def _ld(t):
+    if t.dim() != 2 or t.stride(1) != 1:
+        raise ValueError("block must be a 2-D row-major view (unit column stride)")
+    return t.stride(0)
+
+
+class TetSystem:
+    def __init__(self, vertices, tets, order, density):
+        """vertices (nv,3) float32 HIP tensor, tets (T,N) integer HIP tensor in the reference's local
+        node order, N = 4 / 10."""
+        _hip.require_gpu(vertices, tets)
+        L = _hip.lib()
+        self.order = int(order)
+        self.N = fem_tables.NODES_PER_TET[self.order]
+        if tets.shape[1] != self.N:
+            raise ValueError(f"tets must have {self.N} columns for order {order}")
+        self.device = vertices.device
+        self.vertices = vertices.detach().to(torch.float32).contiguous()
+        self.tets = tets.to(torch.int32).contiguous()
+        self.nv = self.vertices.shape[0]
+        self.n = 3 * self.nv
+        self.T = self.tets.shape[0]
+        self.density = float(density)
+        pat = _hip.Pattern(self.tets.cpu(), self.nv)
+        self.nnzb = pat.nnzb
+        dev = self.device
+        self.rowptr = pat.rowptr.to(dev)
+        self.colidx = pat.colidx.to(dev)
+        self.diagidx = pat.diagidx.to(dev)
+        self.cptr = pat.cptr.to(dev)
+        self.clist = pat.clist.to(dev)
+        self.dtab = torch.from_numpy(fem_tables.stiffness_table(self.order)).to(dev)
+        self.mtab = torch.from_numpy(fem_tables.mass_table(self.order, self.density)).to(dev)
+        self.klam = torch.empty((self.nnzb, 9), dtype=torch.float64, device=dev)
+        self.kmu = torch.empty((self.nnzb, 9), dtype=torch.float64, device=dev)
+        self.ms = torch.empty((self.nnzb,), dtype=torch.float64, device=dev)
+        self._tetgeo = torch.empty((self.T, 13), dtype=torch.float64, device=dev)
+        self.assemble()
+
+    def assemble(self, vertices=None):
+        """Numeric phase only (pattern reused): refresh K_lambda, K_mu, M_s from the coordinates."""
+        if vertices is not None:
+            self.vertices = vertices.detach().to(torch.float32).contiguous()
+        L = _hip.lib()
+        p = _hip.ptr
+        _hip.check(L.ds_assemble_kml(p(self.vertices), p(self.tets), self.T, self.N, self.nv, p(self.cptr),
+                                     p(self.clist), self.nnzb, p(self.dtab), p(self.mtab), p(self._tetgeo),
+                                     p(self.klam), p(self.kmu), p(self.ms), _hip.stream_ptr()), "ds_assemble_kml")
+
+    # scipy views for tests / interop (host copies)
+    def to_scipy(self, lam=None, mu=None):
+        import scipy.sparse as sp
+
+        rp = self.rowptr.cpu().numpy()
+        ci = self.colidx.cpu().numpy()
+        mk = lambda v: sp.bsr_matrix((v.cpu().numpy().reshape(-1, 3, 3), ci, rp), shape=(self.n, self.n)).tocsr()
+        Kl, Km = mk(self.klam), mk(self.kmu)
+        Ms = sp.csr_matrix((self.ms.cpu().numpy(), ci, rp), shape=(self.nv, self.nv))
+        if lam is None:
+            return Kl, Km, Ms
+        return (lam * Kl + mu * Km).tocsr(), sp.kron(Ms, sp.identity(3), format="csr")
+
+
+class HipModalOps:
+    dtype = torch.float32
+
+    def __init__(self, system: TetSystem, lam, mu):
+        self.sys = system
+        self.n = system.n
+        self.nv = system.nv
+        self.device = system.device
+        self._L = _hip.lib()
+        dev = self.device
+        self.k32 = torch.empty((system.nnzb, 9), dtype=torch.float32, device=dev)
+        self.ms32 = torch.empty((system.nnzb,), dtype=torch.float32, device=dev)
+        self.dinv = torch.empty((system.nv, 9), dtype=torch.float32, device=dev)
+        self._gram_ws = None
+        self._tmp = {}
+        self._nrm = torch.empty((2, 1024), dtype=torch.float64, device=dev)
+        self.counts = dict(apply_K_cols=0, apply_M_cols=0, gram=0, mix=0)
+        self.set_material(lam, mu)
+        self.rigid = self._rigid_basis()
+
+    # ------------------------------------------------------------------ material
+    def set_material(self, lam, mu):
+        s = self.sys
+        p = _hip.ptr
+        self.lame = (float(lam), float(mu))
+        _hip.check(self._L.ds_combine_material(p(s.klam), p(s.kmu), p(s.ms), s.nnzb, p(s.diagidx), s.nv,
+                                               float(lam), float(mu), p(self.k32), p(self.ms32), p(self.dinv),
+                                               _hip.stream_ptr()), "ds_combine_material")
+
+    def _rigid_basis(self):
+        """Translations + rotations about the centroid, M-orthonormalised in fp64; stored (n, 8) fp32 with
+        two zero pad columns so every kernel sees a multiple of 4 columns."""
+        v = self.sys.vertices.double()
+        c = v - v.mean(0, keepdim=True)
+        Y = torch.zeros((self.n, 8), dtype=torch.float64, device=self.device)
+        for a in range(3):
+            Y[a::3, a] = 1
+        Y[0::3, 3], Y[1::3, 3] = -c[:, 1], c[:, 0]
+        Y[1::3, 4], Y[2::3, 4] = -c[:, 2], c[:, 1]
+        Y[2::3, 5], Y[0::3, 5] = -c[:, 0], c[:, 2]
+        Y32 = Y.float()
+        MY = torch.empty((self.n, 8), dtype=torch.float64, device=self.device)
+        for _ in range(2):  # second pass removes the fp32 rounding of the first
+            self._spmm(3, self.sys.ms, Y32, MY)
+            G = (Y32.double()[:, :6].T @ MY[:, :6])
+            Lc = torch.linalg.cholesky(0.5 * (G + G.T))
+            Y6 = torch.linalg.solve_triangular(Lc, Y32.double()[:, :6].T, upper=False).T
+            Y32 = torch.zeros_like(Y32)
+            Y32[:, :6] = Y6.float()
+        return Y32.contiguous()
+
+    # ------------------------------------------------------------------ sparse products
+    def _spmm(self, kind, vals, X, out):
+        s = self.sys
+        p = _hip.ptr
+        ncols = X.shape[1]
+        if out.shape != X.shape:
+            raise ValueError("spmm: shape mismatch")
+        maxc = 256 if kind < 2 else 128
+        for c0 in range(0, ncols, maxc):
+            c1 = min(ncols, c0 + maxc)
+            xs, os_ = X[:, c0:c1], out[:, c0:c1]
+            _hip.check(self._L.ds_spmm_bsr3(kind, p(s.rowptr), p(s.colidx), p(vals), s.nv, p(xs), _ld(xs), p(os_),
+                                            _ld(os_), c1 - c0, _hip.stream_ptr()), "ds_spmm_bsr3")
+
+    def apply_K(self, X, out):
+        self._spmm(0, self.k32, X, out)
+        self.counts["apply_K_cols"] += X.shape[1]
+
+    def apply_M(self, X, out):
+        self._spmm(1, self.ms32, X, out)
+        self.counts["apply_M_cols"] += X.shape[1]
+
+    # ------------------------------------------------------------------ tall-skinny dense
+    def gram(self, A, B):
+        p, q = A.shape[1], B.shape[1]
+        need = self._L.ds_gram_workspace_bytes(self.n, p, q)
+        if self._gram_ws is None or self._gram_ws.numel() < need:
+            self._gram_ws = torch.empty((need,), dtype=torch.uint8, device=self.device)
+        G = torch.empty((p, q), dtype=torch.float64, device=self.device)
+        bdt = DS_F64 if B.dtype == torch.float64 else DS_F32
+        pp = _hip.ptr
+        _hip.check(self._L.ds_gram(pp(A), _ld(A), p, pp(B), bdt, _ld(B), q, self.n, pp(G), pp(self._gram_ws),
+                                   self._gram_ws.numel(), _hip.stream_ptr()), "ds_gram")
+        self.counts["gram"] += 1
+        return G
+
+    def _scratch(self, key, shape, dtype):
+        t = self._tmp.get(key)
+        if t is None or t.shape != tuple(shape) or t.dtype != dtype:
+            t = torch.empty(shape, dtype=dtype, device=self.device)
+            self._tmp[key] = t
+        return t
+
+    def mix(self, A, C, out, alpha=1.0, beta=0.0):
+        p, q = C.shape
+        if A.shape[1] != p or out.shape[1] != q:
+            raise ValueError("mix: shape mismatch")
+        C32 = C.to(torch.float32).contiguous()
+        pp = _hip.ptr
+        _hip.check(self._L.ds_mix(pp(A), _ld(A), p, pp(C32), q, pp(out), _ld(out), self.n, float(alpha),
+                                  float(beta), _hip.stream_ptr()), "ds_mix")
+        self.counts["mix"] += 1
+
+    def mix_inplace(self, W, T):
+        tmp = self._scratch("mix_inplace", W.shape, W.dtype)
+        self.mix(W, T, tmp)
+        W.copy_(tmp)
+
+    # ------------------------------------------------------------------ fused elementwise
+    def residual(self, R, MX, X, lam):
+        b = R.shape[1]
+        lam64 = lam.to(torch.float64).contiguous()
+        pp = _hip.ptr
+        _hip.check(self._L.ds_residual(pp(R), _ld(R), pp(MX), _ld(MX), pp(X), _ld(X), pp(lam64), self.n, b,
+                                       pp(self._nrm[0]), pp(self._nrm[1]), _hip.stream_ptr()), "ds_residual")
+        return self._nrm[0, :b].clone(), self._nrm[1, :b].clone()
+
+    def cheb_init(self, R, D, W, c):
+        pp = _hip.ptr
+        _hip.check(self._L.ds_cheb_init(pp(R), _ld(R), pp(D), _ld(D), pp(W), _ld(W), pp(self.dinv), self.nv,
+                                        R.shape[1], float(c), _hip.stream_ptr()), "ds_cheb_init")
+
+    def cheb_step(self, AD, R, D, W, c1, c2):
+        pp = _hip.ptr
+        _hip.check(self._L.ds_cheb_step(pp(AD), _ld(AD), pp(R), _ld(R), pp(D), _ld(D), pp(W), _ld(W), pp(self.dinv),
+                                        self.nv, R.shape[1], float(c1), float(c2), _hip.stream_ptr()), "ds_cheb_step")
+
+    # ------------------------------------------------------------------ fp64 polish
+    def polish_products(self, X):
+        """X^T K_lambda X, X^T K_mu X, X^T M X in fp64 (fp64 values, fp64 accumulation, fp32 X)."""
+        Y = self._scratch("polish", X.shape, torch.float64)
+        out = []
+        for kind, vals in ((2, self.sys.klam), (2, self.sys.kmu), (3, self.sys.ms)):
+            self._spmm(kind, vals, X, Y)
+            out.append(self.gram(X, Y))
+        return tuple(out)

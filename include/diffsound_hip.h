@@ -1,0 +1,146 @@
+/* diffsound_hip.h - C ABI of libdiffsound_hip.so (MI355X / gfx950 only).
+ *
+ * Drop-in boundary for DiffSound's modal-sound hot path.  The reference's only native-op
+ * precedent on this path is
+ *     void assemble_mass_matrix(const Tensor& vertices, const Tensor& tets, Tensor& values,
+ *                               Tensor& rows, Tensor& cols, Tensor& element_mm,
+ *                               const double density, const int order)
+ *     (reference src/cuda/massMatrixDouble.h:14-15, bound in src/cuda/bind.cu:9-12),
+ * whose conventions are kept: the CALLER allocates every input and output buffer, the op fills
+ * outputs in place and owns nothing; errors surface to Python as RuntimeError.  Differences, on
+ * purpose: plain pointers + sizes instead of torch types, an explicit hipStream_t instead of the
+ * legacy default stream (reference src/include/macro.h:146-152), an int status + ds_last_error()
+ * instead of C++ exceptions, and no global mutable state besides the opaque host-side pattern
+ * handle.  Every function is asynchronous on `stream` unless stated otherwise; none allocates or
+ * synchronises, so all of them can be captured into a hipGraph.
+ *
+ * Layout conventions
+ *   - DOF ordering: global DOF 3*node + c (reference src/diffelastic/deform.py:118-125).
+ *   - K, K_lambda, K_mu: BSR with 3x3 blocks on the node-adjacency pattern (rowptr[nv+1],
+ *     colidx[nnzb], ascending per row), values [nnzb][3][3] row-major.
+ *   - M = M_s (x) I3 is stored as the node-level scalar CSR M_s on the same pattern: values [nnzb].
+ *   - dense blocks X are row-major (n x ncols) with an explicit leading dimension `ld` (elements)
+ *     so that column slices of a wider buffer can be passed without copies.
+ *   - dtype codes: DS_F32 = 0, DS_F64 = 1.
+ */
+#ifndef DIFFSOUND_HIP_H
+#define DIFFSOUND_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* ds_stream_t; /* hipStream_t */
+
+enum { DS_F32 = 0, DS_F64 = 1 };
+enum { DS_OK = 0, DS_ERR_ARG = 1, DS_ERR_HIP = 2, DS_ERR_NOMEM = 3 };
+
+/* Thread-local text of the last error returned on this thread ("" if none). */
+const char* ds_last_error(void);
+/* Library ABI version (bumped on any signature change). */
+int ds_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Symbolic phase (HOST, CPU only): node-adjacency BSR pattern + per-block contribution lists.
+ * Replaces the reference's COO triplet emission + coalesce() (src/diffelastic/diff_model.py:
+ * 214-220, 299-312; src/cuda/massMatrixDouble.cu:70-77).  Once per mesh topology.
+ *   tets   : (T x N) int32 host array, N = 4 (ord-1) or 10 (ord-2), reference local node order
+ *            (src/diffelastic/mesh.py:139-154).
+ * Contribution id of element t, local pair (a,b):  t*N*N + a*N + b.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct ds_pattern ds_pattern_t;
+int ds_pattern_build(const int32_t* tets, int64_t T, int N, int64_t nv, int nthreads, ds_pattern_t** out);
+int ds_pattern_sizes(const ds_pattern_t* p, int64_t* nv, int64_t* nnzb, int64_t* ncontrib);
+/* Copies into caller-allocated HOST arrays: rowptr[nv+1], colidx[nnzb], diagidx[nv] (slot of block
+ * (i,i)), cptr[nnzb+1], clist[ncontrib] (contribution ids grouped by block slot, ascending). */
+int ds_pattern_export(const ds_pattern_t* p, int32_t* rowptr, int32_t* colidx, int32_t* diagidx,
+                      int32_t* cptr, int32_t* clist);
+void ds_pattern_free(ds_pattern_t* p);
+
+/* ------------------------------------------------------------------------------------------------
+ * Numeric assembly (DEVICE).  K_lambda, K_mu (geometry-only parts of K = lam*K_lambda + mu*K_mu,
+ * SURVEY.md 0.6) and M_s in one pass, fp64, deterministic (no atomics): one thread per block slot
+ * sums its contribution list in fixed order.  Restates update_stiff_matrix / update_mass_matrix
+ * (reference src/diffelastic/diff_model.py:184-312) with the element integrals in closed form over
+ * the reference's own Gauss rule (tables built by the host from src/diffelastic/gauss.py:17-38).
+ *   verts  : (nv x 3) f32 device          tets : (T x N) i32 device
+ *   dtab   : (N x 4 x N x 4) f64 device,  dtab[a][k][b][l] = sum_g w_g dN_a/dL_k dN_b/dL_l
+ *   mtab   : (N x N) f64 device,          mtab[a][b]       = sum_g w_g N_a N_b   (already * density
+ *            in fp32 where the reference does so, diff_model.py:301-303)
+ *   tetgeo : workspace (T x 13) f64 device (barycentric gradients 4x3 + |det|)
+ *   out    : klam, kmu (nnzb x 9) f64 ; ms (nnzb) f64
+ * ---------------------------------------------------------------------------------------------- */
+int ds_assemble_kml(const float* verts, const int32_t* tets, int64_t T, int N, int64_t nv,
+                    const int32_t* cptr, const int32_t* clist, int64_t nnzb,
+                    const double* dtab, const double* mtab, double* tetgeo,
+                    double* klam, double* kmu, double* ms, ds_stream_t stream);
+
+/* K32 = (float)(lam*K_lambda + mu*K_mu), Ms32 = (float)M_s, and the fp32 inverse of the 3x3 diagonal
+ * blocks of K (block-Jacobi preconditioner).  Per material hypothesis. */
+int ds_combine_material(const double* klam, const double* kmu, const double* ms, int64_t nnzb,
+                        const int32_t* diagidx, int64_t nv, double lam, double mu,
+                        float* k32, float* ms32, float* dinv32, ds_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Block SpMM  Y = A X  on the BSR-3 pattern (the HBM-roofline kernel).  Replaces torch.sparse.mm
+ * in the reference's LOBPCG (src/lobpcg/_linalg_utils.py:36-37) and in get_vals
+ * (src/diffelastic/diff_model.py:395-397).
+ *   kind 0: A = K,   vals (nnzb x 9) f32           X, Y f32
+ *   kind 1: A = M,   vals (nnzb)     f32 (M_s)     X, Y f32
+ *   kind 2: A = K_*, vals (nnzb x 9) f64           X f32, Y f64   (polish / read-out)
+ *   kind 3: A = M,   vals (nnzb)     f64 (M_s)     X f32, Y f64
+ * X: (3nv x ncols) ld = ldx ; Y: (3nv x ncols) ld = ldy ; X and Y must not overlap.
+ * ---------------------------------------------------------------------------------------------- */
+int ds_spmm_bsr3(int kind, const int32_t* rowptr, const int32_t* colidx, const void* vals, int64_t nv,
+                 const void* X, int64_t ldx, void* Y, int64_t ldy, int ncols, ds_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Tall-skinny Gram  G = A^T B  (p x q, fp64, row-major, ld = q) with MFMA, fp64 accumulation.
+ * Replaces the dense (k x n)(n x k) products of Rayleigh-Ritz / svqb / ortho in the reference
+ * (src/lobpcg/_linalg_utils.py:64-73 via torch.matmul).
+ *   A: (n x p) f32, lda ;  B: (n x q) f32 or f64 (b_dtype), ldb
+ *   work: device scratch of ds_gram_workspace_bytes(n, p, q) bytes.
+ * ---------------------------------------------------------------------------------------------- */
+int64_t ds_gram_workspace_bytes(int64_t n, int p, int q);
+int ds_gram(const float* A, int64_t lda, int p, const void* B, int b_dtype, int64_t ldb, int q,
+            int64_t n, double* G, void* work, int64_t work_bytes, ds_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Fused block-vector updates of the eigensolver (all (n x ncols) f32 with leading dimensions).
+ * ---------------------------------------------------------------------------------------------- */
+/* R <- R - MX * diag(lam) ;  rn2[j] = ||R_j||^2, xn2[j] = ||X_j||^2 (f64, zeroed by this call).
+ * (reference update_residual + the norms of update_converged_count, _lobpcg.py:301-333) */
+int ds_residual(float* R, int64_t ldr, const float* MX, int64_t ldm, const float* X, int64_t ldx,
+                const double* lam, int64_t n, int ncols, double* rn2, double* xn2, ds_stream_t stream);
+/* D <- c * T R ; W <- D      (T = block-Jacobi, dinv (nv x 9) f32) */
+int ds_cheb_init(const float* R, int64_t ldr, float* D, int64_t ldd, float* W, int64_t ldw,
+                 const float* dinv, int64_t nv, int ncols, float c, ds_stream_t stream);
+/* R <- R - AD ; D <- c1 D + c2 T R ; W <- W + D */
+int ds_cheb_step(const float* AD, int64_t lda, float* R, int64_t ldr, float* D, int64_t ldd,
+                 float* W, int64_t ldw, const float* dinv, int64_t nv, int ncols, float c1, float c2,
+                 ds_stream_t stream);
+/* Out <- alpha * A C + beta * Out,  A (n x p) f32, C (p x q) f32 row-major device, Out (n x q) f32.
+ * Out must not alias A.  (reference: X <- S Z etc., _lobpcg.py:463-466) */
+int ds_mix(const float* A, int64_t lda, int p, const float* C, int q, float* Out, int64_t ldo,
+           int64_t n, float alpha, float beta, ds_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Damped-oscillator bank (reference src/ddsp/oscillator.py:113-141, 282-310):
+ *   s[a,t] = sum_m amp[a,m] exp(-d_m tau_t) sin(w_m tau_t),  tau_t = (t+1)/sr
+ *   y[a,t] = sum_{j<F} force[a,j] s[a,t-j]                   (causal FIR, cropped to S samples)
+ * d, w: (m) f64 (decay rate and damped angular frequency) ; amp: (A x m) f32 or NULL (= 1) ;
+ * force: (A x F) f32 ; y: (A x S) f32.
+ * Backward: gy (A x S) f32 -> gd, gw (m) f64, gamp (A x m) f32 (may be NULL) ; gs is scratch (A x S) f32.
+ * ---------------------------------------------------------------------------------------------- */
+int ds_osc_bank_fwd(const double* d, const double* w, const float* amp, const float* force,
+                    int A, int m, int F, int S, double sr, float* y, ds_stream_t stream);
+int ds_osc_bank_bwd(const float* gy, const double* d, const double* w, const float* amp,
+                    const float* force, int A, int m, int F, int S, double sr, float* gs,
+                    double* gd, double* gw, float* gamp, ds_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DIFFSOUND_HIP_H */

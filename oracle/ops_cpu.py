@@ -1,0 +1,98 @@
+"""CPU stand-in for the HIP ``ModalOps`` backend (TEST INFRASTRUCTURE ONLY).
+
+Implements the ``ops`` protocol of ``diffsound_amd/lobpcg/modal_solver.py`` with plain
+SciPy / PyTorch-CPU so that (a) the host-side solver logic can be tested without a GPU and
+(b) every HIP kernel has a same-signature oracle to be compared with on the GPU box.
+Never imported by the product package.
+"""
+import numpy as np
+import scipy.sparse as sp
+import torch
+
+
+def rigid_body_basis(verts):
+    """Translations + infinitesimal rotations x cross e_c about the centroid, (3nv, 6) fp64."""
+    v = np.asarray(verts, dtype=np.float64)
+    c = v - v.mean(0)
+    Y = np.zeros((3 * len(v), 6))
+    for a in range(3):
+        Y[a::3, a] = 1
+    Y[0::3, 3], Y[1::3, 3] = -c[:, 1], c[:, 0]
+    Y[1::3, 4], Y[2::3, 4] = -c[:, 2], c[:, 1]
+    Y[2::3, 5], Y[0::3, 5] = -c[:, 0], c[:, 2]
+    return Y
+
+
+class CpuModalOps:
+    def __init__(self, Kl, Km, M3, verts, lam, mu, dtype=torch.float32):
+        self.Kl, self.Km, self.M = Kl.tocsr(), Km.tocsr(), M3.tocsr()
+        self.lame = (float(lam), float(mu))
+        self.n = Kl.shape[0]
+        self.device = torch.device("cpu")
+        self.dtype = dtype
+        self.npdt = np.float32 if dtype == torch.float32 else np.float64
+        K = (lam * self.Kl + mu * self.Km).tocsr()
+        self.K64 = K
+        self.Kd = K.astype(self.npdt)
+        self.Md = self.M.astype(self.npdt)
+        nb = self.n // 3
+        Kb = K.tobsr((3, 3))
+        rows = np.repeat(np.arange(nb), np.diff(Kb.indptr))
+        diag = np.zeros((nb, 3, 3))
+        m = rows == Kb.indices
+        diag[rows[m]] = Kb.data[m]
+        self.Dinv = torch.from_numpy(np.linalg.inv(diag).astype(self.npdt))
+        Y = rigid_body_basis(verts)
+        G = Y.T @ (self.M @ Y)
+        L = np.linalg.cholesky(G)
+        Y = np.linalg.solve(L, Y.T).T
+        self.rigid = torch.from_numpy(Y.astype(self.npdt))
+        self.counts = dict(apply_K_cols=0, apply_M_cols=0, gram=0, mix=0)
+
+    # -- sparse products -----------------------------------------------------------------
+    def apply_K(self, X, out):
+        out.copy_(torch.from_numpy(self.Kd @ X.numpy()))
+        self.counts["apply_K_cols"] += X.shape[1]
+
+    def apply_M(self, X, out):
+        out.copy_(torch.from_numpy(self.Md @ X.numpy()))
+        self.counts["apply_M_cols"] += X.shape[1]
+
+    # -- tall-skinny dense ---------------------------------------------------------------
+    def gram(self, A, B):
+        self.counts["gram"] += 1
+        return A.double().transpose(0, 1) @ B.double()
+
+    def mix(self, A, C, out, alpha=1.0, beta=0.0):
+        self.counts["mix"] += 1
+        r = (A @ C.to(self.dtype)) * alpha
+        if beta != 0.0:
+            r = r + beta * out
+        out.copy_(r)
+
+    def mix_inplace(self, W, T):
+        W.copy_(W @ T.to(self.dtype))
+
+    # -- fused elementwise ---------------------------------------------------------------
+    def residual(self, R, MX, X, lam):
+        R.sub_(MX * lam.to(self.dtype)[None, :])
+        return (R.double() ** 2).sum(0), (X.double() ** 2).sum(0)
+
+    def _bj(self, R):
+        n, c = R.shape
+        return torch.einsum("nij,njc->nic", self.Dinv, R.reshape(-1, 3, c)).reshape(n, c)
+
+    def cheb_init(self, R, D, W, c):
+        D.copy_(self._bj(R) * c)
+        W.copy_(D)
+
+    def cheb_step(self, AD, R, D, W, c1, c2):
+        R.sub_(AD)
+        D.copy_(c1 * D + c2 * self._bj(R))
+        W.add_(D)
+
+    # -- fp64 polish ---------------------------------------------------------------------
+    def polish_products(self, X):
+        Xd = X.double().numpy()
+        f = lambda A: torch.from_numpy(Xd.T @ (A @ Xd))
+        return f(self.Kl), f(self.Km), f(self.M)

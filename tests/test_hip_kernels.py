@@ -1,0 +1,240 @@
+"""Kernel-level parity: every C-ABI entry point against the CPU oracle on the same seeded inputs.
+Run on the GPU box with  pytest -m gpu."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import torch
+
+from oracle import fem
+from oracle import oscillator as oosc
+from oracle.ops_cpu import CpuModalOps
+
+pytestmark = pytest.mark.gpu
+
+MAT = (2700.0, 5e10, 0.25, 6.0, 1e-7)
+
+
+def rel(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no HIP device")
+    return torch.device("cuda:0")
+
+
+def _mesh(name, order):
+    from diffsound_amd import meshgen
+
+    if name == "bowl":
+        m = np.load("tests/golden/g0_bowl_mesh.npz")
+        v, t = torch.from_numpy(m["verts"]), torch.from_numpy(m["tets"]).long()
+    else:
+        v, t = meshgen.kuhn_box(int(name[4:]))
+        v, t = torch.from_numpy(v), torch.from_numpy(t).long()
+    return fem.to_high_order(v, t, order)
+
+
+@pytest.fixture(scope="module", params=[("cube3", 1), ("cube3", 2), ("bowl", 1), ("cube6", 2)])
+def case(request, dev):
+    from diffsound_amd.modal_ops import TetSystem, HipModalOps
+
+    name, order = request.param
+    v, t = _mesh(name, order)
+    d = fem.OracleDeform(v, t, order)
+    Kl = fem.assemble_stiffness(d, 1.0, 0.0)
+    Km = fem.assemble_stiffness(d, 0.0, 1.0)
+    M3, Ms = fem.assemble_mass(v, t, order, MAT[0])
+    lam, mu = fem.lame(MAT[1], MAT[2])
+    sysd = TetSystem(v.to(dev), t.to(dev), order, MAT[0])
+    hops = HipModalOps(sysd, lam, mu)
+    cops = CpuModalOps(Kl, Km, M3, v.numpy(), lam, mu)
+    return dict(v=v, t=t, order=order, Kl=Kl, Km=Km, M3=M3, Ms=Ms, sys=sysd, hops=hops, cops=cops, lam=lam, mu=mu)
+
+
+def test_pattern_and_assembly(case):
+    s = case["sys"]
+    Kl, Km, Ms = s.to_scipy()
+    # pattern == union of the element cliques (same nnz as the reference's coalesced K)
+    t = case["t"].numpy()
+    N = t.shape[1]
+    pairs = np.unique(np.stack([np.repeat(t, N, axis=1).reshape(-1), np.tile(t, (1, N)).reshape(-1)], 1), axis=0)
+    ref_pat = sp.csr_matrix((np.ones(len(pairs)), (pairs[:, 0], pairs[:, 1])), shape=(s.nv, s.nv))
+    ref_pat.sort_indices()
+    assert s.nnzb == ref_pat.nnz
+    assert np.array_equal(s.rowptr.cpu().numpy(), ref_pat.indptr)
+    assert np.array_equal(s.colidx.cpu().numpy(), ref_pat.indices)
+    # values: relative to the largest entry; 2e-6 absorbs the reference's fp32 shape-function gradients
+    x = np.random.default_rng(0).standard_normal((s.n, 4))
+    assert rel(Kl @ x, case["Kl"] @ x) < 2e-6
+    assert rel(Km @ x, case["Km"] @ x) < 2e-6
+    assert rel(sp.kron(Ms, sp.identity(3)) @ x, case["M3"] @ x) < 1e-12
+    # symmetry and rigid-body null space
+    K = case["lam"] * Kl + case["mu"] * Km
+    assert abs(K - K.T).max() / abs(K).max() < 1e-12
+
+
+def test_assembly_deterministic(case):
+    s = case["sys"]
+    a = s.klam.clone(), s.kmu.clone(), s.ms.clone()
+    s.assemble()
+    assert torch.equal(a[0], s.klam) and torch.equal(a[1], s.kmu) and torch.equal(a[2], s.ms)
+
+
+@pytest.mark.parametrize("ncols", [8, 24, 80, 240])
+def test_spmm(case, dev, ncols):
+    h, c = case["hops"], case["cops"]
+    if h.n < 3 * 8:
+        pytest.skip("tiny")
+    g = torch.Generator().manual_seed(ncols)
+    X = torch.randn((h.n, ncols), generator=g)
+    Xd = X.to(dev)
+    for name in ("apply_K", "apply_M"):
+        ref = torch.empty_like(X)
+        getattr(c, name)(X, ref)
+        out = torch.empty_like(Xd)
+        getattr(h, name)(Xd, out)
+        assert rel(out.cpu().numpy(), ref.numpy()) < 5e-6
+    # strided views of a wider buffer (how the solver calls it)
+    if ncols >= 24:
+        big = torch.zeros((h.n, ncols + 16), device=dev)
+        big[:, 8:8 + ncols] = Xd
+        outb = torch.zeros_like(big)
+        h.apply_K(big[:, 8:8 + ncols], outb[:, 8:8 + ncols])
+        ref = torch.empty_like(X)
+        c.apply_K(X, ref)
+        assert rel(outb[:, 8:8 + ncols].cpu().numpy(), ref.numpy()) < 5e-6
+        assert float(outb[:, :8].abs().max()) == 0.0 and float(outb[:, 8 + ncols:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("p,q", [(8, 40), (40, 40), (80, 80), (240, 240), (104, 56)])
+def test_gram(case, dev, p, q):
+    h = case["hops"]
+    g = torch.Generator().manual_seed(p * 1000 + q)
+    A = torch.randn((h.n, p), generator=g)
+    B = torch.randn((h.n, q), generator=g)
+    G = h.gram(A.to(dev), B.to(dev)).cpu()
+    ref = A.double().T @ B.double()
+    assert rel(G.numpy(), ref.numpy()) < 1e-13
+    G64 = h.gram(A.to(dev), B.double().to(dev)).cpu()
+    assert rel(G64.numpy(), ref.numpy()) < 1e-13
+
+
+@pytest.mark.parametrize("p,q", [(8, 40), (80, 40), (240, 80), (216, 72), (80, 200)])
+def test_mix(case, dev, p, q):
+    h = case["hops"]
+    g = torch.Generator().manual_seed(p + q)
+    A = torch.randn((h.n, p), generator=g)
+    C = torch.randn((p, q), generator=g, dtype=torch.float64)
+    O = torch.randn((h.n, q), generator=g)
+    ref = (A.double() @ C)
+    out = O.to(dev).clone()
+    h.mix(A.to(dev), C.to(dev), out)
+    assert rel(out.cpu().numpy(), ref.numpy()) < 2e-6
+    out = O.to(dev).clone()
+    h.mix(A.to(dev), C.to(dev), out, alpha=-1.0, beta=1.0)
+    assert rel(out.cpu().numpy(), (O.double() - ref).numpy()) < 2e-6
+
+
+def test_residual_and_cheb(case, dev):
+    h, c = case["hops"], case["cops"]
+    b = 40
+    g = torch.Generator().manual_seed(5)
+    R = torch.randn((h.n, b), generator=g)
+    MX = torch.randn((h.n, b), generator=g)
+    X = torch.randn((h.n, b), generator=g)
+    lam = torch.rand(b, generator=g, dtype=torch.float64) * 3
+    Rc = R.clone()
+    rn, xn = c.residual(Rc, MX, X, lam)
+    Rd = R.to(dev).clone()
+    rn_d, xn_d = h.residual(Rd, MX.to(dev), X.to(dev), lam.to(dev))
+    assert rel(Rd.cpu().numpy(), Rc.numpy()) < 1e-6
+    assert rel(rn_d.cpu().numpy(), rn.numpy()) < 1e-6 and rel(xn_d.cpu().numpy(), xn.numpy()) < 1e-12
+    # block-Jacobi blocks and the two fused Chebyshev passes
+    assert rel(h.dinv.cpu().numpy().reshape(-1, 3, 3), c.Dinv.numpy()) < 1e-5
+    D, W = torch.empty_like(R), torch.empty_like(R)
+    c.cheb_init(R, D, W, 0.37)
+    Dd, Wd = torch.empty_like(Rd), torch.empty_like(Rd)
+    h.cheb_init(R.to(dev), Dd, Wd, 0.37)
+    assert rel(Dd.cpu().numpy(), D.numpy()) < 1e-5 and rel(Wd.cpu().numpy(), W.numpy()) < 1e-5
+    AD = torch.randn((h.n, b), generator=g) * 0.1
+    R2, R2d = R.clone(), R.to(dev).clone()
+    c.cheb_step(AD, R2, D, W, 0.4, 0.7)
+    h.cheb_step(AD.to(dev), R2d, Dd, Wd, 0.4, 0.7)
+    for a, bb in ((R2d, R2), (Dd, D), (Wd, W)):
+        assert rel(a.cpu().numpy(), bb.numpy()) < 1e-5
+
+
+def test_polish_products(case, dev):
+    h, c = case["hops"], case["cops"]
+    g = torch.Generator().manual_seed(9)
+    X = torch.randn((h.n, 16), generator=g)
+    got = h.polish_products(X.to(dev))
+    want = c.polish_products(X)
+    for a, b in zip(got, want):
+        assert rel(a.cpu().numpy(), b.numpy()) < 2e-6  # assembly tolerance; the products themselves are fp64
+
+
+def test_rigid_basis(case):
+    h = case["hops"]
+    Y = h.rigid[:, :6].double().cpu().numpy()
+    G = Y.T @ (case["M3"] @ Y)
+    assert np.abs(G - np.eye(6)).max() < 1e-5
+    K = case["lam"] * case["Kl"] + case["mu"] * case["Km"]
+    assert np.abs(K @ Y).max() / (abs(K).max() * np.abs(Y).max()) < 1e-5
+
+
+# ------------------------------------------------------------------------------------- oscillator
+@pytest.mark.parametrize("A,m,F,S", [(1, 32, 150, 8000), (3, 16, 150, 4000), (2, 7, 1, 1500), (1, 64, 150, 8000)])
+def test_oscillator_kernels(dev, A, m, F, S):
+    from diffsound_amd import _hip
+
+    L = _hip.lib()
+    g = torch.Generator().manual_seed(A * 100 + m)
+    f = torch.sort(torch.rand(m, generator=g) * 9000 + 300)[0].double()
+    alpha, beta = 6.0, 1e-7
+    w0 = 2 * np.pi * f
+    d = 0.5 * (alpha + beta * w0 ** 2)
+    w = torch.sqrt(w0 ** 2 - d ** 2)
+    amp = torch.rand((A, m), generator=g) + 0.5
+    force = torch.randn((A, F), generator=g)
+    y = torch.empty((A, S), device=dev)
+    p = _hip.ptr
+    dd, wd, ad, fd = d.to(dev), w.to(dev), amp.to(dev), force.to(dev)
+    _hip.check(L.ds_osc_bank_fwd(p(dd), p(wd), p(ad), p(fd), A, m, F, S, 32000.0, p(y), _hip.stream_ptr()), "fwd")
+    ref = oosc.bank_closed_form_f64(f.numpy(), force.numpy(), S, 32000, alpha, beta, amp=amp.numpy())
+    err = np.linalg.norm(y.cpu().numpy() - ref) / np.linalg.norm(ref)
+    assert err < 1e-6, err
+    # backward against fp64 autograd of the closed form
+    gy = torch.randn((A, S), generator=g)
+    dt_, wt_, at_ = d.clone().requires_grad_(True), w.clone().requires_grad_(True), amp.double().clone().requires_grad_(True)
+    tau = (torch.arange(S, dtype=torch.float64) + 1) / 32000
+    modes = torch.exp(-dt_[:, None] * tau[None]) * torch.sin(wt_[:, None] * tau[None])
+    s = (at_[:, :, None] * modes[None]).sum(1)
+    yy = torch.nn.functional.conv1d(s[None], torch.flip(force.double(), [-1])[:, None, :], groups=A, padding=F - 1)[0][:, :S]
+    (yy * gy.double()).sum().backward()
+    gs = torch.empty((A, S), device=dev)
+    gd = torch.empty(m, dtype=torch.float64, device=dev)
+    gw = torch.empty(m, dtype=torch.float64, device=dev)
+    gamp = torch.empty((A, m), device=dev)
+    _hip.check(L.ds_osc_bank_bwd(p(gy.to(dev)), p(dd), p(wd), p(ad), p(fd), A, m, F, S, 32000.0, p(gs), p(gd), p(gw),
+                                 p(gamp), _hip.stream_ptr()), "bwd")
+    assert rel(gd.cpu().numpy(), dt_.grad.numpy()) < 1e-5
+    assert rel(gw.cpu().numpy(), wt_.grad.numpy()) < 1e-5
+    assert rel(gamp.cpu().numpy(), at_.grad.numpy()) < 1e-5
+
+
+def test_errors_are_loud(dev):
+    from diffsound_amd import _hip
+
+    L = _hip.lib()
+    with pytest.raises(RuntimeError):
+        _hip.check(L.ds_spmm_bsr3(7, None, None, None, 0, None, 0, None, 0, 0, None), "ds_spmm_bsr3")
+    with pytest.raises(RuntimeError):
+        from diffsound_amd.modal_ops import TetSystem
+
+        TetSystem(torch.zeros((4, 3)), torch.zeros((1, 4), dtype=torch.int64), 1, 1000.0)  # CPU tensors
