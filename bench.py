@@ -1,0 +1,223 @@
+#!/usr/bin/env python3
+"""Headline benchmark: forward+backward modal-analysis passes/sec on the 100k-tet ord-2 mesh, 64 modes.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+One *step* = every rank runs ``--hyp-per-gpu`` complete passes (numeric assembly, cold-start block
+eigensolve for 64 elastic modes, differentiable frequency read-out, oscillator render, MSE loss,
+backward to (E, nu)) for its own material hypotheses on the shared synthetic mesh, then the scalar
+losses are all-reduced (RCCL) - weak scaling, no other collective.  Rank 0 prints ONE JSON line.
+Inputs are synthetic (Kuhn box mesh) and resident in HBM before the timed region.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+MAT = (2700.0, 5e10, 0.25, 6.0, 1e-7)
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md); ~6300 GB/s achievable
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--cells", type=int, default=26, help="Kuhn box cells per edge (26 -> 105 456 tets)")
+    ap.add_argument("--order", type=int, default=2)
+    ap.add_argument("--modes", type=int, default=64)
+    ap.add_argument("--hyp-per-gpu", type=int, default=1)
+    ap.add_argument("--cheb-degree", type=int, default=8)
+    ap.add_argument("--cheb-ratio", type=float, default=100.0)
+    ap.add_argument("--block", type=int, default=80)
+    ap.add_argument("--warm-start", action="store_true", help="amortised variant: reuse the previous block")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-cells", type=int, default=5)
+    return ap.parse_args()
+
+
+def cpu_baseline(sample_cells, order, modes, full_tets):
+    """The CPU oracle (faithful restatement of the reference loop body) timed on a bounded sample:
+    one full pass on a small Kuhn box of the same kind, extrapolated LINEARLY in the number of tets
+    to the benchmark mesh (optimistic for the CPU: the reference's assembly and ARPACK's LU are
+    super-linear)."""
+    from diffsound_amd import meshgen
+    from oracle import fem, modal
+    from oracle import oscillator as oosc
+
+    torch.set_num_threads(os.cpu_count() or 1)
+    v, t = meshgen.kuhn_box(sample_cells)
+    t0 = time.time()
+    v, t = fem.to_high_order(torch.from_numpy(v), torch.from_numpy(t).long(), order)
+    d = fem.OracleDeform(v, t, order)
+    E = torch.tensor(MAT[1], requires_grad=True)
+    nu = torch.tensor(MAT[2], requires_grad=True)
+    lam, mu = fem.lame(float(E), float(nu))
+    M3, _ = fem.assemble_mass(v, t, order, MAT[0])
+    K = fem.assemble_stiffness_faithful(d, lam, mu)
+    ev, U, _, _ = modal.eigsh_shift_invert(K, M3, modes)
+    f = modal.undamped_freqs_material(d, M3, ev, U, E, nu)
+    force = torch.zeros((1, 150))
+    force[0, 0] = 1
+    sig, _ = oosc.bank(f.float(), force, 8000, 32000, MAT[3], MAT[4])
+    loss = (sig ** 2).mean()
+    loss.backward()
+    dt = time.time() - t0
+    ntets = t.shape[0]
+    scaled = dt * full_tets / ntets
+    return {
+        "value": 1.0 / scaled,
+        "unit": "passes/s",
+        "cores": os.cpu_count() or 1,
+        "kind": "port",
+        "sample": (f"one full fwd+bwd pass of the CPU oracle on a {sample_cells}^3-cell Kuhn box ({ntets} tets, "
+                   f"ord-{order}, {modes} modes) took {dt:.1f} s; extrapolated linearly in tets to {full_tets} tets"),
+        "sample_seconds": dt,
+    }
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus and world > 1:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (there is no CPU path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+
+    from diffsound_amd import meshgen
+    from diffsound_amd.diffelastic.mesh import TetMesh
+    from diffsound_amd.lobpcg.modal_solver import SolverConfig
+    from diffsound_amd.pipeline import ModalPipeline, all_reduce_loss, shard_hypotheses
+
+    # ---- synthetic inputs, resident in HBM before timing -------------------------------------
+    v, t = meshgen.kuhn_box(a.cells)
+    mesh = TetMesh(torch.from_numpy(v).to(dev), torch.from_numpy(t).long().to(dev)).to_high_order(a.order)
+    cfg = SolverConfig(block=a.block, cheb_degree=a.cheb_degree, cheb_ratio=a.cheb_ratio,
+                       lmax_cap=float({1: 4, 2: 10}[a.order]))
+    t_sym = time.time()
+    pipe = ModalPipeline(mesh.vertices, mesh.tets, a.order, a.modes, MAT, solver_config=cfg)
+    torch.cuda.synchronize()
+    t_sym = time.time() - t_sym
+    nhyp = a.hyp_per_gpu * world
+    rng = np.random.default_rng(2024)  # SURVEY.md 8(d) C4 hypothesis ranges
+    Es = rng.uniform(1e10, 1e11, size=max(nhyp, 64))
+    nus = rng.uniform(0.1, 0.4, size=max(nhyp, 64))
+    mine = shard_hypotheses(nhyp, rank, world)
+    # fixed target audio: the material-table hypothesis rendered once (outside the timed region)
+    pipe.assemble()
+    tgt, res0, audio0 = pipe.run_pass(MAT[1], MAT[2], backward=False)
+    pipe.set_target(audio0)
+
+    def step(warm):
+        pipe.assemble()
+        loss_sum = 0.0
+        its = []
+        for h in mine:
+            r, res, _ = pipe.run_pass(float(Es[h]), float(nus[h]), warm=warm.get(h) if a.warm_start else None)
+            if a.warm_start:
+                warm[h] = res.block_vectors
+            loss_sum += r.loss
+            its.append(r.iterations)
+        total = all_reduce_loss(loss_sum, dev)
+        return total, its
+
+    warm = {}
+    for _ in range(a.warmup):
+        step(warm)
+        if not a.warm_start:
+            warm.clear()
+
+    # ---- instrument the dominant kernel: K-SpMM on the b-column block (HIP events on the launch stream)
+    pipe.ops.spmm_event_cols = a.block
+    pipe.ops.spmm_events = []
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.time()
+    iters = []
+    for _ in range(a.steps):
+        total, its = step(warm)
+        iters += its
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.time() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax[0])
+
+    ev_pairs = pipe.ops.spmm_events
+    pipe.ops.spmm_events = None
+    spmm_ms = [s.elapsed_time(e) for s, e in ev_pairs]
+    sysd = pipe.system
+    algo_bytes = sysd.nnzb * (36 + 4) + (sysd.nv + 1) * 4 + 2 * sysd.n * a.block * 4
+    roof = None
+    if spmm_ms:
+        avg_ms = float(np.mean(spmm_ms))
+        achieved = algo_bytes / (avg_ms * 1e-3) / 1e9
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "spmm_pmc_bytes_per_launch.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get(f"cells{a.cells}_cols{a.block}")
+            except Exception:
+                traffic = None
+        roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "kernel": f"spmm_bsr3_kernel<0,float,float,float,4,{a.block // 4}> (K * {a.block}-column block)",
+                "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": avg_ms, "launches_timed": len(spmm_ms)}
+
+    if rank == 0:
+        passes = a.steps * nhyp
+        out = {
+            "metric": "fwd+bwd modal-analysis passes/sec, 100k-tet ord-2 mesh, 64 modes",
+            "value": passes / dt,
+            "unit": "passes/s",
+            "n_gpus": world,
+            "steps": a.steps,
+            "warmup": a.warmup,
+            "ms_per_step": 1e3 * dt / a.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32 iterates / f64 Rayleigh-Ritz",
+            "data": "synthetic",
+            "config": {
+                "workload": (f"Kuhn box {a.cells}^3 cells = {sysd.T} tets, ord-{a.order} ({sysd.nv} nodes, n={sysd.n}, "
+                             f"nnz={sysd.nnzb * 9}), {a.modes} modes, fwd+bwd w.r.t. (E, nu), S=8000 @ 32 kHz"),
+                "hypotheses_per_gpu_per_step": a.hyp_per_gpu,
+                "parallelism": f"dp{world} over material hypotheses, scalar loss all-reduce",
+                "eigensolver": (f"LOBPCG(ortho) block {a.block}, Chebyshev({a.cheb_degree}) block-Jacobi, "
+                                f"cold start{' (warm)' if a.warm_start else ''}, mean iterations {np.mean(iters):.1f}"),
+                "symbolic_pattern_seconds_not_timed": t_sym,
+            },
+            "roofline": roof,
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(a.cpu_sample_cells, a.order, a.modes, sysd.T)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -31,11 +31,16 @@ struct Vec<double, 2> {
 };
 
 // KIND: 0 = 3x3 blocks, 1 = scalar (x I3).  TV value type, TX input type, TY output/accumulator.
-template <int KIND, typename TV, typename TX, typename TY, int VEC>
+// LPN_CT: lanes per node known at compile time (0 = run-time value).  The solver's block widths
+// (b = 72/80 columns and 3b) get their own instantiations: the lane->(node, column) split becomes
+// constant arithmetic, and rocprofv3 reports those launches under their own kernel names.
+template <int KIND, typename TV, typename TX, typename TY, int VEC, int LPN_CT>
 __global__ void __launch_bounds__(256)
     spmm_bsr3_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx,
                      const TV* __restrict__ vals, int64_t nv, const TX* __restrict__ X, int64_t ldx,
-                     TY* __restrict__ Y, int64_t ldy, int ncols, int lpn, int npw, unsigned nblk) {
+                     TY* __restrict__ Y, int64_t ldy, int ncols, int lpn_rt, int npw_rt, unsigned nblk) {
+    const int lpn = LPN_CT ? LPN_CT : lpn_rt;
+    const int npw = LPN_CT ? 64 / LPN_CT : npw_rt;
     const unsigned bid = ds::xcd_remap(blockIdx.x, nblk);
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -97,17 +102,32 @@ __global__ void __launch_bounds__(256)
     }
 }
 
-template <int KIND, typename TV, typename TX, typename TY, int VEC>
-int launch(const int32_t* rowptr, const int32_t* colidx, const void* vals, int64_t nv, const void* X, int64_t ldx,
-           void* Y, int64_t ldy, int ncols, hipStream_t st) {
-    const int lpn = (ncols + VEC - 1) / VEC;  // lanes per node
-    const int npw = 64 / lpn;                 // nodes per wave
+template <int KIND, typename TV, typename TX, typename TY, int VEC, int LPN_CT>
+int launch_ct(const int32_t* rowptr, const int32_t* colidx, const void* vals, int64_t nv, const void* X, int64_t ldx,
+              void* Y, int64_t ldy, int ncols, int lpn, hipStream_t st) {
+    const int npw = 64 / lpn;  // nodes per wave
     const int64_t nblk = ds::ceil_div(nv, (int64_t)npw * 4);
-    spmm_bsr3_kernel<KIND, TV, TX, TY, VEC><<<(unsigned)nblk, 256, 0, st>>>(
+    spmm_bsr3_kernel<KIND, TV, TX, TY, VEC, LPN_CT><<<(unsigned)nblk, 256, 0, st>>>(
         rowptr, colidx, static_cast<const TV*>(vals), nv, static_cast<const TX*>(X), ldx, static_cast<TY*>(Y), ldy,
         ncols, lpn, npw, (unsigned)nblk);
     DS_LAUNCH_CHECK("spmm_bsr3_kernel");
     return DS_OK;
+}
+
+template <int KIND, typename TV, typename TX, typename TY, int VEC>
+int launch(const int32_t* rowptr, const int32_t* colidx, const void* vals, int64_t nv, const void* X, int64_t ldx,
+           void* Y, int64_t ldy, int ncols, hipStream_t st) {
+    const int lpn = (ncols + VEC - 1) / VEC;  // lanes per node
+    if (KIND == 0 && VEC == 4) {              // the eigensolver's stiffness products
+        switch (lpn) {
+            case 18: return launch_ct<KIND, TV, TX, TY, VEC, 18>(rowptr, colidx, vals, nv, X, ldx, Y, ldy, ncols, lpn, st);
+            case 20: return launch_ct<KIND, TV, TX, TY, VEC, 20>(rowptr, colidx, vals, nv, X, ldx, Y, ldy, ncols, lpn, st);
+            case 54: return launch_ct<KIND, TV, TX, TY, VEC, 54>(rowptr, colidx, vals, nv, X, ldx, Y, ldy, ncols, lpn, st);
+            case 60: return launch_ct<KIND, TV, TX, TY, VEC, 60>(rowptr, colidx, vals, nv, X, ldx, Y, ldy, ncols, lpn, st);
+            default: break;
+        }
+    }
+    return launch_ct<KIND, TV, TX, TY, VEC, 0>(rowptr, colidx, vals, nv, X, ldx, Y, ldy, ncols, lpn, st);
 }
 
 }  // namespace

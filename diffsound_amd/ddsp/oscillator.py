@@ -1,0 +1,204 @@
+"""Damped-oscillator modules - host-side mirror of reference src/ddsp/oscillator.py.
+
+Class names, constructor arguments, ``forward`` signatures, returned shapes/dtypes and the
+``damped_freq`` attribute follow the reference; the (A, m, S) signal path itself is ONE fused HIP
+kernel (``ds_osc_bank_fwd`` / ``ds_osc_bank_bwd``) wrapped in a ``torch.autograd.Function``.
+The tiny per-mode parameter algebra (softplus-weighted bins, d = (alpha + beta w0^2)/2,
+w = sqrt(w0^2 - d^2)) stays in torch so autograd reaches every learnable leaf exactly as in the
+reference.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import _hip
+from ..diffelastic.material_model import Material, MatSet  # noqa: F401  (re-exported like the reference)
+
+
+def modifed_sigmoid(x):
+    """reference src/ddsp/utils.py:6-9 (spelling kept)."""
+    return 2 * (torch.sigmoid(x) ** 2.3) + 1e-6
+
+
+class WeightedParam(nn.Module):
+    """Scalar = sum_j v_j softplus(p_j) / sum softplus(p)  (reference oscillator.py:10-21)."""
+
+    def __init__(self, values_list: torch.Tensor):
+        super().__init__()
+        self.values_list = values_list
+        self.probablity = nn.Parameter(torch.zeros(len(values_list)))
+        self.probablity.data.uniform_(-1, 1)
+
+    def forward(self):
+        p = F.softplus(self.probablity)
+        p = p / p.sum()
+        return (self.values_list.to(p.device) * p).sum()
+
+
+class WeightedSum(nn.Module):
+    """reference oscillator.py:23-35."""
+
+    def __init__(self, dims: list, vlist: list):
+        super().__init__()
+        self.register_buffer("values_list", torch.tensor([float(v) for v in vlist], dtype=torch.float32))
+        self.params = nn.Parameter(torch.zeros(*dims, len(self.values_list)))
+        self.params.data.uniform_(-4, 4)
+
+    def forward(self):
+        x = F.softplus(self.params)
+        x = x / x.sum(dim=-1).unsqueeze(-1)
+        return (self.values_list * x).sum(dim=-1)
+
+
+class DirectValue(nn.Module):
+    """reference oscillator.py:38-46."""
+
+    def __init__(self, dims: list):
+        super().__init__()
+        self.value = nn.Parameter(torch.zeros(*dims))
+        self.value.data.uniform_(0, 0.04)
+
+    def forward(self):
+        return modifed_sigmoid(self.value)
+
+
+class _OscBank(torch.autograd.Function):
+    """y[a,t] = sum_j force[a,j] sum_m amp[a,m] exp(-d_m tau) sin(w_m tau) at tau = (t-j+1)/sr."""
+
+    @staticmethod
+    def forward(ctx, d, w, amp, force, S, sr):
+        _hip.require_gpu(d, w, force, amp)
+        d = d.detach().double().contiguous()
+        w = w.detach().double().contiguous()
+        force = force.detach().float().contiguous()
+        ampc = None if amp is None else amp.detach().float().contiguous()
+        A, nF = force.shape
+        m = d.shape[0]
+        y = torch.empty((A, S), dtype=torch.float32, device=force.device)
+        p = _hip.ptr
+        _hip.check(_hip.lib().ds_osc_bank_fwd(p(d), p(w), p(ampc), p(force), A, m, nF, S, float(sr), p(y),
+                                              _hip.stream_ptr()), "ds_osc_bank_fwd")
+        ctx.save_for_backward(d, w, force, ampc if ampc is not None else torch.empty(0, device=force.device))
+        ctx.has_amp = ampc is not None
+        ctx.S, ctx.sr = S, float(sr)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        d, w, force, ampc = ctx.saved_tensors
+        amp = ampc if ctx.has_amp else None
+        A, nF = force.shape
+        m = d.shape[0]
+        gy = gy.float().contiguous()
+        gs = torch.empty_like(gy)
+        gd = torch.empty(m, dtype=torch.float64, device=gy.device)
+        gw = torch.empty(m, dtype=torch.float64, device=gy.device)
+        gamp = torch.empty((A, m), dtype=torch.float32, device=gy.device) if amp is not None else None
+        p = _hip.ptr
+        _hip.check(_hip.lib().ds_osc_bank_bwd(p(gy), p(d), p(w), p(amp), p(force), A, m, nF, ctx.S, ctx.sr, p(gs),
+                                              p(gd), p(gw), p(gamp), _hip.stream_ptr()), "ds_osc_bank_bwd")
+        return gd, gw, gamp, None, None, None
+
+
+def oscillator_bank(d, w, amp, force, sample_num, sr):
+    """Functional entry: d, w (m,) fp64 HIP tensors (autograd ok), amp (A,m) or None, force (A,F)."""
+    return _OscBank.apply(d, w, amp, force, int(sample_num), float(sr))
+
+
+def _device_of(t):
+    if t.is_cuda:
+        return t.device
+    if not torch.cuda.is_available():
+        raise RuntimeError("diffsound_amd: no HIP device available (there is no CPU fallback)")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+class _BankBase(nn.Module):
+    def _setup(self, forces, audio_num, mode_num, sample_num, sr, mat):
+        self.audio_num = audio_num
+        self.sr = sr
+        self.sample_num = sample_num
+        self.mode_num = mode_num
+        self.mat = mat
+        self.force_frame_num = forces.shape[-1]
+        self.register_buffer("_force", forces.detach().reshape(audio_num, -1).float().clone(), persistent=False)
+        # the reference keeps the time-flipped conv1d weight as ``forces`` (oscillator.py:80-82)
+        self.forces = torch.flip(forces.reshape(audio_num, 1, -1), [-1])
+
+    def _render(self, freq_linear, alpha, beta, amp):
+        """freq_linear (m,1) or (m,) any float dtype; alpha/beta python floats or (1,m,1) tensors; amp (A,m,1)|None."""
+        dev = _device_of(self._force)
+        if self._force.device != dev:
+            self._force = self._force.to(dev)
+        f = freq_linear.reshape(self.mode_num).to(dev).double()
+        w0sq = (f * (2 * np.pi)) ** 2
+        if torch.is_tensor(alpha):
+            alpha = alpha.reshape(self.mode_num).to(dev).double()
+        if torch.is_tensor(beta):
+            beta = beta.reshape(self.mode_num).to(dev).double()
+        d = 0.5 * (alpha + beta * w0sq)
+        w = torch.sqrt(w0sq - d ** 2)
+        fd = (w / (2 * np.pi)).float()
+        self.damped_freq = fd.reshape(1, self.mode_num, 1).expand(self.audio_num, self.mode_num, self.sample_num)
+        a = None if amp is None else amp.reshape(self.audio_num, self.mode_num).to(dev)
+        return oscillator_bank(d, w, a, self._force, self.sample_num, self.sr)
+
+
+class TraditionalDampedOscillator(_BankBase):
+    """Fixed Rayleigh damping (alpha, beta from the material), unit amplitudes
+    (reference oscillator.py:246-310)."""
+
+    def __init__(self, forces, audio_num, mode_num, sample_num, sr, mat: Material):
+        super().__init__()
+        self._setup(forces, audio_num, mode_num, sample_num, sr, mat)
+        self.alpha = mat.alpha
+        self.beta = mat.beta
+
+    def forward(self, freq_linear):
+        sig = self._render(freq_linear, float(self.alpha), float(self.beta), None)
+        w = self.damped_freq[0, :, 0].double() * (2 * np.pi)
+        self.undamped_freq = freq_linear.reshape(1, self.mode_num, 1).to(w.device)
+        return sig
+
+
+class DampedOscillator(_BankBase):
+    """Per-mode learnable alpha/beta (64 log-spaced bins) and per-(audio, mode) amplitude
+    (reference oscillator.py:49-141)."""
+
+    def __init__(self, forces, audio_num, mode_num, sample_num, sr, f_range: list, mat: Material):
+        super().__init__()
+        self._setup(forces, audio_num, mode_num, sample_num, sr, mat)
+        bin_num = 64
+        self.alpha_list = torch.exp(torch.linspace(np.log(mat.alpha / 10), np.log(mat.alpha * 10), bin_num))
+        self.alpha = WeightedSum([1, mode_num, 1], list(self.alpha_list))
+        self.beta_list = torch.exp(torch.linspace(np.log(mat.beta / 10), np.log(mat.beta * 10), bin_num))
+        self.beta = WeightedSum([1, mode_num, 1], list(self.beta_list))
+        self.amp = DirectValue([audio_num, mode_num, 1])
+
+    def forward(self, freq_linear, non_linear_rate=0.0, noise_rate=0.0):
+        return self._render(freq_linear, self.alpha(), self.beta(), self.amp())
+
+    def forward_curve(self, freq_linear, damping_curve):
+        """Damping from a host callback per mode, peak-normalised output (reference oscillator.py:143-176)."""
+        fr = freq_linear.detach().cpu().numpy().reshape(-1)
+        damp = torch.tensor([float(damping_curve(fi)) for fi in fr], dtype=torch.float64)
+        dev = _device_of(self._force)
+        if self._force.device != dev:
+            self._force = self._force.to(dev)
+        w0sq = (freq_linear.reshape(self.mode_num).to(dev).double() * (2 * np.pi)) ** 2
+        d = damp.to(dev)
+        w = torch.sqrt(w0sq - d ** 2)
+        self.damped_freq = (w / (2 * np.pi)).float().reshape(1, self.mode_num, 1)
+        sig = oscillator_bank(d, w, None, self._force, self.sample_num, self.sr)
+        return sig / torch.max(torch.abs(sig), dim=1, keepdim=True)[0]
+
+
+def init_damps(osc):
+    """Pre-fit alpha/beta bins to the material table values (reference oscillator.py:314-325)."""
+    optimizer = torch.optim.Adam(list(osc.alpha.parameters()) + list(osc.beta.parameters()), lr=0.01)
+    for _ in range(2000):
+        optimizer.zero_grad()
+        loss = (osc.alpha() - osc.mat.alpha) ** 2 / osc.mat.alpha ** 2 + (osc.beta() - osc.mat.beta) ** 2 / osc.mat.beta ** 2
+        loss.mean().backward()
+        optimizer.step()

@@ -1,0 +1,262 @@
+"""DiffSoundObj and material models - host-side mirror of reference src/diffelastic/diff_model.py.
+
+Same names, constructor arguments, methods, attributes, return shapes/dtypes and autograd
+behaviour (gradients reach ``material_model.{youngs,poisson}.probablity``), so
+``experiments/material_*_train.py`` drop in.  What happens underneath is different:
+
+  update_mass_matrix / update_stiff_matrix  -> one HIP assembly pass producing K_lambda, K_mu, M_s
+       (K is exactly linear in the Lame parameters), reference :184-312
+  eigen_decomposition_arpack (SciPy on the host, :335-369) -> device-resident block eigensolver with
+       analytic rigid-mode deflation; same outputs: ``eigenvalues`` (mode_num,) fp64, ``U_hat``
+       (n, mode_num) fp64 M-orthonormal, ``U_hat_full`` (n, mode_num+6) with the 6 rigid modes first
+  get_undamped_freqs (:371-388)  ->  lambda_i + lam(theta) a_i + mu(theta) b_i - lambda_i m_i with the
+       quadratic forms a_i = u^T K_lambda u, b_i = u^T K_mu u, m_i = u^T M u computed once per
+       eigendecomposition (fp64) instead of a matrix-free (modes x Gauss points) sweep per epoch.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from ..ddsp.oscillator import WeightedParam
+from ..lobpcg.modal_solver import ModalSolver, SolverConfig
+from ..modal_ops import HipModalOps, TetSystem
+from .material_model import Material, MatSet
+from .mesh import TetMesh
+
+
+def _lame(E, nu):
+    return E * nu / ((1 + nu) * (1 - 2 * nu)), E / (2 * (1 + nu))
+
+
+class FixedLinear(nn.Module):
+    """Linear elasticity with fixed (E, nu) (reference :17-48)."""
+
+    def __init__(self, mat: Material):
+        super().__init__()
+        self.youngs = mat.youngs
+        self.poisson = mat.poisson
+        self.mat = mat
+
+    def lame(self):
+        return _lame(torch.tensor(float(self.youngs), dtype=torch.float64),
+                     torch.tensor(float(self.poisson), dtype=torch.float64))
+
+    def get_stress(self, F):
+        lam, mu = _lame(self.youngs, self.poisson)
+        tr = F.diagonal(dim1=-2, dim2=-1).sum(-1)
+        return mu * (F + F.transpose(-1, -2)) + lam * tr[..., None, None] * torch.eye(3, device=F.device, dtype=F.dtype)
+
+    def forward(self, F):
+        return self.get_stress(F)
+
+    def jacobian_F(self):
+        """Constant d vec(P)/d vec(F), (1,3,3,1,3,3) like torch.autograd.functional.jacobian (:45-48)."""
+        lam, mu = _lame(float(self.youngs), float(self.poisson))
+        J = torch.zeros(3, 3, 3, 3, dtype=torch.float64)
+        for i in range(3):
+            for j in range(3):
+                J[i, j, i, j] += mu
+                J[i, j, j, i] += mu
+                J[i, i, j, j] += lam
+        return J.reshape(1, 3, 3, 1, 3, 3)
+
+
+class TrainableLinear(nn.Module):
+    """(E, nu) as softplus-weighted combinations of 16 bins (reference :51-96)."""
+
+    def __init__(self, mat: Material, bin_num=16, baseline=False):
+        super().__init__()
+        self.youngs_list = torch.exp(torch.linspace(np.log(mat.youngs / 10), np.log(mat.youngs * 10), bin_num))
+        if baseline:
+            self.poisson_list = torch.linspace(mat.poisson, mat.poisson, 1)
+        else:
+            self.poisson_list = torch.linspace(0.01, 0.499, bin_num)
+        self.youngs = WeightedParam(self.youngs_list)
+        self.poisson = WeightedParam(self.poisson_list)
+        self.mat = mat
+
+    def lame(self):
+        """(lambda_L, mu) as fp64 0-dim tensors carrying autograd to the bin logits."""
+        return _lame(self.youngs().double(), self.poisson().double())
+
+    def get_stress(self, F):
+        lam, mu = _lame(self.youngs(), self.poisson())
+        tr = F.diagonal(dim1=-2, dim2=-1).sum(-1)
+        return mu * (F + F.transpose(-1, -2)) + lam * tr[..., None, None] * torch.eye(3, device=F.device, dtype=F.dtype)
+
+    def forward(self, F):
+        return self.get_stress(F)
+
+    def jacobian_F(self):
+        lam, mu = _lame(float(self.youngs()), float(self.poisson()))
+        J = torch.zeros(3, 3, 3, 3, dtype=torch.float64)
+        for i in range(3):
+            for j in range(3):
+                J[i, j, i, j] += mu
+                J[i, j, j, i] += mu
+                J[i, i, j, j] += lam
+        return J.reshape(1, 3, 3, 1, 3, 3)
+
+
+def build_model(mesh_dir, mode_num, order, mat, task, vertices=None, tets=None, scale_range=None, init_scale=None):
+    """reference :98-113."""
+    if task == "material" or task == "mat_baseline":
+        mat_model = TrainableLinear
+    elif task == "gt":
+        mat_model = FixedLinear
+    else:
+        raise ValueError("task not defined")
+    model = DiffSoundObj(mesh_dir=mesh_dir, mode_num=mode_num, order=order, mat=mat, mat_model=mat_model, task=task,
+                         vertices=vertices, tets=tets)
+    if task == "material" or task == "mat_baseline":
+        model.init_material_coeffs()
+    return model
+
+
+class DiffSoundObj:
+    def __init__(self, vertices=None, tets=None, mode_num=16, mat=MatSet.Ceramic, order=1, mat_model=FixedLinear,
+                 task=None, mesh_dir=None, solver_config=None):
+        if mesh_dir:
+            self.mesh_dir = mesh_dir
+            self.tetmesh = TetMesh.from_triangle_mesh(mesh_dir).to_high_order(order)
+        else:
+            if not vertices.is_cuda:
+                raise RuntimeError("diffsound_amd: vertices/tets must be HIP tensors (there is no CPU fallback)")
+            self.tetmesh = TetMesh(vertices, tets).to_high_order(order)
+        if task == "mat_baseline":
+            self.material_model = mat_model(Material(mat), baseline=True)
+        else:
+            self.material_model = mat_model(Material(mat))
+        self.mode_num = mode_num
+        self.U_hat_full = None
+        self.task = task
+        self.solver_config = solver_config or SolverConfig()
+        self._system = None
+        self._ops = None
+        self._warm = None
+        self._sparse_cache = {}
+        self.last_result = None
+
+    # ------------------------------------------------------------------ parameters
+    def parameters(self):
+        if self.task == "material":
+            return self.material_model.parameters()
+        if self.task == "mat_baseline":
+            return self.material_model.youngs.parameters()
+        return None
+
+    def init_material_coeffs(self, steps=5000):
+        """Fit the bin logits so that (E, nu) start at the material-table values (reference :154-180)."""
+        opt = torch.optim.Adam(self.material_model.parameters(), lr=5e-3)
+        gt_y, gt_p = self.material_model.mat.youngs, self.material_model.mat.poisson
+        for _ in range(steps):
+            opt.zero_grad()
+            loss = (self.material_model.youngs() - gt_y) ** 2 / gt_y ** 2 + \
+                   (self.material_model.poisson() - gt_p) ** 2 / gt_p ** 2
+            loss.backward()
+            opt.step()
+
+    # ------------------------------------------------------------------ assembly
+    @property
+    def system(self):
+        if self._system is None:
+            self._system = TetSystem(self.tetmesh.vertices, self.tetmesh.tets, self.tetmesh.order,
+                                     self.material_model.mat.density)
+        return self._system
+
+    def _current_lame(self):
+        lam, mu = self.material_model.lame()
+        return float(lam), float(mu)
+
+    def update_mass_matrix(self, density=None):
+        """Numeric assembly (M_s together with K_lambda, K_mu) (reference :222-312)."""
+        if density is not None and self._system is not None and density != self._system.density:
+            self._system = None
+        if self._system is None:
+            _ = self.system
+        else:
+            self._system.assemble(self.tetmesh.vertices)
+        self._sparse_cache.clear()
+
+    def update_stiff_matrix(self, assemble_batch_size=None):
+        """K = lam K_lambda + mu K_mu for the current material (reference :184-220)."""
+        lam, mu = self._current_lame()
+        if self._ops is None or self._ops.sys is not self.system:
+            self._ops = HipModalOps(self.system, lam, mu)
+        else:
+            self._ops.set_material(lam, mu)
+        self._sparse_cache.clear()
+
+    def _bsr_to_sparse(self, which):
+        """torch sparse CSR fp64 view of the assembled matrices (API compatibility: callers read
+        ``stiff_matrix`` / ``mass_matrix`` as torch sparse tensors)."""
+        if which not in self._sparse_cache:
+            s = self.system
+            lam, mu = self._ops.lame if self._ops is not None else self._current_lame()
+            if which == "K":
+                blocks = (lam * s.klam + mu * s.kmu).reshape(-1, 3, 3)
+            else:
+                blocks = s.ms[:, None, None] * torch.eye(3, dtype=torch.float64, device=s.device)
+            bsr = torch.sparse_bsr_tensor(s.rowptr.long(), s.colidx.long(), blocks, size=(s.n, s.n))
+            self._sparse_cache[which] = bsr.to_sparse_coo().coalesce()
+        return self._sparse_cache[which]
+
+    @property
+    def stiff_matrix(self):
+        return self._bsr_to_sparse("K")
+
+    @property
+    def mass_matrix(self):
+        return self._bsr_to_sparse("M")
+
+    # ------------------------------------------------------------------ eigen decomposition
+    def eigen_decomposition(self):
+        """reference :330-369 (assembly + eigsh(k=mode_num+6, sigma=20000) + drop 6 rigid pairs)."""
+        self.update_mass_matrix(self.material_model.mat.density)
+        self.update_stiff_matrix()
+        self.eigen_decomposition_arpack()
+
+    def eigen_decomposition_arpack(self):
+        """Name kept for drop-in compatibility; runs the device-resident block eigensolver."""
+        ops = self._ops
+        solver = ModalSolver(ops, self.solver_config)
+        res = solver.solve(self.mode_num, X0=self._warm)
+        self._warm = res.block_vectors
+        self.last_result = res
+        self.eigenvalues = res.eigenvalues
+        self.U_hat = res.vectors.double()
+        rigid = ops.rigid[:, :6].double()
+        self.U_hat_full = torch.cat([rigid, self.U_hat], dim=1)
+        self._a, self._b, self._m = res.a_lambda, res.b_mu, res.m_diag
+
+    # ------------------------------------------------------------------ differentiable read-outs
+    def get_undamped_freqs(self):
+        """(mode_num, 1) float32; gradient -> material parameters (reference :371-388)."""
+        pred = self.eigenvalues
+        if self.task != "gt":
+            lam, mu = self.material_model.lame()  # autograd leaves live on the host like the reference's
+            dev = pred.device
+            pred = pred + (lam.to(dev) * self._a + mu.to(dev) * self._b) - pred * self._m
+        return (torch.sqrt(pred) / 2 / np.pi).float().unsqueeze(1)
+
+    def get_vals(self):
+        """lambda + diag(U^T K U) - lambda diag(U^T M U), (mode_num, 1) float32 (reference :390-399)."""
+        lam, mu = self._ops.lame
+        pred = self.eigenvalues + (lam * self._a + mu * self._b) - self.eigenvalues * self._m
+        return pred.float().unsqueeze(1)
+
+    def stiff_func(self, x_in):
+        """K(theta) x with autograd to the material parameters (reference :314-328, matrix-free there)."""
+        x = x_in.unsqueeze(1) if x_in.dim() == 1 else x_in
+        ops = self._ops
+        xf = x.detach().float().contiguous()
+        pad = (-xf.shape[1]) % 4
+        if pad:
+            xf = torch.cat([xf, torch.zeros((xf.shape[0], pad), device=xf.device)], dim=1).contiguous()
+        yl = torch.empty(xf.shape, dtype=torch.float64, device=xf.device)
+        ym = torch.empty_like(yl)
+        ops._spmm(2, ops.sys.klam, xf, yl)
+        ops._spmm(2, ops.sys.kmu, xf, ym)
+        lam, mu = self.material_model.lame()
+        out = (lam.to(yl.device) * yl + mu.to(yl.device) * ym)[:, : x.shape[1]].to(x_in.dtype)
+        return out.squeeze(1) if x_in.dim() == 1 else out

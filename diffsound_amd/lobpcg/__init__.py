@@ -1,0 +1,123 @@
+"""``lobpcg`` / ``lobpcg_func`` - the reference's solver API (src/lobpcg/_lobpcg.py:8-25,123-140) on
+top of the MI355X block eigensolver.
+
+Same 17-argument signatures and return values.  Semantics kept: ``B`` is required by
+``lobpcg_func`` and defines dtype/device/size; ``X`` (m x n) fixes the block size; ``largest``
+defaults to True (the reference's default; ``LOBPCG_solver_freq`` passes False); ``tracker(worker)``
+is called after every iteration with ``worker.ivars['istep'|'converged_count']``,
+``worker.tvars['rerr']``, ``worker.E``, ``worker.X`` and may set ``worker.bvars['force_stop']``;
+``ValueError`` when m < 3n; the convergence test is the backward-stable one of
+``update_converged_count`` (:307-333).  Deliberate deviations (documented in DESIGN.md): fp32
+iterates with fp64 Rayleigh-Ritz (the reference can only run fp32), default
+``tol`` = 2e-6 instead of the reference's unreachable 1.5e-8 (dtype-table bug :35-38), a
+Chebyshev block-Jacobi preconditioner when ``iK`` is None (the reference uses none and does not
+converge), ``method`` 'basic' is served by the 'ortho' iteration, ``profiler`` (a TensorBoard log
+dir in the reference) is accepted and ignored - use rocprofv3.
+"""
+from typing import Dict, Optional, Tuple
+
+import torch
+from torch import Tensor
+
+from .modal_solver import ModalSolver, SolverConfig, SolverState
+
+
+class _CallableOps:
+    """Wraps ops so that ``apply_K`` calls a user callable A(X) -> AX (reference _linalg_utils.py:34-35)."""
+
+    def __init__(self, base, fn, sign):
+        self._base, self._fn, self._sign = base, fn, sign
+
+    def __getattr__(self, name):
+        return getattr(self._base, name)
+
+    def apply_K(self, X, out):
+        out.copy_(self._fn(X.contiguous()) * self._sign)
+
+
+def _solve(A, B, k, X, E, n, iK, niter, tol, largest, method, tracker, ortho_iparams, ortho_fparams,
+           ortho_bparams, return_rerr):
+    from ..modal_ops import HipSparseOps
+
+    if not (isinstance(B, torch.Tensor) and B.layout in (torch.sparse_coo, torch.sparse_csr)):
+        raise TypeError("lobpcg_func: B must be a sparse torch tensor")
+    if not B.is_cuda:
+        raise RuntimeError("diffsound_amd.lobpcg: tensors must live on the HIP device (there is no CPU fallback)")
+    m = B.shape[-1]
+    k = (1 if X is None else X.shape[-1]) if k is None else k
+    n = (k if n is None else n) if X is None else X.shape[-1]
+    if m < 3 * n:
+        raise ValueError(
+            "LPBPCG algorithm is not applicable when the number of A rows (={})"
+            " is smaller than 3 x the number of requested eigenpairs (={})".format(m, n))
+    largest = True if largest is None else largest
+    sign = -1.0 if largest else 1.0
+    a_callable = callable(A) and not isinstance(A, torch.Tensor)
+    if a_callable:
+        ops = HipSparseOps(B, B)  # pattern/diagonal from B; K products come from the callable
+        ops = _CallableOps(ops, A, sign)
+    else:
+        ops = HipSparseOps(A if not largest else -A, B)
+    cfg = SolverConfig(block=((n + 3) // 4) * 4, maxit=1000 if niter is None else niter, tol=tol or 0.0)
+    if largest or a_callable:
+        cfg.cheb_degree = 1  # the polynomial preconditioner targets the low end of an SPD spectrum only
+    precond = None
+    if iK is not None:
+        if callable(iK) and not isinstance(iK, torch.Tensor):
+            precond = lambda R, W: W.copy_(iK(R))
+        elif iK.layout in (torch.sparse_coo, torch.sparse_csr):
+            precond = lambda R, W: W.copy_(torch.sparse.mm(iK.to(R.dtype), R))
+        else:
+            precond = lambda R, W: W.copy_(iK.to(R.dtype) @ R)
+    iparams = {"m": m, "n": n, "k": k, "niter": cfg.maxit}
+    if ortho_iparams:
+        iparams.update(ortho_iparams)
+    fparams = {"tol": cfg.tol}
+    if ortho_fparams:
+        fparams.update(ortho_fparams)
+    bparams = {"largest": largest}
+    if ortho_bparams:
+        bparams.update(ortho_bparams)
+    cfg.ortho_passes = max(2, min(3, int(iparams.get("ortho_i_max", 3))))
+    state = SolverState(iparams, fparams, bparams)
+    state.E = E
+    solver = ModalSolver(ops, cfg, precond=precond)
+    if tracker is not None:
+        tracker(state)  # the reference calls the tracker once before the first update (:350-351)
+    res = solver.solve(k, X0=X, tracker=tracker, state=state)
+    Eo = res.eigenvalues * sign
+    out_dtype = torch.float32 if B.dtype not in (torch.float32, torch.float64) else B.dtype
+    Eo, Xo = Eo.to(out_dtype), res.vectors.to(out_dtype)
+    if return_rerr:
+        return Eo, Xo, res.rerr
+    return Eo, Xo
+
+
+def lobpcg(A: Tensor, k: Optional[int] = None, B: Optional[Tensor] = None, X: Optional[Tensor] = None, E=None,
+           n: Optional[int] = None, iK: Optional[Tensor] = None, niter: Optional[int] = None,
+           tol: Optional[float] = None, largest: Optional[bool] = None, method: Optional[str] = None,
+           tracker: Optional[None] = None, ortho_iparams: Optional[Dict[str, int]] = None,
+           ortho_fparams: Optional[Dict[str, float]] = None, ortho_bparams: Optional[Dict[str, bool]] = None,
+           return_rerr=False, profiler=None) -> Tuple[Tensor, Tensor]:
+    """reference _lobpcg.py:8-121 (matrix A, optional B; B=None means the standard problem)."""
+    assert A.shape[-2] == A.shape[-1], A.shape
+    if B is None:
+        nn_ = A.shape[-1]
+        idx = torch.arange(nn_, device=A.device)
+        B = torch.sparse_coo_tensor(torch.stack([idx, idx]), torch.ones(nn_, dtype=A.dtype, device=A.device),
+                                    (nn_, nn_))
+    else:
+        assert A.shape == B.shape, (A.shape, B.shape)
+    return _solve(A, B, k, X, E, n, iK, niter, tol, largest, method, tracker, ortho_iparams, ortho_fparams,
+                  ortho_bparams, return_rerr)
+
+
+def lobpcg_func(A, B: Tensor, k: Optional[int] = None, X: Optional[Tensor] = None, E=None, n: Optional[int] = None,
+                iK: Optional[Tensor] = None, niter: Optional[int] = None, tol: Optional[float] = None,
+                largest: Optional[bool] = None, method: Optional[str] = None, tracker: Optional[None] = None,
+                ortho_iparams: Optional[Dict[str, int]] = None, ortho_fparams: Optional[Dict[str, float]] = None,
+                ortho_bparams: Optional[Dict[str, bool]] = None, return_rerr=False, profiler=None
+                ) -> Tuple[Tensor, Tensor]:
+    """reference _lobpcg.py:123-212 (A may be a tensor, a sparse tensor or a callable X -> A X)."""
+    return _solve(A, B, k, X, E, n, iK, niter, tol, largest, method, tracker, ortho_iparams, ortho_fparams,
+                  ortho_bparams, return_rerr)

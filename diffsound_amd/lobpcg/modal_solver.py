@@ -121,13 +121,35 @@ class ChebyshevBlockJacobi:
             rho = rho_new
 
 
+class SolverState:
+    """What a ``tracker`` callback sees after every iteration - the same fields the reference's worker
+    exposes (src/lobpcg/_lobpcg.py:246-256, 335-342): ``ivars['istep']``, ``ivars['converged_count']``,
+    ``tvars['rerr']``, ``E``, ``X`` and the writable ``bvars['force_stop']``."""
+
+    def __init__(self, iparams, fparams, bparams):
+        self.iparams, self.fparams, self.bparams = iparams, fparams, bparams
+        self.ivars = {"istep": 0, "converged_count": 0, "iterations_left": iparams.get("niter", 0)}
+        self.fvars = {}
+        self.bvars = {"force_stop": False}
+        self.tvars = {}
+        self.E = None
+        self.X = None
+
+
 class ModalSolver:
-    def __init__(self, ops, cfg: Optional[SolverConfig] = None):
+    def __init__(self, ops, cfg: Optional[SolverConfig] = None, precond=None):
+        """precond: optional callable (R, W) -> None writing the preconditioned residual into W
+        (the ``iK`` argument of the reference API); default Chebyshev block-Jacobi."""
         self.ops = ops
         self.cfg = cfg or SolverConfig()
-        self.precond = ChebyshevBlockJacobi(ops, self.cfg.cheb_degree, self.cfg.cheb_ratio,
-                                            self.cfg.power_iters, self.cfg.seed, self.cfg.lmax_safety,
-                                            self.cfg.lmax_cap)
+        if precond is not None:
+            self.precond_apply = precond
+            self.precond = None
+        else:
+            self.precond = ChebyshevBlockJacobi(ops, self.cfg.cheb_degree, self.cfg.cheb_ratio,
+                                                self.cfg.power_iters, self.cfg.seed, self.cfg.lmax_safety,
+                                                self.cfg.lmax_cap)
+            self.precond_apply = self.precond.apply
 
     # ------------------------------------------------------------------ helpers
     def _orthonormalize(self, W, V_blocks, MW):
@@ -137,6 +159,8 @@ class ModalSolver:
         for _ in range(self.cfg.ortho_passes):
             ops.apply_M(W, MW)
             for V in V_blocks:
+                if V is None:
+                    continue
                 C = ops.gram(V, MW)
                 ops.mix(V, C, W, alpha=-1.0, beta=1.0)
             ops.apply_M(W, MW)
@@ -144,18 +168,20 @@ class ModalSolver:
             ops.mix_inplace(W, T)
 
     # ------------------------------------------------------------------ main entry
-    def solve(self, k: int, X0: Optional[torch.Tensor] = None,
-              tracker: Optional[Callable] = None) -> ModalResult:
+    def solve(self, k: int, X0: Optional[torch.Tensor] = None, tracker: Optional[Callable] = None,
+              state: Optional[SolverState] = None) -> ModalResult:
         ops, cfg = self.ops, self.cfg
         n, dev, dt = ops.n, ops.device, ops.dtype
         b = cfg.block or ((k + cfg.guard + 7) // 8) * 8
         if X0 is not None and X0.shape[1] > b:
-            b = X0.shape[1]
-        if n < 3 * b + 6:
-            raise ValueError(
-                "LOBPCG is not applicable when the number of rows (={}) is smaller than 3 x the block size"
-                " (={}) plus the 6 rigid modes".format(n, b))
+            b = ((X0.shape[1] + 3) // 4) * 4
         Y = ops.rigid
+        nrigid = 0 if Y is None else 6
+        if n < 3 * b + nrigid:
+            raise ValueError(
+                "LPBPCG algorithm is not applicable when the number of A rows (={})"
+                " is smaller than 3 x the number of requested eigenpairs (={})".format(n, b))
+        state = state or SolverState({"niter": cfg.maxit, "k": k, "n": b, "m": n}, {}, {})
         S = torch.empty((n, 3 * b), dtype=dt, device=dev)
         S2 = torch.empty((n, 3 * b), dtype=dt, device=dev)
         KS = torch.empty((n, 3 * b), dtype=dt, device=dev)
@@ -164,21 +190,21 @@ class ModalSolver:
         MW = torch.empty((n, b), dtype=dt, device=dev)
 
         X = S[:, :b]
-        if X0 is None:
-            g = torch.Generator(device="cpu").manual_seed(cfg.seed)
-            X.copy_(torch.randn((n, b), generator=g, dtype=torch.float32).to(device=dev, dtype=dt))
-        else:
-            X[:, : X0.shape[1]].copy_(X0.to(dt))
-            if X0.shape[1] < b:
-                g = torch.Generator(device="cpu").manual_seed(cfg.seed)
-                X[:, X0.shape[1]:].copy_(
-                    torch.randn((n, b - X0.shape[1]), generator=g, dtype=torch.float32).to(device=dev, dtype=dt))
+        g = torch.Generator(device="cpu").manual_seed(cfg.seed)
+        nx0 = 0 if X0 is None else X0.shape[1]
+        if nx0:
+            X[:, :nx0].copy_(X0.to(dt))
+        if nx0 < b:
+            X[:, nx0:].copy_(torch.randn((n, b - nx0), generator=g, dtype=torch.float32).to(device=dev, dtype=dt))
         # operator norm estimates with a random block, as the reference does (_lobpcg.py:280-285)
-        ops.apply_K(X, KS[:, :b])
-        ops.apply_M(X, MW)
-        xn = torch.linalg.vector_norm(X.double())
-        A_norm = torch.linalg.vector_norm(KS[:, :b].double()) / xn
-        B_norm = torch.linalg.vector_norm(MW.double()) / xn
+        G0 = torch.randn((n, 8), generator=g, dtype=torch.float32).to(device=dev, dtype=dt)
+        G1 = torch.empty_like(G0)
+        gn = torch.linalg.vector_norm(G0.double())
+        ops.apply_K(G0, G1)
+        A_norm = torch.linalg.vector_norm(G1.double()) / gn
+        ops.apply_M(G0, G1)
+        B_norm = torch.linalg.vector_norm(G1.double()) / gn
+        state.fvars.update(A_norm=float(A_norm), B_norm=float(B_norm))
         tol = cfg.tol or (2e-6 if dt == torch.float32 else 1e-10)
         self._orthonormalize(X, [Y], MW)
         ops.apply_K(X, KS[:, :b])
@@ -197,15 +223,20 @@ class ModalSolver:
             rel = torch.sqrt(rn2 / xn2) / (A_norm + lam.abs() * B_norm)
             if it % cfg.check_every == 0 or it == cfg.maxit:
                 relk = rel[:k]
-                nconv = int((relk < tol).sum())
+                conv = (relk < tol).to(torch.int32)
+                # leading converged pairs only, to keep strict ordering (reference _lobpcg.py:321-328)
+                nconv = int(torch.cumprod(conv, 0).sum())
                 history.append((it, float(relk.max())))
+                state.ivars.update(istep=it, converged_count=nconv, iterations_left=cfg.maxit - it)
+                state.tvars["rerr"] = relk
+                state.E, state.X = lam, X
                 if tracker is not None:
-                    tracker(dict(istep=it, converged_count=nconv, rerr=relk, E=lam[:k], X=X))
-                if nconv >= k or it == cfg.maxit:
+                    tracker(state)
+                if nconv >= k or it == cfg.maxit or state.bvars.get("force_stop", False):
                     break
             w0 = 2 * b if have_p else b
             W = S[:, w0:w0 + b]
-            self.precond.apply(R, W)
+            self.precond_apply(R, W)
             self._orthonormalize(W, [Y, S[:, :w0]], MW)
             sz = w0 + b
             ops.apply_K(S[:, :sz], KS[:, :sz])
@@ -227,9 +258,8 @@ class ModalSolver:
     # ------------------------------------------------------------------ fp64 Rayleigh-Ritz polish
     def _polish(self, X, k, it, rerr, history):
         ops = self.ops
-        Gl, Gm, GM = ops.polish_products(X)  # fp64 (b x b): X^T K_lambda X, X^T K_mu X, X^T M X
-        lamL, mu = ops.lame
-        GA = _sym(lamL * Gl + mu * Gm)
+        GK, coef, GM = ops.polish_products(X)  # fp64 (b x b) Gram matrices of the terms of K, and of M
+        GA = _sym(sum(c * G for c, G in zip(coef, GK)))
         GB = _sym(GM)
         L = torch.linalg.cholesky(GB)
         Li = torch.linalg.solve_triangular(L, torch.eye(L.shape[0], dtype=L.dtype, device=L.device), upper=False)
@@ -238,9 +268,10 @@ class ModalSolver:
         Ck = C[:, :k].contiguous()
         U = torch.empty((ops.n, k), dtype=ops.dtype, device=ops.device)
         ops.mix(X, Ck, U)
-        a = ((Ck.transpose(0, 1) @ _sym(Gl)) * Ck.transpose(0, 1)).sum(1)
-        bq = ((Ck.transpose(0, 1) @ _sym(Gm)) * Ck.transpose(0, 1)).sum(1)
-        m = ((Ck.transpose(0, 1) @ GB) * Ck.transpose(0, 1)).sum(1)
+        quad = lambda G: ((Ck.transpose(0, 1) @ _sym(G)) * Ck.transpose(0, 1)).sum(1)
+        a = quad(GK[0])
+        bq = quad(GK[1]) if len(GK) > 1 else None
+        m = quad(GB)
         Xb = torch.empty_like(X)
         ops.mix(X, C.contiguous(), Xb)
         return ModalResult(E[:k].clone(), U, a, bq, m, iterations=it, rerr=rerr, history=history,

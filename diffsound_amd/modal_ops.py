@@ -81,60 +81,31 @@ class TetSystem:
         return (lam * Kl + mu * Km).tocsr(), sp.kron(Ms, sp.identity(3), format="csr")
 
 
-class HipModalOps:
-    dtype = torch.float32
+class _HipBlockOps:
+    """HIP implementation of the solver's ``ops`` protocol on a BSR-3 pattern (shared part).
 
-    def __init__(self, system: TetSystem, lam, mu):
-        self.sys = system
-        self.n = system.n
-        self.nv = system.nv
-        self.device = system.device
+    Subclasses provide: rowptr, colidx, nv, k32 (nnzb x 9 f32), ms32 (+ m_kind), dinv, rigid,
+    lame and polish_terms()."""
+
+    dtype = torch.float32
+    m_kind = 1  # 1: M = M_s (x) I3 (one scalar per block), 0: general 3x3 blocks
+
+    def _init_common(self, rowptr, colidx, nv, device):
+        self.rowptr, self.colidx = rowptr, colidx
+        self.nv = nv
+        self.n = 3 * nv
+        self.device = device
         self._L = _hip.lib()
-        dev = self.device
-        self.k32 = torch.empty((system.nnzb, 9), dtype=torch.float32, device=dev)
-        self.ms32 = torch.empty((system.nnzb,), dtype=torch.float32, device=dev)
-        self.dinv = torch.empty((system.nv, 9), dtype=torch.float32, device=dev)
         self._gram_ws = None
         self._tmp = {}
-        self._nrm = torch.empty((2, 1024), dtype=torch.float64, device=dev)
+        self._nrm = torch.empty((2, 1024), dtype=torch.float64, device=device)
         self.counts = dict(apply_K_cols=0, apply_M_cols=0, gram=0, mix=0)
-        self.set_material(lam, mu)
-        self.rigid = self._rigid_basis()
-
-    # ------------------------------------------------------------------ material
-    def set_material(self, lam, mu):
-        s = self.sys
-        p = _hip.ptr
-        self.lame = (float(lam), float(mu))
-        _hip.check(self._L.ds_combine_material(p(s.klam), p(s.kmu), p(s.ms), s.nnzb, p(s.diagidx), s.nv,
-                                               float(lam), float(mu), p(self.k32), p(self.ms32), p(self.dinv),
-                                               _hip.stream_ptr()), "ds_combine_material")
-
-    def _rigid_basis(self):
-        """Translations + rotations about the centroid, M-orthonormalised in fp64; stored (n, 8) fp32 with
-        two zero pad columns so every kernel sees a multiple of 4 columns."""
-        v = self.sys.vertices.double()
-        c = v - v.mean(0, keepdim=True)
-        Y = torch.zeros((self.n, 8), dtype=torch.float64, device=self.device)
-        for a in range(3):
-            Y[a::3, a] = 1
-        Y[0::3, 3], Y[1::3, 3] = -c[:, 1], c[:, 0]
-        Y[1::3, 4], Y[2::3, 4] = -c[:, 2], c[:, 1]
-        Y[2::3, 5], Y[0::3, 5] = -c[:, 0], c[:, 2]
-        Y32 = Y.float()
-        MY = torch.empty((self.n, 8), dtype=torch.float64, device=self.device)
-        for _ in range(2):  # second pass removes the fp32 rounding of the first
-            self._spmm(3, self.sys.ms, Y32, MY)
-            G = (Y32.double()[:, :6].T @ MY[:, :6])
-            Lc = torch.linalg.cholesky(0.5 * (G + G.T))
-            Y6 = torch.linalg.solve_triangular(Lc, Y32.double()[:, :6].T, upper=False).T
-            Y32 = torch.zeros_like(Y32)
-            Y32[:, :6] = Y6.float()
-        return Y32.contiguous()
+        # optional profiling hook (bench.py): HIP events around every K-SpMM of ``spmm_event_cols`` columns
+        self.spmm_events = None
+        self.spmm_event_cols = 0
 
     # ------------------------------------------------------------------ sparse products
     def _spmm(self, kind, vals, X, out):
-        s = self.sys
         p = _hip.ptr
         ncols = X.shape[1]
         if out.shape != X.shape:
@@ -143,15 +114,22 @@ class HipModalOps:
         for c0 in range(0, ncols, maxc):
             c1 = min(ncols, c0 + maxc)
             xs, os_ = X[:, c0:c1], out[:, c0:c1]
-            _hip.check(self._L.ds_spmm_bsr3(kind, p(s.rowptr), p(s.colidx), p(vals), s.nv, p(xs), _ld(xs), p(os_),
-                                            _ld(os_), c1 - c0, _hip.stream_ptr()), "ds_spmm_bsr3")
+            timed = self.spmm_events is not None and kind == 0 and (c1 - c0) == self.spmm_event_cols
+            if timed:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            _hip.check(self._L.ds_spmm_bsr3(kind, p(self.rowptr), p(self.colidx), p(vals), self.nv, p(xs), _ld(xs),
+                                            p(os_), _ld(os_), c1 - c0, _hip.stream_ptr()), "ds_spmm_bsr3")
+            if timed:
+                e1.record()
+                self.spmm_events.append((e0, e1))
 
     def apply_K(self, X, out):
         self._spmm(0, self.k32, X, out)
         self.counts["apply_K_cols"] += X.shape[1]
 
     def apply_M(self, X, out):
-        self._spmm(1, self.ms32, X, out)
+        self._spmm(self.m_kind, self.ms32, X, out)
         self.counts["apply_M_cols"] += X.shape[1]
 
     # ------------------------------------------------------------------ tall-skinny dense
@@ -171,7 +149,7 @@ class HipModalOps:
     def _scratch(self, key, shape, dtype):
         t = self._tmp.get(key)
         if t is None or t.shape != tuple(shape) or t.dtype != dtype:
-            t = torch.empty(shape, dtype=dtype, device=self.device)
+            t = torch.empty(tuple(shape), dtype=dtype, device=self.device)
             self._tmp[key] = t
         return t
 
@@ -211,10 +189,117 @@ class HipModalOps:
 
     # ------------------------------------------------------------------ fp64 polish
     def polish_products(self, X):
-        """X^T K_lambda X, X^T K_mu X, X^T M X in fp64 (fp64 values, fp64 accumulation, fp32 X)."""
+        """fp64 Gram matrices of the terms of K and of M on the block X (fp64 values, fp64
+        accumulation, fp32 X): returns ([X^T K_i X], [c_i], X^T M X) with K = sum c_i K_i."""
         Y = self._scratch("polish", X.shape, torch.float64)
-        out = []
-        for kind, vals in ((2, self.sys.klam), (2, self.sys.kmu), (3, self.sys.ms)):
+        kterms, (mkind, mvals) = self.polish_terms()
+        GK, coef = [], []
+        for kind, vals, c in kterms:
             self._spmm(kind, vals, X, Y)
-            out.append(self.gram(X, Y))
-        return tuple(out)
+            GK.append(self.gram(X, Y))
+            coef.append(c)
+        self._spmm(mkind, mvals, X, Y)
+        return GK, coef, self.gram(X, Y)
+
+
+class HipModalOps(_HipBlockOps):
+    """One material hypothesis (lam, mu) on a TetSystem."""
+
+    def __init__(self, system: TetSystem, lam, mu):
+        self.sys = system
+        self._init_common(system.rowptr, system.colidx, system.nv, system.device)
+        dev = self.device
+        self.k32 = torch.empty((system.nnzb, 9), dtype=torch.float32, device=dev)
+        self.ms32 = torch.empty((system.nnzb,), dtype=torch.float32, device=dev)
+        self.dinv = torch.empty((system.nv, 9), dtype=torch.float32, device=dev)
+        self.set_material(lam, mu)
+        self.rigid = self._rigid_basis()
+
+    def set_material(self, lam, mu):
+        s = self.sys
+        p = _hip.ptr
+        self.lame = (float(lam), float(mu))
+        _hip.check(self._L.ds_combine_material(p(s.klam), p(s.kmu), p(s.ms), s.nnzb, p(s.diagidx), s.nv,
+                                               float(lam), float(mu), p(self.k32), p(self.ms32), p(self.dinv),
+                                               _hip.stream_ptr()), "ds_combine_material")
+
+    def _rigid_basis(self):
+        """Translations + rotations about the centroid, M-orthonormalised in fp64; stored (n, 8) fp32 with
+        two zero pad columns so every kernel sees a multiple of 4 columns."""
+        v = self.sys.vertices.double()
+        c = v - v.mean(0, keepdim=True)
+        Y = torch.zeros((self.n, 8), dtype=torch.float64, device=self.device)
+        for a in range(3):
+            Y[a::3, a] = 1
+        Y[0::3, 3], Y[1::3, 3] = -c[:, 1], c[:, 0]
+        Y[1::3, 4], Y[2::3, 4] = -c[:, 2], c[:, 1]
+        Y[2::3, 5], Y[0::3, 5] = -c[:, 0], c[:, 2]
+        Y32 = Y.float()
+        MY = torch.empty((self.n, 8), dtype=torch.float64, device=self.device)
+        for _ in range(2):  # second pass removes the fp32 rounding of the first
+            self._spmm(3, self.sys.ms, Y32, MY)
+            G = (Y32.double()[:, :6].T @ MY[:, :6])
+            Lc = torch.linalg.cholesky(0.5 * (G + G.T))
+            Y6 = torch.linalg.solve_triangular(Lc, Y32.double()[:, :6].T, upper=False).T
+            Y32 = torch.zeros_like(Y32)
+            Y32[:, :6] = Y6.float()
+        return Y32.contiguous()
+
+    def polish_terms(self):
+        lam, mu = self.lame
+        return [(2, self.sys.klam, lam), (2, self.sys.kmu, mu)], (3, self.sys.ms)
+
+
+def _coo_to_bsr3(A, nv, pattern=None):
+    """torch sparse (COO/CSR) (3nv x 3nv) -> (rowptr, colidx, blocks (nnzb,9) fp64) on A's device,
+    on the union pattern ``pattern`` = (rowptr, colidx) if given."""
+    A = A.to_sparse_coo().coalesce()
+    idx, val = A.indices(), A.values().double()
+    bkey = (idx[0] // 3) * nv + (idx[1] // 3)
+    if pattern is None:
+        keys = torch.unique(bkey)
+    else:
+        keys = pattern
+    slot = torch.searchsorted(keys, bkey)
+    if not bool((keys[slot.clamp(max=keys.numel() - 1)] == bkey).all()):
+        raise ValueError("sparse matrix has entries outside the common block pattern")
+    blocks = torch.zeros((keys.numel(), 9), dtype=torch.float64, device=val.device)
+    blocks.view(-1).index_add_(0, slot * 9 + (idx[0] % 3) * 3 + (idx[1] % 3), val)
+    return keys, blocks
+
+
+class HipSparseOps(_HipBlockOps):
+    """Generic pencil (A, B) given as torch sparse tensors on the HIP device (the ``lobpcg_func`` entry).
+    Both are re-blocked into 3x3 node blocks on their common pattern; no rigid-mode deflation."""
+
+    m_kind = 0
+
+    def __init__(self, A, B):
+        _hip.require_gpu(A, B)
+        n = B.shape[-1]
+        if n % 3 != 0 or tuple(A.shape) != (n, n) or tuple(B.shape) != (n, n):
+            raise ValueError("HipSparseOps: A and B must be square with a row count divisible by 3 "
+                             "(3 DOFs per node); got {} and {}".format(tuple(A.shape), tuple(B.shape)))
+        nv = n // 3
+        dev = B.device
+        ka, _ = _coo_to_bsr3(A, nv)
+        kb, _ = _coo_to_bsr3(B, nv)
+        keys = torch.unique(torch.cat([ka, kb, torch.arange(nv, device=dev) * (nv + 1)]))
+        _, self.a64 = _coo_to_bsr3(A, nv, keys)
+        _, self.b64 = _coo_to_bsr3(B, nv, keys)
+        rows = keys // nv
+        rowptr = torch.zeros(nv + 1, dtype=torch.int64, device=dev)
+        rowptr[1:] = torch.cumsum(torch.bincount(rows, minlength=nv), 0)
+        self._init_common(rowptr.to(torch.int32), (keys % nv).to(torch.int32), nv, dev)
+        self.k32 = self.a64.float().contiguous()
+        self.ms32 = self.b64.float().contiguous()
+        diag = self.a64[torch.searchsorted(keys, torch.arange(nv, device=dev) * (nv + 1))].reshape(nv, 3, 3)
+        eye = torch.eye(3, dtype=torch.float64, device=dev)
+        bad = torch.linalg.det(diag).abs() < 1e-300
+        diag = torch.where(bad[:, None, None], eye, diag)
+        self.dinv = torch.linalg.inv(diag).float().reshape(nv, 9).contiguous()
+        self.rigid = None
+        self.lame = None
+
+    def polish_terms(self):
+        return [(2, self.a64, 1.0)], (2, self.b64)

@@ -1,0 +1,118 @@
+"""One forward+backward modal-analysis pass and its data-parallel batching over hypotheses.
+
+A *pass* is the body of the reference training loop with the eigendecomposition every epoch
+(reference experiments/material_sync_train.py:137-167 with EIGEN_DECOMPOSE_CYCLE = 1):
+  1. numeric assembly of K_lambda, K_mu, M_s (symbolic pattern reused),
+  2. K = lam K_lambda + mu K_mu, block eigensolve for ``modes`` elastic modes (cold start),
+  3. f = get_undamped_freqs()         (differentiable read-out through a_i, b_i, m_i),
+  4. oscillator render (A = 1, S samples, impulse force),
+  5. scalar loss (MSE against a fixed target signal),
+  6. backward to (E, nu).
+Hypotheses (E_i, nu_i) on one mesh are independent: rank r of a ``torch.distributed`` job takes
+hypotheses r, r + world, ... ; the ONLY collective is the all-reduce of the scalar loss (RCCL).
+"""
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .ddsp.oscillator import TraditionalDampedOscillator
+from .diffelastic.material_model import Material
+from .lobpcg.modal_solver import ModalSolver, SolverConfig
+from .modal_ops import HipModalOps, TetSystem
+
+
+class DirectLinear(nn.Module):
+    """(E, nu) as direct leaves - one material hypothesis of the inverse-rendering batch."""
+
+    def __init__(self, youngs, poisson, mat):
+        super().__init__()
+        self.E = nn.Parameter(torch.tensor(float(youngs), dtype=torch.float64))
+        self.nu = nn.Parameter(torch.tensor(float(poisson), dtype=torch.float64))
+        self.mat = mat
+
+    def youngs(self):
+        return self.E
+
+    def poisson(self):
+        return self.nu
+
+    def lame(self):
+        E, nu = self.E, self.nu
+        return E * nu / ((1 + nu) * (1 - 2 * nu)), E / (2 * (1 + nu))
+
+
+def shard_hypotheses(num, rank, world):
+    """Indices of the hypotheses owned by ``rank`` (round-robin; embarrassingly parallel)."""
+    return list(range(rank, num, world))
+
+
+@dataclass
+class PassResult:
+    loss: float
+    grad_E: float
+    grad_nu: float
+    freqs: torch.Tensor
+    iterations: int
+    eigenvalues: torch.Tensor
+
+
+class ModalPipeline:
+    """Mesh-bound state shared by all hypotheses on this GPU: pattern, assembled K_lambda/K_mu/M_s,
+    oscillator, target audio."""
+
+    def __init__(self, vertices, tets, order, modes, mat, sample_num=8000, sr=32000, force_frames=150,
+                 solver_config=None, target_freqs=None):
+        self.device = vertices.device
+        self.modes = modes
+        self.mat = Material(mat)
+        self.cfg = solver_config or SolverConfig()
+        self.system = TetSystem(vertices, tets, order, self.mat.density)
+        self.ops = None
+        force = torch.zeros((1, force_frames), device=self.device)
+        force[0, 0] = 1  # impulse (reference material_sync_train.py:103-104)
+        self.osc = TraditionalDampedOscillator(force, 1, modes, sample_num, sr, self.mat)
+        self.target = None
+        self.target_freqs = target_freqs
+        self.vertices = vertices
+
+    def set_target(self, audio):
+        self.target = audio.detach()
+
+    def assemble(self):
+        self.system.assemble()
+
+    def run_pass(self, youngs, poisson, warm=None, backward=True):
+        """Steps 2-6 for one hypothesis (step 1 is ``assemble``)."""
+        model = DirectLinear(youngs, poisson, self.mat)
+        lam, mu = model.lame()
+        if self.ops is None:
+            self.ops = HipModalOps(self.system, float(lam), float(mu))
+        else:
+            self.ops.set_material(float(lam), float(mu))
+        res = ModalSolver(self.ops, self.cfg).solve(self.modes, X0=warm)
+        ev = res.eigenvalues
+        dev = ev.device
+        pred = ev + (lam.to(dev) * res.a_lambda + mu.to(dev) * res.b_mu) - ev * res.m_diag
+        freqs = (torch.sqrt(pred) / 2 / np.pi).float().unsqueeze(1)
+        audio = self.osc(freqs)
+        if self.target is None:
+            loss = (audio ** 2).mean()
+        else:
+            loss = ((audio - self.target) ** 2).mean()
+        gE = gnu = float("nan")
+        if backward:
+            loss.backward()
+            gE, gnu = float(model.E.grad), float(model.nu.grad)
+        return PassResult(float(loss), gE, gnu, freqs.detach(), res.iterations, ev), res, audio.detach()
+
+
+def all_reduce_loss(loss_sum, device):
+    """Sum of per-rank loss sums.  The data path has no other collective."""
+    import torch.distributed as dist
+
+    t = torch.tensor([loss_sum], dtype=torch.float64, device=device)
+    if dist.is_available() and dist.is_initialized():
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return float(t[0])

@@ -95,4 +95,4 @@ class CpuModalOps:
     def polish_products(self, X):
         Xd = X.double().numpy()
         f = lambda A: torch.from_numpy(Xd.T @ (A @ Xd))
-        return f(self.Kl), f(self.Km), f(self.M)
+        return [f(self.Kl), f(self.Km)], list(self.lame), f(self.M)

@@ -1,0 +1,1 @@
+from diffsound_amd.diffelastic.mesh import TetMesh, read_gmsh22, write_gmsh22  # noqa: F401
