@@ -12,9 +12,13 @@
 // exact, accumulation is fp64: the Rayleigh-Ritz matrix keeps ~1e-16 relative accuracy although
 // the iterates are fp32).
 //
-// Decomposition: a wave owns a (16*TI x 16*TJ) output tile in registers; a workgroup = 2x2 waves
-// streams the same rows (shared through L1/L2); grid.y splits the rows; partial tiles go to a
-// workspace [nsplit][p][q] that a second kernel sums in fixed order (deterministic, no atomics).
+// Decomposition: a wave owns a (48 x 48) output tile = 3x3 MFMA accumulators (72 VGPRs); a workgroup
+// = 2x2 waves streams the same 16-row batches (shared through L1/L2); grid.y splits the rows.  The
+// row loop is software-pipelined by hand: the 24 operand loads of batch t+1 are in flight while the
+// 36 MFMAs of batch t issue (the first version waited on every 4-row step and ran 10x below the
+// MFMA rate).  Partial tiles go to a workspace [nsplit][p][q] that a second kernel sums in fixed
+// order: deterministic, no atomics.  With `symmetric`, only workgroup tiles on or above the
+// diagonal are computed and the reduction mirrors them (A^T (K A) for symmetric K).
 #include <algorithm>
 
 #include "ds_common.h"
@@ -23,18 +27,54 @@ namespace {
 
 using d4 = __attribute__((ext_vector_type(4))) double;
 
-constexpr int TI = 3, TJ = 3;          // MFMA tiles per wave in i / j
-constexpr int WT = 16 * TI;            // wave tile edge (48)
-constexpr int BT = 2 * WT;             // workgroup tile edge (96)
-constexpr int ROWS_PER_STEP = 4;
+constexpr int TI = 3, TJ = 3;  // MFMA tiles per wave in i / j
+constexpr int WT = 16 * TI;    // wave tile edge (48)
+constexpr int BT = 2 * WT;     // workgroup tile edge (96)
+constexpr int KS = 4;          // MFMA k-steps (of 4 rows) per pipelined batch
+constexpr int RB = 4 * KS;     // rows per batch (16)
+
+template <typename TB>
+struct Batch {
+    float a[KS][TI];
+    TB b[KS][TJ];
+};
+
+template <typename TB>
+__device__ __forceinline__ void load_batch(Batch<TB>& t, const float* __restrict__ A, int64_t lda,
+                                           const TB* __restrict__ B, int64_t ldb, int64_t r0, int64_t r_end, int lr,
+                                           int acol, int bcol, const bool (&ia)[TI], const bool (&jb)[TJ]) {
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        const int64_t r = r0 + 4 * s + lr;
+        const bool rv = r < r_end;
+        const float* ap = A + r * lda + acol;
+        const TB* bp = B + r * ldb + bcol;
+#pragma unroll
+        for (int a = 0; a < TI; ++a) t.a[s][a] = (rv && ia[a]) ? ap[a * 16] : 0.f;
+#pragma unroll
+        for (int b = 0; b < TJ; ++b) t.b[s][b] = (rv && jb[b]) ? bp[b * 16] : (TB)0;
+    }
+}
+
+template <typename TB>
+__device__ __forceinline__ void mfma_batch(const Batch<TB>& t, d4 (&acc)[TI][TJ]) {
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+#pragma unroll
+        for (int a = 0; a < TI; ++a)
+#pragma unroll
+            for (int b = 0; b < TJ; ++b)
+                acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)t.a[s][a], (double)t.b[s][b], acc[a][b], 0, 0, 0);
+}
 
 template <typename TB>
 __global__ void __launch_bounds__(256)
     gram_partial_kernel(const float* __restrict__ A, int64_t lda, int p, const TB* __restrict__ B, int64_t ldb, int q,
-                        int64_t n, int64_t rows_per_split, int tiles_j, double* __restrict__ ws) {
+                        int64_t n, int64_t rows_per_split, int tiles_j, int symmetric, double* __restrict__ ws) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int ti = blockIdx.x / tiles_j, tj = blockIdx.x - ti * tiles_j;
+    if (symmetric && tj < ti) return;  // mirrored by the reduction
     const int i0 = ti * BT + (wave >> 1) * WT;
     const int j0 = tj * BT + (wave & 1) * WT;
     const int64_t r_begin = (int64_t)blockIdx.y * rows_per_split;
@@ -52,28 +92,18 @@ __global__ void __launch_bounds__(256)
     for (int a = 0; a < TI; ++a) ia[a] = (i0 + a * 16 + lc) < p;
 #pragma unroll
     for (int b = 0; b < TJ; ++b) jb[b] = (j0 + b * 16 + lc) < q;
-    const bool wave_active = (i0 < p) && (j0 < q);
 
-    if (wave_active) {
-#pragma unroll 4
-        for (int64_t r = r_begin + lr; r < r_end + lr; r += ROWS_PER_STEP) {
-            // r - lr is wave-uniform; rows past r_end contribute zeros
-            const bool rv = r < r_end;
-            const float* ap = A + r * lda + i0 + lc;
-            const TB* bp = B + r * ldb + j0 + lc;
-            double av[TI], bv[TJ];
-#pragma unroll
-            for (int a = 0; a < TI; ++a) av[a] = (rv && ia[a]) ? (double)ap[a * 16] : 0.0;
-#pragma unroll
-            for (int b = 0; b < TJ; ++b) bv[b] = (rv && jb[b]) ? (double)bp[b * 16] : 0.0;
-#pragma unroll
-            for (int a = 0; a < TI; ++a)
-#pragma unroll
-                for (int b = 0; b < TJ; ++b)
-                    acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[a], bv[b], acc[a][b], 0, 0, 0);
+    if ((i0 < p) && (j0 < q)) {  // wave-uniform
+        Batch<TB> cur, nxt;
+        load_batch(cur, A, lda, B, ldb, r_begin, r_end, lr, i0 + lc, j0 + lc, ia, jb);
+        for (int64_t r0 = r_begin; r0 < r_end; r0 += RB) {
+            const int64_t rn = r0 + RB;
+            if (rn < r_end) load_batch(nxt, A, lda, B, ldb, rn, r_end, lr, i0 + lc, j0 + lc, ia, jb);
+            mfma_batch(cur, acc);
+            cur = nxt;
         }
     }
-    // partial tile -> workspace (every element of [p][q] is written by exactly one lane per split)
+    // partial tile -> workspace (every element of the computed tiles is written by exactly one lane)
     double* w = ws + (int64_t)blockIdx.y * p * q;
 #pragma unroll
     for (int a = 0; a < TI; ++a)
@@ -87,12 +117,29 @@ __global__ void __launch_bounds__(256)
             }
 }
 
-__global__ void gram_reduce_kernel(const double* __restrict__ ws, int nsplit, int64_t pq, double* __restrict__ G) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= pq) return;
+// G[i][j] = sum_s ws[s][i][j]; 4 lanes-groups share the split loop of one element and merge through LDS
+// in fixed order.  With symmetric != 0 an element below the computed block-upper part reads its mirror.
+__global__ void __launch_bounds__(256)
+    gram_reduce_kernel(const double* __restrict__ ws, int nsplit, int p, int q, int symmetric,
+                       double* __restrict__ G) {
+    __shared__ double part[4][64];
+    const int e = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int64_t pq = (int64_t)p * q;
+    const int64_t idx = (int64_t)blockIdx.x * 64 + e;
     double s = 0.0;
-    for (int k = 0; k < nsplit; ++k) s += ws[(int64_t)k * pq + i];
-    G[i] = s;
+    if (idx < pq) {
+        int i = (int)(idx / q), j = (int)(idx - (int64_t)i * q);
+        if (symmetric && (j / BT) < (i / BT)) {
+            const int t = i;
+            i = j;
+            j = t;
+        }
+        const double* src = ws + (int64_t)i * q + j;
+        for (int k = grp; k < nsplit; k += 4) s += src[(int64_t)k * pq];
+    }
+    part[grp][e] = s;
+    __syncthreads();
+    if (grp == 0 && idx < pq) G[idx] = (part[0][e] + part[1][e]) + (part[2][e] + part[3][e]);
 }
 
 struct Plan {
@@ -105,11 +152,11 @@ Plan make_plan(int64_t n, int p, int q) {
     pl.tiles_i = (int)ds::ceil_div(p, BT);
     pl.tiles_j = (int)ds::ceil_div(q, BT);
     const int64_t tiles = (int64_t)pl.tiles_i * pl.tiles_j;
-    int64_t nsplit = ds::ceil_div(1024, tiles);               // ~4 workgroups per CU
-    nsplit = std::min<int64_t>(nsplit, ds::ceil_div(n, 256));  // at least 256 rows per split
+    int64_t nsplit = ds::ceil_div(768, tiles);                  // ~3 workgroups per CU
+    nsplit = std::min<int64_t>(nsplit, ds::ceil_div(n, 512));   // at least 512 rows per split
     nsplit = std::max<int64_t>(nsplit, 1);
     int64_t rps = ds::ceil_div(n, nsplit);
-    rps = ds::ceil_div(rps, ROWS_PER_STEP) * ROWS_PER_STEP;
+    rps = ds::ceil_div(rps, RB) * RB;
     pl.rows_per_split = rps;
     pl.nsplit = (int)ds::ceil_div(n, rps);
     return pl;
@@ -124,11 +171,12 @@ extern "C" int64_t ds_gram_workspace_bytes(int64_t n, int p, int q) {
 }
 
 extern "C" int ds_gram(const float* A, int64_t lda, int p, const void* B, int b_dtype, int64_t ldb, int q, int64_t n,
-                       double* G, void* work, int64_t work_bytes, ds_stream_t stream) {
+                       int symmetric, double* G, void* work, int64_t work_bytes, ds_stream_t stream) {
     DS_REQUIRE(A && B && G && work, "ds_gram: null pointer");
     DS_REQUIRE(n > 0 && p > 0 && q > 0, "ds_gram: empty problem");
     DS_REQUIRE(lda >= p && ldb >= q, "ds_gram: leading dimension smaller than the block width");
     DS_REQUIRE(b_dtype == DS_F32 || b_dtype == DS_F64, "ds_gram: bad dtype code %d", b_dtype);
+    DS_REQUIRE(!symmetric || p == q, "ds_gram: symmetric needs p == q");
     const Plan pl = make_plan(n, p, q);
     DS_REQUIRE(work_bytes >= (int64_t)pl.nsplit * p * q * (int64_t)sizeof(double),
                "ds_gram: workspace too small (%lld bytes given)", (long long)work_bytes);
@@ -137,13 +185,13 @@ extern "C" int ds_gram(const float* A, int64_t lda, int p, const void* B, int b_
     double* ws = static_cast<double*>(work);
     if (b_dtype == DS_F32)
         gram_partial_kernel<float><<<grid, 256, 0, st>>>(A, lda, p, static_cast<const float*>(B), ldb, q, n,
-                                                         pl.rows_per_split, pl.tiles_j, ws);
+                                                         pl.rows_per_split, pl.tiles_j, symmetric, ws);
     else
         gram_partial_kernel<double><<<grid, 256, 0, st>>>(A, lda, p, static_cast<const double*>(B), ldb, q, n,
-                                                          pl.rows_per_split, pl.tiles_j, ws);
+                                                          pl.rows_per_split, pl.tiles_j, symmetric, ws);
     DS_LAUNCH_CHECK("gram_partial_kernel");
     const int64_t pq = (int64_t)p * q;
-    gram_reduce_kernel<<<(unsigned)ds::ceil_div(pq, 256), 256, 0, st>>>(ws, pl.nsplit, pq, G);
+    gram_reduce_kernel<<<(unsigned)ds::ceil_div(pq, 64), 256, 0, st>>>(ws, pl.nsplit, p, q, symmetric, G);
     DS_LAUNCH_CHECK("gram_reduce_kernel");
     return DS_OK;
 }

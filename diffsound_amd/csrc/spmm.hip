@@ -11,6 +11,8 @@
 // node groups share a wave.  Block values are fetched by all lanes of a group from the same
 // address (hardware broadcast).  Accumulation in registers, one store per output element.
 // Algorithmic bytes per launch: nnzb*(vals + 4) + (nv+1)*4 + 2*3nv*ncols*sizeof(T).
+#include <cstdlib>
+
 #include "ds_common.h"
 
 namespace {
@@ -130,6 +132,161 @@ int launch(const int32_t* rowptr, const int32_t* colidx, const void* vals, int64
     return launch_ct<KIND, TV, TX, TY, VEC, 0>(rowptr, colidx, vals, nv, X, ldx, Y, ldy, ncols, lpn, st);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Fast path for the f32 products of the eigensolver: ONE WAVE PER NODE, block metadata on the scalar
+// path.  The node index is wave-uniform, so rowptr / colidx / the 3x3 values come through s_load
+// (scalar cache, no vector-memory instructions, no dependent vector round trip before the X loads).
+// RS = 3 (ncols <= 84): lane (cl, r) loads the 16 bytes [cl*4, cl*4+4) of input row r of the
+//   neighbour, i.e. ONE 16-byte load instruction per block fetches the whole 3 x ncols panel; each
+//   lane accumulates its row's contribution to all three output rows and the three lane groups are
+//   merged by two cross-lane shuffles at the end (KIND 1, M = M_s (x) I3, needs no merge: row r only
+//   feeds row r).
+// RS = 1 (ncols <= 256): lane cl loads its 16 bytes of all three rows (three loads per block).
+#define DS_KEEP_SCALAR(x) asm volatile("" : "+s"(x))
+
+template <int KIND, int RS>
+__device__ __forceinline__ void wn_block(const float* __restrict__ vals, int64_t k, int r,
+                                         const __attribute__((ext_vector_type(4))) float& x0,
+                                         const __attribute__((ext_vector_type(4))) float& x1,
+                                         const __attribute__((ext_vector_type(4))) float& x2,
+                                         __attribute__((ext_vector_type(4))) float& acc0,
+                                         __attribute__((ext_vector_type(4))) float& acc1,
+                                         __attribute__((ext_vector_type(4))) float& acc2) {
+    if (KIND == 0) {
+        const float* a = vals + k * 9;
+        float a0 = a[0], a1 = a[1], a2 = a[2], a3 = a[3], a4 = a[4], a5 = a[5], a6 = a[6], a7 = a[7], a8 = a[8];
+        // pin the nine values to SGPRs: they must arrive through s_load, not as per-lane vector loads
+        DS_KEEP_SCALAR(a0); DS_KEEP_SCALAR(a1); DS_KEEP_SCALAR(a2); DS_KEEP_SCALAR(a3); DS_KEEP_SCALAR(a4);
+        DS_KEEP_SCALAR(a5); DS_KEEP_SCALAR(a6); DS_KEEP_SCALAR(a7); DS_KEEP_SCALAR(a8);
+        if (RS == 3) {
+            const float c0 = r == 0 ? a0 : (r == 1 ? a1 : a2);
+            const float c1 = r == 0 ? a3 : (r == 1 ? a4 : a5);
+            const float c2 = r == 0 ? a6 : (r == 1 ? a7 : a8);
+            acc0 += c0 * x0;
+            acc1 += c1 * x0;
+            acc2 += c2 * x0;
+        } else {
+            acc0 += a0 * x0 + a1 * x1 + a2 * x2;
+            acc1 += a3 * x0 + a4 * x1 + a5 * x2;
+            acc2 += a6 * x0 + a7 * x1 + a8 * x2;
+        }
+    } else {
+        float m = vals[k];
+        DS_KEEP_SCALAR(m);
+        acc0 += m * x0;
+        if (RS == 1) {
+            acc1 += m * x1;
+            acc2 += m * x2;
+        }
+    }
+}
+
+template <int KIND, int RS, int LPN_CT>
+__global__ void __launch_bounds__(256)
+    spmm_wave_node_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx,
+                          const float* __restrict__ vals, int64_t nv, const float* __restrict__ X, int64_t ldx,
+                          float* __restrict__ Y, int64_t ldy, int lpn_rt, unsigned nblk) {
+    using f4 = __attribute__((ext_vector_type(4))) float;
+    const int lpn = LPN_CT ? LPN_CT : lpn_rt;
+    const unsigned bid = ds::xcd_remap(blockIdx.x, nblk);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t node = (int64_t)bid * 4 + wave;
+    if (node >= nv) return;  // wave-uniform
+    const int r_raw = RS == 3 ? lane / lpn : 0;
+    const int cl_raw = lane - r_raw * lpn;
+    const bool active = r_raw < RS && cl_raw < lpn;
+    // idle lanes shadow a valid lane (no exec-mask branches inside the loop); they never store
+    const int r = active ? r_raw : 0;
+    const int cl = active ? cl_raw : 0;
+    const int c0 = cl * 4;
+    const int kb = rowptr[node], ke = rowptr[node + 1];
+    f4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0, acc2 = acc0;
+    const float* xbase = X + (int64_t)r * ldx + c0;
+    const int64_t ldx3 = 3 * ldx;
+    int k = kb;
+    for (; k + 4 <= ke; k += 4) {
+        // four neighbour ids first (scalar loads), then all vector loads, then the arithmetic
+        const int j0 = colidx[k], j1 = colidx[k + 1], j2 = colidx[k + 2], j3 = colidx[k + 3];
+        const float* p0 = xbase + (int64_t)j0 * ldx3;
+        const float* p1 = xbase + (int64_t)j1 * ldx3;
+        const float* p2 = xbase + (int64_t)j2 * ldx3;
+        const float* p3 = xbase + (int64_t)j3 * ldx3;
+        f4 xa[4], xb[4], xc[4];
+        xa[0] = *reinterpret_cast<const f4*>(p0);
+        xa[1] = *reinterpret_cast<const f4*>(p1);
+        xa[2] = *reinterpret_cast<const f4*>(p2);
+        xa[3] = *reinterpret_cast<const f4*>(p3);
+        if (RS == 1) {
+            xb[0] = *reinterpret_cast<const f4*>(p0 + ldx);
+            xb[1] = *reinterpret_cast<const f4*>(p1 + ldx);
+            xb[2] = *reinterpret_cast<const f4*>(p2 + ldx);
+            xb[3] = *reinterpret_cast<const f4*>(p3 + ldx);
+            xc[0] = *reinterpret_cast<const f4*>(p0 + 2 * ldx);
+            xc[1] = *reinterpret_cast<const f4*>(p1 + 2 * ldx);
+            xc[2] = *reinterpret_cast<const f4*>(p2 + 2 * ldx);
+            xc[3] = *reinterpret_cast<const f4*>(p3 + 2 * ldx);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) wn_block<KIND, RS>(vals, k + u, r, xa[u], xb[u], xc[u], acc0, acc1, acc2);
+    }
+    for (; k < ke; ++k) {
+        const float* p0 = xbase + (int64_t)colidx[k] * ldx3;
+        f4 xa = *reinterpret_cast<const f4*>(p0), xb = xa, xc = xa;
+        if (RS == 1) {
+            xb = *reinterpret_cast<const f4*>(p0 + ldx);
+            xc = *reinterpret_cast<const f4*>(p0 + 2 * ldx);
+        }
+        wn_block<KIND, RS>(vals, k, r, xa, xb, xc, acc0, acc1, acc2);
+    }
+    if (RS == 3 && KIND == 0) {
+        // merge the three row groups: lanes [0,lpn) += lanes [lpn,2lpn) + lanes [2lpn,3lpn)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            acc0[v] += __shfl(acc0[v], lane + lpn) + __shfl(acc0[v], lane + 2 * lpn);
+            acc1[v] += __shfl(acc1[v], lane + lpn) + __shfl(acc1[v], lane + 2 * lpn);
+            acc2[v] += __shfl(acc2[v], lane + lpn) + __shfl(acc2[v], lane + 2 * lpn);
+        }
+    }
+    float* yp = Y + (node * 3) * ldy + c0;
+    if (RS == 3 && KIND == 1) {
+        if (active) *reinterpret_cast<f4*>(yp + (int64_t)r * ldy) = acc0;
+    } else if (active && r_raw == 0) {
+        *reinterpret_cast<f4*>(yp) = acc0;
+        *reinterpret_cast<f4*>(yp + ldy) = acc1;
+        *reinterpret_cast<f4*>(yp + 2 * ldy) = acc2;
+    }
+}
+
+template <int KIND, int RS, int LPN_CT>
+int launch_wn(const int32_t* rowptr, const int32_t* colidx, const void* vals, int64_t nv, const void* X, int64_t ldx,
+              void* Y, int64_t ldy, int lpn, hipStream_t st) {
+    const int64_t nblk = ds::ceil_div(nv, 4);
+    spmm_wave_node_kernel<KIND, RS, LPN_CT><<<(unsigned)nblk, 256, 0, st>>>(
+        rowptr, colidx, static_cast<const float*>(vals), nv, static_cast<const float*>(X), ldx,
+        static_cast<float*>(Y), ldy, lpn, (unsigned)nblk);
+    DS_LAUNCH_CHECK("spmm_wave_node_kernel");
+    return DS_OK;
+}
+
+template <int KIND>
+int launch_fast(const int32_t* rowptr, const int32_t* colidx, const void* vals, int64_t nv, const void* X, int64_t ldx,
+                void* Y, int64_t ldy, int ncols, hipStream_t st) {
+    const int lpn = ncols / 4;
+    if (lpn <= 21) {
+        switch (lpn) {  // the solver's block widths get compile-time lane splits and their own kernel names
+            case 18: return launch_wn<KIND, 3, 18>(rowptr, colidx, vals, nv, X, ldx, Y, ldy, lpn, st);
+            case 20: return launch_wn<KIND, 3, 20>(rowptr, colidx, vals, nv, X, ldx, Y, ldy, lpn, st);
+            default: return launch_wn<KIND, 3, 0>(rowptr, colidx, vals, nv, X, ldx, Y, ldy, lpn, st);
+        }
+    }
+    switch (lpn) {
+        case 54: return launch_wn<KIND, 1, 54>(rowptr, colidx, vals, nv, X, ldx, Y, ldy, lpn, st);
+        case 60: return launch_wn<KIND, 1, 60>(rowptr, colidx, vals, nv, X, ldx, Y, ldy, lpn, st);
+        default: return launch_wn<KIND, 1, 0>(rowptr, colidx, vals, nv, X, ldx, Y, ldy, lpn, st);
+    }
+}
+
 }  // namespace
 
 extern "C" int ds_spmm_bsr3(int kind, const int32_t* rowptr, const int32_t* colidx, const void* vals, int64_t nv,
@@ -145,6 +302,10 @@ extern "C" int ds_spmm_bsr3(int kind, const int32_t* rowptr, const int32_t* coli
     if (!f64out) {
         // float4 path needs 16-byte aligned rows; float2 path 8-byte
         if (ncols % 4 == 0 && ncols <= 256 && (xalign & 15) == 0 && (yalign & 15) == 0) {
+            static const bool legacy = getenv("DS_SPMM_LEGACY") != nullptr;  // A/B switch for benchmarking
+            if (!legacy)
+                return kind == 0 ? launch_fast<0>(rowptr, colidx, vals, nv, X, ldx, Y, ldy, ncols, st)
+                                 : launch_fast<1>(rowptr, colidx, vals, nv, X, ldx, Y, ldy, ncols, st);
             return kind == 0 ? launch<0, float, float, float, 4>(rowptr, colidx, vals, nv, X, ldx, Y, ldy, ncols, st)
                              : launch<1, float, float, float, 4>(rowptr, colidx, vals, nv, X, ldx, Y, ldy, ncols, st);
         }

@@ -197,8 +197,12 @@ class DiffSoundObj:
                 blocks = (lam * s.klam + mu * s.kmu).reshape(-1, 3, 3)
             else:
                 blocks = s.ms[:, None, None] * torch.eye(3, dtype=torch.float64, device=s.device)
-            bsr = torch.sparse_bsr_tensor(s.rowptr.long(), s.colidx.long(), blocks, size=(s.n, s.n))
-            self._sparse_cache[which] = bsr.to_sparse_coo().coalesce()
+            coo = torch.sparse_bsr_tensor(s.rowptr.long(), s.colidx.long(), blocks, size=(s.n, s.n)).to_sparse_coo()
+            if s.perm is not None:  # internal (Morton) -> the caller's DOF numbering
+                idx = coo.indices()
+                ext = 3 * s.perm[idx // 3] + idx % 3
+                coo = torch.sparse_coo_tensor(ext, coo.values(), (s.n, s.n))
+            self._sparse_cache[which] = coo.coalesce()
         return self._sparse_cache[which]
 
     @property
@@ -224,8 +228,9 @@ class DiffSoundObj:
         self._warm = res.block_vectors
         self.last_result = res
         self.eigenvalues = res.eigenvalues
-        self.U_hat = res.vectors.double()
-        rigid = ops.rigid[:, :6].double()
+        # the solver works in the system's internal (Morton) node order; hand modes back in the caller's
+        self.U_hat = self.system.rows_to_external(res.vectors).double()
+        rigid = self.system.rows_to_external(ops.rigid[:, :6]).double()
         self.U_hat_full = torch.cat([rigid, self.U_hat], dim=1)
         self._a, self._b, self._m = res.a_lambda, res.b_mu, res.m_diag
 
@@ -249,7 +254,7 @@ class DiffSoundObj:
         """K(theta) x with autograd to the material parameters (reference :314-328, matrix-free there)."""
         x = x_in.unsqueeze(1) if x_in.dim() == 1 else x_in
         ops = self._ops
-        xf = x.detach().float().contiguous()
+        xf = self.system.rows_to_internal(x.detach().float()).contiguous()
         pad = (-xf.shape[1]) % 4
         if pad:
             xf = torch.cat([xf, torch.zeros((xf.shape[0], pad), device=xf.device)], dim=1).contiguous()
@@ -258,5 +263,5 @@ class DiffSoundObj:
         ops._spmm(2, ops.sys.klam, xf, yl)
         ops._spmm(2, ops.sys.kmu, xf, ym)
         lam, mu = self.material_model.lame()
-        out = (lam.to(yl.device) * yl + mu.to(yl.device) * ym)[:, : x.shape[1]].to(x_in.dtype)
+        out = self.system.rows_to_external(lam.to(yl.device) * yl + mu.to(yl.device) * ym)[:, : x.shape[1]].to(x_in.dtype)
         return out.squeeze(1) if x_in.dim() == 1 else out

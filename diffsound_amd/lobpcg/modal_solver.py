@@ -73,6 +73,31 @@ def _svqb_transform(G, tau=1e-12):
     return (d[:, None] * Z) * torch.rsqrt(E)[None, :]
 
 
+def _orthonormalizer(G):
+    """T with (W T)^T M (W T) = I from G = W^T M W: Cholesky-QR on the diagonally scaled Gram matrix
+    (one potrf + one small triangular solve), falling back to the clamped-eigenvalue transform of the
+    reference's svqb when the factorisation breaks down (rank-deficient block)."""
+    G = _sym(G)
+    d = torch.rsqrt(torch.clamp(G.diagonal(), min=1e-300))
+    L, info = torch.linalg.cholesky_ex(G * d[:, None] * d[None, :])
+    if int(info) != 0 or not bool(torch.isfinite(L).all()):
+        return _svqb_transform(G)
+    Li = torch.linalg.solve_triangular(L, torch.eye(L.shape[0], dtype=L.dtype, device=L.device), upper=False)
+    return d[:, None] * Li.transpose(0, 1)
+
+
+def _orthonormal_columns(Tm):
+    """Orthonormal basis (Euclidean, coefficient space) of the columns of the small dense Tm (r x c):
+    scaled Cholesky-QR with a Householder-QR fallback."""
+    G = Tm.transpose(0, 1) @ Tm
+    d = torch.rsqrt(torch.clamp(G.diagonal(), min=1e-300))
+    L, info = torch.linalg.cholesky_ex(_sym(G) * d[:, None] * d[None, :])
+    if int(info) != 0 or not bool(torch.isfinite(L).all()):
+        return torch.linalg.qr(Tm).Q
+    Li = torch.linalg.solve_triangular(L, torch.eye(L.shape[0], dtype=L.dtype, device=L.device), upper=False)
+    return Tm @ (d[:, None] * Li.transpose(0, 1))
+
+
 class ChebyshevBlockJacobi:
     """W = p(T K) T R with T = inverse 3x3 diagonal blocks of K and p the degree-(d-1) Chebyshev
     polynomial that approximates 1/x on [lmax/ratio, lmax] (Saad, Iterative Methods, Alg. 12.1).
@@ -152,19 +177,17 @@ class ModalSolver:
             self.precond_apply = self.precond.apply
 
     # ------------------------------------------------------------------ helpers
-    def _orthonormalize(self, W, V_blocks, MW):
-        """Make W M-orthogonal to every block in V_blocks and M-orthonormal (reference _get_ortho,
+    def _orthonormalize(self, W, V, MW):
+        """Make W M-orthogonal to the block V (may be None) and M-orthonormal (reference _get_ortho,
         _lobpcg.py:587-679, with a fixed number of passes instead of host-synchronising norms)."""
         ops = self.ops
         for _ in range(self.cfg.ortho_passes):
-            ops.apply_M(W, MW)
-            for V in V_blocks:
-                if V is None:
-                    continue
+            if V is not None and V.shape[1] > 0:
+                ops.apply_M(W, MW)
                 C = ops.gram(V, MW)
                 ops.mix(V, C, W, alpha=-1.0, beta=1.0)
             ops.apply_M(W, MW)
-            T = _svqb_transform(ops.gram(W, MW))
+            T = _orthonormalizer(ops.gram(W, MW, symmetric=True))
             ops.mix_inplace(W, T)
 
     # ------------------------------------------------------------------ main entry
@@ -182,14 +205,21 @@ class ModalSolver:
                 "LPBPCG algorithm is not applicable when the number of A rows (={})"
                 " is smaller than 3 x the number of requested eigenpairs (={})".format(n, b))
         state = state or SolverState({"niter": cfg.maxit, "k": k, "n": b, "m": n}, {}, {})
-        S = torch.empty((n, 3 * b), dtype=dt, device=dev)
-        S2 = torch.empty((n, 3 * b), dtype=dt, device=dev)
+        # One row-major buffer [Y | X | P | W]: the rigid basis rides in front of the search basis so the
+        # projection against [Y, X, P] is ONE Gram + ONE update launch; the active basis S[:, ny:] is what
+        # the stiffness SpMM and the Rayleigh-Ritz Gram see.
+        ny = 0 if Y is None else Y.shape[1]
+        S = torch.empty((n, ny + 3 * b), dtype=dt, device=dev)
+        S2 = torch.empty((n, ny + 3 * b), dtype=dt, device=dev)
+        if ny:
+            S[:, :ny].copy_(Y)
+            S2[:, :ny].copy_(Y)
         KS = torch.empty((n, 3 * b), dtype=dt, device=dev)
         R = torch.empty((n, b), dtype=dt, device=dev)
         MX = torch.empty((n, b), dtype=dt, device=dev)
         MW = torch.empty((n, b), dtype=dt, device=dev)
 
-        X = S[:, :b]
+        X = S[:, ny:ny + b]
         g = torch.Generator(device="cpu").manual_seed(cfg.seed)
         nx0 = 0 if X0 is None else X0.shape[1]
         if nx0:
@@ -206,18 +236,19 @@ class ModalSolver:
         B_norm = torch.linalg.vector_norm(G1.double()) / gn
         state.fvars.update(A_norm=float(A_norm), B_norm=float(B_norm))
         tol = cfg.tol or (2e-6 if dt == torch.float32 else 1e-10)
-        self._orthonormalize(X, [Y], MW)
+        self._orthonormalize(X, S[:, :ny], MW)
         ops.apply_K(X, KS[:, :b])
-        lam, Z = torch.linalg.eigh(_sym(ops.gram(X, KS[:, :b])))
-        ops.mix(S[:, :b], Z, S2[:, :b])
+        lam, Z = torch.linalg.eigh(_sym(ops.gram(X, KS[:, :b], symmetric=True)))
+        ops.mix(X, Z, S2[:, ny:ny + b])
         S, S2 = S2, S
         ops.mix(KS[:, :b], Z, R)  # R holds K X for the first residual
         have_p = False
         history = []
         rel = None
         it = 0
+        eye_b = torch.eye(b, dtype=torch.float64, device=dev)
         for it in range(cfg.maxit + 1):
-            X = S[:, :b]
+            X = S[:, ny:ny + b]
             ops.apply_M(X, MX)
             rn2, xn2 = ops.residual(R, MX, X, lam)  # R <- R - MX*lam in place; ||R_j||^2, ||X_j||^2 (fp64)
             rel = torch.sqrt(rn2 / xn2) / (A_norm + lam.abs() * B_norm)
@@ -235,24 +266,28 @@ class ModalSolver:
                 if nconv >= k or it == cfg.maxit or state.bvars.get("force_stop", False):
                     break
             w0 = 2 * b if have_p else b
-            W = S[:, w0:w0 + b]
+            W = S[:, ny + w0:ny + w0 + b]
             self.precond_apply(R, W)
-            self._orthonormalize(W, [Y, S[:, :w0]], MW)
+            self._orthonormalize(W, S[:, :ny + w0], MW)
             sz = w0 + b
-            ops.apply_K(S[:, :sz], KS[:, :sz])
-            E_, Z = torch.linalg.eigh(_sym(ops.gram(S[:, :sz], KS[:, :sz])))
+            Sa = S[:, ny:ny + sz]
+            ops.apply_K(Sa, KS[:, :sz])
+            E_, Z = torch.linalg.eigh(_sym(ops.gram(Sa, KS[:, :sz], symmetric=True)))
             lam = E_[:b].clone()
-            Z1 = Z[:, :b]
-            # P = S Z2 basis((Z[:b, b:])^T): the part of the discarded Ritz space that overlaps old X
-            Q = torch.linalg.qr(Z[:b, b:].transpose(0, 1).contiguous()).Q
-            Zp = Z[:, b:] @ Q
-            ops.mix(S[:, :sz], Z1, S2[:, :b])
-            ops.mix(S[:, :sz], Zp, S2[:, b:2 * b])
+            Z1 = Z[:, :b].contiguous()
+            # P spans (I - Z1 Z1^T) E_x: the part of the old X that left the new Ritz block - the same
+            # space as the reference's S Z2 basis((Z[:b, b:])^T) (_lobpcg.py:466), but it needs only the b
+            # wanted Ritz vectors and a b x b Cholesky instead of a Householder QR of a (2b x b) matrix.
+            Tm = -Z1 @ Z1[:b, :].transpose(0, 1)
+            Tm[:b] += eye_b
+            Zp = _orthonormal_columns(Tm)
+            ops.mix(Sa, Z1, S2[:, ny:ny + b])
+            ops.mix(Sa, Zp, S2[:, ny + b:ny + 2 * b])
             ops.mix(KS[:, :sz], Z1, R)  # K X_new for the next residual
             S, S2 = S2, S
             have_p = True
 
-        X = S[:, :b]
+        X = S[:, ny:ny + b]
         return self._polish(X, k, it, rel[:k] if rel is not None else None, history)
 
     # ------------------------------------------------------------------ fp64 Rayleigh-Ritz polish

@@ -101,11 +101,13 @@ int ds_spmm_bsr3(int kind, const int32_t* rowptr, const int32_t* colidx, const v
  * Replaces the dense (k x n)(n x k) products of Rayleigh-Ritz / svqb / ortho in the reference
  * (src/lobpcg/_linalg_utils.py:64-73 via torch.matmul).
  *   A: (n x p) f32, lda ;  B: (n x q) f32 or f64 (b_dtype), ldb
+ *   symmetric != 0 (needs p == q): the caller asserts G is symmetric (e.g. S^T (K S)); only the
+ *     block-upper part is computed and mirrored.
  *   work: device scratch of ds_gram_workspace_bytes(n, p, q) bytes.
  * ---------------------------------------------------------------------------------------------- */
 int64_t ds_gram_workspace_bytes(int64_t n, int p, int q);
 int ds_gram(const float* A, int64_t lda, int p, const void* B, int b_dtype, int64_t ldb, int q,
-            int64_t n, double* G, void* work, int64_t work_bytes, ds_stream_t stream);
+            int64_t n, int symmetric, double* G, void* work, int64_t work_bytes, ds_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Fused block-vector updates of the eigensolver (all (n x ncols) f32 with leading dimensions).

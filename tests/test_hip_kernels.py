@@ -50,7 +50,7 @@ def case(request, dev):
     Km = fem.assemble_stiffness(d, 0.0, 1.0)
     M3, Ms = fem.assemble_mass(v, t, order, MAT[0])
     lam, mu = fem.lame(MAT[1], MAT[2])
-    sysd = TetSystem(v.to(dev), t.to(dev), order, MAT[0])
+    sysd = TetSystem(v.to(dev), t.to(dev), order, MAT[0], reorder=False)  # kernel parity in the caller's numbering
     hops = HipModalOps(sysd, lam, mu)
     cops = CpuModalOps(Kl, Km, M3, v.numpy(), lam, mu)
     return dict(v=v, t=t, order=order, Kl=Kl, Km=Km, M3=M3, Ms=Ms, sys=sysd, hops=hops, cops=cops, lam=lam, mu=mu)
@@ -76,6 +76,28 @@ def test_pattern_and_assembly(case):
     # symmetry and rigid-body null space
     K = case["lam"] * Kl + case["mu"] * Km
     assert abs(K - K.T).max() / abs(K).max() < 1e-12
+
+
+def test_morton_reordering_is_transparent(case, dev):
+    """Internal Morton renumbering: same matrices in the caller's numbering, same products."""
+    from diffsound_amd.modal_ops import HipModalOps, TetSystem
+
+    s0 = case["sys"]
+    s1 = TetSystem(case["v"].to(dev), case["t"].to(dev), case["order"], MAT[0], reorder=True)
+    assert sorted(s1.perm.cpu().tolist()) == list(range(s0.nv))
+    K0, M0 = s0.to_scipy(case["lam"], case["mu"])
+    K1, M1 = s1.to_scipy(case["lam"], case["mu"])
+    assert abs(K0 - K1).max() / abs(K0).max() < 1e-14 and abs(M0 - M1).max() / abs(M0).max() < 1e-14
+    h1 = HipModalOps(s1, case["lam"], case["mu"])
+    g = torch.Generator().manual_seed(3)
+    X = torch.randn((s0.n, 24), generator=g).to(dev)
+    Y0 = torch.empty_like(X)
+    case["hops"].apply_K(X, Y0)
+    Xi = s1.rows_to_internal(X).contiguous()
+    Yi = torch.empty_like(Xi)
+    h1.apply_K(Xi, Yi)
+    assert rel(s1.rows_to_external(Yi).cpu().numpy(), Y0.cpu().numpy()) < 5e-6
+    assert torch.equal(s1.rows_to_external(s1.rows_to_internal(X)), X)
 
 
 def test_assembly_deterministic(case):
@@ -122,6 +144,13 @@ def test_gram(case, dev, p, q):
     assert rel(G.numpy(), ref.numpy()) < 1e-13
     G64 = h.gram(A.to(dev), B.double().to(dev)).cpu()
     assert rel(G64.numpy(), ref.numpy()) < 1e-13
+    if p == q:  # symmetric mode: block-upper part computed, rest mirrored
+        Bs = (B + A) if p == q else B
+        KA = torch.from_numpy(np.asarray(case["cops"].Md @ A.numpy()))
+        Gs = h.gram(A.to(dev), KA.to(dev), symmetric=True).cpu()
+        refs = A.double().T @ KA.double()
+        assert rel(Gs.numpy(), refs.numpy()) < 1e-6  # M A is only fp32-symmetric
+        assert rel(Gs.numpy(), Gs.numpy().T) < 1e-6
 
 
 @pytest.mark.parametrize("p,q", [(8, 40), (80, 40), (240, 80), (216, 72), (80, 200)])

@@ -45,7 +45,7 @@ def test_bowl_eigenvalues_vs_reference(golden, dev, order, fixture):
     assert np.abs((lam * res.a_lambda + mu * res.b_mu).cpu().numpy() / ev - 1).max() < 1e-9
     assert np.abs(res.m_diag.cpu().numpy() - 1).max() < 1e-9
     # invariant-subspace check of the eigenvectors against M (mode order canonicalised by sorting)
-    U = res.vectors.double().cpu().numpy()
+    U = sysd.rows_to_external(res.vectors).double().cpu().numpy()
     K, M3 = sysd.to_scipy(lam, mu)
     R = K @ U - (M3 @ U) * ev[None, :]
     # backward-stable residual of the reference's convergence test (src/lobpcg/_lobpcg.py:318):
