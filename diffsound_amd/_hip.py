@@ -28,8 +28,8 @@ _SIGNATURES = {
     "ds_pattern_export": (_I, [_P, _P, _P, _P, _P, _P]),
     "ds_pattern_free": (None, [_P]),
     "ds_assemble_kml": (_I, [_P, _P, _I64, _I, _I64, _P, _P, _I64, _P, _P, _P, _P, _P, _P, _P]),
-    "ds_combine_material": (_I, [_P, _P, _P, _I64, _P, _I64, _D, _D, _P, _P, _P, _P]),
-    "ds_spmm_bsr3": (_I, [_I, _P, _P, _P, _I64, _P, _I64, _P, _I64, _I, _P]),
+    "ds_combine_material": (_I, [_P, _P, _P, _I64, _P, _I64, _D, _D, _P, _P, _P, _P, _P]),
+    "ds_spmm_bsr3": (_I, [_I, _P, _P, _P, _P, _I64, _P, _I64, _P, _I64, _I, _P]),
     "ds_gram_workspace_bytes": (_I64, [_I64, _I, _I]),
     "ds_gram": (_I, [_P, _I64, _I, _P, _I, _I64, _I, _I64, _I, _P, _P, _I64, _P]),
     "ds_residual": (_I, [_P, _I64, _P, _I64, _P, _I64, _P, _I64, _I, _P, _P, _P]),

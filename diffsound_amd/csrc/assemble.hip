@@ -135,9 +135,17 @@ __global__ void __launch_bounds__(256) assemble_blocks_kernel(const int32_t* __r
 
 __global__ void combine_values_kernel(const double* __restrict__ klam, const double* __restrict__ kmu,
                                       const double* __restrict__ ms, int64_t nnzb, double lam, double mu,
-                                      float* __restrict__ k32, float* __restrict__ ms32) {
+                                      float* __restrict__ k32, float* __restrict__ k32t, float* __restrict__ ms32) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < nnzb * 9) k32[i] = (float)(lam * klam[i] + mu * kmu[i]);
+    if (i < nnzb * 9) {
+        const float v = (float)(lam * klam[i] + mu * kmu[i]);
+        k32[i] = v;
+        if (k32t) {
+            const int64_t blk = i / 9;
+            const int e = (int)(i - blk * 9), row = e / 3, col = e - row * 3;
+            k32t[blk * 9 + col * 3 + row] = v;
+        }
+    }
     if (i < nnzb) ms32[i] = (float)ms[i];
 }
 
@@ -193,12 +201,12 @@ extern "C" int ds_assemble_kml(const float* verts, const int32_t* tets, int64_t 
 
 extern "C" int ds_combine_material(const double* klam, const double* kmu, const double* ms, int64_t nnzb,
                                    const int32_t* diagidx, int64_t nv, double lam, double mu, float* k32,
-                                   float* ms32, float* dinv32, ds_stream_t stream) {
+                                   float* k32t, float* ms32, float* dinv32, ds_stream_t stream) {
     DS_REQUIRE(klam && kmu && ms && diagidx && k32 && ms32 && dinv32, "ds_combine_material: null pointer");
     DS_REQUIRE(nnzb > 0 && nv > 0, "ds_combine_material: empty problem");
     hipStream_t st = ds::as_stream(stream);
     combine_values_kernel<<<(unsigned)ds::ceil_div(nnzb * 9, 256), 256, 0, st>>>(klam, kmu, ms, nnzb, lam, mu, k32,
-                                                                                 ms32);
+                                                                                 k32t, ms32);
     DS_LAUNCH_CHECK("combine_values_kernel");
     diag_inverse_kernel<<<(unsigned)ds::ceil_div(nv, 256), 256, 0, st>>>(klam, kmu, diagidx, nv, lam, mu, dinv32);
     DS_LAUNCH_CHECK("diag_inverse_kernel");

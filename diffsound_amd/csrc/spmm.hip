@@ -11,6 +11,7 @@
 // node groups share a wave.  Block values are fetched by all lanes of a group from the same
 // address (hardware broadcast).  Accumulation in registers, one store per output element.
 // Algorithmic bytes per launch: nnzb*(vals + 4) + (nv+1)*4 + 2*3nv*ncols*sizeof(T).
+#include <algorithm>
 #include <cstdlib>
 
 #include "ds_common.h"
@@ -142,51 +143,23 @@ int launch(const int32_t* rowptr, const int32_t* colidx, const void* vals, int64
 //   merged by two cross-lane shuffles at the end (KIND 1, M = M_s (x) I3, needs no merge: row r only
 //   feeds row r).
 // RS = 1 (ncols <= 256): lane cl loads its 16 bytes of all three rows (three loads per block).
-#define DS_KEEP_SCALAR(x) asm volatile("" : "+s"(x))
-
-template <int KIND, int RS>
-__device__ __forceinline__ void wn_block(const float* __restrict__ vals, int64_t k, int r,
-                                         const __attribute__((ext_vector_type(4))) float& x0,
-                                         const __attribute__((ext_vector_type(4))) float& x1,
-                                         const __attribute__((ext_vector_type(4))) float& x2,
-                                         __attribute__((ext_vector_type(4))) float& acc0,
-                                         __attribute__((ext_vector_type(4))) float& acc1,
-                                         __attribute__((ext_vector_type(4))) float& acc2) {
-    if (KIND == 0) {
-        const float* a = vals + k * 9;
-        float a0 = a[0], a1 = a[1], a2 = a[2], a3 = a[3], a4 = a[4], a5 = a[5], a6 = a[6], a7 = a[7], a8 = a[8];
-        // pin the nine values to SGPRs: they must arrive through s_load, not as per-lane vector loads
-        DS_KEEP_SCALAR(a0); DS_KEEP_SCALAR(a1); DS_KEEP_SCALAR(a2); DS_KEEP_SCALAR(a3); DS_KEEP_SCALAR(a4);
-        DS_KEEP_SCALAR(a5); DS_KEEP_SCALAR(a6); DS_KEEP_SCALAR(a7); DS_KEEP_SCALAR(a8);
-        if (RS == 3) {
-            const float c0 = r == 0 ? a0 : (r == 1 ? a1 : a2);
-            const float c1 = r == 0 ? a3 : (r == 1 ? a4 : a5);
-            const float c2 = r == 0 ? a6 : (r == 1 ? a7 : a8);
-            acc0 += c0 * x0;
-            acc1 += c1 * x0;
-            acc2 += c2 * x0;
-        } else {
-            acc0 += a0 * x0 + a1 * x1 + a2 * x2;
-            acc1 += a3 * x0 + a4 * x1 + a5 * x2;
-            acc2 += a6 * x0 + a7 * x1 + a8 * x2;
-        }
-    } else {
-        float m = vals[k];
-        DS_KEEP_SCALAR(m);
-        acc0 += m * x0;
-        if (RS == 1) {
-            acc1 += m * x1;
-            acc2 += m * x2;
-        }
-    }
-}
+// Row metadata is fetched COOPERATIVELY once per row: lane l loads neighbour id l of the row (one
+// coalesced load) and the row's 3x3 values stream into a per-wave LDS slab with coalesced loads; per
+// block, the id comes back with v_readlane (scalar address arithmetic) and the coefficients with LDS
+// broadcast reads.  The vector-memory pipe then carries only the X panels.  (Two earlier versions:
+// s_load per block -> nine dependent scalar round trips per four blocks; per-lane vector loads of the
+// coefficients -> 720 redundant bytes per block through the texture-addresser, as much as the X panel.
+// Both sat at 1.3 TB/s.)
+constexpr int WN_CHUNK = 64;  // blocks of a row staged per pass
 
 template <int KIND, int RS, int LPN_CT>
 __global__ void __launch_bounds__(256)
     spmm_wave_node_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx,
-                          const float* __restrict__ vals, int64_t nv, const float* __restrict__ X, int64_t ldx,
-                          float* __restrict__ Y, int64_t ldy, int lpn_rt, unsigned nblk) {
+                          const float* __restrict__ vals, const float* __restrict__ vals_t, int64_t nv,
+                          const float* __restrict__ X, int64_t ldx, float* __restrict__ Y, int64_t ldy, int lpn_rt,
+                          unsigned nblk) {
     using f4 = __attribute__((ext_vector_type(4))) float;
+    __shared__ float s_vals[4][WN_CHUNK * 9];
     const int lpn = LPN_CT ? LPN_CT : lpn_rt;
     const unsigned bid = ds::xcd_remap(blockIdx.x, nblk);
     const int lane = threadIdx.x & 63;
@@ -200,44 +173,89 @@ __global__ void __launch_bounds__(256)
     const int r = active ? r_raw : 0;
     const int cl = active ? cl_raw : 0;
     const int c0 = cl * 4;
-    const int kb = rowptr[node], ke = rowptr[node + 1];
-    f4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0, acc2 = acc0;
     const float* xbase = X + (int64_t)r * ldx + c0;
     const int64_t ldx3 = 3 * ldx;
-    int k = kb;
-    for (; k + 4 <= ke; k += 4) {
-        // four neighbour ids first (scalar loads), then all vector loads, then the arithmetic
-        const int j0 = colidx[k], j1 = colidx[k + 1], j2 = colidx[k + 2], j3 = colidx[k + 3];
-        const float* p0 = xbase + (int64_t)j0 * ldx3;
-        const float* p1 = xbase + (int64_t)j1 * ldx3;
-        const float* p2 = xbase + (int64_t)j2 * ldx3;
-        const float* p3 = xbase + (int64_t)j3 * ldx3;
-        f4 xa[4], xb[4], xc[4];
-        xa[0] = *reinterpret_cast<const f4*>(p0);
-        xa[1] = *reinterpret_cast<const f4*>(p1);
-        xa[2] = *reinterpret_cast<const f4*>(p2);
-        xa[3] = *reinterpret_cast<const f4*>(p3);
-        if (RS == 1) {
-            xb[0] = *reinterpret_cast<const f4*>(p0 + ldx);
-            xb[1] = *reinterpret_cast<const f4*>(p1 + ldx);
-            xb[2] = *reinterpret_cast<const f4*>(p2 + ldx);
-            xb[3] = *reinterpret_cast<const f4*>(p3 + ldx);
-            xc[0] = *reinterpret_cast<const f4*>(p0 + 2 * ldx);
-            xc[1] = *reinterpret_cast<const f4*>(p1 + 2 * ldx);
-            xc[2] = *reinterpret_cast<const f4*>(p2 + 2 * ldx);
-            xc[3] = *reinterpret_cast<const f4*>(p3 + 2 * ldx);
+    const int kb = rowptr[node], ke = rowptr[node + 1];
+    float* sv = s_vals[wave];
+    f4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0, acc2 = acc0;
+    for (int kc = kb; kc < ke; kc += WN_CHUNK) {
+        const int cnt = min(WN_CHUNK, ke - kc);  // wave-uniform
+        const int colreg = lane < cnt ? colidx[kc + lane] : 0;
+        float mreg = 0.f;
+        if (KIND == 1) {
+            mreg = lane < cnt ? vals[kc + lane] : 0.f;
+        } else if (RS == 3) {
+            const float* vsrc = vals + (int64_t)kc * 9;
+            for (int t = lane; t < cnt * 9; t += 64) sv[t] = vsrc[t];
+            // same-wave LDS write -> read: order them without a workgroup barrier (rows differ in length)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
+        int u = 0;
+        for (; u + 4 <= cnt; u += 4) {
+            f4 xa[4], xb[4], xc[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) wn_block<KIND, RS>(vals, k + u, r, xa[u], xb[u], xc[u], acc0, acc1, acc2);
-    }
-    for (; k < ke; ++k) {
-        const float* p0 = xbase + (int64_t)colidx[k] * ldx3;
-        f4 xa = *reinterpret_cast<const f4*>(p0), xb = xa, xc = xa;
-        if (RS == 1) {
-            xb = *reinterpret_cast<const f4*>(p0 + ldx);
-            xc = *reinterpret_cast<const f4*>(p0 + 2 * ldx);
+            for (int q = 0; q < 4; ++q) {
+                const int j = __builtin_amdgcn_readlane(colreg, u + q);
+                const float* p = xbase + (int64_t)j * ldx3;
+                xa[q] = *reinterpret_cast<const f4*>(p);
+                if (RS == 1) {
+                    xb[q] = *reinterpret_cast<const f4*>(p + ldx);
+                    xc[q] = *reinterpret_cast<const f4*>(p + 2 * ldx);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (KIND == 1) {
+                    const float m = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mreg), u + q));
+                    acc0 += m * xa[q];
+                    if (RS == 1) {
+                        acc1 += m * xb[q];
+                        acc2 += m * xc[q];
+                    }
+                } else if (RS == 3) {
+                    const float* a = sv + (u + q) * 9 + r;  // column r of the block
+                    acc0 += a[0] * xa[q];
+                    acc1 += a[3] * xa[q];
+                    acc2 += a[6] * xa[q];
+                } else {
+                    const float* a = vals + (int64_t)(kc + u + q) * 9;  // same address in every lane: one request
+                    acc0 += a[0] * xa[q] + a[1] * xb[q] + a[2] * xc[q];
+                    acc1 += a[3] * xa[q] + a[4] * xb[q] + a[5] * xc[q];
+                    acc2 += a[6] * xa[q] + a[7] * xb[q] + a[8] * xc[q];
+                }
+            }
         }
-        wn_block<KIND, RS>(vals, k, r, xa, xb, xc, acc0, acc1, acc2);
+        for (; u < cnt; ++u) {
+            const int j = __builtin_amdgcn_readlane(colreg, u);
+            const float* p = xbase + (int64_t)j * ldx3;
+            const f4 x0 = *reinterpret_cast<const f4*>(p);
+            if (KIND == 1) {
+                const float m = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mreg), u));
+                acc0 += m * x0;
+                if (RS == 1) {
+                    acc1 += m * *reinterpret_cast<const f4*>(p + ldx);
+                    acc2 += m * *reinterpret_cast<const f4*>(p + 2 * ldx);
+                }
+            } else if (RS == 3) {
+                const float* a = sv + u * 9 + r;
+                acc0 += a[0] * x0;
+                acc1 += a[3] * x0;
+                acc2 += a[6] * x0;
+            } else {
+                const float* a = vals + (int64_t)(kc + u) * 9;
+                const f4 x1 = *reinterpret_cast<const f4*>(p + ldx);
+                const f4 x2 = *reinterpret_cast<const f4*>(p + 2 * ldx);
+                acc0 += a[0] * x0 + a[1] * x1 + a[2] * x2;
+                acc1 += a[3] * x0 + a[4] * x1 + a[5] * x2;
+                acc2 += a[6] * x0 + a[7] * x1 + a[8] * x2;
+            }
+        }
+        if (KIND == 0 && RS == 3 && kc + WN_CHUNK < ke) {  // the slab is rewritten by the next pass
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
     }
     if (RS == 3 && KIND == 0) {
         // merge the three row groups: lanes [0,lpn) += lanes [lpn,2lpn) + lanes [2lpn,3lpn)
@@ -259,38 +277,39 @@ __global__ void __launch_bounds__(256)
 }
 
 template <int KIND, int RS, int LPN_CT>
-int launch_wn(const int32_t* rowptr, const int32_t* colidx, const void* vals, int64_t nv, const void* X, int64_t ldx,
-              void* Y, int64_t ldy, int lpn, hipStream_t st) {
+int launch_wn(const int32_t* rowptr, const int32_t* colidx, const void* vals, const void* vals_t, int64_t nv,
+              const void* X, int64_t ldx, void* Y, int64_t ldy, int lpn, hipStream_t st) {
     const int64_t nblk = ds::ceil_div(nv, 4);
     spmm_wave_node_kernel<KIND, RS, LPN_CT><<<(unsigned)nblk, 256, 0, st>>>(
-        rowptr, colidx, static_cast<const float*>(vals), nv, static_cast<const float*>(X), ldx,
-        static_cast<float*>(Y), ldy, lpn, (unsigned)nblk);
+        rowptr, colidx, static_cast<const float*>(vals), static_cast<const float*>(vals_t), nv,
+        static_cast<const float*>(X), ldx, static_cast<float*>(Y), ldy, lpn, (unsigned)nblk);
     DS_LAUNCH_CHECK("spmm_wave_node_kernel");
     return DS_OK;
 }
 
 template <int KIND>
-int launch_fast(const int32_t* rowptr, const int32_t* colidx, const void* vals, int64_t nv, const void* X, int64_t ldx,
-                void* Y, int64_t ldy, int ncols, hipStream_t st) {
+int launch_fast(const int32_t* rowptr, const int32_t* colidx, const void* vals, const void* vals_t, int64_t nv,
+                const void* X, int64_t ldx, void* Y, int64_t ldy, int ncols, hipStream_t st) {
     const int lpn = ncols / 4;
     if (lpn <= 21) {
         switch (lpn) {  // the solver's block widths get compile-time lane splits and their own kernel names
-            case 18: return launch_wn<KIND, 3, 18>(rowptr, colidx, vals, nv, X, ldx, Y, ldy, lpn, st);
-            case 20: return launch_wn<KIND, 3, 20>(rowptr, colidx, vals, nv, X, ldx, Y, ldy, lpn, st);
-            default: return launch_wn<KIND, 3, 0>(rowptr, colidx, vals, nv, X, ldx, Y, ldy, lpn, st);
+            case 18: return launch_wn<KIND, 3, 18>(rowptr, colidx, vals, vals_t, nv, X, ldx, Y, ldy, lpn, st);
+            case 20: return launch_wn<KIND, 3, 20>(rowptr, colidx, vals, vals_t, nv, X, ldx, Y, ldy, lpn, st);
+            default: return launch_wn<KIND, 3, 0>(rowptr, colidx, vals, vals_t, nv, X, ldx, Y, ldy, lpn, st);
         }
     }
     switch (lpn) {
-        case 54: return launch_wn<KIND, 1, 54>(rowptr, colidx, vals, nv, X, ldx, Y, ldy, lpn, st);
-        case 60: return launch_wn<KIND, 1, 60>(rowptr, colidx, vals, nv, X, ldx, Y, ldy, lpn, st);
-        default: return launch_wn<KIND, 1, 0>(rowptr, colidx, vals, nv, X, ldx, Y, ldy, lpn, st);
+        case 54: return launch_wn<KIND, 1, 54>(rowptr, colidx, vals, vals_t, nv, X, ldx, Y, ldy, lpn, st);
+        case 60: return launch_wn<KIND, 1, 60>(rowptr, colidx, vals, vals_t, nv, X, ldx, Y, ldy, lpn, st);
+        default: return launch_wn<KIND, 1, 0>(rowptr, colidx, vals, vals_t, nv, X, ldx, Y, ldy, lpn, st);
     }
 }
 
 }  // namespace
 
-extern "C" int ds_spmm_bsr3(int kind, const int32_t* rowptr, const int32_t* colidx, const void* vals, int64_t nv,
-                            const void* X, int64_t ldx, void* Y, int64_t ldy, int ncols, ds_stream_t stream) {
+extern "C" int ds_spmm_bsr3(int kind, const int32_t* rowptr, const int32_t* colidx, const void* vals,
+                            const void* vals_t, int64_t nv, const void* X, int64_t ldx, void* Y, int64_t ldy,
+                            int ncols, ds_stream_t stream) {
     DS_REQUIRE(rowptr && colidx && vals && X && Y, "ds_spmm_bsr3: null pointer");
     DS_REQUIRE(nv > 0 && ncols > 0, "ds_spmm_bsr3: empty problem");
     DS_REQUIRE(kind >= 0 && kind <= 3, "ds_spmm_bsr3: unknown kind %d", kind);
@@ -304,8 +323,8 @@ extern "C" int ds_spmm_bsr3(int kind, const int32_t* rowptr, const int32_t* coli
         if (ncols % 4 == 0 && ncols <= 256 && (xalign & 15) == 0 && (yalign & 15) == 0) {
             static const bool legacy = getenv("DS_SPMM_LEGACY") != nullptr;  // A/B switch for benchmarking
             if (!legacy)
-                return kind == 0 ? launch_fast<0>(rowptr, colidx, vals, nv, X, ldx, Y, ldy, ncols, st)
-                                 : launch_fast<1>(rowptr, colidx, vals, nv, X, ldx, Y, ldy, ncols, st);
+                return kind == 0 ? launch_fast<0>(rowptr, colidx, vals, vals_t, nv, X, ldx, Y, ldy, ncols, st)
+                                 : launch_fast<1>(rowptr, colidx, vals, vals_t, nv, X, ldx, Y, ldy, ncols, st);
             return kind == 0 ? launch<0, float, float, float, 4>(rowptr, colidx, vals, nv, X, ldx, Y, ldy, ncols, st)
                              : launch<1, float, float, float, 4>(rowptr, colidx, vals, nv, X, ldx, Y, ldy, ncols, st);
         }

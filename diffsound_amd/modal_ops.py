@@ -132,6 +132,7 @@ class _HipBlockOps:
 
     dtype = torch.float32
     m_kind = 1  # 1: M = M_s (x) I3 (one scalar per block), 0: general 3x3 blocks
+    k32t = None
 
     def _init_common(self, rowptr, colidx, nv, device):
         self.rowptr, self.colidx = rowptr, colidx
@@ -161,8 +162,9 @@ class _HipBlockOps:
             if timed:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-            _hip.check(self._L.ds_spmm_bsr3(kind, p(self.rowptr), p(self.colidx), p(vals), self.nv, p(xs), _ld(xs),
-                                            p(os_), _ld(os_), c1 - c0, _hip.stream_ptr()), "ds_spmm_bsr3")
+            vt = self.k32t if (kind == 0 and vals is self.k32) else None
+            _hip.check(self._L.ds_spmm_bsr3(kind, p(self.rowptr), p(self.colidx), p(vals), p(vt), self.nv, p(xs),
+                                            _ld(xs), p(os_), _ld(os_), c1 - c0, _hip.stream_ptr()), "ds_spmm_bsr3")
             if timed:
                 e1.record()
                 self.spmm_events.append((e0, e1))
@@ -253,6 +255,7 @@ class HipModalOps(_HipBlockOps):
         self._init_common(system.rowptr, system.colidx, system.nv, system.device)
         dev = self.device
         self.k32 = torch.empty((system.nnzb, 9), dtype=torch.float32, device=dev)
+        self.k32t = torch.empty((system.nnzb, 9), dtype=torch.float32, device=dev)  # blocks transposed
         self.ms32 = torch.empty((system.nnzb,), dtype=torch.float32, device=dev)
         self.dinv = torch.empty((system.nv, 9), dtype=torch.float32, device=dev)
         self.set_material(lam, mu)
@@ -263,8 +266,8 @@ class HipModalOps(_HipBlockOps):
         p = _hip.ptr
         self.lame = (float(lam), float(mu))
         _hip.check(self._L.ds_combine_material(p(s.klam), p(s.kmu), p(s.ms), s.nnzb, p(s.diagidx), s.nv,
-                                               float(lam), float(mu), p(self.k32), p(self.ms32), p(self.dinv),
-                                               _hip.stream_ptr()), "ds_combine_material")
+                                               float(lam), float(mu), p(self.k32), p(self.k32t), p(self.ms32),
+                                               p(self.dinv), _hip.stream_ptr()), "ds_combine_material")
 
     def _rigid_basis(self):
         """Translations + rotations about the centroid, M-orthonormalised in fp64; stored (n, 8) fp32 with
@@ -335,6 +338,7 @@ class HipSparseOps(_HipBlockOps):
         rowptr[1:] = torch.cumsum(torch.bincount(rows, minlength=nv), 0)
         self._init_common(rowptr.to(torch.int32), (keys % nv).to(torch.int32), nv, dev)
         self.k32 = self.a64.float().contiguous()
+        self.k32t = self.k32.reshape(-1, 3, 3).transpose(1, 2).reshape(-1, 9).contiguous()
         self.ms32 = self.b64.float().contiguous()
         diag = self.a64[torch.searchsorted(keys, torch.arange(nv, device=dev) * (nv + 1))].reshape(nv, 3, 3)
         eye = torch.eye(3, dtype=torch.float64, device=dev)

@@ -77,11 +77,12 @@ int ds_assemble_kml(const float* verts, const int32_t* tets, int64_t T, int N, i
                     const double* dtab, const double* mtab, double* tetgeo,
                     double* klam, double* kmu, double* ms, ds_stream_t stream);
 
-/* K32 = (float)(lam*K_lambda + mu*K_mu), Ms32 = (float)M_s, and the fp32 inverse of the 3x3 diagonal
- * blocks of K (block-Jacobi preconditioner).  Per material hypothesis. */
+/* K32 = (float)(lam*K_lambda + mu*K_mu) (k32t: the same with every 3x3 block transposed, may be NULL),
+ * Ms32 = (float)M_s, and the fp32 inverse of the 3x3 diagonal blocks of K (block-Jacobi preconditioner).
+ * Per material hypothesis. */
 int ds_combine_material(const double* klam, const double* kmu, const double* ms, int64_t nnzb,
                         const int32_t* diagidx, int64_t nv, double lam, double mu,
-                        float* k32, float* ms32, float* dinv32, ds_stream_t stream);
+                        float* k32, float* k32t, float* ms32, float* dinv32, ds_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Block SpMM  Y = A X  on the BSR-3 pattern (the HBM-roofline kernel).  Replaces torch.sparse.mm
@@ -91,10 +92,13 @@ int ds_combine_material(const double* klam, const double* kmu, const double* ms,
  *   kind 1: A = M,   vals (nnzb)     f32 (M_s)     X, Y f32
  *   kind 2: A = K_*, vals (nnzb x 9) f64           X f32, Y f64   (polish / read-out)
  *   kind 3: A = M,   vals (nnzb)     f64 (M_s)     X f32, Y f64
+ * vals_t (kind 0 only, may be NULL): the same blocks stored transposed, vals_t[k][r][i] = K_k[i][r]
+ *   (ds_combine_material writes it); enables the one-load-per-block path for ncols <= 84.
  * X: (3nv x ncols) ld = ldx ; Y: (3nv x ncols) ld = ldy ; X and Y must not overlap.
  * ---------------------------------------------------------------------------------------------- */
-int ds_spmm_bsr3(int kind, const int32_t* rowptr, const int32_t* colidx, const void* vals, int64_t nv,
-                 const void* X, int64_t ldx, void* Y, int64_t ldy, int ncols, ds_stream_t stream);
+int ds_spmm_bsr3(int kind, const int32_t* rowptr, const int32_t* colidx, const void* vals,
+                 const void* vals_t, int64_t nv, const void* X, int64_t ldx, void* Y, int64_t ldy, int ncols,
+                 ds_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Tall-skinny Gram  G = A^T B  (p x q, fp64, row-major, ld = q) with MFMA, fp64 accumulation.

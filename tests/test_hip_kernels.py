@@ -263,7 +263,7 @@ def test_errors_are_loud(dev):
 
     L = _hip.lib()
     with pytest.raises(RuntimeError):
-        _hip.check(L.ds_spmm_bsr3(7, None, None, None, 0, None, 0, None, 0, 0, None), "ds_spmm_bsr3")
+        _hip.check(L.ds_spmm_bsr3(7, None, None, None, None, 0, None, 0, None, 0, 0, None), "ds_spmm_bsr3")
     with pytest.raises(RuntimeError):
         from diffsound_amd.modal_ops import TetSystem
 

@@ -9,7 +9,7 @@ cells = int(sys.argv[1]) if len(sys.argv) > 1 else 26
 dev = torch.device('cuda')
 v, t = meshgen.kuhn_box(cells)
 mesh = TetMesh(torch.from_numpy(v).to(dev), torch.from_numpy(t).long().to(dev)).to_high_order(2)
-for reorder in (False, True):
+for reorder in (True,):
     sysd = TetSystem(mesh.vertices, mesh.tets, 2, 2700.0, reorder=reorder)
     ops = HipModalOps(sysd, 2e10, 2e10)
     for ncols in (80, 240):
