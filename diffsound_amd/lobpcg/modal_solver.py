@@ -88,14 +88,18 @@ def _orthonormalizer(G):
 
 def _orthonormal_columns(Tm):
     """Orthonormal basis (Euclidean, coefficient space) of the columns of the small dense Tm (r x c):
-    scaled Cholesky-QR with a Householder-QR fallback."""
-    G = Tm.transpose(0, 1) @ Tm
-    d = torch.rsqrt(torch.clamp(G.diagonal(), min=1e-300))
-    L, info = torch.linalg.cholesky_ex(_sym(G) * d[:, None] * d[None, :])
-    if int(info) != 0 or not bool(torch.isfinite(L).all()):
-        return torch.linalg.qr(Tm).Q
-    Li = torch.linalg.solve_triangular(L, torch.eye(L.shape[0], dtype=L.dtype, device=L.device), upper=False)
-    return Tm @ (d[:, None] * Li.transpose(0, 1))
+    scaled Cholesky-QR applied twice (one pass leaves an orthogonality error eps*cond^2, which would
+    put a 1e-8 floor under the fp64 residuals), with a Householder-QR fallback."""
+    Q = Tm
+    for _ in range(2):
+        G = Q.transpose(0, 1) @ Q
+        d = torch.rsqrt(torch.clamp(G.diagonal(), min=1e-300))
+        L, info = torch.linalg.cholesky_ex(_sym(G) * d[:, None] * d[None, :])
+        if int(info) != 0 or not bool(torch.isfinite(L).all()):
+            return torch.linalg.qr(Tm).Q
+        Li = torch.linalg.solve_triangular(L, torch.eye(L.shape[0], dtype=L.dtype, device=L.device), upper=False)
+        Q = Q @ (d[:, None] * Li.transpose(0, 1))
+    return Q
 
 
 class ChebyshevBlockJacobi:

@@ -1,0 +1,95 @@
+"""The C-ABI library loads on a CPU-only box and exports every symbol the header declares; the
+host-side symbolic phase (ds_pattern_*) is exercised for real (it needs no GPU)."""
+import os
+import re
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _lib():
+    from diffsound_amd import _hip
+
+    if not os.path.exists(_hip.LIB_PATH):
+        import __graft_entry__ as g
+
+        g.build()
+    return _hip
+
+
+def test_header_symbols_exported():
+    _hip = _lib()
+    header = open(os.path.join(ROOT, "include", "diffsound_hip.h")).read()
+    declared = set(re.findall(r"\b(ds_[a-z0-9_]+)\s*\(", header))
+    declared -= {"ds_pattern_t", "ds_stream_t"}
+    assert declared, "no declarations parsed"
+    lib = _hip.lib()
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in include/diffsound_hip.h but not exported"
+    assert declared == set(_hip.EXPORTED_SYMBOLS), (declared ^ set(_hip.EXPORTED_SYMBOLS))
+    assert lib.ds_abi_version() == 3
+    assert lib.ds_last_error() is not None
+
+
+def _clique_pattern(t, nv):
+    N = t.shape[1]
+    pairs = np.unique(np.stack([np.repeat(t, N, axis=1).reshape(-1), np.tile(t, (1, N)).reshape(-1)], 1), axis=0)
+    ref = sp.csr_matrix((np.ones(len(pairs)), (pairs[:, 0], pairs[:, 1])), shape=(nv, nv))
+    ref.sort_indices()
+    return ref
+
+
+@pytest.mark.parametrize("order", [1, 2])
+def test_pattern_build(order):
+    _hip = _lib()
+    from diffsound_amd import meshgen
+    from oracle import fem
+
+    v, t = meshgen.kuhn_box(3)
+    v, t = fem.to_high_order(torch.from_numpy(v), torch.from_numpy(t).long(), order)
+    nv = v.shape[0]
+    for threads in (1, 3):
+        pat = _hip.Pattern(t.to(torch.int32).contiguous(), nv, nthreads=threads)
+        ref = _clique_pattern(t.numpy(), nv)
+        assert pat.nnzb == ref.nnz
+        assert np.array_equal(pat.rowptr.numpy(), ref.indptr)
+        assert np.array_equal(pat.colidx.numpy(), ref.indices)
+        N = t.shape[1]
+        cl = pat.clist.numpy().astype(np.int64)
+        slot = np.repeat(np.arange(pat.nnzb), np.diff(pat.cptr.numpy()))
+        te, a, b = cl // (N * N), (cl % (N * N)) // N, cl % N
+        rows = np.repeat(np.arange(nv), np.diff(pat.rowptr.numpy()))
+        tn = t.numpy()
+        assert np.array_equal(tn[te, a], rows[slot]) and np.array_equal(tn[te, b], pat.colidx.numpy()[slot])
+        assert np.array_equal(np.sort(cl), np.arange(len(cl)))  # every contribution exactly once
+        assert all(np.all(np.diff(cl[s:e]) > 0) for s, e in zip(pat.cptr.numpy()[:50], pat.cptr.numpy()[1:51]))
+        assert np.array_equal(pat.colidx.numpy()[pat.diagidx.numpy()], np.arange(nv))
+
+
+def test_pattern_errors_are_loud():
+    _hip = _lib()
+    bad = torch.zeros((2, 5), dtype=torch.int32)
+    with pytest.raises(RuntimeError, match="N must be 4 or 10"):
+        _hip.Pattern(bad, 4)
+    oob = torch.tensor([[0, 1, 2, 9]], dtype=torch.int32)
+    with pytest.raises(RuntimeError, match="out of range"):
+        _hip.Pattern(oob, 4)
+    with pytest.raises(ValueError):
+        _hip.Pattern(torch.zeros((2, 4), dtype=torch.int64), 4)
+
+
+def test_no_cpu_fallback():
+    """Product entry points refuse CPU tensors instead of silently computing on the host."""
+    from diffsound_amd.diffelastic.diff_model import DiffSoundObj
+    from diffsound_amd.modal_ops import TetSystem
+
+    v = torch.rand((8, 3))
+    t = torch.tensor([[0, 1, 2, 3]])
+    with pytest.raises(RuntimeError, match="HIP"):
+        TetSystem(v, t, 1, 1000.0)
+    with pytest.raises(RuntimeError, match="HIP"):
+        DiffSoundObj(vertices=v, tets=t, mode_num=2)

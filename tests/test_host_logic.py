@@ -1,0 +1,82 @@
+"""Host-side logic of the product package that needs no GPU: element tables vs the reference's
+(golden) constants, synthetic mesh generator, Morton ordering, Gmsh I/O, hypothesis sharding."""
+import numpy as np
+import pytest
+import torch
+
+from diffsound_amd import fem_tables, meshgen
+from diffsound_amd.diffelastic import mesh as dmesh
+from diffsound_amd.modal_ops import morton_order
+from diffsound_amd.pipeline import shard_hypotheses
+
+
+@pytest.mark.parametrize("order", [1, 2])
+def test_tables_match_reference_constants(golden, order):
+    g = golden("g1_constants.npz")
+    pts, w = fem_tables.gauss_rule(order)
+    assert np.array_equal(pts, g[f"gauss_pts_o{order}"]) and np.array_equal(w, g[f"gauss_w_o{order}"])
+    assert np.array_equal(fem_tables.shape_values(pts, order), g[f"N_o{order}"])
+    assert np.array_equal(fem_tables.shape_gradients(pts, order), g[f"dN_dL_o{order}"])
+    N = fem_tables.NODES_PER_TET[order]
+    ref_mm = g[f"elem_mass_o{order}"].reshape(N, 3, N, 3)[:, 0, :, 0]
+    assert np.array_equal(fem_tables.mass_table_f32(order), ref_mm)
+    # stiffness table = the reference's Gauss sum of dN (x) dN
+    dN = g[f"dN_dL_o{order}"].astype(np.float64)
+    ref = np.einsum("g,gak,gbl->akbl", g[f"gauss_w_o{order}"].astype(np.float64), dN, dN)
+    assert np.allclose(fem_tables.stiffness_table(order), ref, rtol=0, atol=1e-15)
+
+
+def test_kuhn_box_matches_fixture(golden):
+    g = golden("g2_cube2.npz")
+    v, t = meshgen.kuhn_box(2)
+    assert np.array_equal(v, g["verts"]) and np.array_equal(t, g["tets"])
+    v, t = meshgen.kuhn_box(26)
+    assert t.shape == (105456, 4) and v.shape == (27 ** 3, 3)
+    # conforming, positive total volume = box volume
+    p = v[t].astype(np.float64)
+    vol = np.abs(np.linalg.det(p[:, :3] - p[:, 3:4])).sum() / 6
+    assert abs(vol / (0.10 * 0.08 * 0.06) - 1) < 1e-5
+
+
+def test_to_high_order_matches_reference(golden):
+    g = golden("g2_cube2.npz")
+    m = dmesh.TetMesh(torch.from_numpy(g["verts"]), torch.from_numpy(g["tets"])).to_high_order(2)
+    assert np.array_equal(m.vertices.numpy(), g["o2_vertices"]) and np.array_equal(m.tets.numpy(), g["o2_tets"])
+    assert np.array_equal(m.transform_matrix.numpy(), g["o2_transform"])
+
+
+def test_morton_order_is_a_locality_preserving_permutation():
+    v, _ = meshgen.kuhn_box(8)
+    perm = morton_order(torch.from_numpy(v))
+    assert sorted(perm.tolist()) == list(range(len(v)))
+    p = v[perm.numpy()]
+    # consecutive nodes are close: mean hop is a small multiple of the grid step
+    hop = np.linalg.norm(np.diff(p, axis=0), axis=1).mean()
+    assert hop < 3 * 0.1 / 8
+
+
+def test_gmsh_roundtrip(tmp_path):
+    v, t = meshgen.kuhn_box(2)
+    path = str(tmp_path / "m.msh")
+    dmesh.write_gmsh22(path, v, t)
+    pts, tets = dmesh.read_gmsh22(path)
+    assert np.allclose(pts, v) and np.array_equal(tets, t)
+
+
+def test_gmsh_reader_on_reference_style_file(golden):
+    # the bowl fixture was read from the reference's Gmsh 2.2 binary file; re-emit and re-read it
+    m = golden("g0_bowl_mesh.npz")
+    import tempfile, os
+
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "bowl.obj_.msh")
+        dmesh.write_gmsh22(path, m["verts"], m["tets"])
+        pts, tets = dmesh.read_gmsh22(path)
+    assert np.array_equal(pts.astype(np.float32), m["verts"]) and np.array_equal(tets, m["tets"])
+
+
+def test_shard_hypotheses_partitions():
+    for num, world in ((64, 8), (7, 2), (3, 4)):
+        parts = [shard_hypotheses(num, r, world) for r in range(world)]
+        assert sorted(sum(parts, [])) == list(range(num))
+        assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1

@@ -1,0 +1,94 @@
+"""The solver driver (host logic of diffsound_amd.lobpcg.modal_solver) on CPU, with the oracle's
+CpuModalOps standing in for the HIP kernels: convergence to ARPACK's eigenvalues, tracker contract,
+force_stop, warm start, the reference's ValueError."""
+import numpy as np
+import pytest
+import scipy.sparse.linalg as spla
+import torch
+
+from diffsound_amd import meshgen
+from diffsound_amd.lobpcg.modal_solver import ModalSolver, SolverConfig
+from oracle import fem
+from oracle.ops_cpu import CpuModalOps
+
+MAT = (2700.0, 5e10, 0.25)
+
+
+@pytest.fixture(scope="module")
+def cube():
+    v, t = meshgen.kuhn_box(4)
+    v, t = fem.to_high_order(torch.from_numpy(v), torch.from_numpy(t).long(), 2)
+    d = fem.OracleDeform(v, t, 2)
+    Kl, Km = fem.assemble_stiffness(d, 1.0, 0.0), fem.assemble_stiffness(d, 0.0, 1.0)
+    M3, _ = fem.assemble_mass(v, t, 2, MAT[0])
+    lam, mu = fem.lame(MAT[1], MAT[2])
+    K = (lam * Kl + mu * Km).tocsr()
+    ref = np.sort(spla.eigsh(K, M=M3, k=16 + 6, sigma=20000, return_eigenvectors=False))[6:]
+    return dict(Kl=Kl, Km=Km, M3=M3, v=v.numpy(), lam=lam, mu=mu, ref=ref, K=K)
+
+
+@pytest.mark.parametrize("dtype,tol_eig", [(torch.float32, 1e-6), (torch.float64, 1e-9)])
+def test_converges_to_arpack(cube, dtype, tol_eig):
+    ops = CpuModalOps(cube["Kl"], cube["Km"], cube["M3"], cube["v"], cube["lam"], cube["mu"], dtype=dtype)
+    # The oracle's K restates the reference's fp32 shape-function gradients, so its rigid modes are only
+    # null vectors to ~1e-8 ||K||; with the ANALYTIC rigid basis deflated, the backward
+    # residual of the fp64 run therefore floors near 1e-8 (the HIP assembly is fp64 and has no such floor).
+    tol = 0.0 if dtype == torch.float32 else 5e-8
+    res = ModalSolver(ops, SolverConfig(block=24, lmax_cap=10.0, tol=tol)).solve(16)
+    ev = res.eigenvalues.numpy()
+    assert np.abs(ev - cube["ref"]).max() / cube["ref"].max() < tol_eig
+    assert np.abs(ev / cube["ref"] - 1).max() < 100 * tol_eig
+    assert res.iterations < 60
+    lam, mu = cube["lam"], cube["mu"]
+    assert np.abs((lam * res.a_lambda + mu * res.b_mu).numpy() / ev - 1).max() < 1e-9
+    U = res.vectors.double().numpy()
+    assert np.abs(U.T @ (cube["M3"] @ U) - np.eye(16)).max() < 1e-5
+    # rigid modes were deflated: modes are M-orthogonal to the rigid basis
+    Y = ops.rigid.double().numpy()
+    assert np.abs(Y.T @ (cube["M3"] @ U)).max() < 1e-5
+
+
+def test_tracker_contract_and_force_stop(cube):
+    ops = CpuModalOps(cube["Kl"], cube["Km"], cube["M3"], cube["v"], cube["lam"], cube["mu"])
+    seen = []
+
+    def tracker(w):
+        seen.append((w.ivars["istep"], w.ivars["converged_count"], w.tvars["rerr"].shape[0]))
+        if w.ivars["istep"] == 3:
+            w.bvars["force_stop"] = True
+
+    res = ModalSolver(ops, SolverConfig(block=24)).solve(16, tracker=tracker)
+    assert [s[0] for s in seen] == [0, 1, 2, 3] and res.iterations == 3
+    assert all(s[2] == 16 for s in seen)
+    counts = [s[1] for s in seen]
+    assert counts == sorted(counts)
+
+
+def test_warm_start_needs_fewer_iterations(cube):
+    ops = CpuModalOps(cube["Kl"], cube["Km"], cube["M3"], cube["v"], cube["lam"], cube["mu"])
+    cold = ModalSolver(ops, SolverConfig(block=24)).solve(16)
+    lam2, mu2 = fem.lame(MAT[1] * 1.05, MAT[2] + 0.01)
+    ops2 = CpuModalOps(cube["Kl"], cube["Km"], cube["M3"], cube["v"], lam2, mu2)
+    warm = ModalSolver(ops2, SolverConfig(block=24)).solve(16, X0=cold.block_vectors)
+    cold2 = ModalSolver(ops2, SolverConfig(block=24)).solve(16)
+    assert warm.iterations < cold2.iterations
+    assert np.abs(warm.eigenvalues.numpy() / cold2.eigenvalues.numpy() - 1).max() < 1e-6
+
+
+def test_too_small_problem_raises_like_the_reference(cube):
+    ops = CpuModalOps(cube["Kl"], cube["Km"], cube["M3"], cube["v"], cube["lam"], cube["mu"])
+    with pytest.raises(ValueError, match="not applicable"):
+        ModalSolver(ops, SolverConfig(block=ops.n // 3 + 8)).solve(ops.n // 3)
+
+
+def test_underestimated_lmax_is_guarded(cube):
+    """The power-iteration estimate of lambda_max(T K) times its safety factor bounds the true value."""
+    ops = CpuModalOps(cube["Kl"], cube["Km"], cube["M3"], cube["v"], cube["lam"], cube["mu"], dtype=torch.float64)
+    s = ModalSolver(ops, SolverConfig(block=24))
+    n = ops.n
+    import scipy.sparse as sp
+
+    Dinv = sp.block_diag([b for b in ops.Dinv.numpy()], format="csr")
+    true = spla.eigs(Dinv @ cube["K"], k=1, which="LM", return_eigenvectors=False, tol=1e-6).real.max()
+    assert s.precond.lmax >= true
+    assert s.precond.lmax <= 10.0 * 1.2
