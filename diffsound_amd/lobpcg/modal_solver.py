@@ -39,6 +39,7 @@ class SolverConfig:
     maxit: int = 400
     ortho_passes: int = 2
     check_every: int = 1
+    lock: bool = True  # hard-lock converged leading columns (reference S_ = S[:, nc:ns])
     seed: int = 0
     cheb_degree: int = 8  # terms of the Chebyshev polynomial preconditioner (1 = plain block-Jacobi)
     cheb_ratio: float = 100.0  # the polynomial targets the interval [lmax/ratio, lmax] of T K
@@ -246,53 +247,65 @@ class ModalSolver:
         ops.mix(X, Z, S2[:, ny:ny + b])
         S, S2 = S2, S
         ops.mix(KS[:, :b], Z, R)  # R holds K X for the first residual
-        have_p = False
         history = []
-        rel = None
         it = 0
-        eye_b = torch.eye(b, dtype=torch.float64, device=dev)
+        ncl = 0  # locked (converged) leading columns, kept a multiple of 4 for 16-byte aligned slices
+        npc = 0  # columns of P
+        rel = torch.full((b,), float("inf"), dtype=torch.float64, device=dev)
         for it in range(cfg.maxit + 1):
+            na = b - ncl
             X = S[:, ny:ny + b]
-            ops.apply_M(X, MX)
-            rn2, xn2 = ops.residual(R, MX, X, lam)  # R <- R - MX*lam in place; ||R_j||^2, ||X_j||^2 (fp64)
-            rel = torch.sqrt(rn2 / xn2) / (A_norm + lam.abs() * B_norm)
-            if it % cfg.check_every == 0 or it == cfg.maxit:
-                relk = rel[:k]
-                conv = (relk < tol).to(torch.int32)
-                # leading converged pairs only, to keep strict ordering (reference _lobpcg.py:321-328)
-                nconv = int(torch.cumprod(conv, 0).sum())
-                history.append((it, float(relk.max())))
-                state.ivars.update(istep=it, converged_count=nconv, iterations_left=cfg.maxit - it)
-                state.tvars["rerr"] = relk
-                state.E, state.X = lam, X
-                if tracker is not None:
-                    tracker(state)
-                if nconv >= k or it == cfg.maxit or state.bvars.get("force_stop", False):
-                    break
-            w0 = 2 * b if have_p else b
-            W = S[:, ny + w0:ny + w0 + b]
-            self.precond_apply(R, W)
-            self._orthonormalize(W, S[:, :ny + w0], MW)
-            sz = w0 + b
-            Sa = S[:, ny:ny + sz]
+            Xa = X[:, ncl:]
+            ops.apply_M(Xa, MX[:, :na])
+            # R <- K X - M X lam on the active columns (in place), with ||R_j||^2 and ||X_j||^2 in fp64
+            rn2, xn2 = ops.residual(R[:, :na], MX[:, :na], Xa, lam[ncl:])
+            rel[ncl:] = torch.sqrt(rn2 / xn2) / (A_norm + lam[ncl:].abs() * B_norm)
+            relk = rel[:k]
+            conv = (relk < tol).to(torch.int32)
+            # leading converged pairs only, to keep strict ordering (reference _lobpcg.py:321-328)
+            nconv = int(torch.cumprod(conv, 0).sum())
+            history.append((it, float(relk.max())))
+            state.ivars.update(istep=it, converged_count=nconv, iterations_left=cfg.maxit - it)
+            state.tvars["rerr"] = relk
+            state.E, state.X = lam, X
+            if tracker is not None:
+                tracker(state)
+            if nconv >= k or it == cfg.maxit or state.bvars.get("force_stop", False):
+                break
+            # hard locking as in the reference (S_ = S[:, nc:ns], _lobpcg.py:458): converged leading columns
+            # leave the Rayleigh-Ritz problem, the residual block and the preconditioner; they stay in V
+            new_ncl = (nconv // 4) * 4 if cfg.lock else 0
+            if new_ncl > ncl:
+                shift = new_ncl - ncl
+                R[:, :na - shift].copy_(R[:, shift:na].clone())
+                ncl = new_ncl
+                na = b - ncl
+            w0 = ny + b + npc
+            W = S[:, w0:w0 + na]
+            self.precond_apply(R[:, :na], W)
+            self._orthonormalize(W, S[:, :w0], MW[:, :na])
+            sz = na + npc + na
+            Sa = S[:, ny + ncl:ny + ncl + sz]
             ops.apply_K(Sa, KS[:, :sz])
             E_, Z = torch.linalg.eigh(_sym(ops.gram(Sa, KS[:, :sz], symmetric=True)))
-            lam = E_[:b].clone()
-            Z1 = Z[:, :b].contiguous()
-            # P spans (I - Z1 Z1^T) E_x: the part of the old X that left the new Ritz block - the same
-            # space as the reference's S Z2 basis((Z[:b, b:])^T) (_lobpcg.py:466), but it needs only the b
-            # wanted Ritz vectors and a b x b Cholesky instead of a Householder QR of a (2b x b) matrix.
-            Tm = -Z1 @ Z1[:b, :].transpose(0, 1)
-            Tm[:b] += eye_b
+            lam[ncl:] = E_[:na]
+            Z1 = Z[:, :na].contiguous()
+            # P spans (I - Z1 Z1^T) E_x: the part of the old active X that left the new Ritz block - the same
+            # space as the reference's S Z2 basis((Z[:b, b:])^T) (_lobpcg.py:466), but it needs only the
+            # wanted Ritz vectors and a small Cholesky instead of a Householder QR of a (2b x b) matrix.
+            Tm = -Z1 @ Z1[:na, :].transpose(0, 1)
+            Tm[:na] += torch.eye(na, dtype=torch.float64, device=dev)
             Zp = _orthonormal_columns(Tm)
-            ops.mix(Sa, Z1, S2[:, ny:ny + b])
-            ops.mix(Sa, Zp, S2[:, ny + b:ny + 2 * b])
-            ops.mix(KS[:, :sz], Z1, R)  # K X_new for the next residual
+            if ncl:
+                S2[:, ny:ny + ncl].copy_(S[:, ny:ny + ncl])
+            ops.mix(Sa, Z1, S2[:, ny + ncl:ny + b])
+            ops.mix(Sa, Zp, S2[:, ny + b:ny + b + na])
+            ops.mix(KS[:, :sz], Z1, R[:, :na])  # K X_new for the next residual
             S, S2 = S2, S
-            have_p = True
+            npc = na
 
         X = S[:, ny:ny + b]
-        return self._polish(X, k, it, rel[:k] if rel is not None else None, history)
+        return self._polish(X, k, it, rel[:k].clone(), history)
 
     # ------------------------------------------------------------------ fp64 Rayleigh-Ritz polish
     def _polish(self, X, k, it, rerr, history):
