@@ -152,12 +152,23 @@ int launch(const int32_t* rowptr, const int32_t* colidx, const void* vals, int64
 // Both sat at 1.3 TB/s.)
 constexpr int WN_CHUNK = 64;  // blocks of a row staged per pass
 
-template <int KIND, int RS, int LPN_CT>
+// Optional fused epilogue (EPI = 1, KIND 0, RS 3): one term of the Chebyshev block-Jacobi polynomial,
+//   Y_i <- X_i + c1 (X_i - Y_i) + c2 T_i (R0_i - (K X)_i)        (Y holds W_{k-1} on entry, W_{k+1} on exit)
+// so a preconditioner term is ONE launch and the product K X never goes to HBM.
+struct ChebEpilogue {
+    const float* r0;
+    int64_t ldr;
+    const float* dinv;
+    float c1, c2;
+    int first;  // W_{k-1} = 0: do not read Y
+};
+
+template <int KIND, int RS, int LPN_CT, int EPI>
 __global__ void __launch_bounds__(256)
     spmm_wave_node_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx,
                           const float* __restrict__ vals, const float* __restrict__ vals_t, int64_t nv,
                           const float* __restrict__ X, int64_t ldx, float* __restrict__ Y, int64_t ldy, int lpn_rt,
-                          unsigned nblk) {
+                          unsigned nblk, ChebEpilogue epi) {
     using f4 = __attribute__((ext_vector_type(4))) float;
     __shared__ float s_vals[4][WN_CHUNK * 9];
     const int lpn = LPN_CT ? LPN_CT : lpn_rt;
@@ -267,7 +278,31 @@ __global__ void __launch_bounds__(256)
         }
     }
     float* yp = Y + (node * 3) * ldy + c0;
-    if (RS == 3 && KIND == 1) {
+    if (EPI == 1) {
+        if (active && r_raw == 0) {
+            const float* rp = epi.r0 + (node * 3) * epi.ldr + c0;
+            const float* xp = X + (node * 3) * ldx + c0;
+            const float* d = epi.dinv + node * 9;
+            const f4 q0 = *reinterpret_cast<const f4*>(rp) - acc0;
+            const f4 q1 = *reinterpret_cast<const f4*>(rp + epi.ldr) - acc1;
+            const f4 q2 = *reinterpret_cast<const f4*>(rp + 2 * epi.ldr) - acc2;
+            const f4 t0 = d[0] * q0 + d[1] * q1 + d[2] * q2;
+            const f4 t1 = d[3] * q0 + d[4] * q1 + d[5] * q2;
+            const f4 t2 = d[6] * q0 + d[7] * q1 + d[8] * q2;
+            const f4 w0 = *reinterpret_cast<const f4*>(xp);
+            const f4 w1 = *reinterpret_cast<const f4*>(xp + ldx);
+            const f4 w2 = *reinterpret_cast<const f4*>(xp + 2 * ldx);
+            f4 o0 = w0 + epi.c2 * t0, o1 = w1 + epi.c2 * t1, o2 = w2 + epi.c2 * t2;
+            if (!epi.first) {
+                o0 += epi.c1 * (w0 - *reinterpret_cast<const f4*>(yp));
+                o1 += epi.c1 * (w1 - *reinterpret_cast<const f4*>(yp + ldy));
+                o2 += epi.c1 * (w2 - *reinterpret_cast<const f4*>(yp + 2 * ldy));
+            }
+            *reinterpret_cast<f4*>(yp) = o0;
+            *reinterpret_cast<f4*>(yp + ldy) = o1;
+            *reinterpret_cast<f4*>(yp + 2 * ldy) = o2;
+        }
+    } else if (RS == 3 && KIND == 1) {
         if (active) *reinterpret_cast<f4*>(yp + (int64_t)r * ldy) = acc0;
     } else if (active && r_raw == 0) {
         *reinterpret_cast<f4*>(yp) = acc0;
@@ -276,13 +311,14 @@ __global__ void __launch_bounds__(256)
     }
 }
 
-template <int KIND, int RS, int LPN_CT>
+template <int KIND, int RS, int LPN_CT, int EPI = 0>
 int launch_wn(const int32_t* rowptr, const int32_t* colidx, const void* vals, const void* vals_t, int64_t nv,
-              const void* X, int64_t ldx, void* Y, int64_t ldy, int lpn, hipStream_t st) {
+              const void* X, int64_t ldx, void* Y, int64_t ldy, int lpn, hipStream_t st,
+              ChebEpilogue epi = ChebEpilogue{nullptr, 0, nullptr, 0.f, 0.f, 0}) {
     const int64_t nblk = ds::ceil_div(nv, 4);
-    spmm_wave_node_kernel<KIND, RS, LPN_CT><<<(unsigned)nblk, 256, 0, st>>>(
+    spmm_wave_node_kernel<KIND, RS, LPN_CT, EPI><<<(unsigned)nblk, 256, 0, st>>>(
         rowptr, colidx, static_cast<const float*>(vals), static_cast<const float*>(vals_t), nv,
-        static_cast<const float*>(X), ldx, static_cast<float*>(Y), ldy, lpn, (unsigned)nblk);
+        static_cast<const float*>(X), ldx, static_cast<float*>(Y), ldy, lpn, (unsigned)nblk, epi);
     DS_LAUNCH_CHECK("spmm_wave_node_kernel");
     return DS_OK;
 }
@@ -339,4 +375,25 @@ extern "C" int ds_spmm_bsr3(int kind, const int32_t* rowptr, const int32_t* coli
                "ds_spmm_bsr3: f64-output blocks need an even column count <= 128 and aligned rows (ncols=%d)", ncols);
     return kind == 2 ? launch<0, double, float, double, 2>(rowptr, colidx, vals, nv, X, ldx, Y, ldy, ncols, st)
                      : launch<1, double, float, double, 2>(rowptr, colidx, vals, nv, X, ldx, Y, ldy, ncols, st);
+}
+
+extern "C" int ds_cheb_spmm(const int32_t* rowptr, const int32_t* colidx, const float* vals, int64_t nv, const float* W,
+                            int64_t ldw, float* Wprev, int64_t ldp, const float* R0, int64_t ldr, const float* dinv,
+                            int ncols, float c1, float c2, int first, ds_stream_t stream) {
+    DS_REQUIRE(rowptr && colidx && vals && W && Wprev && R0 && dinv, "ds_cheb_spmm: null pointer");
+    DS_REQUIRE(nv > 0 && ncols > 0 && ncols % 4 == 0 && ncols <= 84, "ds_cheb_spmm: ncols must be a multiple of 4 <= 84");
+    DS_REQUIRE(ldw >= ncols && ldp >= ncols && ldr >= ncols, "ds_cheb_spmm: leading dimension smaller than ncols");
+    const uintptr_t al = reinterpret_cast<uintptr_t>(W) | reinterpret_cast<uintptr_t>(Wprev) |
+                         reinterpret_cast<uintptr_t>(R0) | (uintptr_t)(ldw * 4) | (uintptr_t)(ldp * 4) |
+                         (uintptr_t)(ldr * 4);
+    DS_REQUIRE((al & 15) == 0, "ds_cheb_spmm: rows must be 16-byte aligned");
+    DS_REQUIRE(W != Wprev, "ds_cheb_spmm: W and Wprev must be different buffers");
+    hipStream_t st = ds::as_stream(stream);
+    const ChebEpilogue epi{R0, ldr, dinv, c1, c2, first};
+    const int lpn = ncols / 4;
+    switch (lpn) {
+        case 18: return launch_wn<0, 3, 18, 1>(rowptr, colidx, vals, nullptr, nv, W, ldw, Wprev, ldp, lpn, st, epi);
+        case 20: return launch_wn<0, 3, 20, 1>(rowptr, colidx, vals, nullptr, nv, W, ldw, Wprev, ldp, lpn, st, epi);
+        default: return launch_wn<0, 3, 0, 1>(rowptr, colidx, vals, nullptr, nv, W, ldw, Wprev, ldp, lpn, st, epi);
+    }
 }

@@ -133,7 +133,7 @@ class ChebyshevBlockJacobi:
         self._AD = None
 
     def apply(self, R, W):
-        """Destroys R.  W <- preconditioned residual."""
+        """W <- preconditioned residual (R may be destroyed)."""
         ops = self.ops
         theta = 0.5 * (self.lmax + self.lmin)
         delta = 0.5 * (self.lmax - self.lmin)
@@ -141,6 +141,20 @@ class ChebyshevBlockJacobi:
             self._D = torch.empty_like(R)
             self._AD = torch.empty_like(R)
         D, AD = self._D, self._AD
+        if hasattr(ops, "cheb_spmm") and R.shape[1] <= 84 and self.degree > 1:
+            # three-term form W_{k+1} = W_k + c1 (W_k - W_{k-1}) + c2 T (R0 - K W_k): one fused launch per
+            # term, ping-ponging between W and a scratch block so that the last term lands in W
+            bufs = (W, D) if (self.degree - 1) % 2 == 0 else (D, W)
+            ops.cheb_init(R, AD, bufs[0], 1.0 / theta)  # W_1 = T R0 / theta  (W_0 = 0)
+            sigma1 = theta / delta
+            rho = 1.0 / sigma1
+            cur = 0
+            for k in range(1, self.degree):
+                rho_new = 1.0 / (2.0 * sigma1 - rho)
+                ops.cheb_spmm(bufs[cur], bufs[1 - cur], R, rho_new * rho, 2.0 * rho_new / delta, first=(k == 1))
+                rho = rho_new
+                cur = 1 - cur
+            return
         ops.cheb_init(R, D, W, 1.0 / theta)  # D = T R / theta ; W = D
         sigma1 = theta / delta
         rho = 1.0 / sigma1

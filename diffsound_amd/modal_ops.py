@@ -146,6 +146,7 @@ class _HipBlockOps:
         self.counts = dict(apply_K_cols=0, apply_M_cols=0, gram=0, mix=0)
         # optional profiling hook (bench.py): HIP events around every K-SpMM of ``spmm_event_cols`` columns
         self.spmm_events = None
+        self.cheb_events = None
         self.spmm_event_cols = 0
 
     # ------------------------------------------------------------------ sparse products
@@ -231,6 +232,25 @@ class _HipBlockOps:
         pp = _hip.ptr
         _hip.check(self._L.ds_cheb_step(pp(AD), _ld(AD), pp(R), _ld(R), pp(D), _ld(D), pp(W), _ld(W), pp(self.dinv),
                                         self.nv, R.shape[1], float(c1), float(c2), _hip.stream_ptr()), "ds_cheb_step")
+
+    def cheb_spmm(self, Wk, Wprev, R0, c1, c2, first):
+        """Wprev <- Wk + c1 (Wk - Wprev) + c2 T (R0 - K Wk): one fused launch per polynomial term."""
+        pp = _hip.ptr
+        timed = self.cheb_events is not None and Wk.shape[1] == self.spmm_event_cols and not first
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        self._cheb_spmm_launch(Wk, Wprev, R0, c1, c2, first)
+        if timed:
+            e1.record()
+            self.cheb_events.append((e0, e1))
+
+    def _cheb_spmm_launch(self, Wk, Wprev, R0, c1, c2, first):
+        pp = _hip.ptr
+        _hip.check(self._L.ds_cheb_spmm(pp(self.rowptr), pp(self.colidx), pp(self.k32), self.nv, pp(Wk), _ld(Wk),
+                                        pp(Wprev), _ld(Wprev), pp(R0), _ld(R0), pp(self.dinv), Wk.shape[1],
+                                        float(c1), float(c2), int(bool(first)), _hip.stream_ptr()), "ds_cheb_spmm")
+        self.counts["apply_K_cols"] += Wk.shape[1]
 
     # ------------------------------------------------------------------ fp64 polish
     def polish_products(self, X):

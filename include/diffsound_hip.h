@@ -127,6 +127,12 @@ int ds_cheb_init(const float* R, int64_t ldr, float* D, int64_t ldd, float* W, i
 int ds_cheb_step(const float* AD, int64_t lda, float* R, int64_t ldr, float* D, int64_t ldd,
                  float* W, int64_t ldw, const float* dinv, int64_t nv, int ncols, float c1, float c2,
                  ds_stream_t stream);
+/* One fused term of the Chebyshev block-Jacobi polynomial preconditioner (three-term form):
+ *   W_next <- W + c1 (W - W_prev) + c2 T (R0 - K W),   written over W_prev ;  first != 0: W_prev = 0, not read.
+ * K: (rowptr, colidx, vals f32 (nnzb x 9)); ncols a multiple of 4, <= 84; W and W_prev distinct buffers. */
+int ds_cheb_spmm(const int32_t* rowptr, const int32_t* colidx, const float* vals, int64_t nv,
+                 const float* W, int64_t ldw, float* Wprev, int64_t ldp, const float* R0, int64_t ldr,
+                 const float* dinv, int ncols, float c1, float c2, int first, ds_stream_t stream);
 /* Out <- alpha * A C + beta * Out,  A (n x p) f32, C (p x q) f32 row-major device, Out (n x q) f32.
  * Out must not alias A.  (reference: X <- S Z etc., _lobpcg.py:463-466) */
 int ds_mix(const float* A, int64_t lda, int p, const float* C, int q, float* Out, int64_t ldo,

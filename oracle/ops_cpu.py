@@ -91,6 +91,14 @@ class CpuModalOps:
         D.copy_(c1 * D + c2 * self._bj(R))
         W.add_(D)
 
+    def cheb_spmm(self, Wk, Wprev, R0, c1, c2, first):
+        KW = torch.from_numpy(self.Kd @ Wk.numpy())
+        new = Wk + c2 * self._bj(R0 - KW)
+        if not first:
+            new = new + c1 * (Wk - Wprev)
+        Wprev.copy_(new)
+        self.counts["apply_K_cols"] += Wk.shape[1]
+
     # -- fp64 polish ---------------------------------------------------------------------
     def polish_products(self, X):
         Xd = X.double().numpy()

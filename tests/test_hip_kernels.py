@@ -198,6 +198,23 @@ def test_residual_and_cheb(case, dev):
         assert rel(a.cpu().numpy(), bb.numpy()) < 1e-5
 
 
+@pytest.mark.parametrize("ncols,first", [(80, True), (80, False), (72, False), (24, False), (4, False)])
+def test_fused_chebyshev_spmm(case, dev, ncols, first):
+    h, c = case["hops"], case["cops"]
+    g = torch.Generator().manual_seed(ncols + int(first))
+    W = torch.randn((h.n, ncols), generator=g)
+    Wp = torch.randn((h.n, ncols), generator=g)
+    R0 = torch.randn((h.n, ncols), generator=g) * 1e10
+    Wp_ref = Wp.clone()
+    c.cheb_spmm(W, Wp_ref, R0, 0.31, 0.77, first)
+    # through strided views of a wider buffer, like the solver
+    big = torch.zeros((h.n, ncols + 8), device=dev)
+    big[:, 8:] = W.to(dev)
+    Wp_d = Wp.to(dev).clone()
+    h.cheb_spmm(big[:, 8:], Wp_d, R0.to(dev), 0.31, 0.77, first)
+    assert rel(Wp_d.cpu().numpy(), Wp_ref.numpy()) < 5e-6
+
+
 def test_polish_products(case, dev):
     h, c = case["hops"], case["cops"]
     g = torch.Generator().manual_seed(9)
