@@ -36,8 +36,8 @@ def parse():
     ap.add_argument("--order", type=int, default=2)
     ap.add_argument("--modes", type=int, default=64)
     ap.add_argument("--hyp-per-gpu", type=int, default=1)
-    ap.add_argument("--cheb-degree", type=int, default=24)
-    ap.add_argument("--cheb-ratio", type=float, default=100.0)
+    ap.add_argument("--cheb-degree", type=int, default=48)
+    ap.add_argument("--cheb-ratio", type=float, default=800.0)
     ap.add_argument("--block", type=int, default=80)
     ap.add_argument("--warm-start", action="store_true", help="amortised variant: reuse the previous block")
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -36,6 +36,12 @@ _SIGNATURES = {
     "ds_cheb_init": (_I, [_P, _I64, _P, _I64, _P, _I64, _P, _I64, _I, _F, _P]),
     "ds_cheb_step": (_I, [_P, _I64, _P, _I64, _P, _I64, _P, _I64, _P, _I64, _I, _F, _F, _P]),
     "ds_cheb_spmm": (_I, [_P, _P, _P, _I64, _P, _I64, _P, _I64, _P, _I64, _P, _I, _F, _F, _I, _P]),
+    "ds_tiles_build": (_I, [_P, _P, _I64, _I, _I, ctypes.POINTER(_P)]),
+    "ds_tiles_sizes": (_I, [_P, ctypes.POINTER(_I64), ctypes.POINTER(_I64)]),
+    "ds_tiles_export": (_I, [_P, _P, _P, _P, _P]),
+    "ds_tiles_free": (None, [_P]),
+    "ds_spmm_tiled": (_I, [_I, _P, _P, _I64, _P, _P, _P, _P, _I64, _I, _P, _I64, _P, _I64, _P, _I64, _P, _I, _F, _F,
+                           _I, _P]),
     "ds_mix": (_I, [_P, _I64, _I, _P, _I, _P, _I64, _I64, _F, _F, _P]),
     "ds_osc_bank_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _D, _P, _P]),
     "ds_osc_bank_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _D, _P, _P, _P, _P, _P]),
@@ -107,3 +113,24 @@ class Pattern:
                                           ptr(self.cptr), ptr(self.clist)), "ds_pattern_export")
         finally:
             lib().ds_pattern_free(handle)
+
+
+class Tiles:
+    """Row tiles for the LDS-tiled SpMM (ds_tiles_build): host arrays tnode, tuptr, ulist (int32), lidx (int16 bits)."""
+
+    def __init__(self, rowptr_cpu, colidx_cpu, nv, nu_max=80, nb_max=8):
+        handle = ctypes.c_void_p()
+        check(lib().ds_tiles_build(ptr(rowptr_cpu), ptr(colidx_cpu), nv, nu_max, nb_max, ctypes.byref(handle)),
+              "ds_tiles_build")
+        try:
+            a, b = _I64(), _I64()
+            check(lib().ds_tiles_sizes(handle, ctypes.byref(a), ctypes.byref(b)), "ds_tiles_sizes")
+            self.ntiles, self.nu_total, self.nu_max = a.value, b.value, nu_max
+            self.tnode = torch.empty(self.ntiles + 1, dtype=torch.int32)
+            self.tuptr = torch.empty(self.ntiles + 1, dtype=torch.int32)
+            self.ulist = torch.empty(self.nu_total, dtype=torch.int32)
+            self.lidx = torch.empty(colidx_cpu.numel(), dtype=torch.int16)  # uint16 payload
+            check(lib().ds_tiles_export(handle, ptr(self.tnode), ptr(self.tuptr), ptr(self.ulist), ptr(self.lidx)),
+                  "ds_tiles_export")
+        finally:
+            lib().ds_tiles_free(handle)

@@ -377,6 +377,175 @@ extern "C" int ds_spmm_bsr3(int kind, const int32_t* rowptr, const int32_t* coli
                      : launch<1, double, float, double, 2>(rowptr, colidx, vals, nv, X, ldx, Y, ldy, ncols, st);
 }
 
+// ------------------------------------------------------------------------------------------------
+// LDS-tiled variant for <= 84 columns.  The wave-per-node kernel above fetches every neighbour panel
+// once per block: 27.8 panels per node, 4.0 GB through L2 per 80-column product on the benchmark mesh,
+// which pins it at the ~70 GB/s per CU that a CU can gather from L2 (guides/MI355X_MICROARCH.md,
+// "Indexed rows").  Here a workgroup owns a tile of consecutive (Morton-ordered) nodes whose neighbour
+// sets overlap heavily; it stages the tile's UNIQUE neighbour panels once in LDS (coalesced 16-byte
+// loads), and the per-block loads become LDS reads.  L2 -> CU traffic drops by the reuse factor of the
+// tiling (about 2x at 80 panels per tile), HBM traffic is unchanged (compulsory).
+template <int EPI, int LPN_CT>
+__global__ void __launch_bounds__(256)
+    spmm_tile_kernel(const int32_t* __restrict__ rowptr, const float* __restrict__ vals, int64_t nv,
+                     const int32_t* __restrict__ tnode, const int32_t* __restrict__ tuptr,
+                     const int32_t* __restrict__ ulist, const uint16_t* __restrict__ lidx,
+                     const float* __restrict__ X, int64_t ldx, float* __restrict__ Y, int64_t ldy, int lpn_rt,
+                     unsigned ntiles, ChebEpilogue epi) {
+    using f4 = __attribute__((ext_vector_type(4))) float;
+    extern __shared__ __attribute__((aligned(16))) float s_dyn[];  // [nu][3][lpn] float4 panels
+    constexpr int TCH = 32;  // blocks of a row staged per pass (small slab: two workgroups per CU must fit)
+    __shared__ float s_vals[4][TCH * 9];
+    const int lpn = LPN_CT ? LPN_CT : lpn_rt;
+    const unsigned tile = ds::xcd_remap(blockIdx.x, ntiles);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int n0 = tnode[tile], n1 = tnode[tile + 1];
+    const int u0 = tuptr[tile], nu = tuptr[tile + 1] - u0;
+    f4* panels = reinterpret_cast<f4*>(s_dyn);
+    // ---- stage the unique neighbour panels (3 rows x lpn float4 each).  All neighbour ids first, then all
+    //      panel loads, then the LDS writes: two memory round trips per tile instead of two per item.
+    const int row_items = 3 * lpn;
+    const int total = nu * row_items;
+    constexpr int MAXIT = 20;  // >= nu_max * 3 * lpn / 256 for every admitted (nu_max, lpn): checked on the host
+    int64_t src[MAXIT];
+#pragma unroll
+    for (int j = 0; j < MAXIT; ++j) {
+        const int it = threadIdx.x + 256 * j;
+        const int itc = it < total ? it : 0;
+        const int u = itc / row_items;
+        const int rem = itc - u * row_items;  // = r * lpn + q
+        const int r = rem / lpn, q = rem - r * lpn;
+        src[j] = ((int64_t)ulist[u0 + u] * 3 + r) * ldx + q * 4;
+    }
+    f4 stage[MAXIT];
+#pragma unroll
+    for (int j = 0; j < MAXIT; ++j) stage[j] = *reinterpret_cast<const f4*>(X + src[j]);
+#pragma unroll
+    for (int j = 0; j < MAXIT; ++j) {
+        const int it = threadIdx.x + 256 * j;
+        if (it < total) panels[it] = stage[j];
+    }
+    __syncthreads();
+    // ---- rows of the tile: wave w takes nodes n0 + w, n0 + w + 4, ...
+    const int r_raw = lane / lpn;
+    const int cl_raw = lane - r_raw * lpn;
+    const bool active = r_raw < 3 && cl_raw < lpn;
+    const int r = active ? r_raw : 0;
+    const int cl = active ? cl_raw : 0;
+    const int c0 = cl * 4;
+    float* sv = s_vals[wave];
+    const f4* prow = panels + r * lpn + cl;  // + lid * 3 * lpn
+    for (int64_t node = n0 + wave; node < n1; node += 4) {
+        const int kb = rowptr[node], ke = rowptr[node + 1];
+        f4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0, acc2 = acc0;
+        for (int kc = kb; kc < ke; kc += TCH) {
+            const int cnt = min(TCH, ke - kc);
+            const int lidreg = lane < cnt ? (int)lidx[kc + lane] : 0;
+            const float* vsrc = vals + (int64_t)kc * 9;
+            for (int t = lane; t < cnt * 9; t += 64) sv[t] = vsrc[t];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll 4
+            for (int u = 0; u < cnt; ++u) {
+                const int lid = __builtin_amdgcn_readlane(lidreg, u);
+                const f4 x = prow[lid * row_items];
+                const float* a = sv + u * 9 + r;  // column r of the block
+                acc0 += a[0] * x;
+                acc1 += a[3] * x;
+                acc2 += a[6] * x;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            acc0[v] += __shfl(acc0[v], lane + lpn) + __shfl(acc0[v], lane + 2 * lpn);
+            acc1[v] += __shfl(acc1[v], lane + lpn) + __shfl(acc1[v], lane + 2 * lpn);
+            acc2[v] += __shfl(acc2[v], lane + lpn) + __shfl(acc2[v], lane + 2 * lpn);
+        }
+        float* yp = Y + (node * 3) * ldy + c0;
+        if (active && r_raw == 0) {
+            if (EPI == 1) {
+                const float* rp = epi.r0 + (node * 3) * epi.ldr + c0;
+                const float* xp = X + (node * 3) * ldx + c0;
+                const float* d = epi.dinv + node * 9;
+                const f4 q0 = *reinterpret_cast<const f4*>(rp) - acc0;
+                const f4 q1 = *reinterpret_cast<const f4*>(rp + epi.ldr) - acc1;
+                const f4 q2 = *reinterpret_cast<const f4*>(rp + 2 * epi.ldr) - acc2;
+                const f4 t0 = d[0] * q0 + d[1] * q1 + d[2] * q2;
+                const f4 t1 = d[3] * q0 + d[4] * q1 + d[5] * q2;
+                const f4 t2 = d[6] * q0 + d[7] * q1 + d[8] * q2;
+                const f4 w0 = *reinterpret_cast<const f4*>(xp);
+                const f4 w1 = *reinterpret_cast<const f4*>(xp + ldx);
+                const f4 w2 = *reinterpret_cast<const f4*>(xp + 2 * ldx);
+                f4 o0 = w0 + epi.c2 * t0, o1 = w1 + epi.c2 * t1, o2 = w2 + epi.c2 * t2;
+                if (!epi.first) {
+                    o0 += epi.c1 * (w0 - *reinterpret_cast<const f4*>(yp));
+                    o1 += epi.c1 * (w1 - *reinterpret_cast<const f4*>(yp + ldy));
+                    o2 += epi.c1 * (w2 - *reinterpret_cast<const f4*>(yp + 2 * ldy));
+                }
+                *reinterpret_cast<f4*>(yp) = o0;
+                *reinterpret_cast<f4*>(yp + ldy) = o1;
+                *reinterpret_cast<f4*>(yp + 2 * ldy) = o2;
+            } else {
+                *reinterpret_cast<f4*>(yp) = acc0;
+                *reinterpret_cast<f4*>(yp + ldy) = acc1;
+                *reinterpret_cast<f4*>(yp + 2 * ldy) = acc2;
+            }
+        }
+    }
+}
+
+template <int EPI, int LPN_CT>
+int launch_tile(const int32_t* rowptr, const float* vals, int64_t nv, const int32_t* tnode, const int32_t* tuptr,
+                const int32_t* ulist, const uint16_t* lidx, int64_t ntiles, int nu_max, const float* X, int64_t ldx,
+                float* Y, int64_t ldy, int lpn, hipStream_t st, ChebEpilogue epi) {
+    const size_t lds = (size_t)nu_max * 3 * lpn * 16;
+    static bool attr_set = false;
+    if (lds > 48 * 1024 && !attr_set) {
+        // opt in to large dynamic LDS once per instantiation
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&spmm_tile_kernel<EPI, LPN_CT>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        attr_set = true;
+    }
+    spmm_tile_kernel<EPI, LPN_CT><<<(unsigned)ntiles, 256, lds, st>>>(rowptr, vals, nv, tnode, tuptr, ulist, lidx, X,
+                                                                      ldx, Y, ldy, lpn, (unsigned)ntiles, epi);
+    DS_LAUNCH_CHECK("spmm_tile_kernel");
+    return DS_OK;
+}
+
+extern "C" int ds_spmm_tiled(int epilogue, const int32_t* rowptr, const float* vals, int64_t nv, const int32_t* tnode,
+                             const int32_t* tuptr, const int32_t* ulist, const uint16_t* lidx, int64_t ntiles,
+                             int nu_max, const float* X, int64_t ldx, float* Y, int64_t ldy, const float* R0,
+                             int64_t ldr, const float* dinv, int ncols, float c1, float c2, int first,
+                             ds_stream_t stream) {
+    DS_REQUIRE(rowptr && vals && tnode && tuptr && ulist && lidx && X && Y, "ds_spmm_tiled: null pointer");
+    DS_REQUIRE(epilogue == 0 || (R0 && dinv), "ds_spmm_tiled: the Chebyshev epilogue needs R0 and dinv");
+    DS_REQUIRE(nv > 0 && ntiles > 0 && ncols > 0 && ncols % 4 == 0 && ncols <= 84,
+               "ds_spmm_tiled: ncols must be a multiple of 4 <= 84");
+    DS_REQUIRE(ldx >= ncols && ldy >= ncols, "ds_spmm_tiled: leading dimension smaller than ncols");
+    DS_REQUIRE(X != Y, "ds_spmm_tiled: X and Y must be different buffers");
+    const int lpn = ncols / 4;
+    DS_REQUIRE(nu_max > 0 && (size_t)nu_max * 3 * lpn <= 20 * 256,
+               "ds_spmm_tiled: nu_max * 3 * ncols/4 must be <= 5120 (staging registers / LDS)");
+    uintptr_t al = reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(Y) | (uintptr_t)(ldx * 4) |
+                   (uintptr_t)(ldy * 4);
+    if (epilogue) al |= reinterpret_cast<uintptr_t>(R0) | (uintptr_t)(ldr * 4);
+    DS_REQUIRE((al & 15) == 0, "ds_spmm_tiled: rows must be 16-byte aligned");
+    hipStream_t st = ds::as_stream(stream);
+    const ChebEpilogue epi{R0, ldr, dinv, c1, c2, first};
+    if (epilogue) {
+        if (lpn == 20)
+            return launch_tile<1, 20>(rowptr, vals, nv, tnode, tuptr, ulist, lidx, ntiles, nu_max, X, ldx, Y, ldy, lpn, st, epi);
+        return launch_tile<1, 0>(rowptr, vals, nv, tnode, tuptr, ulist, lidx, ntiles, nu_max, X, ldx, Y, ldy, lpn, st, epi);
+    }
+    if (lpn == 20)
+        return launch_tile<0, 20>(rowptr, vals, nv, tnode, tuptr, ulist, lidx, ntiles, nu_max, X, ldx, Y, ldy, lpn, st, epi);
+    return launch_tile<0, 0>(rowptr, vals, nv, tnode, tuptr, ulist, lidx, ntiles, nu_max, X, ldx, Y, ldy, lpn, st, epi);
+}
+
 extern "C" int ds_cheb_spmm(const int32_t* rowptr, const int32_t* colidx, const float* vals, int64_t nv, const float* W,
                             int64_t ldw, float* Wprev, int64_t ldp, const float* R0, int64_t ldr, const float* dinv,
                             int ncols, float c1, float c2, int first, ds_stream_t stream) {

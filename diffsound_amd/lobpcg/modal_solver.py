@@ -103,6 +103,43 @@ def _orthonormal_columns(Tm):
     return Q
 
 
+class _one_thread:
+    """LAPACK on <= 3b x 3b matrices is fastest single-threaded (measured on the MI355X host: 240 x 240
+    fp64 eigh 3.2 ms with 1 thread incl. both PCIe hops, 5.7 ms with rocSOLVER's launch-bound syevd,
+    150 ms with the default 128 threads)."""
+
+    def __enter__(self):
+        self.n = torch.get_num_threads()
+        torch.set_num_threads(1)
+
+    def __exit__(self, *a):
+        torch.set_num_threads(self.n)
+
+
+def _small(fn, dev, *mats):
+    """Run the small dense step ``fn`` on host copies of ``mats`` (fp64) and return its results on ``dev``."""
+    if dev.type != "cuda":
+        return fn(*mats)
+    host = [m.cpu() for m in mats]
+    with _one_thread():
+        out = fn(*host)
+    if isinstance(out, tuple):
+        return tuple(o.to(dev, non_blocking=True) for o in out)
+    return out.to(dev, non_blocking=True)
+
+
+def _rr_step(GA, na):
+    """Rayleigh-Ritz on the active basis: lowest na Ritz pairs and the coefficient block of the new P."""
+    E_, Z = torch.linalg.eigh(_sym(GA))
+    Z1 = Z[:, :na].contiguous()
+    # P spans (I - Z1 Z1^T) E_x: the part of the old active X that left the new Ritz block - the same space
+    # as the reference's S Z2 basis((Z[:b, b:])^T) (_lobpcg.py:466), but it needs only the wanted Ritz
+    # vectors and a small Cholesky instead of a Householder QR of a (2b x b) matrix.
+    Tm = -Z1 @ Z1[:na, :].transpose(0, 1)
+    Tm[:na] += torch.eye(na, dtype=GA.dtype, device=GA.device)
+    return E_[:na].contiguous(), Z1, _orthonormal_columns(Tm).contiguous()
+
+
 class ChebyshevBlockJacobi:
     """W = p(T K) T R with T = inverse 3x3 diagonal blocks of K and p the degree-(d-1) Chebyshev
     polynomial that approximates 1/x on [lmax/ratio, lmax] (Saad, Iterative Methods, Alg. 12.1).
@@ -206,7 +243,7 @@ class ModalSolver:
                 C = ops.gram(V, MW)
                 ops.mix(V, C, W, alpha=-1.0, beta=1.0)
             ops.apply_M(W, MW)
-            T = _orthonormalizer(ops.gram(W, MW, symmetric=True))
+            T = _small(_orthonormalizer, ops.device, ops.gram(W, MW, symmetric=True))
             ops.mix_inplace(W, T)
 
     # ------------------------------------------------------------------ main entry
@@ -257,7 +294,8 @@ class ModalSolver:
         tol = cfg.tol or (2e-6 if dt == torch.float32 else 1e-10)
         self._orthonormalize(X, S[:, :ny], MW)
         ops.apply_K(X, KS[:, :b])
-        lam, Z = torch.linalg.eigh(_sym(ops.gram(X, KS[:, :b], symmetric=True)))
+        lam, Z = _small(lambda G: torch.linalg.eigh(_sym(G)), dev, ops.gram(X, KS[:, :b], symmetric=True))
+        lam = lam.clone()
         ops.mix(X, Z, S2[:, ny:ny + b])
         S, S2 = S2, S
         ops.mix(KS[:, :b], Z, R)  # R holds K X for the first residual
@@ -301,15 +339,8 @@ class ModalSolver:
             sz = na + npc + na
             Sa = S[:, ny + ncl:ny + ncl + sz]
             ops.apply_K(Sa, KS[:, :sz])
-            E_, Z = torch.linalg.eigh(_sym(ops.gram(Sa, KS[:, :sz], symmetric=True)))
-            lam[ncl:] = E_[:na]
-            Z1 = Z[:, :na].contiguous()
-            # P spans (I - Z1 Z1^T) E_x: the part of the old active X that left the new Ritz block - the same
-            # space as the reference's S Z2 basis((Z[:b, b:])^T) (_lobpcg.py:466), but it needs only the
-            # wanted Ritz vectors and a small Cholesky instead of a Householder QR of a (2b x b) matrix.
-            Tm = -Z1 @ Z1[:na, :].transpose(0, 1)
-            Tm[:na] += torch.eye(na, dtype=torch.float64, device=dev)
-            Zp = _orthonormal_columns(Tm)
+            Ea, Z1, Zp = _small(lambda G: _rr_step(G, na), dev, ops.gram(Sa, KS[:, :sz], symmetric=True))
+            lam[ncl:] = Ea
             if ncl:
                 S2[:, ny:ny + ncl].copy_(S[:, ny:ny + ncl])
             ops.mix(Sa, Z1, S2[:, ny + ncl:ny + b])
@@ -327,10 +358,14 @@ class ModalSolver:
         GK, coef, GM = ops.polish_products(X)  # fp64 (b x b) Gram matrices of the terms of K, and of M
         GA = _sym(sum(c * G for c, G in zip(coef, GK)))
         GB = _sym(GM)
-        L = torch.linalg.cholesky(GB)
-        Li = torch.linalg.solve_triangular(L, torch.eye(L.shape[0], dtype=L.dtype, device=L.device), upper=False)
-        E, Zt = torch.linalg.eigh(_sym(Li @ GA @ Li.transpose(0, 1)))
-        C = Li.transpose(0, 1) @ Zt  # generalized eigenvectors, C^T GB C = I
+
+        def gen_eigh(GA_, GB_):
+            L = torch.linalg.cholesky(GB_)
+            Li = torch.linalg.solve_triangular(L, torch.eye(L.shape[0], dtype=L.dtype), upper=False)
+            E_, Zt = torch.linalg.eigh(_sym(Li @ GA_ @ Li.transpose(0, 1)))
+            return E_, Li.transpose(0, 1) @ Zt  # generalized eigenvectors, C^T GB C = I
+
+        E, C = _small(gen_eigh, ops.device, GA, GB)
         Ck = C[:, :k].contiguous()
         U = torch.empty((ops.n, k), dtype=ops.dtype, device=ops.device)
         ops.mix(X, Ck, U)

@@ -9,6 +9,7 @@
 No operation here has a CPU implementation; tensors must be HIP tensors.
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -81,6 +82,16 @@ class TetSystem:
         self.kmu = torch.empty((self.nnzb, 9), dtype=torch.float64, device=dev)
         self.ms = torch.empty((self.nnzb,), dtype=torch.float64, device=dev)
         self._tetgeo = torch.empty((self.T, 13), dtype=torch.float64, device=dev)
+        # row tiles for the LDS-tiled SpMM (only worthwhile with the Morton numbering)
+        self.tiles = None
+        if reorder and os.environ.get("DS_SPMM_TILED", "1") != "0":
+            try:
+                tl = _hip.Tiles(pat.rowptr, pat.colidx, self.nv, nu_max=int(os.environ.get("DS_TILE_NU", "76")),
+                                nb_max=int(os.environ.get("DS_TILE_NB", "8")))
+                self.tiles = dict(ntiles=tl.ntiles, nu_max=tl.nu_max, tnode=tl.tnode.to(dev), tuptr=tl.tuptr.to(dev),
+                                  ulist=tl.ulist.to(dev), lidx=tl.lidx.to(dev))
+            except RuntimeError:
+                self.tiles = None  # a row with more neighbours than a tile holds: keep the untiled kernels
         self.assemble()
 
     def rows_to_external(self, X):
@@ -171,7 +182,10 @@ class _HipBlockOps:
                 self.spmm_events.append((e0, e1))
 
     def apply_K(self, X, out):
-        self._spmm(0, self.k32, X, out)
+        if self._has_tiles(X.shape[1]) and X.shape[1] % 4 == 0 and X.shape[1] >= 16:
+            self._tiled(0, X, out, None, 0.0, 0.0, False)
+        else:
+            self._spmm(0, self.k32, X, out)
         self.counts["apply_K_cols"] += X.shape[1]
 
     def apply_M(self, X, out):
@@ -245,7 +259,23 @@ class _HipBlockOps:
             e1.record()
             self.cheb_events.append((e0, e1))
 
+    def _tiled(self, epilogue, X, Y, R0, c1, c2, first):
+        t = self.sys.tiles
+        pp = _hip.ptr
+        _hip.check(self._L.ds_spmm_tiled(epilogue, pp(self.rowptr), pp(self.k32), self.nv, pp(t["tnode"]),
+                                         pp(t["tuptr"]), pp(t["ulist"]), pp(t["lidx"]), t["ntiles"], t["nu_max"],
+                                         pp(X), _ld(X), pp(Y), _ld(Y), pp(R0), 0 if R0 is None else _ld(R0),
+                                         pp(self.dinv), X.shape[1], float(c1), float(c2), int(bool(first)),
+                                         _hip.stream_ptr()), "ds_spmm_tiled")
+
+    def _has_tiles(self, ncols):
+        return getattr(getattr(self, "sys", None), "tiles", None) is not None and ncols <= 84
+
     def _cheb_spmm_launch(self, Wk, Wprev, R0, c1, c2, first):
+        if self._has_tiles(Wk.shape[1]):
+            self._tiled(1, Wk, Wprev, R0, c1, c2, first)
+            self.counts["apply_K_cols"] += Wk.shape[1]
+            return
         pp = _hip.ptr
         _hip.check(self._L.ds_cheb_spmm(pp(self.rowptr), pp(self.colidx), pp(self.k32), self.nv, pp(Wk), _ld(Wk),
                                         pp(Wprev), _ld(Wprev), pp(R0), _ld(R0), pp(self.dinv), Wk.shape[1],

@@ -59,6 +59,17 @@ int ds_pattern_export(const ds_pattern_t* p, int32_t* rowptr, int32_t* colidx, i
                       int32_t* cptr, int32_t* clist);
 void ds_pattern_free(ds_pattern_t* p);
 
+/* Row tiles for the LDS-tiled SpMM (HOST): consecutive nodes are grouped greedily so that the union of
+ * their neighbour sets has <= nu_max members and a tile has <= nb_max nodes.  Exports tnode[ntiles+1]
+ * (node ranges), tuptr[ntiles+1] + ulist[nu_total] (unique neighbour ids per tile, ascending) and
+ * lidx[nnzb] (uint16: position of colidx[k] in its tile's list).  Fails if one row alone exceeds nu_max. */
+typedef struct ds_tiles ds_tiles_t;
+int ds_tiles_build(const int32_t* rowptr, const int32_t* colidx, int64_t nv, int nu_max, int nb_max,
+                   ds_tiles_t** out);
+int ds_tiles_sizes(const ds_tiles_t* t, int64_t* ntiles, int64_t* nu_total);
+int ds_tiles_export(const ds_tiles_t* t, int32_t* tnode, int32_t* tuptr, int32_t* ulist, uint16_t* lidx);
+void ds_tiles_free(ds_tiles_t* t);
+
 /* ------------------------------------------------------------------------------------------------
  * Numeric assembly (DEVICE).  K_lambda, K_mu (geometry-only parts of K = lam*K_lambda + mu*K_mu,
  * SURVEY.md 0.6) and M_s in one pass, fp64, deterministic (no atomics): one thread per block slot
@@ -133,6 +144,12 @@ int ds_cheb_step(const float* AD, int64_t lda, float* R, int64_t ldr, float* D, 
 int ds_cheb_spmm(const int32_t* rowptr, const int32_t* colidx, const float* vals, int64_t nv,
                  const float* W, int64_t ldw, float* Wprev, int64_t ldp, const float* R0, int64_t ldr,
                  const float* dinv, int ncols, float c1, float c2, int first, ds_stream_t stream);
+/* LDS-tiled form of the two above for ncols <= 84 on the row tiles of ds_tiles_build (nu_max as given there):
+ * epilogue 0: Y <- K X ; epilogue 1: Y (= W_prev) <- X + c1 (X - Y) + c2 T (R0 - K X). */
+int ds_spmm_tiled(int epilogue, const int32_t* rowptr, const float* vals, int64_t nv, const int32_t* tnode,
+                  const int32_t* tuptr, const int32_t* ulist, const uint16_t* lidx, int64_t ntiles, int nu_max,
+                  const float* X, int64_t ldx, float* Y, int64_t ldy, const float* R0, int64_t ldr,
+                  const float* dinv, int ncols, float c1, float c2, int first, ds_stream_t stream);
 /* Out <- alpha * A C + beta * Out,  A (n x p) f32, C (p x q) f32 row-major device, Out (n x q) f32.
  * Out must not alias A.  (reference: X <- S Z etc., _lobpcg.py:463-466) */
 int ds_mix(const float* A, int64_t lda, int p, const float* C, int q, float* Out, int64_t ldo,

@@ -100,6 +100,33 @@ def test_morton_reordering_is_transparent(case, dev):
     assert torch.equal(s1.rows_to_external(s1.rows_to_internal(X)), X)
 
 
+@pytest.mark.parametrize("ncols", [80, 72, 40, 16])
+def test_tiled_spmm_matches_untiled(case, dev, ncols):
+    """LDS-tiled kernels (plain product and fused Chebyshev term) on the Morton-ordered system."""
+    from diffsound_amd.modal_ops import HipModalOps, TetSystem
+
+    s1 = TetSystem(case["v"].to(dev), case["t"].to(dev), case["order"], MAT[0], reorder=True)
+    if s1.tiles is None:
+        pytest.skip("a row exceeds the tile capacity")
+    h1 = HipModalOps(s1, case["lam"], case["mu"])
+    g = torch.Generator().manual_seed(ncols)
+    X = torch.randn((s1.n, ncols), generator=g).to(dev)
+    Wp = torch.randn((s1.n, ncols), generator=g).to(dev)
+    R0 = (torch.randn((s1.n, ncols), generator=g) * 1e10).to(dev)
+    Yt = torch.empty_like(X)
+    h1._tiled(0, X, Yt, None, 0.0, 0.0, False)
+    Yu = torch.empty_like(X)
+    h1._spmm(0, h1.k32, X, Yu)
+    assert rel(Yt.cpu().numpy(), Yu.cpu().numpy()) < 2e-6
+    for first in (True, False):
+        a, b = Wp.clone(), Wp.clone()
+        h1._tiled(1, X, a, R0, 0.31, 0.77, first)
+        tiles, s1.tiles = s1.tiles, None
+        h1._cheb_spmm_launch(X, b, R0, 0.31, 0.77, first)
+        s1.tiles = tiles
+        assert rel(a.cpu().numpy(), b.cpu().numpy()) < 2e-6
+
+
 def test_assembly_deterministic(case):
     s = case["sys"]
     a = s.klam.clone(), s.kmu.clone(), s.ms.clone()

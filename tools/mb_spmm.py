@@ -24,3 +24,16 @@ for reorder in (True,):
             vb = 36 if name == 'K' else 4
             bytes_ = sysd.nnzb * (vb + 4) + (sysd.nv + 1) * 4 + 2 * sysd.n * ncols * 4
             print(f"reorder={reorder} {name} ncols={ncols}: {ms:.3f} ms  {bytes_/ms/1e6:.0f} GB/s algorithmic")
+
+    # fused Chebyshev term, tiled vs untiled
+    ncols = 80
+    W = torch.randn(sysd.n, ncols, device=dev); Wp = torch.randn_like(W); R0 = torch.randn_like(W)
+    for label, fn in (("tiled" if sysd.tiles else "untiled", lambda: ops._cheb_spmm_launch(W, Wp, R0, 0.3, 0.7, False)),):
+        fn(); torch.cuda.synchronize()
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20): fn()
+        e1.record(); torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 20
+        bytes_ = sysd.nnzb * 40 + (sysd.nv + 1) * 4 + sysd.nv * 36 + 4 * sysd.n * ncols * 4
+        print(f"fused cheb term ({label}) ncols={ncols}: {ms:.3f} ms  {bytes_/ms/1e6:.0f} GB/s algorithmic; tiles={sysd.tiles['ntiles'] if sysd.tiles else 0}")
