@@ -385,8 +385,14 @@ extern "C" int ds_spmm_bsr3(int kind, const int32_t* rowptr, const int32_t* coli
 // sets overlap heavily; it stages the tile's UNIQUE neighbour panels once in LDS (coalesced 16-byte
 // loads), and the per-block loads become LDS reads.  L2 -> CU traffic drops by the reuse factor of the
 // tiling (about 2x at 80 panels per tile), HBM traffic is unchanged (compulsory).
+constexpr int TILE_MAXIT = 20;  // staging items per thread: nu_max * 3 * lpn <= 20 * 256 (checked on the host)
+
+// Persistent form: the grid is sized to the chip (2 workgroups per CU), every workgroup walks a contiguous
+// range of tiles, and the staging is software-pipelined through registers two tiles deep:
+//   ids(t+2) -> panels(t+1) in flight in VGPRs while the rows of tile t are computed out of LDS.
+// (One workgroup per tile spent more time in dispatch - 31k launches with 80 KB of LDS each - than in work.)
 template <int EPI, int LPN_CT>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 2)
     spmm_tile_kernel(const int32_t* __restrict__ rowptr, const float* __restrict__ vals, int64_t nv,
                      const int32_t* __restrict__ tnode, const int32_t* __restrict__ tuptr,
                      const int32_t* __restrict__ ulist, const uint16_t* __restrict__ lidx,
@@ -397,37 +403,15 @@ __global__ void __launch_bounds__(256)
     constexpr int TCH = 32;  // blocks of a row staged per pass (small slab: two workgroups per CU must fit)
     __shared__ float s_vals[4][TCH * 9];
     const int lpn = LPN_CT ? LPN_CT : lpn_rt;
-    const unsigned tile = ds::xcd_remap(blockIdx.x, ntiles);
+    const int row_items = 3 * lpn;
+    const unsigned G = gridDim.x;
+    const unsigned wg = ds::xcd_remap(blockIdx.x, G);
+    const unsigned t_begin = (unsigned)(((uint64_t)wg * ntiles) / G);
+    const unsigned t_end = (unsigned)(((uint64_t)(wg + 1) * ntiles) / G);
+    if (t_begin >= t_end) return;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int n0 = tnode[tile], n1 = tnode[tile + 1];
-    const int u0 = tuptr[tile], nu = tuptr[tile + 1] - u0;
     f4* panels = reinterpret_cast<f4*>(s_dyn);
-    // ---- stage the unique neighbour panels (3 rows x lpn float4 each).  All neighbour ids first, then all
-    //      panel loads, then the LDS writes: two memory round trips per tile instead of two per item.
-    const int row_items = 3 * lpn;
-    const int total = nu * row_items;
-    constexpr int MAXIT = 20;  // >= nu_max * 3 * lpn / 256 for every admitted (nu_max, lpn): checked on the host
-    int64_t src[MAXIT];
-#pragma unroll
-    for (int j = 0; j < MAXIT; ++j) {
-        const int it = threadIdx.x + 256 * j;
-        const int itc = it < total ? it : 0;
-        const int u = itc / row_items;
-        const int rem = itc - u * row_items;  // = r * lpn + q
-        const int r = rem / lpn, q = rem - r * lpn;
-        src[j] = ((int64_t)ulist[u0 + u] * 3 + r) * ldx + q * 4;
-    }
-    f4 stage[MAXIT];
-#pragma unroll
-    for (int j = 0; j < MAXIT; ++j) stage[j] = *reinterpret_cast<const f4*>(X + src[j]);
-#pragma unroll
-    for (int j = 0; j < MAXIT; ++j) {
-        const int it = threadIdx.x + 256 * j;
-        if (it < total) panels[it] = stage[j];
-    }
-    __syncthreads();
-    // ---- rows of the tile: wave w takes nodes n0 + w, n0 + w + 4, ...
     const int r_raw = lane / lpn;
     const int cl_raw = lane - r_raw * lpn;
     const bool active = r_raw < 3 && cl_raw < lpn;
@@ -435,64 +419,107 @@ __global__ void __launch_bounds__(256)
     const int cl = active ? cl_raw : 0;
     const int c0 = cl * 4;
     float* sv = s_vals[wave];
-    const f4* prow = panels + r * lpn + cl;  // + lid * 3 * lpn
-    for (int64_t node = n0 + wave; node < n1; node += 4) {
-        const int kb = rowptr[node], ke = rowptr[node + 1];
-        f4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0, acc2 = acc0;
-        for (int kc = kb; kc < ke; kc += TCH) {
-            const int cnt = min(TCH, ke - kc);
-            const int lidreg = lane < cnt ? (int)lidx[kc + lane] : 0;
-            const float* vsrc = vals + (int64_t)kc * 9;
-            for (int t = lane; t < cnt * 9; t += 64) sv[t] = vsrc[t];
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll 4
-            for (int u = 0; u < cnt; ++u) {
-                const int lid = __builtin_amdgcn_readlane(lidreg, u);
-                const f4 x = prow[lid * row_items];
-                const float* a = sv + u * 9 + r;  // column r of the block
-                acc0 += a[0] * x;
-                acc1 += a[3] * x;
-                acc2 += a[6] * x;
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-        }
+    const f4* prow = panels + r * lpn + cl;  // + lid * row_items
+
+    // staging item it = threadIdx.x + 256 j  ->  (panel u, row rr, 16-byte chunk q); recomputed where needed
+    auto load_ids = [&](unsigned tile, int (&ids)[TILE_MAXIT]) {
+        const int u0 = tuptr[tile], nu = tuptr[tile + 1] - u0;
 #pragma unroll
-        for (int v = 0; v < 4; ++v) {
-            acc0[v] += __shfl(acc0[v], lane + lpn) + __shfl(acc0[v], lane + 2 * lpn);
-            acc1[v] += __shfl(acc1[v], lane + lpn) + __shfl(acc1[v], lane + 2 * lpn);
-            acc2[v] += __shfl(acc2[v], lane + lpn) + __shfl(acc2[v], lane + 2 * lpn);
+        for (int j = 0; j < TILE_MAXIT; ++j) {
+            const int u = (threadIdx.x + 256 * j) / row_items;
+            ids[j] = ulist[u0 + (u < nu ? u : 0)];
         }
-        float* yp = Y + (node * 3) * ldy + c0;
-        if (active && r_raw == 0) {
-            if (EPI == 1) {
-                const float* rp = epi.r0 + (node * 3) * epi.ldr + c0;
-                const float* xp = X + (node * 3) * ldx + c0;
-                const float* d = epi.dinv + node * 9;
-                const f4 q0 = *reinterpret_cast<const f4*>(rp) - acc0;
-                const f4 q1 = *reinterpret_cast<const f4*>(rp + epi.ldr) - acc1;
-                const f4 q2 = *reinterpret_cast<const f4*>(rp + 2 * epi.ldr) - acc2;
-                const f4 t0 = d[0] * q0 + d[1] * q1 + d[2] * q2;
-                const f4 t1 = d[3] * q0 + d[4] * q1 + d[5] * q2;
-                const f4 t2 = d[6] * q0 + d[7] * q1 + d[8] * q2;
-                const f4 w0 = *reinterpret_cast<const f4*>(xp);
-                const f4 w1 = *reinterpret_cast<const f4*>(xp + ldx);
-                const f4 w2 = *reinterpret_cast<const f4*>(xp + 2 * ldx);
-                f4 o0 = w0 + epi.c2 * t0, o1 = w1 + epi.c2 * t1, o2 = w2 + epi.c2 * t2;
-                if (!epi.first) {
-                    o0 += epi.c1 * (w0 - *reinterpret_cast<const f4*>(yp));
-                    o1 += epi.c1 * (w1 - *reinterpret_cast<const f4*>(yp + ldy));
-                    o2 += epi.c1 * (w2 - *reinterpret_cast<const f4*>(yp + 2 * ldy));
+    };
+    auto load_panels = [&](const int (&ids)[TILE_MAXIT], f4 (&st)[TILE_MAXIT]) {
+#pragma unroll
+        for (int j = 0; j < TILE_MAXIT; ++j) {
+            const int it = threadIdx.x + 256 * j;
+            const int rem = it - (it / row_items) * row_items;  // = rr * lpn + q
+            const int rr = rem / lpn, q = rem - rr * lpn;
+            st[j] = *reinterpret_cast<const f4*>(X + ((int64_t)ids[j] * 3 + rr) * ldx + q * 4);
+        }
+    };
+
+    int ids[TILE_MAXIT];
+    f4 stage[TILE_MAXIT];
+    load_ids(t_begin, ids);
+    load_panels(ids, stage);
+    if (t_begin + 1 < t_end) load_ids(t_begin + 1, ids);
+
+    for (unsigned tile = t_begin; tile < t_end; ++tile) {
+        const int n0 = tnode[tile], n1 = tnode[tile + 1];
+        const int total = (tuptr[tile + 1] - tuptr[tile]) * row_items;
+        __syncthreads();  // every wave is done reading the previous tile's panels
+#pragma unroll
+        for (int j = 0; j < TILE_MAXIT; ++j) {
+            const int it = threadIdx.x + 256 * j;
+            if (it < total) panels[it] = stage[j];
+        }
+        __syncthreads();
+        // keep the pipeline full: panels of tile+1 (ids already here), ids of tile+2
+        if (tile + 1 < t_end) {
+            load_panels(ids, stage);
+            if (tile + 2 < t_end) load_ids(tile + 2, ids);
+        }
+        // ---- rows of the tile: wave w takes nodes n0 + w, n0 + w + 4, ...
+        for (int64_t node = n0 + wave; node < n1; node += 4) {
+            const int kb = rowptr[node], ke = rowptr[node + 1];
+            f4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0, acc2 = acc0;
+            for (int kc = kb; kc < ke; kc += TCH) {
+                const int cnt = min(TCH, ke - kc);
+                const int lidreg = lane < cnt ? (int)lidx[kc + lane] : 0;
+                const float* vsrc = vals + (int64_t)kc * 9;
+                for (int t = lane; t < cnt * 9; t += 64) sv[t] = vsrc[t];
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll 4
+                for (int u = 0; u < cnt; ++u) {
+                    const int lid = __builtin_amdgcn_readlane(lidreg, u);
+                    const f4 x = prow[lid * row_items];
+                    const float* a = sv + u * 9 + r;  // column r of the block
+                    acc0 += a[0] * x;
+                    acc1 += a[3] * x;
+                    acc2 += a[6] * x;
                 }
-                *reinterpret_cast<f4*>(yp) = o0;
-                *reinterpret_cast<f4*>(yp + ldy) = o1;
-                *reinterpret_cast<f4*>(yp + 2 * ldy) = o2;
-            } else {
-                *reinterpret_cast<f4*>(yp) = acc0;
-                *reinterpret_cast<f4*>(yp + ldy) = acc1;
-                *reinterpret_cast<f4*>(yp + 2 * ldy) = acc2;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                acc0[v] += __shfl(acc0[v], lane + lpn) + __shfl(acc0[v], lane + 2 * lpn);
+                acc1[v] += __shfl(acc1[v], lane + lpn) + __shfl(acc1[v], lane + 2 * lpn);
+                acc2[v] += __shfl(acc2[v], lane + lpn) + __shfl(acc2[v], lane + 2 * lpn);
+            }
+            float* yp = Y + (node * 3) * ldy + c0;
+            if (active && r_raw == 0) {
+                if (EPI == 1) {
+                    const float* rp = epi.r0 + (node * 3) * epi.ldr + c0;
+                    const float* xp = X + (node * 3) * ldx + c0;
+                    const float* d = epi.dinv + node * 9;
+                    const f4 q0 = *reinterpret_cast<const f4*>(rp) - acc0;
+                    const f4 q1 = *reinterpret_cast<const f4*>(rp + epi.ldr) - acc1;
+                    const f4 q2 = *reinterpret_cast<const f4*>(rp + 2 * epi.ldr) - acc2;
+                    const f4 t0 = d[0] * q0 + d[1] * q1 + d[2] * q2;
+                    const f4 t1 = d[3] * q0 + d[4] * q1 + d[5] * q2;
+                    const f4 t2 = d[6] * q0 + d[7] * q1 + d[8] * q2;
+                    const f4 w0 = *reinterpret_cast<const f4*>(xp);
+                    const f4 w1 = *reinterpret_cast<const f4*>(xp + ldx);
+                    const f4 w2 = *reinterpret_cast<const f4*>(xp + 2 * ldx);
+                    f4 o0 = w0 + epi.c2 * t0, o1 = w1 + epi.c2 * t1, o2 = w2 + epi.c2 * t2;
+                    if (!epi.first) {
+                        o0 += epi.c1 * (w0 - *reinterpret_cast<const f4*>(yp));
+                        o1 += epi.c1 * (w1 - *reinterpret_cast<const f4*>(yp + ldy));
+                        o2 += epi.c1 * (w2 - *reinterpret_cast<const f4*>(yp + 2 * ldy));
+                    }
+                    *reinterpret_cast<f4*>(yp) = o0;
+                    *reinterpret_cast<f4*>(yp + ldy) = o1;
+                    *reinterpret_cast<f4*>(yp + 2 * ldy) = o2;
+                } else {
+                    *reinterpret_cast<f4*>(yp) = acc0;
+                    *reinterpret_cast<f4*>(yp + ldy) = acc1;
+                    *reinterpret_cast<f4*>(yp + 2 * ldy) = acc2;
+                }
             }
         }
     }
@@ -510,8 +537,10 @@ int launch_tile(const int32_t* rowptr, const float* vals, int64_t nv, const int3
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         attr_set = true;
     }
-    spmm_tile_kernel<EPI, LPN_CT><<<(unsigned)ntiles, 256, lds, st>>>(rowptr, vals, nv, tnode, tuptr, ulist, lidx, X,
-                                                                      ldx, Y, ldy, lpn, (unsigned)ntiles, epi);
+    static const int wg_per_cu = getenv("DS_TILE_WGPCU") ? atoi(getenv("DS_TILE_WGPCU")) : 2;
+    const unsigned grid = (unsigned)std::min<int64_t>(ntiles, 256 * (int64_t)std::max(1, wg_per_cu));
+    spmm_tile_kernel<EPI, LPN_CT><<<grid, 256, lds, st>>>(rowptr, vals, nv, tnode, tuptr, ulist, lidx, X, ldx, Y, ldy,
+                                                          lpn, (unsigned)ntiles, epi);
     DS_LAUNCH_CHECK("spmm_tile_kernel");
     return DS_OK;
 }

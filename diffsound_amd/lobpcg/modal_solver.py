@@ -149,8 +149,8 @@ class ChebyshevBlockJacobi:
         self.ops = ops
         self.degree = max(1, int(degree))
         n, dev, dt = ops.n, ops.device, ops.dtype
-        g = torch.Generator(device="cpu").manual_seed(seed + 17)
-        x = torch.randn((n, 8), generator=g, dtype=torch.float32).to(device=dev, dtype=dt)
+        g = torch.Generator(device=dev).manual_seed(seed + 17)  # device-side RNG: no 100 MB host round trip
+        x = torch.randn((n, 8), generator=g, dtype=torch.float32, device=dev).to(dt)
         y = torch.empty_like(x)
         z = torch.empty_like(x)
         lm = None
@@ -276,14 +276,14 @@ class ModalSolver:
         MW = torch.empty((n, b), dtype=dt, device=dev)
 
         X = S[:, ny:ny + b]
-        g = torch.Generator(device="cpu").manual_seed(cfg.seed)
+        g = torch.Generator(device=dev).manual_seed(cfg.seed)
         nx0 = 0 if X0 is None else X0.shape[1]
         if nx0:
             X[:, :nx0].copy_(X0.to(dt))
         if nx0 < b:
-            X[:, nx0:].copy_(torch.randn((n, b - nx0), generator=g, dtype=torch.float32).to(device=dev, dtype=dt))
+            X[:, nx0:].copy_(torch.randn((n, b - nx0), generator=g, dtype=torch.float32, device=dev).to(dt))
         # operator norm estimates with a random block, as the reference does (_lobpcg.py:280-285)
-        G0 = torch.randn((n, 8), generator=g, dtype=torch.float32).to(device=dev, dtype=dt)
+        G0 = torch.randn((n, 8), generator=g, dtype=torch.float32, device=dev).to(dt)
         G1 = torch.empty_like(G0)
         gn = torch.linalg.vector_norm(G0.double())
         ops.apply_K(G0, G1)

@@ -82,9 +82,11 @@ class TetSystem:
         self.kmu = torch.empty((self.nnzb, 9), dtype=torch.float64, device=dev)
         self.ms = torch.empty((self.nnzb,), dtype=torch.float64, device=dev)
         self._tetgeo = torch.empty((self.T, 13), dtype=torch.float64, device=dev)
-        # row tiles for the LDS-tiled SpMM (only worthwhile with the Morton numbering)
+        # Row tiles for the LDS-tiled SpMM (needs the Morton numbering).  EXPERIMENTAL and off by default:
+        # correct (tests/test_hip_kernels.py::test_tiled_spmm_matches_untiled) but, at 8 waves per CU, still
+        # 2x slower than the wave-per-node kernel - every per-node global latency is exposed.
         self.tiles = None
-        if reorder and os.environ.get("DS_SPMM_TILED", "1") != "0":
+        if reorder and os.environ.get("DS_SPMM_TILED", "0") == "1":
             try:
                 tl = _hip.Tiles(pat.rowptr, pat.colidx, self.nv, nu_max=int(os.environ.get("DS_TILE_NU", "76")),
                                 nb_max=int(os.environ.get("DS_TILE_NB", "8")))

@@ -105,7 +105,13 @@ def test_tiled_spmm_matches_untiled(case, dev, ncols):
     """LDS-tiled kernels (plain product and fused Chebyshev term) on the Morton-ordered system."""
     from diffsound_amd.modal_ops import HipModalOps, TetSystem
 
-    s1 = TetSystem(case["v"].to(dev), case["t"].to(dev), case["order"], MAT[0], reorder=True)
+    import os
+
+    os.environ["DS_SPMM_TILED"] = "1"
+    try:
+        s1 = TetSystem(case["v"].to(dev), case["t"].to(dev), case["order"], MAT[0], reorder=True)
+    finally:
+        os.environ.pop("DS_SPMM_TILED", None)
     if s1.tiles is None:
         pytest.skip("a row exceeds the tile capacity")
     h1 = HipModalOps(s1, case["lam"], case["mu"])
