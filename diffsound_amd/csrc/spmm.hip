@@ -385,14 +385,14 @@ extern "C" int ds_spmm_bsr3(int kind, const int32_t* rowptr, const int32_t* coli
 // sets overlap heavily; it stages the tile's UNIQUE neighbour panels once in LDS (coalesced 16-byte
 // loads), and the per-block loads become LDS reads.  L2 -> CU traffic drops by the reuse factor of the
 // tiling (about 2x at 80 panels per tile), HBM traffic is unchanged (compulsory).
-constexpr int TILE_MAXIT = 20;  // staging items per thread: nu_max * 3 * lpn <= 20 * 256 (checked on the host)
+// NW waves per workgroup; MAXIT staging items per thread: nu_max * 3 * lpn <= MAXIT * 64 * NW (checked on the host)
 
 // Persistent form: the grid is sized to the chip (2 workgroups per CU), every workgroup walks a contiguous
 // range of tiles, and the staging is software-pipelined through registers two tiles deep:
 //   ids(t+2) -> panels(t+1) in flight in VGPRs while the rows of tile t are computed out of LDS.
 // (One workgroup per tile spent more time in dispatch - 31k launches with 80 KB of LDS each - than in work.)
-template <int EPI, int LPN_CT>
-__global__ void __launch_bounds__(256, 2)
+template <int EPI, int LPN_CT, int NW, int MAXIT>
+__global__ void __launch_bounds__(64 * NW)
     spmm_tile_kernel(const int32_t* __restrict__ rowptr, const float* __restrict__ vals, int64_t nv,
                      const int32_t* __restrict__ tnode, const int32_t* __restrict__ tuptr,
                      const int32_t* __restrict__ ulist, const uint16_t* __restrict__ lidx,
@@ -400,8 +400,9 @@ __global__ void __launch_bounds__(256, 2)
                      unsigned ntiles, ChebEpilogue epi) {
     using f4 = __attribute__((ext_vector_type(4))) float;
     extern __shared__ __attribute__((aligned(16))) float s_dyn[];  // [nu][3][lpn] float4 panels
-    constexpr int TCH = 32;  // blocks of a row staged per pass (small slab: two workgroups per CU must fit)
-    __shared__ float s_vals[4][TCH * 9];
+    constexpr int TCH = NW > 4 ? 16 : 32;  // blocks of a row staged per pass (small per-wave slab)
+    constexpr int NT = 64 * NW;
+    __shared__ float s_vals[NW][TCH * 9];
     const int lpn = LPN_CT ? LPN_CT : lpn_rt;
     const int row_items = 3 * lpn;
     const unsigned G = gridDim.x;
@@ -422,26 +423,26 @@ __global__ void __launch_bounds__(256, 2)
     const f4* prow = panels + r * lpn + cl;  // + lid * row_items
 
     // staging item it = threadIdx.x + 256 j  ->  (panel u, row rr, 16-byte chunk q); recomputed where needed
-    auto load_ids = [&](unsigned tile, int (&ids)[TILE_MAXIT]) {
+    auto load_ids = [&](unsigned tile, int (&ids)[MAXIT]) {
         const int u0 = tuptr[tile], nu = tuptr[tile + 1] - u0;
 #pragma unroll
-        for (int j = 0; j < TILE_MAXIT; ++j) {
-            const int u = (threadIdx.x + 256 * j) / row_items;
+        for (int j = 0; j < MAXIT; ++j) {
+            const int u = (threadIdx.x + NT * j) / row_items;
             ids[j] = ulist[u0 + (u < nu ? u : 0)];
         }
     };
-    auto load_panels = [&](const int (&ids)[TILE_MAXIT], f4 (&st)[TILE_MAXIT]) {
+    auto load_panels = [&](const int (&ids)[MAXIT], f4 (&st)[MAXIT]) {
 #pragma unroll
-        for (int j = 0; j < TILE_MAXIT; ++j) {
-            const int it = threadIdx.x + 256 * j;
+        for (int j = 0; j < MAXIT; ++j) {
+            const int it = threadIdx.x + NT * j;
             const int rem = it - (it / row_items) * row_items;  // = rr * lpn + q
             const int rr = rem / lpn, q = rem - rr * lpn;
             st[j] = *reinterpret_cast<const f4*>(X + ((int64_t)ids[j] * 3 + rr) * ldx + q * 4);
         }
     };
 
-    int ids[TILE_MAXIT];
-    f4 stage[TILE_MAXIT];
+    int ids[MAXIT];
+    f4 stage[MAXIT];
     load_ids(t_begin, ids);
     load_panels(ids, stage);
     if (t_begin + 1 < t_end) load_ids(t_begin + 1, ids);
@@ -451,8 +452,8 @@ __global__ void __launch_bounds__(256, 2)
         const int total = (tuptr[tile + 1] - tuptr[tile]) * row_items;
         __syncthreads();  // every wave is done reading the previous tile's panels
 #pragma unroll
-        for (int j = 0; j < TILE_MAXIT; ++j) {
-            const int it = threadIdx.x + 256 * j;
+        for (int j = 0; j < MAXIT; ++j) {
+            const int it = threadIdx.x + NT * j;
             if (it < total) panels[it] = stage[j];
         }
         __syncthreads();
@@ -462,7 +463,7 @@ __global__ void __launch_bounds__(256, 2)
             if (tile + 2 < t_end) load_ids(tile + 2, ids);
         }
         // ---- rows of the tile: wave w takes nodes n0 + w, n0 + w + 4, ...
-        for (int64_t node = n0 + wave; node < n1; node += 4) {
+        for (int64_t node = n0 + wave; node < n1; node += NW) {
             const int kb = rowptr[node], ke = rowptr[node + 1];
             f4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0, acc2 = acc0;
             for (int kc = kb; kc < ke; kc += TCH) {
@@ -525,24 +526,37 @@ __global__ void __launch_bounds__(256, 2)
     }
 }
 
+template <int EPI, int LPN_CT, int NW, int MAXIT>
+int launch_tile_nw(const int32_t* rowptr, const float* vals, int64_t nv, const int32_t* tnode, const int32_t* tuptr,
+                const int32_t* ulist, const uint16_t* lidx, int64_t ntiles, int nu_max, const float* X, int64_t ldx,
+                float* Y, int64_t ldy, int lpn, hipStream_t st, ChebEpilogue epi) {
+    const size_t lds = (size_t)nu_max * 3 * lpn * 16;
+    static size_t attr_bytes = 0;
+    if (lds > 48 * 1024 && lds > attr_bytes) {  // opt in to large dynamic LDS (per instantiation, grows only)
+        int rc = ds::check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&spmm_tile_kernel<EPI, LPN_CT, NW, MAXIT>),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
+                               "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
+        if (rc != DS_OK) return rc;
+        attr_bytes = lds;
+    }
+    static const int wg_per_cu = getenv("DS_TILE_WGPCU") ? atoi(getenv("DS_TILE_WGPCU")) : (NW > 4 ? 1 : 2);
+    const unsigned grid = (unsigned)std::min<int64_t>(ntiles, 256 * (int64_t)std::max(1, wg_per_cu));
+    spmm_tile_kernel<EPI, LPN_CT, NW, MAXIT><<<grid, 64 * NW, lds, st>>>(rowptr, vals, nv, tnode, tuptr, ulist, lidx, X, ldx, Y, ldy,
+                                                          lpn, (unsigned)ntiles, epi);
+    DS_LAUNCH_CHECK("spmm_tile_kernel");
+    return DS_OK;
+}
+
 template <int EPI, int LPN_CT>
 int launch_tile(const int32_t* rowptr, const float* vals, int64_t nv, const int32_t* tnode, const int32_t* tuptr,
                 const int32_t* ulist, const uint16_t* lidx, int64_t ntiles, int nu_max, const float* X, int64_t ldx,
                 float* Y, int64_t ldy, int lpn, hipStream_t st, ChebEpilogue epi) {
-    const size_t lds = (size_t)nu_max * 3 * lpn * 16;
-    static bool attr_set = false;
-    if (lds > 48 * 1024 && !attr_set) {
-        // opt in to large dynamic LDS once per instantiation
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&spmm_tile_kernel<EPI, LPN_CT>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-        attr_set = true;
-    }
-    static const int wg_per_cu = getenv("DS_TILE_WGPCU") ? atoi(getenv("DS_TILE_WGPCU")) : 2;
-    const unsigned grid = (unsigned)std::min<int64_t>(ntiles, 256 * (int64_t)std::max(1, wg_per_cu));
-    spmm_tile_kernel<EPI, LPN_CT><<<grid, 256, lds, st>>>(rowptr, vals, nv, tnode, tuptr, ulist, lidx, X, ldx, Y, ldy,
-                                                          lpn, (unsigned)ntiles, epi);
-    DS_LAUNCH_CHECK("spmm_tile_kernel");
-    return DS_OK;
+    // small tiles: 4 waves, two workgroups per CU; large tiles (more reuse): 16 waves, one workgroup per CU
+    if ((size_t)nu_max * 3 * lpn <= 20 * 256 && nu_max <= 80)
+        return launch_tile_nw<EPI, LPN_CT, 4, 20>(rowptr, vals, nv, tnode, tuptr, ulist, lidx, ntiles, nu_max, X, ldx, Y,
+                                                  ldy, lpn, st, epi);
+    return launch_tile_nw<EPI, LPN_CT, 16, 9>(rowptr, vals, nv, tnode, tuptr, ulist, lidx, ntiles, nu_max, X, ldx, Y, ldy,
+                                              lpn, st, epi);
 }
 
 extern "C" int ds_spmm_tiled(int epilogue, const int32_t* rowptr, const float* vals, int64_t nv, const int32_t* tnode,
@@ -557,8 +571,8 @@ extern "C" int ds_spmm_tiled(int epilogue, const int32_t* rowptr, const float* v
     DS_REQUIRE(ldx >= ncols && ldy >= ncols, "ds_spmm_tiled: leading dimension smaller than ncols");
     DS_REQUIRE(X != Y, "ds_spmm_tiled: X and Y must be different buffers");
     const int lpn = ncols / 4;
-    DS_REQUIRE(nu_max > 0 && (size_t)nu_max * 3 * lpn <= 20 * 256,
-               "ds_spmm_tiled: nu_max * 3 * ncols/4 must be <= 5120 (staging registers / LDS)");
+    DS_REQUIRE(nu_max > 0 && (size_t)nu_max * 3 * lpn <= 9 * 1024 && (size_t)nu_max * 3 * lpn * 16 <= 142 * 1024,
+               "ds_spmm_tiled: nu_max * 3 * ncols/4 must be <= 9088 (staging registers / LDS)");
     uintptr_t al = reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(Y) | (uintptr_t)(ldx * 4) |
                    (uintptr_t)(ldy * 4);
     if (epilogue) al |= reinterpret_cast<uintptr_t>(R0) | (uintptr_t)(ldr * 4);

@@ -197,7 +197,7 @@ class DiffSoundObj:
                 blocks = (lam * s.klam + mu * s.kmu).reshape(-1, 3, 3)
             else:
                 blocks = s.ms[:, None, None] * torch.eye(3, dtype=torch.float64, device=s.device)
-            coo = torch.sparse_bsr_tensor(s.rowptr.long(), s.colidx.long(), blocks, size=(s.n, s.n)).to_sparse_coo()
+            coo = torch.sparse_bsr_tensor(s.rowptr.long(), s.colidx.long(), blocks, size=(s.n, s.n)).to_sparse_coo().coalesce()
             if s.perm is not None:  # internal (Morton) -> the caller's DOF numbering
                 idx = coo.indices()
                 ext = 3 * s.perm[idx // 3] + idx % 3

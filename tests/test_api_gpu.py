@@ -1,0 +1,213 @@
+"""Drop-in operator API on the GPU against outputs of the reference itself (golden fixtures):
+DiffSoundObj / TrainableLinear / build_model semantics, oscillators, lobpcg_func.  pytest -m gpu."""
+import numpy as np
+import pytest
+import scipy.linalg as sla
+import torch
+
+pytestmark = pytest.mark.gpu
+
+FREQ_TOL = 5e-5   # stated tolerance on frequencies
+AUDIO_TOL = 1e-3  # rel-L2 on rendered audio
+GRAD_TOL = 2e-3   # gradients w.r.t. the material logits (the reference's own fp32 bracket is noisy at 1e-4)
+
+
+def rel(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no HIP device")
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def bowl(golden, dev):
+    m = golden("g0_bowl_mesh.npz")
+    g = golden("g3_bowl_o1.npz")
+    v = torch.from_numpy(m["verts"]).to(dev)
+    t = torch.from_numpy(m["tets"]).long().to(dev)
+    return g, v, t
+
+
+def _model(g, v, t, task):
+    from src.diffelastic.diff_model import DiffSoundObj, FixedLinear, TrainableLinear
+
+    mat = tuple(float(x) for x in g["mat"])
+    mm = FixedLinear if task == "gt" else TrainableLinear
+    obj = DiffSoundObj(vertices=v, tets=t, mode_num=int(g["mode_num"]), mat=mat, order=1, mat_model=mm, task=task)
+    if task != "gt":
+        with torch.no_grad():
+            obj.material_model.youngs.probablity.copy_(torch.from_numpy(g[f"{task}_youngs_logits"]))
+            obj.material_model.poisson.probablity.copy_(torch.from_numpy(g[f"{task}_poisson_logits"]))
+    return obj
+
+
+def test_gt_model_matches_reference(bowl):
+    g, v, t = bowl
+    obj = _model(g, v, t, "gt")
+    obj.eigen_decomposition()
+    assert rel(obj.eigenvalues.cpu().numpy(), g["eigenvalues"]) < 1e-4
+    f = obj.get_undamped_freqs()
+    assert f.shape == (int(g["mode_num"]), 1) and f.dtype == torch.float32
+    assert rel(f.cpu().numpy(), g["gt_freqs"]) < FREQ_TOL
+    vals = obj.get_vals()
+    assert vals.shape == f.shape and vals.dtype == torch.float32
+    assert rel(vals.cpu().numpy(), g["get_vals"]) < 1e-4
+    assert obj.parameters() is None
+    # matrices in the caller's numbering, as torch sparse tensors like the reference's attributes
+    x = torch.from_numpy(g["x_probe"]).to(v.device)
+    assert rel(torch.sparse.mm(obj.stiff_matrix, x).cpu().numpy(), g["Kx"]) < 2e-6
+    assert rel(torch.sparse.mm(obj.mass_matrix, x).cpu().numpy(), g["Mx"]) < 1e-9
+    # modes: M-orthonormal, rigid block first in U_hat_full, same invariant subspaces as ARPACK's
+    U = obj.U_hat
+    assert obj.U_hat_full.shape == (U.shape[0], U.shape[1] + 6) and U.dtype == torch.float64
+    MU = torch.sparse.mm(obj.mass_matrix, U)
+    assert float((U.T @ MU - torch.eye(U.shape[1], device=U.device, dtype=U.dtype)).abs().max()) < 1e-4
+    ref4 = torch.from_numpy(g["U_hat_first4"]).to(U.device)
+    Mref = torch.sparse.mm(obj.mass_matrix, ref4)
+    for pair in ((0, 1), (2, 3)):  # near-degenerate pairs of the bowl: compare the 2-D subspaces, not columns
+        C = U[:, list(pair)].T @ Mref[:, list(pair)]
+        sv = torch.linalg.svdvals(C)
+        assert float(sv.min()) > 1 - 1e-3
+
+
+@pytest.mark.parametrize("task", ["material", "mat_baseline"])
+def test_trainable_model_gradients_match_reference(bowl, task):
+    from src.ddsp.oscillator import TraditionalDampedOscillator
+    from src.diffelastic.diff_model import Material
+
+    g, v, t = bowl
+    obj = _model(g, v, t, task)
+    assert abs(float(obj.material_model.youngs()) / float(g[f"{task}_youngs"]) - 1) < 1e-6
+    assert abs(float(obj.material_model.poisson()) / float(g[f"{task}_poisson"]) - 1) < 1e-6
+    params = list(obj.parameters())
+    assert len(params) == (2 if task == "material" else 1)
+    obj.eigen_decomposition()
+    assert rel(obj.eigenvalues.cpu().numpy(), g[f"{task}_eigenvalues"]) < 1e-4
+    f = obj.get_undamped_freqs()
+    assert rel(f.detach().cpu().numpy(), g[f"{task}_freqs"]) < FREQ_TOL
+    f.sum().backward()
+    gy = obj.material_model.youngs.probablity.grad.numpy()
+    assert rel(gy, g[f"{task}_grad_youngs_logits"]) < GRAD_TOL
+    if task == "material":
+        assert rel(obj.material_model.poisson.probablity.grad.numpy(), g[f"{task}_grad_poisson_logits"]) < GRAD_TOL
+    # the training-loop body: oscillator + MSE against the gt audio, gradient to the logits
+    mat = tuple(float(x) for x in g["mat"])
+    forces = torch.zeros((1, 150), device=v.device)
+    forces[0, 0] = 1
+    osc = TraditionalDampedOscillator(forces, 1, int(g["mode_num"]), 8000, 32000, Material(mat))
+    gt_audio = osc(torch.from_numpy(g["gt_freqs"]).to(v.device)).detach()
+    for p in obj.material_model.parameters():
+        p.grad = None
+    sig = osc(obj.get_undamped_freqs().float() * 1.01)
+    loss = ((sig - gt_audio) ** 2).mean()
+    loss.backward()
+    assert abs(float(loss) / float(g[f"{task}_loop_loss"]) - 1) < 5e-3
+    assert rel(obj.material_model.youngs.probablity.grad.numpy(), g[f"{task}_loop_grad_youngs_logits"]) < 2e-2
+    if task == "material":
+        assert rel(obj.material_model.poisson.probablity.grad.numpy(), g[f"{task}_loop_grad_poisson_logits"]) < 2e-2
+
+
+def test_stiff_func_matches_matrix(bowl):
+    g, v, t = bowl
+    obj = _model(g, v, t, "material")
+    obj.eigen_decomposition()
+    U = obj.U_hat[:, :5].float()
+    KU = torch.sparse.mm(obj.stiff_matrix, U.double())
+    sf = obj.stiff_func(U)
+    assert sf.shape == U.shape
+    assert rel(sf.detach().cpu().numpy(), KU.cpu().numpy()) < 1e-5
+    assert obj.stiff_func(U[:, 0]).shape == (U.shape[0],)
+
+
+def test_warm_started_redecomposition(bowl):
+    """Second eigen_decomposition after a parameter step re-uses the previous block (training loop pattern)."""
+    g, v, t = bowl
+    obj = _model(g, v, t, "material")
+    obj.eigen_decomposition()
+    it0 = obj.last_result.iterations
+    with torch.no_grad():
+        obj.material_model.youngs.probablity.add_(0.01)
+    obj.eigen_decomposition()
+    assert obj.last_result.iterations < it0
+
+
+def test_traditional_oscillator_matches_reference(golden, dev):
+    from src.ddsp.oscillator import TraditionalDampedOscillator
+    from src.diffelastic.diff_model import Material
+
+    g = golden("g5_oscillator.npz")
+    mat = tuple(float(x) for x in g["mat"])
+    for name in ("impulse", "random"):
+        force = torch.from_numpy(g[f"trad_{name}_force"]).to(dev)
+        osc = TraditionalDampedOscillator(force, 1, 32, 8000, 32000, Material(mat)).cuda()
+        f = torch.from_numpy(g["freqs"]).to(dev).requires_grad_(True)
+        sig = osc(f)
+        assert sig.shape == (1, 8000) and sig.dtype == torch.float32
+        ref = g[f"trad_{name}_signal"]
+        assert np.linalg.norm(sig.detach().cpu().numpy() - ref) / np.linalg.norm(ref) < AUDIO_TOL
+        assert osc.damped_freq.shape == (1, 32, 8000)
+        assert rel(osc.damped_freq[:, :, 0].detach().cpu().numpy(), g[f"trad_{name}_damped_freq"]) < 1e-5
+        (sig ** 2).mean().backward()
+        gref = g[f"trad_{name}_grad_f"]
+        assert np.linalg.norm(f.grad.cpu().numpy() - gref) / np.linalg.norm(gref) < 1e-2
+
+
+def test_damped_oscillator_matches_reference(golden, dev):
+    from src.ddsp.oscillator import DampedOscillator
+    from src.diffelastic.diff_model import Material
+
+    g = golden("g5_oscillator.npz")
+    mat = tuple(float(x) for x in g["mat"])
+    forces = torch.from_numpy(g["damped_forces"]).to(dev)
+    osc = DampedOscillator(forces, 3, 32, 8000, 32000, [0.0, 1.0], Material(mat)).cuda()
+    with torch.no_grad():
+        osc.alpha.params.copy_(torch.from_numpy(g["damped_alpha_params"]))
+        osc.beta.params.copy_(torch.from_numpy(g["damped_beta_params"]))
+        osc.amp.value.copy_(torch.from_numpy(g["damped_amp_value"]))
+    assert rel(osc.alpha().detach().cpu().numpy(), g["damped_alpha"]) < 1e-5
+    assert rel(osc.amp().detach().cpu().numpy(), g["damped_amp"]) < 1e-5
+    f = torch.from_numpy(g["freqs"]).to(dev).requires_grad_(True)
+    sig = osc(f)
+    ref = g["damped_signal"]
+    assert sig.shape == (3, 8000)
+    assert np.linalg.norm(sig.detach().cpu().numpy() - ref) / np.linalg.norm(ref) < AUDIO_TOL
+    (sig ** 2).mean().backward()
+    for got, key in ((f.grad, "damped_grad_f"), (osc.alpha.params.grad, "damped_grad_alpha_params"),
+                     (osc.beta.params.grad, "damped_grad_beta_params"), (osc.amp.value.grad, "damped_grad_amp_value")):
+        want = g[key]
+        assert np.linalg.norm(got.cpu().numpy() - want) / np.linalg.norm(want) < 1e-2, key
+
+
+def test_lobpcg_func_api(golden, dev):
+    """lobpcg_func(A, B, k, largest=False/True, tracker) and LOBPCG_solver_freq on the reference's own test
+    matrices (2^3 cube, ord-2, fp32), against a dense generalized eigensolve."""
+    from src.lobpcg import lobpcg_func
+    from src.utils.utils import LOBPCG_solver_freq
+
+    g = golden("g6_lobpcg_ref.npz")
+    Kd, Md = g["K"].astype(np.float64), g["M"].astype(np.float64)
+    w = sla.eigh(Kd, Md, eigvals_only=True)
+    K = torch.from_numpy(g["K"]).to(dev).to_sparse()
+    M = torch.from_numpy(g["M"]).to(dev).to_sparse()
+    seen = []
+    E, X = lobpcg_func(K, M, 14, largest=False, niter=200, tracker=lambda wk: seen.append(wk.ivars["istep"]))
+    assert E.shape == (14,) and X.shape == (Kd.shape[0], 14) and E.dtype == torch.float32
+    scale = w[6:14].max()
+    assert np.abs(E.cpu().numpy()[6:] - w[6:14]).max() / scale < 1e-4      # elastic modes
+    assert np.abs(E.cpu().numpy()[:6]).max() / scale < 1e-4                # six rigid modes ~ 0
+    assert seen[:2] == [0, 0] and seen[-1] >= 1                             # tracker before and after step 0
+    Xd = X.double().cpu().numpy()
+    assert np.abs(Xd.T @ Md @ Xd - np.eye(14)).max() < 1e-3
+    vals, vecs = LOBPCG_solver_freq(K, M, niter=200, k=8)
+    assert vals.shape == (8,) and vecs.shape == (Kd.shape[0], 8)
+    assert np.abs(vals.cpu().numpy() - w[6:14]).max() / scale < 1e-4
+    El, _ = lobpcg_func(K, M, 4, niter=300)                                 # reference default: largest=True
+    assert np.abs(El.cpu().numpy() - w[::-1][:4]).max() / w.max() < 1e-3
+    with pytest.raises(ValueError, match="not applicable"):
+        lobpcg_func(K, M, Kd.shape[0] // 2)
