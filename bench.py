@@ -202,13 +202,14 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32 iterates / f64 Rayleigh-Ritz",
+            "dtype": "f32",
             "data": "synthetic",
             "config": {
                 "workload": (f"Kuhn box {a.cells}^3 cells = {sysd.T} tets, ord-{a.order} ({sysd.nv} nodes, n={sysd.n}, "
                              f"nnz={sysd.nnzb * 9}), {a.modes} modes, fwd+bwd w.r.t. (E, nu), S=8000 @ 32 kHz"),
                 "hypotheses_per_gpu_per_step": a.hyp_per_gpu,
                 "parallelism": f"dp{world} over material hypotheses, scalar loss all-reduce",
+                "precision": "fp32 block vectors and SpMM, fp64 Gram accumulation / Rayleigh-Ritz / read-out",
                 "eigensolver": (f"LOBPCG(ortho) block {a.block}, Chebyshev({a.cheb_degree}) block-Jacobi, "
                                 f"cold start{' (warm)' if a.warm_start else ''}, mean iterations {np.mean(iters):.1f}"),
                 "symbolic_pattern_seconds_not_timed": t_sym,
