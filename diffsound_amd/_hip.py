@@ -42,6 +42,12 @@ _SIGNATURES = {
     "ds_tiles_free": (None, [_P]),
     "ds_spmm_tiled": (_I, [_I, _P, _P, _I64, _P, _P, _P, _P, _I64, _I, _P, _I64, _P, _I64, _P, _I64, _P, _I, _F, _F,
                            _I, _P]),
+    "ds_groups_build": (_I, [_P, _P, _I64, ctypes.POINTER(_P)]),
+    "ds_groups_sizes": (_I, [_P, ctypes.POINTER(_I64), ctypes.POINTER(_I64)]),
+    "ds_groups_export": (_I, [_P, _P, _P, _P, _P]),
+    "ds_groups_free": (None, [_P]),
+    "ds_pack_groups": (_I, [_P, _P, _I64, _P, _P]),
+    "ds_spmm_grouped": (_I, [_I, _P, _P, _P, _P, _I64, _P, _I64, _P, _I64, _P, _I64, _P, _I, _F, _F, _I, _P]),
     "ds_mix": (_I, [_P, _I64, _I, _P, _I, _P, _I64, _I64, _F, _F, _P]),
     "ds_osc_bank_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _D, _P, _P]),
     "ds_osc_bank_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _D, _P, _P, _P, _P, _P]),
@@ -134,3 +140,23 @@ class Tiles:
                   "ds_tiles_export")
         finally:
             lib().ds_tiles_free(handle)
+
+
+class Groups:
+    """Node groups for the register-blocked SpMM (ds_groups_build): host arrays gptr, gent, goff, kperm (int32)."""
+
+    def __init__(self, rowptr_cpu, colidx_cpu, nv):
+        handle = ctypes.c_void_p()
+        check(lib().ds_groups_build(ptr(rowptr_cpu), ptr(colidx_cpu), nv, ctypes.byref(handle)), "ds_groups_build")
+        try:
+            a, b = _I64(), _I64()
+            check(lib().ds_groups_sizes(handle, ctypes.byref(a), ctypes.byref(b)), "ds_groups_sizes")
+            self.ngroups, self.ne = a.value, b.value
+            self.gptr = torch.empty(self.ngroups + 1, dtype=torch.int32)
+            self.gent = torch.empty(self.ne, dtype=torch.int32)
+            self.goff = torch.empty(self.ne + 1, dtype=torch.int32)
+            self.kperm = torch.empty(colidx_cpu.numel(), dtype=torch.int32)
+            check(lib().ds_groups_export(handle, ptr(self.gptr), ptr(self.gent), ptr(self.goff), ptr(self.kperm)),
+                  "ds_groups_export")
+        finally:
+            lib().ds_groups_free(handle)

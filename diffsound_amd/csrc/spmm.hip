@@ -152,6 +152,14 @@ int launch(const int32_t* rowptr, const int32_t* colidx, const void* vals, int64
 // Both sat at 1.3 TB/s.)
 constexpr int WN_CHUNK = 64;  // blocks of a row staged per pass
 
+// X panels are fetched with buffer loads: the lane's byte offset inside a 3-row panel is loop-invariant
+// (voffset) and the neighbour's panel start is a wave-uniform scalar (soffset = id * panel bytes), so the
+// per-block address arithmetic is one s_mul_i32 instead of a 64-bit multiply-add per lane.
+using f4v = __attribute__((ext_vector_type(4))) float;
+__device__ __forceinline__ f4v buf_load4(__amdgpu_buffer_rsrc_t rsrc, int voff, int soff) {
+    return __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 0));
+}
+
 // Optional fused epilogue (EPI = 1, KIND 0, RS 3): one term of the Chebyshev block-Jacobi polynomial,
 //   Y_i <- X_i + c1 (X_i - Y_i) + c2 T_i (R0_i - (K X)_i)        (Y holds W_{k-1} on entry, W_{k+1} on exit)
 // so a preconditioner term is ONE launch and the product K X never goes to HBM.
@@ -186,6 +194,11 @@ __global__ void __launch_bounds__(256)
     const int c0 = cl * 4;
     const float* xbase = X + (int64_t)r * ldx + c0;
     const int64_t ldx3 = 3 * ldx;
+    // whole X block as one buffer (host guarantees 3 nv ldx 4 < 2^32)
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(X), 0, (int)(unsigned)(3 * nv * ldx * 4), 0x00020000);
+    const int xvoff = (int)(((int64_t)r * ldx + c0) * 4);
+    const int panel_bytes = (int)(ldx3 * 4);
     const int kb = rowptr[node], ke = rowptr[node + 1];
     float* sv = s_vals[wave];
     f4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0, acc2 = acc0;
@@ -204,20 +217,22 @@ __global__ void __launch_bounds__(256)
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
         int u = 0;
-        for (; u + 4 <= cnt; u += 4) {
-            f4 xa[4], xb[4], xc[4];
+        // UX panel loads in flight per wave before the first use: the kernel is latency-bound (72 % of wave
+        // cycles parked in s_waitcnt with 4 in flight), so depth, not bandwidth, is what to raise
+        constexpr int UX = RS == 3 ? 8 : 4;
+        for (; u + UX <= cnt; u += UX) {
+            f4 xa[UX], xb[UX], xc[UX];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int j = __builtin_amdgcn_readlane(colreg, u + q);
-                const float* p = xbase + (int64_t)j * ldx3;
-                xa[q] = *reinterpret_cast<const f4*>(p);
+            for (int q = 0; q < UX; ++q) {
+                const int soff = __builtin_amdgcn_readlane(colreg, u + q) * panel_bytes;
+                xa[q] = buf_load4(xrsrc, xvoff, soff);
                 if (RS == 1) {
-                    xb[q] = *reinterpret_cast<const f4*>(p + ldx);
-                    xc[q] = *reinterpret_cast<const f4*>(p + 2 * ldx);
+                    xb[q] = buf_load4(xrsrc, xvoff + (int)(ldx * 4), soff);
+                    xc[q] = buf_load4(xrsrc, xvoff + (int)(ldx * 8), soff);
                 }
             }
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
+            for (int q = 0; q < UX; ++q) {
                 if (KIND == 1) {
                     const float m = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mreg), u + q));
                     acc0 += m * xa[q];
@@ -358,7 +373,8 @@ extern "C" int ds_spmm_bsr3(int kind, const int32_t* rowptr, const int32_t* coli
         // float4 path needs 16-byte aligned rows; float2 path 8-byte
         if (ncols % 4 == 0 && ncols <= 256 && (xalign & 15) == 0 && (yalign & 15) == 0) {
             static const bool legacy = getenv("DS_SPMM_LEGACY") != nullptr;  // A/B switch for benchmarking
-            if (!legacy)
+            // the fast path addresses X through one buffer descriptor (32-bit byte offsets)
+            if (!legacy && 3 * nv * ldx * 4 < ((int64_t)1 << 32))
                 return kind == 0 ? launch_fast<0>(rowptr, colidx, vals, vals_t, nv, X, ldx, Y, ldy, ncols, st)
                                  : launch_fast<1>(rowptr, colidx, vals, vals_t, nv, X, ldx, Y, ldy, ncols, st);
             return kind == 0 ? launch<0, float, float, float, 4>(rowptr, colidx, vals, nv, X, ldx, Y, ldy, ncols, st)
@@ -589,6 +605,196 @@ extern "C" int ds_spmm_tiled(int epilogue, const int32_t* rowptr, const float* v
     return launch_tile<0, 0>(rowptr, vals, nv, tnode, tuptr, ulist, lidx, ntiles, nu_max, X, ldx, Y, ldy, lpn, st, epi);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Register-blocked variant for <= 84 columns: FOUR consecutive nodes per wave, union column list.
+// The wave-per-node kernel is pinned at the rate a CU can gather rows from L2 (4.0 GB of neighbour
+// panels per 80-column product).  Neighbouring (Morton-ordered) nodes share ~40 % of their neighbours,
+// so walking the union of four rows loads each shared panel once: 64 panel loads per group instead
+// of 111.  Block values come in group order (contiguous per chunk of the union list), staged in a
+// per-wave LDS slab; presence masks and value offsets travel with v_readlane, all wave-uniform.
+constexpr int GR_CH = 24;  // union entries staged per pass (<= 63: goff needs cnt + 1 lanes)
+
+template <int EPI, int LPN_CT>
+__global__ void __launch_bounds__(256)
+    spmm_group_kernel(const int32_t* __restrict__ gptr, const int32_t* __restrict__ gent,
+                      const int32_t* __restrict__ goff, const float* __restrict__ kgrp, int64_t nv,
+                      const float* __restrict__ X, int64_t ldx, float* __restrict__ Y, int64_t ldy, int lpn_rt,
+                      unsigned nblk, ChebEpilogue epi) {
+    using f4 = __attribute__((ext_vector_type(4))) float;
+    __shared__ float s_k[4][GR_CH * 4 * 9];
+    const int lpn = LPN_CT ? LPN_CT : lpn_rt;
+    const unsigned bid = ds::xcd_remap(blockIdx.x, nblk);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t grp = (int64_t)bid * 4 + wave;
+    const int64_t n0 = grp * 4;
+    if (n0 >= nv) return;  // wave-uniform
+    const int r_raw = lane / lpn;
+    const int cl_raw = lane - r_raw * lpn;
+    const bool active = r_raw < 3 && cl_raw < lpn;
+    const int r = active ? r_raw : 0;
+    const int cl = active ? cl_raw : 0;
+    const int c0 = cl * 4;
+    const float* xbase = X + (int64_t)r * ldx + c0;
+    const int64_t ldx3 = 3 * ldx;
+    float* sk = s_k[wave];
+    const float* skr = sk + r * 3;  // column r of a (transposed) block: 3 contiguous floats
+    f4 acc[4][3];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int i = 0; i < 3; ++i) acc[q][i] = f4{0.f, 0.f, 0.f, 0.f};
+    const int e0 = gptr[grp], e1 = gptr[grp + 1];
+    for (int ec = e0; ec < e1; ec += GR_CH) {
+        const int cnt = min(GR_CH, e1 - ec);  // wave-uniform
+        const int entreg = lane < cnt ? gent[ec + lane] : 0;
+        const int offreg = lane <= cnt ? goff[ec + lane] : 0;
+        const int b0 = __builtin_amdgcn_readlane(offreg, 0);
+        const int nb = __builtin_amdgcn_readlane(offreg, cnt) - b0;  // blocks in this chunk
+        const float* ksrc = kgrp + (int64_t)b0 * 9;
+        for (int t = lane; t < nb * 9; t += 64) sk[t] = ksrc[t];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        int u = 0;
+        for (; u + 4 <= cnt; u += 4) {
+            int ent[4], bo[4];
+            f4 x[4];
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                ent[v] = __builtin_amdgcn_readlane(entreg, u + v);
+                bo[v] = __builtin_amdgcn_readlane(offreg, u + v) - b0;
+                x[v] = *reinterpret_cast<const f4*>(xbase + (int64_t)(ent[v] & 0x0fffffff) * ldx3);
+            }
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const unsigned mask = (unsigned)ent[v] >> 28;
+                int p = bo[v];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (mask & (1u << q)) {  // wave-uniform
+                        const float* a = skr + p * 9;
+                        acc[q][0] += a[0] * x[v];
+                        acc[q][1] += a[1] * x[v];
+                        acc[q][2] += a[2] * x[v];
+                        ++p;
+                    }
+                }
+            }
+        }
+        for (; u < cnt; ++u) {
+            const int ent = __builtin_amdgcn_readlane(entreg, u);
+            int p = __builtin_amdgcn_readlane(offreg, u) - b0;
+            const f4 x = *reinterpret_cast<const f4*>(xbase + (int64_t)(ent & 0x0fffffff) * ldx3);
+            const unsigned mask = (unsigned)ent >> 28;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (mask & (1u << q)) {
+                    const float* a = skr + p * 9;
+                    acc[q][0] += a[0] * x;
+                    acc[q][1] += a[1] * x;
+                    acc[q][2] += a[2] * x;
+                    ++p;
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int64_t node = n0 + q;
+        if (node >= nv) break;  // wave-uniform
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int v = 0; v < 4; ++v)
+                acc[q][i][v] += __shfl(acc[q][i][v], lane + lpn) + __shfl(acc[q][i][v], lane + 2 * lpn);
+        float* yp = Y + (node * 3) * ldy + c0;
+        if (active && r_raw == 0) {
+            if (EPI == 1) {
+                const float* rp = epi.r0 + (node * 3) * epi.ldr + c0;
+                const float* xp = X + (node * 3) * ldx + c0;
+                const float* d = epi.dinv + node * 9;
+                const f4 q0 = *reinterpret_cast<const f4*>(rp) - acc[q][0];
+                const f4 q1 = *reinterpret_cast<const f4*>(rp + epi.ldr) - acc[q][1];
+                const f4 q2 = *reinterpret_cast<const f4*>(rp + 2 * epi.ldr) - acc[q][2];
+                const f4 t0 = d[0] * q0 + d[1] * q1 + d[2] * q2;
+                const f4 t1 = d[3] * q0 + d[4] * q1 + d[5] * q2;
+                const f4 t2 = d[6] * q0 + d[7] * q1 + d[8] * q2;
+                const f4 w0 = *reinterpret_cast<const f4*>(xp);
+                const f4 w1 = *reinterpret_cast<const f4*>(xp + ldx);
+                const f4 w2 = *reinterpret_cast<const f4*>(xp + 2 * ldx);
+                f4 o0 = w0 + epi.c2 * t0, o1 = w1 + epi.c2 * t1, o2 = w2 + epi.c2 * t2;
+                if (!epi.first) {
+                    o0 += epi.c1 * (w0 - *reinterpret_cast<const f4*>(yp));
+                    o1 += epi.c1 * (w1 - *reinterpret_cast<const f4*>(yp + ldy));
+                    o2 += epi.c1 * (w2 - *reinterpret_cast<const f4*>(yp + 2 * ldy));
+                }
+                *reinterpret_cast<f4*>(yp) = o0;
+                *reinterpret_cast<f4*>(yp + ldy) = o1;
+                *reinterpret_cast<f4*>(yp + 2 * ldy) = o2;
+            } else {
+                *reinterpret_cast<f4*>(yp) = acc[q][0];
+                *reinterpret_cast<f4*>(yp + ldy) = acc[q][1];
+                *reinterpret_cast<f4*>(yp + 2 * ldy) = acc[q][2];
+            }
+        }
+    }
+}
+
+__global__ void pack_groups_kernel(const float* __restrict__ vals_t, const int32_t* __restrict__ kperm, int64_t nnzb,
+                                   float* __restrict__ kgrp) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nnzb * 9) return;
+    const int64_t p = i / 9;
+    kgrp[i] = vals_t[(int64_t)kperm[p] * 9 + (i - p * 9)];
+}
+
+template <int EPI, int LPN_CT>
+int launch_group(const int32_t* gptr, const int32_t* gent, const int32_t* goff, const float* kgrp, int64_t nv,
+                 const float* X, int64_t ldx, float* Y, int64_t ldy, int lpn, hipStream_t st, ChebEpilogue epi) {
+    const int64_t ngroups = ds::ceil_div(nv, 4);
+    const int64_t nblk = ds::ceil_div(ngroups, 4);
+    spmm_group_kernel<EPI, LPN_CT><<<(unsigned)nblk, 256, 0, st>>>(gptr, gent, goff, kgrp, nv, X, ldx, Y, ldy, lpn,
+                                                                   (unsigned)nblk, epi);
+    DS_LAUNCH_CHECK("spmm_group_kernel");
+    return DS_OK;
+}
+
+extern "C" int ds_pack_groups(const float* vals_t, const int32_t* kperm, int64_t nnzb, float* kgrp,
+                              ds_stream_t stream) {
+    DS_REQUIRE(vals_t && kperm && kgrp && nnzb > 0, "ds_pack_groups: bad argument");
+    pack_groups_kernel<<<(unsigned)ds::ceil_div(nnzb * 9, 256), 256, 0, ds::as_stream(stream)>>>(vals_t, kperm, nnzb,
+                                                                                                kgrp);
+    DS_LAUNCH_CHECK("pack_groups_kernel");
+    return DS_OK;
+}
+
+extern "C" int ds_spmm_grouped(int epilogue, const int32_t* gptr, const int32_t* gent, const int32_t* goff,
+                               const float* kgrp, int64_t nv, const float* X, int64_t ldx, float* Y, int64_t ldy,
+                               const float* R0, int64_t ldr, const float* dinv, int ncols, float c1, float c2,
+                               int first, ds_stream_t stream) {
+    DS_REQUIRE(gptr && gent && goff && kgrp && X && Y, "ds_spmm_grouped: null pointer");
+    DS_REQUIRE(epilogue == 0 || (R0 && dinv), "ds_spmm_grouped: the Chebyshev epilogue needs R0 and dinv");
+    DS_REQUIRE(nv > 0 && ncols > 0 && ncols % 4 == 0 && ncols <= 84, "ds_spmm_grouped: ncols must be a multiple of 4 <= 84");
+    DS_REQUIRE(ldx >= ncols && ldy >= ncols, "ds_spmm_grouped: leading dimension smaller than ncols");
+    DS_REQUIRE(X != Y, "ds_spmm_grouped: X and Y must be different buffers");
+    uintptr_t al = reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(Y) | (uintptr_t)(ldx * 4) |
+                   (uintptr_t)(ldy * 4);
+    if (epilogue) al |= reinterpret_cast<uintptr_t>(R0) | (uintptr_t)(ldr * 4);
+    DS_REQUIRE((al & 15) == 0, "ds_spmm_grouped: rows must be 16-byte aligned");
+    hipStream_t st = ds::as_stream(stream);
+    const ChebEpilogue epi{R0, ldr, dinv, c1, c2, first};
+    const int lpn = ncols / 4;
+    if (epilogue) {
+        if (lpn == 20) return launch_group<1, 20>(gptr, gent, goff, kgrp, nv, X, ldx, Y, ldy, lpn, st, epi);
+        return launch_group<1, 0>(gptr, gent, goff, kgrp, nv, X, ldx, Y, ldy, lpn, st, epi);
+    }
+    if (lpn == 20) return launch_group<0, 20>(gptr, gent, goff, kgrp, nv, X, ldx, Y, ldy, lpn, st, epi);
+    return launch_group<0, 0>(gptr, gent, goff, kgrp, nv, X, ldx, Y, ldy, lpn, st, epi);
+}
+
 extern "C" int ds_cheb_spmm(const int32_t* rowptr, const int32_t* colidx, const float* vals, int64_t nv, const float* W,
                             int64_t ldw, float* Wprev, int64_t ldp, const float* R0, int64_t ldr, const float* dinv,
                             int ncols, float c1, float c2, int first, ds_stream_t stream) {
@@ -600,6 +806,7 @@ extern "C" int ds_cheb_spmm(const int32_t* rowptr, const int32_t* colidx, const 
                          (uintptr_t)(ldr * 4);
     DS_REQUIRE((al & 15) == 0, "ds_cheb_spmm: rows must be 16-byte aligned");
     DS_REQUIRE(W != Wprev, "ds_cheb_spmm: W and Wprev must be different buffers");
+    DS_REQUIRE(3 * nv * ldw * 4 < ((int64_t)1 << 32), "ds_cheb_spmm: block larger than 4 GiB");
     hipStream_t st = ds::as_stream(stream);
     const ChebEpilogue epi{R0, ldr, dinv, c1, c2, first};
     const int lpn = ncols / 4;

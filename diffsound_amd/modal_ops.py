@@ -94,6 +94,14 @@ class TetSystem:
                                   ulist=tl.ulist.to(dev), lidx=tl.lidx.to(dev))
             except RuntimeError:
                 self.tiles = None  # a row with more neighbours than a tile holds: keep the untiled kernels
+        # Node groups for the register-blocked SpMM (4 nodes per wave share their neighbour loads: 1.7x fewer
+        # panel loads).  EXPERIMENTAL, opt-in: correct, but no faster than the wave-per-node kernel, which PMC
+        # counters show to be bound by fp32 FMA issue + load latency rather than by gathered bytes.
+        self.groups = None
+        if os.environ.get("DS_SPMM_GROUPED", "0") == "1":
+            gr = _hip.Groups(pat.rowptr, pat.colidx, self.nv)
+            self.groups = dict(ne=gr.ne, gptr=gr.gptr.to(dev), gent=gr.gent.to(dev), goff=gr.goff.to(dev),
+                               kperm=gr.kperm.to(dev))
         self.assemble()
 
     def rows_to_external(self, X):
@@ -146,6 +154,7 @@ class _HipBlockOps:
     dtype = torch.float32
     m_kind = 1  # 1: M = M_s (x) I3 (one scalar per block), 0: general 3x3 blocks
     k32t = None
+    kgrp = None  # transposed blocks in node-group order (register-blocked SpMM)
 
     def _init_common(self, rowptr, colidx, nv, device):
         self.rowptr, self.colidx = rowptr, colidx
@@ -186,6 +195,8 @@ class _HipBlockOps:
     def apply_K(self, X, out):
         if self._has_tiles(X.shape[1]) and X.shape[1] % 4 == 0 and X.shape[1] >= 16:
             self._tiled(0, X, out, None, 0.0, 0.0, False)
+        elif self._has_groups(X.shape[1]) and X.shape[1] >= 16:
+            self._grouped(0, X, out, None, 0.0, 0.0, False)
         else:
             self._spmm(0, self.k32, X, out)
         self.counts["apply_K_cols"] += X.shape[1]
@@ -270,10 +281,26 @@ class _HipBlockOps:
                                          pp(self.dinv), X.shape[1], float(c1), float(c2), int(bool(first)),
                                          _hip.stream_ptr()), "ds_spmm_tiled")
 
+    def _grouped(self, epilogue, X, Y, R0, c1, c2, first):
+        g = self.sys.groups
+        pp = _hip.ptr
+        _hip.check(self._L.ds_spmm_grouped(epilogue, pp(g["gptr"]), pp(g["gent"]), pp(g["goff"]), pp(self.kgrp), self.nv,
+                                           pp(X), _ld(X), pp(Y), _ld(Y), pp(R0), 0 if R0 is None else _ld(R0),
+                                           pp(self.dinv), X.shape[1], float(c1), float(c2), int(bool(first)),
+                                           _hip.stream_ptr()), "ds_spmm_grouped")
+
+    def _has_groups(self, ncols):
+        return (self.kgrp is not None and getattr(getattr(self, "sys", None), "groups", None) is not None
+                and ncols <= 84 and ncols % 4 == 0)
+
     def _has_tiles(self, ncols):
         return getattr(getattr(self, "sys", None), "tiles", None) is not None and ncols <= 84
 
     def _cheb_spmm_launch(self, Wk, Wprev, R0, c1, c2, first):
+        if self._has_groups(Wk.shape[1]) and not self._has_tiles(Wk.shape[1]):
+            self._grouped(1, Wk, Wprev, R0, c1, c2, first)
+            self.counts["apply_K_cols"] += Wk.shape[1]
+            return
         if self._has_tiles(Wk.shape[1]):
             self._tiled(1, Wk, Wprev, R0, c1, c2, first)
             self.counts["apply_K_cols"] += Wk.shape[1]
@@ -320,6 +347,11 @@ class HipModalOps(_HipBlockOps):
         _hip.check(self._L.ds_combine_material(p(s.klam), p(s.kmu), p(s.ms), s.nnzb, p(s.diagidx), s.nv,
                                                float(lam), float(mu), p(self.k32), p(self.k32t), p(self.ms32),
                                                p(self.dinv), _hip.stream_ptr()), "ds_combine_material")
+        if s.groups is not None:
+            if self.kgrp is None:
+                self.kgrp = torch.empty((s.nnzb, 9), dtype=torch.float32, device=self.device)
+            _hip.check(self._L.ds_pack_groups(p(self.k32t), p(s.groups["kperm"]), s.nnzb, p(self.kgrp),
+                                              _hip.stream_ptr()), "ds_pack_groups")
 
     def _rigid_basis(self):
         """Translations + rotations about the centroid, M-orthonormalised in fp64; stored (n, 8) fp32 with

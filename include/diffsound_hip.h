@@ -70,6 +70,15 @@ int ds_tiles_sizes(const ds_tiles_t* t, int64_t* ntiles, int64_t* nu_total);
 int ds_tiles_export(const ds_tiles_t* t, int32_t* tnode, int32_t* tuptr, int32_t* ulist, uint16_t* lidx);
 void ds_tiles_free(ds_tiles_t* t);
 
+/* Node groups for the register-blocked SpMM (HOST): 4 consecutive nodes share one wave and walk the union of
+ * their column lists.  Exports gptr[ngroups+1], gent[ne] (column id | presence mask << 28), goff[ne+1] (block
+ * offsets into the group-ordered value copy) and kperm[nnzb] (group-ordered position -> BSR slot). */
+typedef struct ds_groups ds_groups_t;
+int ds_groups_build(const int32_t* rowptr, const int32_t* colidx, int64_t nv, ds_groups_t** out);
+int ds_groups_sizes(const ds_groups_t* g, int64_t* ngroups, int64_t* ne);
+int ds_groups_export(const ds_groups_t* g, int32_t* gptr, int32_t* gent, int32_t* goff, int32_t* kperm);
+void ds_groups_free(ds_groups_t* g);
+
 /* ------------------------------------------------------------------------------------------------
  * Numeric assembly (DEVICE).  K_lambda, K_mu (geometry-only parts of K = lam*K_lambda + mu*K_mu,
  * SURVEY.md 0.6) and M_s in one pass, fp64, deterministic (no atomics): one thread per block slot
@@ -150,6 +159,13 @@ int ds_spmm_tiled(int epilogue, const int32_t* rowptr, const float* vals, int64_
                   const int32_t* tuptr, const int32_t* ulist, const uint16_t* lidx, int64_t ntiles, int nu_max,
                   const float* X, int64_t ldx, float* Y, int64_t ldy, const float* R0, int64_t ldr,
                   const float* dinv, int ncols, float c1, float c2, int first, ds_stream_t stream);
+/* Register-blocked form (4 nodes per wave, union column list; see ds_groups_build) for ncols <= 84.
+ * kgrp: (nnzb x 9) f32 = the TRANSPOSED blocks in group order, kgrp[p] = vals_t[kperm[p]] (ds_pack_groups).
+ * epilogue 0: Y <- K X ; epilogue 1: Y (= W_prev) <- X + c1 (X - Y) + c2 T (R0 - K X). */
+int ds_pack_groups(const float* vals_t, const int32_t* kperm, int64_t nnzb, float* kgrp, ds_stream_t stream);
+int ds_spmm_grouped(int epilogue, const int32_t* gptr, const int32_t* gent, const int32_t* goff, const float* kgrp,
+                    int64_t nv, const float* X, int64_t ldx, float* Y, int64_t ldy, const float* R0, int64_t ldr,
+                    const float* dinv, int ncols, float c1, float c2, int first, ds_stream_t stream);
 /* Out <- alpha * A C + beta * Out,  A (n x p) f32, C (p x q) f32 row-major device, Out (n x q) f32.
  * Out must not alias A.  (reference: X <- S Z etc., _lobpcg.py:463-466) */
 int ds_mix(const float* A, int64_t lda, int p, const float* C, int q, float* Out, int64_t ldo,

@@ -133,6 +133,39 @@ def test_tiled_spmm_matches_untiled(case, dev, ncols):
         assert rel(a.cpu().numpy(), b.cpu().numpy()) < 2e-6
 
 
+@pytest.mark.parametrize("ncols", [80, 72, 40, 16])
+def test_grouped_spmm_matches_untiled(case, dev, ncols):
+    """Register-blocked kernels (4 nodes per wave) on both node orderings."""
+    from diffsound_amd.modal_ops import HipModalOps, TetSystem
+
+    import os
+
+    for reorder in (False, True):
+        os.environ["DS_SPMM_GROUPED"] = "1"
+        try:
+            s1 = TetSystem(case["v"].to(dev), case["t"].to(dev), case["order"], MAT[0], reorder=reorder)
+        finally:
+            os.environ.pop("DS_SPMM_GROUPED", None)
+        assert s1.groups is not None
+        h1 = HipModalOps(s1, case["lam"], case["mu"])
+        g = torch.Generator().manual_seed(ncols)
+        X = torch.randn((s1.n, ncols), generator=g).to(dev)
+        Wp = torch.randn((s1.n, ncols), generator=g).to(dev)
+        R0 = (torch.randn((s1.n, ncols), generator=g) * 1e10).to(dev)
+        Yg = torch.empty_like(X)
+        h1._grouped(0, X, Yg, None, 0.0, 0.0, False)
+        Yu = torch.empty_like(X)
+        h1._spmm(0, h1.k32, X, Yu)
+        assert rel(Yg.cpu().numpy(), Yu.cpu().numpy()) < 2e-6
+        for first in (True, False):
+            a, b = Wp.clone(), Wp.clone()
+            h1._grouped(1, X, a, R0, 0.31, 0.77, first)
+            groups, s1.groups = s1.groups, None
+            h1._cheb_spmm_launch(X, b, R0, 0.31, 0.77, first)
+            s1.groups = groups
+            assert rel(a.cpu().numpy(), b.cpu().numpy()) < 2e-6
+
+
 def test_assembly_deterministic(case):
     s = case["sys"]
     a = s.klam.clone(), s.kmu.clone(), s.ms.clone()

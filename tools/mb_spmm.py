@@ -28,7 +28,7 @@ for reorder in (True,):
     # fused Chebyshev term, tiled vs untiled
     ncols = 80
     W = torch.randn(sysd.n, ncols, device=dev); Wp = torch.randn_like(W); R0 = torch.randn_like(W)
-    for label, fn in (("tiled" if sysd.tiles else "untiled", lambda: ops._cheb_spmm_launch(W, Wp, R0, 0.3, 0.7, False)),):
+    for label, fn in (("tiled" if sysd.tiles else ("grouped" if sysd.groups else "untiled"), lambda: ops._cheb_spmm_launch(W, Wp, R0, 0.3, 0.7, False)),):
         fn(); torch.cuda.synchronize()
         e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
         e0.record()
