@@ -1,0 +1,144 @@
+"""BASELINE.json sizes on the GPU.
+
+configs[1] (10k-tet ord-1 mesh, 32 modes, forward only) is small enough for the CPU oracle, so it is a
+direct parity test; configs[2] (100k-tet ord-2, 64 modes) is checked through size-independent properties:
+residuals recomputed in fp64 by an independent kernel path, M-orthonormality, exact scaling of the spectrum
+with Young's modulus, mass conservation, rigid-body null space, run-to-run reproducibility.  pytest -m gpu."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import fem, modal
+from oracle import oscillator as oosc
+
+pytestmark = pytest.mark.gpu
+MAT = (2700.0, 5e10, 0.25, 6.0, 1e-7)
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no HIP device")
+    return torch.device("cuda:0")
+
+
+def test_config1_10k_tet_ord1_forward_matches_oracle(dev):
+    from diffsound_amd import meshgen
+    from diffsound_amd.diffelastic.mesh import TetMesh
+    from diffsound_amd.pipeline import ModalPipeline
+
+    v, t = meshgen.kuhn_box(12)  # 10 368 tets, 2197 nodes
+    mesh = TetMesh(torch.from_numpy(v).to(dev), torch.from_numpy(t).long().to(dev)).to_high_order(1)
+    pipe = ModalPipeline(mesh.vertices, mesh.tets, 1, 32, MAT)
+    pipe.assemble()
+    r, res, audio = pipe.run_pass(MAT[1], MAT[2], backward=False)
+    vo, to = torch.from_numpy(v), torch.from_numpy(t).long()
+    d = fem.OracleDeform(vo, to, 1)
+    lam, mu = fem.lame(MAT[1], MAT[2])
+    K = fem.assemble_stiffness(d, lam, mu)
+    M3, _ = fem.assemble_mass(vo, to, 1, MAT[0])
+    ev, U, _, _ = modal.eigsh_shift_invert(K, M3, 32)
+    assert np.abs(res.eigenvalues.cpu().numpy() / ev - 1).max() < 1e-4
+    f_ref = torch.from_numpy(np.sqrt(ev) / 2 / np.pi).float().reshape(-1, 1)
+    assert np.abs(r.freqs.cpu().numpy() / f_ref.numpy() - 1).max() < 5e-5
+    force = torch.zeros((1, 150))
+    force[0, 0] = 1
+    sig, _ = oosc.bank(f_ref, force, 8000, 32000, MAT[3], MAT[4])
+    assert float((audio.cpu() - sig).norm() / sig.norm()) < 1e-3
+
+
+@pytest.fixture(scope="module")
+def c3(dev):
+    from diffsound_amd import meshgen
+    from diffsound_amd.diffelastic.mesh import TetMesh
+    from diffsound_amd.lobpcg.modal_solver import ModalSolver, SolverConfig
+    from diffsound_amd.modal_ops import HipModalOps, TetSystem
+
+    v, t = meshgen.kuhn_box(26)  # 105 456 tets
+    mesh = TetMesh(torch.from_numpy(v).to(dev), torch.from_numpy(t).long().to(dev)).to_high_order(2)
+    sysd = TetSystem(mesh.vertices, mesh.tets, 2, MAT[0])
+    lam, mu = fem.lame(MAT[1], MAT[2])
+    ops = HipModalOps(sysd, lam, mu)
+    cfg = SolverConfig(block=80, cheb_degree=48, cheb_ratio=800.0, lmax_cap=10.0)
+    res = ModalSolver(ops, cfg).solve(64)
+    return dict(sys=sysd, ops=ops, res=res, cfg=cfg, mesh=mesh, lam=lam, mu=mu, v=v, t=t)
+
+
+def test_c3_sizes(c3):
+    s = c3["sys"]
+    assert s.T == 105456 and s.nv == 148877 and s.n == 446631 and s.nnzb * 9 == 37227537
+
+
+def test_c3_residuals_in_fp64_by_an_independent_path(c3):
+    """||K u - lambda M u|| / (||u|| (||K|| + lambda ||M||)) with K, M applied by the fp64-valued kernels
+    (kinds 2/3), not by the fp32 kernels the solver iterated with."""
+    s, ops, res = c3["sys"], c3["ops"], c3["res"]
+    U = res.vectors.contiguous()
+    n, k = U.shape
+    KU = torch.zeros((n, k), dtype=torch.float64, device=U.device)
+    tmp = torch.empty_like(KU)
+    for vals, c in ((s.klam, c3["lam"]), (s.kmu, c3["mu"])):
+        ops._spmm(2, vals, U, tmp)
+        KU += c * tmp
+    MU = torch.empty_like(KU)
+    ops._spmm(3, s.ms, U, MU)
+    ev = res.eigenvalues
+    R = KU - MU * ev[None, :]
+    g = torch.Generator(device=U.device).manual_seed(1)
+    G = torch.randn((n, 8), generator=g, device=U.device)
+    KG = torch.empty((n, 8), dtype=torch.float64, device=U.device)
+    MG = torch.empty_like(KG)
+    KG.zero_()
+    for vals, c in ((s.klam, c3["lam"]), (s.kmu, c3["mu"])):
+        t2 = torch.empty_like(KG)
+        ops._spmm(2, vals, G, t2)
+        KG += c * t2
+    ops._spmm(3, s.ms, G, MG)
+    An = float(KG.norm() / G.double().norm())
+    Bn = float(MG.norm() / G.double().norm())
+    rerr = R.norm(dim=0) / (U.double().norm(dim=0) * (An + ev * Bn))
+    assert float(rerr.max()) < 1e-5
+    # M-orthonormality and Rayleigh quotients from the same fp64 products
+    UtMU = U.double().T @ MU
+    assert float((UtMU - torch.eye(k, device=U.device, dtype=torch.float64)).abs().max()) < 1e-4
+    rq = (U.double() * KU).sum(0) / (U.double() * MU).sum(0)
+    assert float((rq / ev - 1).abs().max()) < 1e-7
+    assert bool((ev[1:] >= ev[:-1]).all()) and float(ev[0]) > 0
+    # read-out identities
+    assert float(((c3["lam"] * res.a_lambda + c3["mu"] * res.b_mu) / ev - 1).abs().max()) < 1e-9
+
+
+def test_c3_spectrum_scales_with_youngs_modulus(c3):
+    """K(2E, nu) = 2 K(E, nu): every eigenvalue doubles (an independent cold-start solve)."""
+    from diffsound_amd.lobpcg.modal_solver import ModalSolver
+
+    ops = c3["ops"]
+    ops.set_material(2 * c3["lam"], 2 * c3["mu"])
+    try:
+        res2 = ModalSolver(ops, c3["cfg"]).solve(64)
+    finally:
+        ops.set_material(c3["lam"], c3["mu"])
+    ratio = (res2.eigenvalues / c3["res"].eigenvalues).cpu().numpy()
+    assert np.abs(ratio - 2).max() < 1e-5
+
+
+def test_c3_mass_conservation_and_rigid_null_space(c3):
+    s, ops = c3["sys"], c3["ops"]
+    box_volume = 0.10 * 0.08 * 0.06
+    # sum(M)/3 = rho * volume ; M = M_s (x) I3 so sum(M)/3 = sum(M_s)
+    assert abs(float(s.ms.sum()) / (MAT[0] * box_volume) - 1) < 1e-5
+    Y = ops.rigid[:, :8].contiguous()
+    KY = torch.empty_like(Y)
+    ops.apply_K(Y, KY)
+    G = torch.randn_like(Y)
+    KG = torch.empty_like(Y)
+    ops.apply_K(G, KG)
+    scale = float(KG.norm() / G.norm()) * float(Y[:, :6].norm())
+    assert float(KY[:, :6].norm()) / scale < 1e-5
+
+
+def test_c3_reproducible(c3):
+    from diffsound_amd.lobpcg.modal_solver import ModalSolver
+
+    res2 = ModalSolver(c3["ops"], c3["cfg"]).solve(64)
+    assert float((res2.eigenvalues / c3["res"].eigenvalues - 1).abs().max()) < 1e-9
