@@ -211,3 +211,47 @@ def test_lobpcg_func_api(golden, dev):
     assert np.abs(El.cpu().numpy() - w[::-1][:4]).max() / w.max() < 1e-3
     with pytest.raises(ValueError, match="not applicable"):
         lobpcg_func(K, M, Kd.shape[0] // 2)
+
+
+def test_material_fit_loop_runs_like_the_reference_script(golden, dev):
+    """The reference training loop (experiments/material_sync_train.py:137-167, shortened): eigendecomposition
+    every 15 epochs, get_undamped_freqs -> oscillator -> loss -> Adam step.  The recovered Young's modulus must
+    move from the initial guess towards the target."""
+    from torch.optim import Adam
+
+    from src.ddsp.oscillator import TraditionalDampedOscillator
+    from src.diffelastic.diff_model import DiffSoundObj, FixedLinear, Material, TrainableLinear
+
+    m = golden("g0_bowl_mesh.npz")
+    v = torch.from_numpy(m["verts"]).to(dev)
+    t = torch.from_numpy(m["tets"]).long().to(dev)
+    modes = 16
+    target_mat = (2700.0, 6.0e10, 0.25, 6.0, 1e-7)
+    init_mat = (2700.0, 4.0e10, 0.25, 6.0, 1e-7)
+    forces = torch.zeros((1, 150), device=dev)
+    forces[0, 0] = 1
+    gt = DiffSoundObj(vertices=v, tets=t, mode_num=modes, mat=target_mat, order=1, mat_model=FixedLinear, task="gt")
+    gt.eigen_decomposition()
+    gt_f = gt.get_undamped_freqs().float()
+    osc = TraditionalDampedOscillator(forces, 1, modes, 8000, 32000, Material(init_mat)).cuda()
+    torch.manual_seed(0)
+    model = DiffSoundObj(vertices=v, tets=t, mode_num=modes, mat=init_mat, order=1, mat_model=TrainableLinear,
+                         task="mat_baseline")
+    model.init_material_coeffs(steps=800)
+    e0 = float(model.material_model.youngs())
+    assert abs(e0 / init_mat[1] - 1) < 0.05
+    opt = Adam(model.parameters(), lr=2e-2)
+    losses = []
+    for epoch in range(45):
+        if epoch % 15 == 0:
+            model.eigen_decomposition()
+        f = model.get_undamped_freqs().float()
+        _ = osc(f)  # rendered audio (the spectral loss head is outside the hot path)
+        loss = (((f - gt_f) / gt_f) ** 2).mean()
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        losses.append(float(loss))
+    e1 = float(model.material_model.youngs())
+    assert losses[-1] < 0.5 * losses[0]
+    assert abs(e1 - target_mat[1]) < abs(e0 - target_mat[1])
