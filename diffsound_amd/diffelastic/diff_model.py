@@ -113,6 +113,24 @@ def build_model(mesh_dir, mode_num, order, mat, task, vertices=None, tets=None, 
     return model
 
 
+class _GetVals(torch.autograd.Function):
+    """vals_i = lambda_i + u_i^T K(x) u_i - lambda_i u_i^T M(x) u_i with detached (lambda_i, u_i): forward from the
+    solver's fp64 quadratic forms, backward to the node coordinates by the ds_geometry_grad kernel."""
+
+    @staticmethod
+    def forward(ctx, vertices, obj, vals):
+        ctx.obj = obj
+        return vals.clone()
+
+    @staticmethod
+    def backward(ctx, gout):
+        obj = ctx.obj
+        g = gout.reshape(-1).double()
+        lam, mu = obj._ops.lame
+        grad = obj.system.geometry_grad(obj.last_result.vectors, g, g * obj.eigenvalues, lam, mu)
+        return grad.to(obj.tetmesh.vertices.dtype), None, None
+
+
 class DiffSoundObj:
     def __init__(self, vertices=None, tets=None, mode_num=16, mat=MatSet.Ceramic, order=1, mat_model=FixedLinear,
                  task=None, mesh_dir=None, solver_config=None):
@@ -247,8 +265,10 @@ class DiffSoundObj:
     def get_vals(self):
         """lambda + diag(U^T K U) - lambda diag(U^T M U), (mode_num, 1) float32 (reference :390-399)."""
         lam, mu = self._ops.lame
-        pred = self.eigenvalues + (lam * self._a + mu * self._b) - self.eigenvalues * self._m
-        return pred.float().unsqueeze(1)
+        pred = (self.eigenvalues + (lam * self._a + mu * self._b) - self.eigenvalues * self._m).float().unsqueeze(1)
+        if self.tetmesh.vertices.requires_grad:  # geometry tasks: gradient -> vertices
+            pred = _GetVals.apply(self.tetmesh.vertices, self, pred)
+        return pred
 
     def stiff_func(self, x_in):
         """K(theta) x with autograd to the material parameters (reference :314-328, matrix-free there)."""

@@ -104,3 +104,21 @@ def mass_table(order, density):
     """mtab (N,N) fp64 = fp32(M^ * density): the reference multiplies the fp32 table by the density
     in fp32 before the fp64 |det| comes in (diff_model.py:301-303)."""
     return (mass_table_f32(order) * np.float32(density)).astype(np.float64)
+
+
+@functools.lru_cache(maxsize=None)
+def minimal_gradient_rule(order):
+    """(dN/dL at the points (ng, N, 4) fp64, weights (ng,) fp64) of the smallest rule that integrates
+    grad N_a . grad N_b exactly: 1 point for P1 (constant gradients), the 4-point degree-2 rule for P2.
+    Weights are scaled to the total of the reference's fp32 rule so that the element energy matches the
+    assembled K to rounding."""
+    total = float(gauss_rule(order)[1].astype(np.float64).sum())
+    if order == 1:
+        pts = np.full((1, 4), 0.25)
+        w = np.array([total])
+    else:
+        a, b = (5 + 3 * np.sqrt(5)) / 20, (5 - np.sqrt(5)) / 20
+        pts = np.full((4, 4), b)
+        pts[np.arange(4), np.arange(4)] = a
+        w = np.full(4, total / 4)
+    return np.ascontiguousarray(shape_gradients(pts, order)), w

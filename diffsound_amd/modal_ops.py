@@ -127,6 +127,23 @@ class TetSystem:
                                      p(self.clist), self.nnzb, p(self.dtab), p(self.mtab), p(self._tetgeo),
                                      p(self.klam), p(self.kmu), p(self.ms), _hip.stream_ptr()), "ds_assemble_kml")
 
+    def geometry_grad(self, U, gk, gm, lam, mu):
+        """d/dx sum_i gk_i u_i^T K u_i - gm_i u_i^T M u_i  ->  (nv, 3) fp64 in the caller's node numbering.
+        U: (n, m) f32 modes in INTERNAL order (as the solver returns them); geometry = last assemble()."""
+        order = self.order
+        gt, gw = fem_tables.minimal_gradient_rule(order)
+        dev = self.device
+        gtab = torch.from_numpy(gt).to(dev)
+        gwt = torch.from_numpy(gw).to(dev)
+        grad = torch.zeros((self.nv, 3), dtype=torch.float64, device=dev)
+        U = U.contiguous()
+        p = _hip.ptr
+        _hip.check(_hip.lib().ds_geometry_grad(p(self.tets), self.T, self.N, self.nv, p(self._tetgeo), p(U), U.stride(0),
+                                               U.shape[1], p(gk.double().contiguous()), p(gm.double().contiguous()),
+                                               float(lam), float(mu), p(gtab), p(gwt), gt.shape[0], p(self.mtab), p(grad),
+                                               _hip.stream_ptr()), "ds_geometry_grad")
+        return grad if self.perm is None else grad[self.inv_perm]
+
     # scipy views for tests / interop (host copies, in the caller's node numbering)
     def to_scipy(self, lam=None, mu=None):
         import scipy.sparse as sp

@@ -172,6 +172,19 @@ int ds_mix(const float* A, int64_t lda, int p, const float* C, int q, float* Out
            int64_t n, float alpha, float beta, ds_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Geometry backward of the modal read-out (reference: autograd through get_vals -> K, M -> vertices,
+ * src/diffelastic/diff_model.py:390-399 with deform.py:35-68,136-147, mesh.py:58-99):
+ *   grad += d/dx sum_i gk[i] u_i^T K(x) u_i - gm[i] u_i^T M(x) u_i      (gm[i] = gk[i] * lambda_i)
+ * tetgeo: the (T x 13) geometry workspace filled by ds_assemble_kml for the SAME coordinates;
+ * U: (3nv x m) f32 modes; gtab (ng x N x 4) f64 = dN_a/dL_k at ng <= 4 quadrature points, gw (ng) weights
+ * (a rule exact for degree 2(order-1)); mtab as in ds_assemble_kml; grad: (nv x 3) f64, ACCUMULATED with fp64
+ * atomics (the caller zeroes it). */
+int ds_geometry_grad(const int32_t* tets, int64_t T, int N, int64_t nv, const double* tetgeo, const float* U,
+                     int64_t ldu, int m, const double* gk, const double* gm, double lam, double mu,
+                     const double* gtab, const double* gw, int ng, const double* mtab, double* grad,
+                     ds_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Damped-oscillator bank (reference src/ddsp/oscillator.py:113-141, 282-310):
  *   s[a,t] = sum_m amp[a,m] exp(-d_m tau_t) sin(w_m tau_t),  tau_t = (t+1)/sr
  *   y[a,t] = sum_{j<F} force[a,j] s[a,t-j]                   (causal FIR, cropped to S samples)

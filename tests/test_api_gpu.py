@@ -255,3 +255,29 @@ def test_material_fit_loop_runs_like_the_reference_script(golden, dev):
     e1 = float(model.material_model.youngs())
     assert losses[-1] < 0.5 * losses[0]
     assert abs(e1 - target_mat[1]) < abs(e0 - target_mat[1])
+
+
+@pytest.mark.parametrize("order", [1, 2])
+def test_geometry_backward_matches_reference(golden, dev, order):
+    """d(sum get_vals)/d(vertices) on the 4^3 cube against the reference's autograd (G4 fixture,
+    reference diff_model.py:390-399 through K, M, torch.inverse / det)."""
+    from src.diffelastic.diff_model import DiffSoundObj, FixedLinear
+
+    g = golden("g4_cube4_geometry.npz")
+    mat = tuple(float(x) for x in g["mat"])
+    v = torch.from_numpy(g["verts"]).to(dev).requires_grad_(True)
+    t = torch.from_numpy(g["tets"]).to(dev)
+    obj = DiffSoundObj(vertices=v, tets=t, mode_num=8, mat=mat, order=order, mat_model=FixedLinear, task="gt")
+    obj.eigen_decomposition()
+    vals = obj.get_vals()
+    assert rel(vals.detach().cpu().numpy(), g[f"o{order}_vals"]) < 1e-4
+    vals.sum().backward(retain_graph=True)  # the ord-2 lifting graph is reused below
+    got = v.grad.cpu().numpy()
+    want = g[f"o{order}_grad_vertices"]
+    assert got.shape == want.shape
+    assert np.linalg.norm(got - want) / np.linalg.norm(want) < 2e-3
+    # weighted upstream gradient as well (the thickness/morphing losses are not plain sums)
+    v.grad = None
+    w = torch.linspace(0.5, 1.5, 8, device=dev).reshape(8, 1)
+    (obj.get_vals() * w).sum().backward()
+    assert np.isfinite(v.grad.cpu().numpy()).all() and float(v.grad.abs().max()) > 0
