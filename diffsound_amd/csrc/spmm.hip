@@ -176,7 +176,7 @@ __global__ void __launch_bounds__(256)
     spmm_wave_node_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx,
                           const float* __restrict__ vals, const float* __restrict__ vals_t, int64_t nv,
                           const float* __restrict__ X, int64_t ldx, float* __restrict__ Y, int64_t ldy, int lpn_rt,
-                          unsigned nblk, ChebEpilogue epi) {
+                          unsigned nblk, ChebEpilogue epi, int big) {
     using f4 = __attribute__((ext_vector_type(4))) float;
     __shared__ float s_vals[4][WN_CHUNK * 9];
     const int lpn = LPN_CT ? LPN_CT : lpn_rt;
@@ -196,7 +196,7 @@ __global__ void __launch_bounds__(256)
     const int64_t ldx3 = 3 * ldx;
     // whole X block as one buffer (host guarantees 3 nv ldx 4 < 2^32)
     const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(X), 0, (int)(unsigned)(3 * nv * ldx * 4), 0x00020000);
+        const_cast<float*>(X), 0, big ? 0 : (int)(unsigned)(3 * nv * ldx * 4), 0x00020000);
     const int xvoff = (int)(((int64_t)r * ldx + c0) * 4);
     const int panel_bytes = (int)(ldx3 * 4);
     const int kb = rowptr[node], ke = rowptr[node + 1];
@@ -224,11 +224,21 @@ __global__ void __launch_bounds__(256)
             f4 xa[UX], xb[UX], xc[UX];
 #pragma unroll
             for (int q = 0; q < UX; ++q) {
-                const int soff = __builtin_amdgcn_readlane(colreg, u + q) * panel_bytes;
-                xa[q] = buf_load4(xrsrc, xvoff, soff);
-                if (RS == 1) {
-                    xb[q] = buf_load4(xrsrc, xvoff + (int)(ldx * 4), soff);
-                    xc[q] = buf_load4(xrsrc, xvoff + (int)(ldx * 8), soff);
+                const int j = __builtin_amdgcn_readlane(colreg, u + q);
+                if (!big) {  // wave-uniform: blocks under 4 GiB go through the buffer descriptor
+                    const int soff = j * panel_bytes;
+                    xa[q] = buf_load4(xrsrc, xvoff, soff);
+                    if (RS == 1) {
+                        xb[q] = buf_load4(xrsrc, xvoff + (int)(ldx * 4), soff);
+                        xc[q] = buf_load4(xrsrc, xvoff + (int)(ldx * 8), soff);
+                    }
+                } else {
+                    const float* p = xbase + (int64_t)j * ldx3;
+                    xa[q] = *reinterpret_cast<const f4*>(p);
+                    if (RS == 1) {
+                        xb[q] = *reinterpret_cast<const f4*>(p + ldx);
+                        xc[q] = *reinterpret_cast<const f4*>(p + 2 * ldx);
+                    }
                 }
             }
 #pragma unroll
@@ -333,7 +343,8 @@ int launch_wn(const int32_t* rowptr, const int32_t* colidx, const void* vals, co
     const int64_t nblk = ds::ceil_div(nv, 4);
     spmm_wave_node_kernel<KIND, RS, LPN_CT, EPI><<<(unsigned)nblk, 256, 0, st>>>(
         rowptr, colidx, static_cast<const float*>(vals), static_cast<const float*>(vals_t), nv,
-        static_cast<const float*>(X), ldx, static_cast<float*>(Y), ldy, lpn, (unsigned)nblk, epi);
+        static_cast<const float*>(X), ldx, static_cast<float*>(Y), ldy, lpn, (unsigned)nblk, epi,
+        (3 * nv * ldx * 4 >= ((int64_t)1 << 32)) ? 1 : 0);
     DS_LAUNCH_CHECK("spmm_wave_node_kernel");
     return DS_OK;
 }
@@ -374,7 +385,7 @@ extern "C" int ds_spmm_bsr3(int kind, const int32_t* rowptr, const int32_t* coli
         if (ncols % 4 == 0 && ncols <= 256 && (xalign & 15) == 0 && (yalign & 15) == 0) {
             static const bool legacy = getenv("DS_SPMM_LEGACY") != nullptr;  // A/B switch for benchmarking
             // the fast path addresses X through one buffer descriptor (32-bit byte offsets)
-            if (!legacy && 3 * nv * ldx * 4 < ((int64_t)1 << 32))
+            if (!legacy)
                 return kind == 0 ? launch_fast<0>(rowptr, colidx, vals, vals_t, nv, X, ldx, Y, ldy, ncols, st)
                                  : launch_fast<1>(rowptr, colidx, vals, vals_t, nv, X, ldx, Y, ldy, ncols, st);
             return kind == 0 ? launch<0, float, float, float, 4>(rowptr, colidx, vals, nv, X, ldx, Y, ldy, ncols, st)
@@ -806,7 +817,6 @@ extern "C" int ds_cheb_spmm(const int32_t* rowptr, const int32_t* colidx, const 
                          (uintptr_t)(ldr * 4);
     DS_REQUIRE((al & 15) == 0, "ds_cheb_spmm: rows must be 16-byte aligned");
     DS_REQUIRE(W != Wprev, "ds_cheb_spmm: W and Wprev must be different buffers");
-    DS_REQUIRE(3 * nv * ldw * 4 < ((int64_t)1 << 32), "ds_cheb_spmm: block larger than 4 GiB");
     hipStream_t st = ds::as_stream(stream);
     const ChebEpilogue epi{R0, ldr, dinv, c1, c2, first};
     const int lpn = ncols / 4;
