@@ -202,3 +202,71 @@ def init_damps(osc):
         loss = (osc.alpha() - osc.mat.alpha) ** 2 / osc.mat.alpha ** 2 + (osc.beta() - osc.mat.beta) ** 2 / osc.mat.beta ** 2
         loss.mean().backward()
         optimizer.step()
+
+
+class FilteredNoise(nn.Module):
+    """Time-varying filtered white noise (DDSP style): per 64-sample frame a learnable magnitude response
+    (65 bins) is turned into a Hann-windowed linear-phase FIR, applied to a fresh white-noise frame by FFT
+    convolution, and the frames are overlap-added.  Interface of reference src/ddsp/filtered_noise.py:7-67
+    (``coefficient_bank`` parameter, ``forward() -> (noise_num, sample_num)``); plain torch.fft plumbing, the
+    noise branch is outside the hot path."""
+
+    def __init__(self, noise_num, sample_num, filter_coeff_length=65, frame_length=64, attenuate_gain=1.0,
+                 device="cuda"):
+        super().__init__()
+        self.noise_num, self.sample_num = noise_num, sample_num
+        self.filter_coeff_length, self.frame_length, self.attenuate_gain = filter_coeff_length, frame_length, attenuate_gain
+        self.coefficient_bank = nn.Parameter(torch.zeros(noise_num, sample_num // frame_length + 1, filter_coeff_length))
+        self.coefficient_bank.data.uniform_(-1, 1)
+
+    def forward(self):
+        mag = modifed_sigmoid(self.coefficient_bank)
+        B, nf, L = mag.shape
+        taps = 2 * L - 1
+        dev = mag.device
+        ir = torch.fft.irfft(torch.complex(mag, torch.zeros_like(mag)), n=taps, dim=-1)  # zero-phase
+        ir = torch.roll(ir, L - 1, dims=-1) * torch.hann_window(taps, dtype=torch.float32, device=dev)
+        nfft = taps + self.frame_length - 1
+        noise = torch.rand(B, nf, self.frame_length, device=dev) * 2 - 1
+        frames = torch.fft.irfft(torch.fft.rfft(noise, n=nfft) * torch.fft.rfft(ir, n=nfft), n=nfft)
+        frames = frames * self.attenuate_gain
+        total = (nf - 1) * self.frame_length + nfft
+        out = F.fold(frames.transpose(1, 2), output_size=(1, total), kernel_size=(1, nfft),
+                     stride=(1, self.frame_length)).reshape(B, total)
+        return out[:, : self.sample_num]
+
+
+class GTDampedOscillator(_BankBase):
+    """Free-running bank with learnable frequencies (softplus-weighted over ``f_range``), dampings and
+    amplitudes, used to pre-fit recorded audio (reference oscillator.py:178-243,
+    experiments/material_real_train.py:113-134).  The time-varying ``freq_nonlinear`` branch of the
+    reference (an (A, m, S, len(f_range)) parameter that its own callers always run with
+    ``non_linear_rate = 0``) is not materialised; a non-zero rate raises."""
+
+    def __init__(self, forces, audio_num, mode_num, sample_num, sr, f_range: list, mat: Material):
+        super().__init__()
+        self._setup(forces, audio_num, mode_num, sample_num, sr, mat)
+        self.freq_linear = WeightedSum([1, mode_num, 1], f_range)
+        bin_num = 64
+        self.alpha_list = torch.exp(torch.linspace(np.log(mat.alpha / 10), np.log(mat.alpha * 100), bin_num))
+        self.alpha = WeightedSum([1, mode_num, 1], list(self.alpha_list))
+        self.beta_list = torch.exp(torch.linspace(np.log(mat.beta / 10), np.log(mat.beta * 100), bin_num))
+        self.beta = WeightedSum([1, mode_num, 1], list(self.beta_list))
+        self.amp = DirectValue([audio_num, mode_num, 1])
+        self.noise = FilteredNoise(audio_num, sample_num)
+
+    def damping(self):
+        lbd = (self.freq_linear() * 2 * np.pi) ** 2
+        return 0.5 * (self.alpha() + self.beta() * lbd)
+
+    def forward(self, non_linear_rate=0.0, noise_rate=0.0):
+        if non_linear_rate != 0.0:
+            raise NotImplementedError("GTDampedOscillator: the time-varying frequency branch is not built "
+                                      "(the reference's callers use non_linear_rate = 0)")
+        sig = self._render(self.freq_linear(), self.alpha(), self.beta(), self.amp())
+        fd = self.damped_freq[0, :, 0].double()
+        d = self.damping().reshape(-1).double().to(fd.device)
+        self.undamped_freq = (torch.sqrt((2 * np.pi * fd) ** 2 + d ** 2) / (2 * np.pi)).float().reshape(1, -1, 1)
+        if noise_rate != 0.0:
+            sig = sig + self.noise() * noise_rate
+        return sig

@@ -1,2 +1,3 @@
-from diffsound_amd.ddsp.oscillator import (DampedOscillator, DirectValue, TraditionalDampedOscillator,  # noqa: F401
-                                           WeightedParam, WeightedSum, init_damps, oscillator_bank)
+from diffsound_amd.ddsp.oscillator import (DampedOscillator, DirectValue, FilteredNoise, GTDampedOscillator,  # noqa: F401
+                                           TraditionalDampedOscillator, WeightedParam, WeightedSum, init_damps,
+                                           oscillator_bank)

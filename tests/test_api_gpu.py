@@ -281,3 +281,41 @@ def test_geometry_backward_matches_reference(golden, dev, order):
     w = torch.linspace(0.5, 1.5, 8, device=dev).reshape(8, 1)
     (obj.get_vals() * w).sum().backward()
     assert np.isfinite(v.grad.cpu().numpy()).all() and float(v.grad.abs().max()) > 0
+
+
+def test_gt_oscillator_and_forward_curve(dev):
+    """GTDampedOscillator (pre-fit bank, reference oscillator.py:178-243) and DampedOscillator.forward_curve
+    (:143-176) against the oracle's restatement of the same signal path."""
+    from oracle import oscillator as oosc
+    from src.ddsp.oscillator import DampedOscillator, GTDampedOscillator
+    from src.diffelastic.diff_model import Material
+
+    mat = (2700.0, 5e10, 0.25, 6.0, 1e-7)
+    torch.manual_seed(3)
+    A, m, S, sr = 2, 24, 4000, 32000
+    forces = torch.randn((A, 150), device=dev)
+    f_range = list(np.linspace(300.0, 9000.0, 40))
+    osc = GTDampedOscillator(forces, A, m, S, sr, f_range, Material(mat)).cuda()
+    sig = osc()
+    assert sig.shape == (A, S)
+    f = osc.freq_linear().detach().reshape(m, 1).cpu()
+    ref, _ = oosc.bank(f, forces.cpu(), S, sr, osc.alpha().detach().cpu(), osc.beta().detach().cpu(), osc.amp().detach().cpu())
+    assert float((sig.detach().cpu() - ref).norm() / ref.norm()) < 1e-3
+    (sig ** 2).mean().backward()
+    assert osc.freq_linear.params.grad is not None and float(osc.freq_linear.params.grad.abs().max()) > 0
+    assert osc.damping().shape == (1, m, 1)
+    assert rel(osc.undamped_freq.detach().reshape(-1).cpu().numpy(), f.reshape(-1).numpy()) < 1e-5
+    noisy = osc(noise_rate=1e-3)
+    assert noisy.shape == (A, S) and float((noisy - osc()).detach().abs().max()) > 0
+    with pytest.raises(NotImplementedError):
+        osc(non_linear_rate=0.1)
+    # forward_curve: damping from a host callback per mode, peak-normalised
+    dosc = DampedOscillator(forces, A, m, S, sr, f_range, Material(mat)).cuda()
+    curve = lambda fr: 3.0 + 2e-7 * (2 * np.pi * fr) ** 2
+    fl = torch.sort(torch.rand(m) * 8000 + 400)[0].reshape(m, 1).to(dev)
+    out = dosc.forward_curve(fl, curve)
+    dvals = torch.tensor([curve(float(x)) for x in fl.reshape(-1).cpu()], dtype=torch.float64)
+    refc = oosc.bank_closed_form_f64(fl.cpu().numpy(), forces.cpu().numpy(), S, sr, 2 * dvals.numpy(), 0.0)
+    refc = refc / np.abs(refc).max(axis=1, keepdims=True)
+    assert np.linalg.norm(out.cpu().numpy() - refc) / np.linalg.norm(refc) < 1e-3
+    assert float(out.abs().max()) == pytest.approx(1.0, abs=1e-6)
