@@ -39,6 +39,12 @@ def parse():
     ap.add_argument("--cheb-degree", type=int, default=48)
     ap.add_argument("--cheb-ratio", type=float, default=800.0)
     ap.add_argument("--block", type=int, default=80)
+    ap.add_argument("--precond", default="auto", choices=["auto", "chebyshev", "twolevel"],
+                    help="auto = two-level V-cycle on ord-2 meshes, one-level Chebyshev polynomial otherwise")
+    ap.add_argument("--smooth-degree", type=int, default=3)
+    ap.add_argument("--smooth-ratio", type=float, default=10.0)
+    ap.add_argument("--coarse-degree", type=int, default=24)
+    ap.add_argument("--coarse-ratio", type=float, default=400.0)
     ap.add_argument("--warm-start", action="store_true", help="amortised variant: reuse the previous block")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-cells", type=int, default=5)
@@ -111,7 +117,8 @@ def main():
     v, t = meshgen.kuhn_box(a.cells)
     mesh = TetMesh(torch.from_numpy(v).to(dev), torch.from_numpy(t).long().to(dev)).to_high_order(a.order)
     cfg = SolverConfig(block=a.block, cheb_degree=a.cheb_degree, cheb_ratio=a.cheb_ratio,
-                       lmax_cap=float({1: 4, 2: 10}[a.order]))
+                       lmax_cap=float({1: 4, 2: 10}[a.order]), precond=a.precond, smooth_degree=a.smooth_degree,
+                       smooth_ratio=a.smooth_ratio, coarse_degree=a.coarse_degree, coarse_ratio=a.coarse_ratio)
     t_sym = time.time()
     pipe = ModalPipeline(mesh.vertices, mesh.tets, a.order, a.modes, MAT, solver_config=cfg)
     torch.cuda.synchronize()
@@ -189,6 +196,11 @@ def main():
                            f"on the {a.block}-column block"),
                 "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": avg_ms, "launches_timed": len(spmm_ms)}
 
+    if getattr(pipe.ops, "coarse", None) is not None and a.precond != "chebyshev":
+        precond_desc = (f"two-level V-cycle: Chebyshev({a.smooth_degree}, ratio {a.smooth_ratio:g}) block-Jacobi smoother + "
+                        f"corner-node P1 level Chebyshev({a.coarse_degree}, ratio {a.coarse_ratio:g})")
+    else:
+        precond_desc = f"Chebyshev({a.cheb_degree}) block-Jacobi"
     if rank == 0:
         passes = a.steps * nhyp
         out = {
@@ -210,7 +222,7 @@ def main():
                 "hypotheses_per_gpu_per_step": a.hyp_per_gpu,
                 "parallelism": f"dp{world} over material hypotheses, scalar loss all-reduce",
                 "precision": "fp32 block vectors and SpMM, fp64 Gram accumulation / Rayleigh-Ritz / read-out",
-                "eigensolver": (f"LOBPCG(ortho) block {a.block}, Chebyshev({a.cheb_degree}) block-Jacobi, "
+                "eigensolver": (f"LOBPCG(ortho) block {a.block}, {precond_desc}, "
                                 f"cold start{' (warm)' if a.warm_start else ''}, mean iterations {np.mean(iters):.1f}"),
                 "symbolic_pattern_seconds_not_timed": t_sym,
             },

@@ -36,6 +36,8 @@ _SIGNATURES = {
     "ds_cheb_init": (_I, [_P, _I64, _P, _I64, _P, _I64, _P, _I64, _I, _F, _P]),
     "ds_cheb_step": (_I, [_P, _I64, _P, _I64, _P, _I64, _P, _I64, _P, _I64, _I, _F, _F, _P]),
     "ds_cheb_spmm": (_I, [_P, _P, _P, _I64, _P, _I64, _P, _I64, _P, _I64, _P, _I, _F, _F, _I, _P]),
+    "ds_spmm_residual": (_I, [_P, _P, _P, _I64, _P, _I64, _P, _I64, _P, _I64, _I, _P]),
+    "ds_scalar_csr_spmm": (_I, [_P, _P, _P, _I64, _P, _I64, _P, _I64, _I, _F, _P]),
     "ds_tiles_build": (_I, [_P, _P, _I64, _I, _I, ctypes.POINTER(_P)]),
     "ds_tiles_sizes": (_I, [_P, ctypes.POINTER(_I64), ctypes.POINTER(_I64)]),
     "ds_tiles_export": (_I, [_P, _P, _P, _P, _P]),

@@ -168,7 +168,7 @@ struct ChebEpilogue {
     int64_t ldr;
     const float* dinv;
     float c1, c2;
-    int first;  // W_{k-1} = 0: do not read Y
+    int first;  // W_{k-1} = 0: Y is not read
 };
 
 template <int KIND, int RS, int LPN_CT, int EPI>
@@ -322,10 +322,21 @@ __global__ void __launch_bounds__(256)
                 o0 += epi.c1 * (w0 - *reinterpret_cast<const f4*>(yp));
                 o1 += epi.c1 * (w1 - *reinterpret_cast<const f4*>(yp + ldy));
                 o2 += epi.c1 * (w2 - *reinterpret_cast<const f4*>(yp + 2 * ldy));
+            } else {  // W_prev = 0 (not read)
+                o0 += epi.c1 * w0;
+                o1 += epi.c1 * w1;
+                o2 += epi.c1 * w2;
             }
             *reinterpret_cast<f4*>(yp) = o0;
             *reinterpret_cast<f4*>(yp + ldy) = o1;
             *reinterpret_cast<f4*>(yp + 2 * ldy) = o2;
+        }
+    } else if (EPI == 2) {  // Y = R0 - K X (block residual feeding the coarse-level restriction)
+        if (active && r_raw == 0) {
+            const float* rp = epi.r0 + (node * 3) * epi.ldr + c0;
+            *reinterpret_cast<f4*>(yp) = *reinterpret_cast<const f4*>(rp) - acc0;
+            *reinterpret_cast<f4*>(yp + ldy) = *reinterpret_cast<const f4*>(rp + epi.ldr) - acc1;
+            *reinterpret_cast<f4*>(yp + 2 * ldy) = *reinterpret_cast<const f4*>(rp + 2 * epi.ldr) - acc2;
         }
     } else if (RS == 3 && KIND == 1) {
         if (active) *reinterpret_cast<f4*>(yp + (int64_t)r * ldy) = acc0;
@@ -539,6 +550,10 @@ __global__ void __launch_bounds__(64 * NW)
                         o0 += epi.c1 * (w0 - *reinterpret_cast<const f4*>(yp));
                         o1 += epi.c1 * (w1 - *reinterpret_cast<const f4*>(yp + ldy));
                         o2 += epi.c1 * (w2 - *reinterpret_cast<const f4*>(yp + 2 * ldy));
+                    } else {  // W_prev = 0 (not read)
+                        o0 += epi.c1 * w0;
+                        o1 += epi.c1 * w1;
+                        o2 += epi.c1 * w2;
                     }
                     *reinterpret_cast<f4*>(yp) = o0;
                     *reinterpret_cast<f4*>(yp + ldy) = o1;
@@ -741,6 +756,10 @@ __global__ void __launch_bounds__(256)
                     o0 += epi.c1 * (w0 - *reinterpret_cast<const f4*>(yp));
                     o1 += epi.c1 * (w1 - *reinterpret_cast<const f4*>(yp + ldy));
                     o2 += epi.c1 * (w2 - *reinterpret_cast<const f4*>(yp + 2 * ldy));
+                } else {  // W_prev = 0 (not read)
+                    o0 += epi.c1 * w0;
+                    o1 += epi.c1 * w1;
+                    o2 += epi.c1 * w2;
                 }
                 *reinterpret_cast<f4*>(yp) = o0;
                 *reinterpret_cast<f4*>(yp + ldy) = o1;
@@ -824,5 +843,27 @@ extern "C" int ds_cheb_spmm(const int32_t* rowptr, const int32_t* colidx, const 
         case 18: return launch_wn<0, 3, 18, 1>(rowptr, colidx, vals, nullptr, nv, W, ldw, Wprev, ldp, lpn, st, epi);
         case 20: return launch_wn<0, 3, 20, 1>(rowptr, colidx, vals, nullptr, nv, W, ldw, Wprev, ldp, lpn, st, epi);
         default: return launch_wn<0, 3, 0, 1>(rowptr, colidx, vals, nullptr, nv, W, ldw, Wprev, ldp, lpn, st, epi);
+    }
+}
+
+// Y = R0 - K X on a block of <= 84 columns: the residual the two-level preconditioner restricts to the
+// corner-node (P1) level, produced without writing K X to HBM.
+extern "C" int ds_spmm_residual(const int32_t* rowptr, const int32_t* colidx, const float* vals, int64_t nv,
+                                const float* X, int64_t ldx, const float* R0, int64_t ldr, float* Y, int64_t ldy,
+                                int ncols, ds_stream_t stream) {
+    DS_REQUIRE(rowptr && colidx && vals && X && R0 && Y, "ds_spmm_residual: null pointer");
+    DS_REQUIRE(nv > 0 && ncols > 0 && ncols % 4 == 0 && ncols <= 84, "ds_spmm_residual: ncols must be a multiple of 4 <= 84");
+    DS_REQUIRE(ldx >= ncols && ldy >= ncols && ldr >= ncols, "ds_spmm_residual: leading dimension smaller than ncols");
+    const uintptr_t al = reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(Y) |
+                         reinterpret_cast<uintptr_t>(R0) | (uintptr_t)(ldx * 4) | (uintptr_t)(ldy * 4) |
+                         (uintptr_t)(ldr * 4);
+    DS_REQUIRE((al & 15) == 0, "ds_spmm_residual: rows must be 16-byte aligned");
+    DS_REQUIRE(X != Y, "ds_spmm_residual: X and Y must be different buffers");
+    hipStream_t st = ds::as_stream(stream);
+    const ChebEpilogue epi{R0, ldr, nullptr, 0.f, 0.f, 0};
+    const int lpn = ncols / 4;
+    switch (lpn) {
+        case 20: return launch_wn<0, 3, 20, 2>(rowptr, colidx, vals, nullptr, nv, X, ldx, Y, ldy, lpn, st, epi);
+        default: return launch_wn<0, 3, 0, 2>(rowptr, colidx, vals, nullptr, nv, X, ldx, Y, ldy, lpn, st, epi);
     }
 }

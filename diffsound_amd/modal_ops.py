@@ -102,7 +102,47 @@ class TetSystem:
             gr = _hip.Groups(pat.rowptr, pat.colidx, self.nv)
             self.groups = dict(ne=gr.ne, gptr=gr.gptr.to(dev), gent=gr.gent.to(dev), goff=gr.goff.to(dev),
                                kperm=gr.kperm.to(dev))
+        self._coarse = None
         self.assemble()
+
+    def coarse_level(self):
+        """ord-2 meshes only: the corner-node (P1) sub-mesh as an ord-1 ``TetSystem`` plus the transfer
+        operators between the two levels, both in internal numbering.  P1 is a subspace of P2 on the same
+        tets, so the ord-1 stiffness of the sub-mesh IS the Galerkin operator P^T K P, with P = "corner
+        copies its coarse value, mid-edge node (reference mesh.py:139-154) averages its edge's end points".
+        Returns None when there is no such level (ord-1 mesh, or nodes that no tet references)."""
+        if self._coarse is not None or self.order != 2:
+            return self._coarse
+        dev = self.device
+        tets = self.tets.long()
+        cs = fem_tables.CORNER_SLOTS[2]
+        corners = torch.unique(tets[:, list(cs)])  # ascending internal ids: the sub-mesh inherits the Morton order
+        cid = torch.full((self.nv,), -1, dtype=torch.int64, device=dev)
+        cid[corners] = torch.arange(corners.numel(), device=dev)
+        pa, pb = cid.clone(), cid.clone()
+        for slot, (p_, q_) in fem_tables._MID.items():
+            pa[tets[:, slot]] = cid[tets[:, cs[p_]]]
+            pb[tets[:, slot]] = cid[tets[:, cs[q_]]]
+        if bool((pa < 0).any()) or bool((pb < 0).any()):
+            return None
+        nvc = corners.numel()
+        csys = TetSystem(self.vertices[corners], cid[tets[:, list(cs)]], 1, self.density, reorder=False)
+        i32 = lambda t: t.to(torch.int32).contiguous()
+        fine = torch.arange(self.nv, device=dev)
+        mid = pa != pb
+        # restriction rows (coarse node <- itself, weight 1, and the mid-edge nodes of its edges, weight 1/2)
+        rrow = torch.cat([pa, pb[mid]])
+        rcol = torch.cat([fine, fine[mid]])
+        rw = torch.cat([torch.where(mid, 0.5, 1.0), torch.full((int(mid.sum()),), 0.5, device=dev)])
+        o = torch.argsort(rrow, stable=True)
+        rptr = torch.zeros(nvc + 1, dtype=torch.int64, device=dev)
+        rptr[1:] = torch.cumsum(torch.bincount(rrow, minlength=nvc), 0)
+        self._coarse = dict(
+            sys=csys, corners=corners,
+            pptr=i32(torch.arange(0, 2 * self.nv + 1, 2, device=dev)), pcol=i32(torch.stack([pa, pb], 1).reshape(-1)),
+            pw=torch.full((2 * self.nv,), 0.5, dtype=torch.float32, device=dev),
+            rptr=i32(rptr), rcol=i32(rcol[o]), rw=rw[o].float().contiguous())
+        return self._coarse
 
     def rows_to_external(self, X):
         """(n x c) block in internal DOF order -> the caller's node numbering."""
@@ -126,6 +166,8 @@ class TetSystem:
         _hip.check(L.ds_assemble_kml(p(self.vertices), p(self.tets), self.T, self.N, self.nv, p(self.cptr),
                                      p(self.clist), self.nnzb, p(self.dtab), p(self.mtab), p(self._tetgeo),
                                      p(self.klam), p(self.kmu), p(self.ms), _hip.stream_ptr()), "ds_assemble_kml")
+        if getattr(self, "_coarse", None) is not None:
+            self._coarse["sys"].assemble(self.vertices[self._coarse["corners"]])
 
     def geometry_grad(self, U, gk, gm, lam, mu):
         """d/dx sum_i gk_i u_i^T K u_i - gm_i u_i^T M u_i  ->  (nv, 3) fp64 in the caller's node numbering.
@@ -289,6 +331,32 @@ class _HipBlockOps:
             e1.record()
             self.cheb_events.append((e0, e1))
 
+    # ------------------------------------------------------------------ two-level preconditioner pieces
+    coarse = None  # ops of the corner-node level (HipModalOps on an ord-2 mesh sets it)
+
+    def spmm_residual(self, X, R0, Y):
+        """Y <- R0 - K X (<= 84 columns, one fused launch)."""
+        pp = _hip.ptr
+        _hip.check(self._L.ds_spmm_residual(pp(self.rowptr), pp(self.colidx), pp(self.k32), self.nv, pp(X), _ld(X),
+                                            pp(R0), _ld(R0), pp(Y), _ld(Y), X.shape[1], _hip.stream_ptr()),
+                   "ds_spmm_residual")
+        self.counts["apply_K_cols"] += X.shape[1]
+
+    def _transfer(self, ptr_, col, w, nrows, X, Y, beta):
+        pp = _hip.ptr
+        _hip.check(self._L.ds_scalar_csr_spmm(pp(ptr_), pp(col), pp(w), nrows, pp(X), _ld(X), pp(Y), _ld(Y),
+                                              X.shape[1], float(beta), _hip.stream_ptr()), "ds_scalar_csr_spmm")
+
+    def restrict(self, Rf, Rc):
+        """Rc <- P^T Rf (fine block -> corner-node level)."""
+        t = self._xfer
+        self._transfer(t["rptr"], t["rcol"], t["rw"], self.coarse.nv, Rf, Rc, 0.0)
+
+    def prolong_add(self, Ec, Wf):
+        """Wf <- Wf + P Ec."""
+        t = self._xfer
+        self._transfer(t["pptr"], t["pcol"], t["pw"], self.nv, Ec, Wf, 1.0)
+
     def _tiled(self, epilogue, X, Y, R0, c1, c2, first):
         t = self.sys.tiles
         pp = _hip.ptr
@@ -346,7 +414,9 @@ class _HipBlockOps:
 class HipModalOps(_HipBlockOps):
     """One material hypothesis (lam, mu) on a TetSystem."""
 
-    def __init__(self, system: TetSystem, lam, mu):
+    def __init__(self, system: TetSystem, lam, mu, two_level=None, _level=0):
+        """two_level: build the corner-node level for the two-level preconditioner (ord-2 meshes; default on,
+        ``DS_TWOLEVEL=0`` turns it off)."""
         self.sys = system
         self._init_common(system.rowptr, system.colidx, system.nv, system.device)
         dev = self.device
@@ -354,11 +424,20 @@ class HipModalOps(_HipBlockOps):
         self.k32t = torch.empty((system.nnzb, 9), dtype=torch.float32, device=dev)  # blocks transposed
         self.ms32 = torch.empty((system.nnzb,), dtype=torch.float32, device=dev)
         self.dinv = torch.empty((system.nv, 9), dtype=torch.float32, device=dev)
+        if two_level is None:
+            two_level = os.environ.get("DS_TWOLEVEL", "1") != "0"
+        if two_level and _level == 0 and system.order == 2:
+            lvl = system.coarse_level()
+            if lvl is not None:
+                self._xfer = lvl
+                self.coarse = HipModalOps(lvl["sys"], lam, mu, two_level=False, _level=1)
         self.set_material(lam, mu)
-        self.rigid = self._rigid_basis()
+        self.rigid = self._rigid_basis() if _level == 0 else None
 
     def set_material(self, lam, mu):
         s = self.sys
+        if self.coarse is not None:
+            self.coarse.set_material(lam, mu)
         p = _hip.ptr
         self.lame = (float(lam), float(mu))
         _hip.check(self._L.ds_combine_material(p(s.klam), p(s.kmu), p(s.ms), s.nnzb, p(s.diagidx), s.nv,

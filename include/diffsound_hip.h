@@ -153,6 +153,18 @@ int ds_cheb_step(const float* AD, int64_t lda, float* R, int64_t ldr, float* D, 
 int ds_cheb_spmm(const int32_t* rowptr, const int32_t* colidx, const float* vals, int64_t nv,
                  const float* W, int64_t ldw, float* Wprev, int64_t ldp, const float* R0, int64_t ldr,
                  const float* dinv, int ncols, float c1, float c2, int first, ds_stream_t stream);
+/* Y <- R0 - K X on a block of <= 84 columns (X, Y distinct): the fine-level residual that the two-level
+ * preconditioner restricts to the corner-node level; K X itself is never written. */
+int ds_spmm_residual(const int32_t* rowptr, const int32_t* colidx, const float* vals, int64_t nv,
+                     const float* X, int64_t ldx, const float* R0, int64_t ldr, float* Y, int64_t ldy,
+                     int ncols, ds_stream_t stream);
+/* Y_i <- beta Y_i + sum_k w[k] X_{colidx[k]}, k in [rowptr[i], rowptr[i+1]), on 3 x ncols node panels
+ * (nrows output nodes; X may have a different node count): prolongation / restriction between an ord-2
+ * mesh and its corner-node ord-1 sub-mesh (the P1 space written in the P2 nodal basis; node layout of
+ * reference src/diffelastic/mesh.py:139-154).  ncols a multiple of 4, 16-byte aligned rows. */
+int ds_scalar_csr_spmm(const int32_t* rowptr, const int32_t* colidx, const float* w, int64_t nrows,
+                       const float* X, int64_t ldx, float* Y, int64_t ldy, int ncols, float beta,
+                       ds_stream_t stream);
 /* LDS-tiled form of the two above for ncols <= 84 on the row tiles of ds_tiles_build (nu_max as given there):
  * epilogue 0: Y <- K X ; epilogue 1: Y (= W_prev) <- X + c1 (X - Y) + c2 T (R0 - K X). */
 int ds_spmm_tiled(int epilogue, const int32_t* rowptr, const float* vals, int64_t nv, const int32_t* tnode,

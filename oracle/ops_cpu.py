@@ -23,8 +23,51 @@ def rigid_body_basis(verts):
     return Y
 
 
+def corner_embedding(tets, nv):
+    """(nv x nvc) node-level matrix of the P1-in-P2 embedding of an ord-2 mesh: a corner node copies its
+    coarse value, a mid-edge node (local slots of reference mesh.py:139-154) averages its two end points."""
+    tn = np.asarray(tets)
+    corners = np.unique(tn[:, [0, 2, 4, 9]])
+    cid = -np.ones(nv, dtype=np.int64)
+    cid[corners] = np.arange(len(corners))
+    pa, pb = cid.copy(), cid.copy()
+    for slot, (p, q) in {1: (0, 2), 3: (2, 4), 5: (4, 0), 6: (0, 9), 7: (2, 9), 8: (4, 9)}.items():
+        pa[tn[:, slot]] = cid[tn[:, p]]
+        pb[tn[:, slot]] = cid[tn[:, q]]
+    assert (pa >= 0).all() and (pb >= 0).all()
+    rows = np.repeat(np.arange(nv), 2)
+    return sp.csr_matrix((np.full(2 * nv, 0.5), (rows, np.stack([pa, pb], 1).ravel())), shape=(nv, len(corners)))
+
+
+class _CpuLevel:
+    """The K-only part of the protocol on one level (what the preconditioner touches)."""
+
+    def __init__(self, K, dtype):
+        self.n = K.shape[0]
+        self.device = torch.device("cpu")
+        self.dtype = dtype
+        self.npdt = np.float32 if dtype == torch.float32 else np.float64
+        self.Kd = K.astype(self.npdt).tocsr()
+        nb = self.n // 3
+        Kb = K.tobsr((3, 3))
+        rows = np.repeat(np.arange(nb), np.diff(Kb.indptr))
+        diag = np.zeros((nb, 3, 3))
+        m = rows == Kb.indices
+        diag[rows[m]] = Kb.data[m]
+        self.Dinv = torch.from_numpy(np.linalg.inv(diag).astype(self.npdt))
+        self.counts = dict(apply_K_cols=0, apply_M_cols=0, gram=0, mix=0)
+
+    apply_K = lambda self, X, out: CpuModalOps.apply_K(self, X, out)
+    _bj = lambda self, R: CpuModalOps._bj(self, R)
+    cheb_init = lambda self, R, D, W, c: CpuModalOps.cheb_init(self, R, D, W, c)
+    cheb_step = lambda self, AD, R, D, W, c1, c2: CpuModalOps.cheb_step(self, AD, R, D, W, c1, c2)
+    cheb_spmm = lambda self, Wk, Wprev, R0, c1, c2, first: CpuModalOps.cheb_spmm(self, Wk, Wprev, R0, c1, c2, first)
+
+
 class CpuModalOps:
-    def __init__(self, Kl, Km, M3, verts, lam, mu, dtype=torch.float32):
+    def __init__(self, Kl, Km, M3, verts, lam, mu, dtype=torch.float32, tets=None):
+        """tets: the ord-2 connectivity; given, the corner-node level of the two-level preconditioner is
+        built as the Galerkin product P^T K P."""
         self.Kl, self.Km, self.M = Kl.tocsr(), Km.tocsr(), M3.tocsr()
         self.lame = (float(lam), float(mu))
         self.n = Kl.shape[0]
@@ -48,6 +91,23 @@ class CpuModalOps:
         Y = np.linalg.solve(L, Y.T).T
         self.rigid = torch.from_numpy(Y.astype(self.npdt))
         self.counts = dict(apply_K_cols=0, apply_M_cols=0, gram=0, mix=0)
+        self.coarse = None
+        if tets is not None:
+            P = sp.kron(corner_embedding(tets, nb), sp.identity(3), format="csr")
+            self.P = P.astype(self.npdt)
+            self.PT = self.P.T.tocsr()
+            self.coarse = _CpuLevel((P.T @ K @ P).tocsr(), dtype)
+
+    # -- two-level pieces ------------------------------------------------------------------
+    def spmm_residual(self, X, R0, Y):
+        Y.copy_(R0 - torch.from_numpy(self.Kd @ X.numpy()))
+        self.counts["apply_K_cols"] += X.shape[1]
+
+    def restrict(self, Rf, Rc):
+        Rc.copy_(torch.from_numpy(self.PT @ Rf.numpy()))
+
+    def prolong_add(self, Ec, Wf):
+        Wf.add_(torch.from_numpy(self.P @ Ec.numpy()))
 
     # -- sparse products -----------------------------------------------------------------
     def apply_K(self, X, out):
@@ -94,8 +154,7 @@ class CpuModalOps:
     def cheb_spmm(self, Wk, Wprev, R0, c1, c2, first):
         KW = torch.from_numpy(self.Kd @ Wk.numpy())
         new = Wk + c2 * self._bj(R0 - KW)
-        if not first:
-            new = new + c1 * (Wk - Wprev)
+        new = new + c1 * (Wk if first else Wk - Wprev)  # first: W_prev = 0 and is not read
         Wprev.copy_(new)
         self.counts["apply_K_cols"] += Wk.shape[1]
 

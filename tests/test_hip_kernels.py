@@ -52,7 +52,7 @@ def case(request, dev):
     lam, mu = fem.lame(MAT[1], MAT[2])
     sysd = TetSystem(v.to(dev), t.to(dev), order, MAT[0], reorder=False)  # kernel parity in the caller's numbering
     hops = HipModalOps(sysd, lam, mu)
-    cops = CpuModalOps(Kl, Km, M3, v.numpy(), lam, mu)
+    cops = CpuModalOps(Kl, Km, M3, v.numpy(), lam, mu, tets=t.numpy() if order == 2 else None)
     return dict(v=v, t=t, order=order, Kl=Kl, Km=Km, M3=M3, Ms=Ms, sys=sysd, hops=hops, cops=cops, lam=lam, mu=mu)
 
 
@@ -279,6 +279,66 @@ def test_fused_chebyshev_spmm(case, dev, ncols, first):
     Wp_d = Wp.to(dev).clone()
     h.cheb_spmm(big[:, 8:], Wp_d, R0.to(dev), 0.31, 0.77, first)
     assert rel(Wp_d.cpu().numpy(), Wp_ref.numpy()) < 5e-6
+
+
+@pytest.mark.parametrize("ncols", [80, 40, 8])
+def test_two_level_pieces(case, dev, ncols):
+    """Corner-node level of the two-level preconditioner: the ord-1 assembly of the corner sub-mesh is the Galerkin
+    operator P^T K P of the oracle, and the transfer / fused-residual kernels match the oracle's matrices."""
+    h, c = case["hops"], case["cops"]
+    if case["order"] != 2:
+        assert h.coarse is None
+        pytest.skip("no coarse level on an ord-1 mesh")
+    hc, cc = h.coarse, c.coarse
+    assert hc is not None and hc.n == cc.n
+    g = torch.Generator().manual_seed(ncols)
+    Xc = torch.randn((cc.n, ncols), generator=g)
+    Xf = torch.randn((c.n, ncols), generator=g)
+    R0 = torch.randn((c.n, ncols), generator=g) * 1e10
+    ref = torch.empty_like(Xc)
+    cc.apply_K(Xc, ref)
+    out = torch.empty((hc.n, ncols), device=dev)
+    hc.apply_K(Xc.to(dev), out)
+    assert rel(out.cpu().numpy(), ref.numpy()) < 5e-6  # Galerkin identity
+    assert rel(hc.dinv.cpu().numpy().reshape(-1, 3, 3), cc.Dinv.numpy()) < 1e-5
+    # restriction, prolongation (accumulating), fused residual
+    rc_ref = torch.empty_like(Xc)
+    c.restrict(Xf, rc_ref)
+    rc = torch.empty((hc.n, ncols), device=dev)
+    h.restrict(Xf.to(dev), rc)
+    assert rel(rc.cpu().numpy(), rc_ref.numpy()) < 1e-6
+    wf_ref = Xf.clone()
+    c.prolong_add(Xc, wf_ref)
+    big = torch.zeros((h.n, ncols + 4), device=dev)  # strided view, like the solver's W
+    big[:, 4:] = Xf.to(dev)
+    h.prolong_add(Xc.to(dev), big[:, 4:])
+    assert rel(big[:, 4:].cpu().numpy(), wf_ref.numpy()) < 1e-6
+    assert float(big[:, :4].abs().max()) == 0.0
+    y_ref = torch.empty_like(Xf)
+    c.spmm_residual(Xf, R0, y_ref)
+    y = torch.empty((h.n, ncols), device=dev)
+    h.spmm_residual(big[:, 4:].contiguous() * 0 + Xf.to(dev), R0.to(dev), y)
+    assert rel(y.cpu().numpy(), y_ref.numpy()) < 5e-6
+
+
+def test_two_level_cycle_matches_oracle(case, dev):
+    from diffsound_amd.lobpcg.modal_solver import SolverConfig, TwoLevelChebyshev
+
+    h, c = case["hops"], case["cops"]
+    if case["order"] != 2:
+        pytest.skip("no coarse level on an ord-1 mesh")
+    cfg = SolverConfig(lmax_cap=10.0, smooth_degree=3, coarse_degree=12, coarse_ratio=50.0)
+    ph, pc = TwoLevelChebyshev(h, cfg), TwoLevelChebyshev(c, cfg)
+    assert abs(ph.smooth.lmax / pc.smooth.lmax - 1) < 0.05 and abs(ph.coarse.lmax / pc.coarse.lmax - 1) < 0.05
+    for a, b in ((ph.smooth, pc.smooth), (ph.coarse, pc.coarse)):  # same polynomial on both sides
+        a.lmax, a.lmin = b.lmax, b.lmin
+    g = torch.Generator().manual_seed(5)
+    R = torch.randn((c.n, 96), generator=g) * 1e9  # 96 columns: two chunks
+    Wc = torch.empty_like(R)
+    pc.apply(R.clone(), Wc)
+    Wh = torch.empty((h.n, 96), device=dev)
+    ph.apply(R.to(dev), Wh)
+    assert rel(Wh.cpu().numpy(), Wc.numpy()) < 2e-4
 
 
 def test_polish_products(case, dev):

@@ -23,7 +23,15 @@ def wrap(obj, name, label=None):
 for n in ('apply_K', 'apply_M', 'gram', 'mix', 'mix_inplace', 'residual', 'cheb_init', 'cheb_spmm', 'polish_products'):
     wrap(ops, n)
 wrap(ms, '_small', 'host_dense')
-cfg = ms.SolverConfig(block=80, cheb_degree=int(os.environ.get('DEG', 48)), cheb_ratio=float(os.environ.get('RATIO', 800)), lmax_cap=10.0)
+E_ = os.environ.get
+cfg = ms.SolverConfig(block=int(E_('BLOCK', 80)), cheb_degree=int(E_('DEG', 48)), cheb_ratio=float(E_('RATIO', 800)), lmax_cap=10.0,
+                      precond=E_('PRECOND', 'auto'), smooth_degree=int(E_('SD', 3)), smooth_ratio=float(E_('SR', 10)),
+                      coarse_degree=int(E_('CD', 24)), coarse_ratio=float(E_('CR', 400)))
+if ops.coarse is not None:
+    for n in ('apply_K', 'cheb_init', 'cheb_spmm'):
+        wrap(ops.coarse, n, 'coarse_' + n)
+    for n in ('spmm_residual', 'restrict', 'prolong_add'):
+        wrap(ops, n)
 for rep in range(2):
     acc.clear(); cnt.clear()
     torch.cuda.synchronize(); t0 = time.time()
