@@ -37,7 +37,8 @@ class SolverConfig:
     # scale, so 2e-6 is ~6x above the floor; the fp64 polish then yields eigenvalues good to ~1e-8.
     tol: float = 0.0  # 0 -> 2e-6 for fp32 iterates, 1e-10 for fp64
     maxit: int = 400
-    ortho_passes: int = 2
+    ortho_passes: int = 2  # at most; a pass is skipped when the previous one left eps * amplification < ortho_tol
+    ortho_tol: float = 2e-6
     check_every: int = 1
     lock: bool = True  # hard-lock converged leading columns (reference S_ = S[:, nc:ns])
     seed: int = 0
@@ -85,13 +86,28 @@ def _orthonormalizer(G):
     """T with (W T)^T M (W T) = I from G = W^T M W: Cholesky-QR on the diagonally scaled Gram matrix
     (one potrf + one small triangular solve), falling back to the clamped-eigenvalue transform of the
     reference's svqb when the factorisation breaks down (rank-deficient block)."""
+    return _orthonormalizer_q(G)[0]
+
+
+def _orthonormalizer_q(G):
+    """(T, amp): T as in ``_orthonormalizer``; ``amp`` (python float) estimates by how much the storage rounding
+    of W is amplified in the orthogonality of the result, amp = max(1 / min diag(chol) (a lower bound of the
+    scaled block's condition), sqrt(removed / kept) per column).  An optional extra last row of G carries the
+    squared M-norms of what the preceding projection removed from each column."""
+    rem = None
+    if G.shape[0] == G.shape[1] + 1:
+        G, rem = G[:-1], G[-1]
     G = _sym(G)
-    d = torch.rsqrt(torch.clamp(G.diagonal(), min=1e-300))
+    diag = torch.clamp(G.diagonal(), min=1e-300)
+    d = torch.rsqrt(diag)
     L, info = torch.linalg.cholesky_ex(G * d[:, None] * d[None, :])
     if int(info) != 0 or not bool(torch.isfinite(L).all()):
-        return _svqb_transform(G)
+        return _svqb_transform(G), float("inf")
+    amp = 1.0 / max(float(L.diagonal().min()), 1e-300)
+    if rem is not None:
+        amp = max(amp, float(torch.sqrt(rem / diag).max()))
     Li = torch.linalg.solve_triangular(L, torch.eye(L.shape[0], dtype=L.dtype, device=L.device), upper=False)
-    return d[:, None] * Li.transpose(0, 1)
+    return d[:, None] * Li.transpose(0, 1), amp
 
 
 def _orthonormal_columns(Tm):
@@ -131,7 +147,7 @@ def _small(fn, dev, *mats):
     with _one_thread():
         out = fn(*host)
     if isinstance(out, tuple):
-        return tuple(o.to(dev, non_blocking=True) for o in out)
+        return tuple(o.to(dev, non_blocking=True) if torch.is_tensor(o) else o for o in out)
     return out.to(dev, non_blocking=True)
 
 
@@ -294,6 +310,7 @@ class ModalSolver:
         (the ``iK`` argument of the reference API); default Chebyshev block-Jacobi."""
         self.ops = ops
         self.cfg = cfg or SolverConfig()
+        self.ortho_log = []
         if precond is not None:
             self.precond_apply = precond
             self.precond = None
@@ -313,15 +330,25 @@ class ModalSolver:
     def _orthonormalize(self, W, V, MW):
         """Make W M-orthogonal to the block V (may be None) and M-orthonormal (reference _get_ortho,
         _lobpcg.py:587-679, with a fixed number of passes instead of host-synchronising norms)."""
-        ops = self.ops
-        for _ in range(self.cfg.ortho_passes):
+        ops, cfg = self.ops, self.cfg
+        eps = 6e-8 if ops.dtype == torch.float32 else 1.1e-16
+        for ip in range(cfg.ortho_passes):
+            G = None
             if V is not None and V.shape[1] > 0:
                 ops.apply_M(W, MW)
                 C = ops.gram(V, MW)
                 ops.mix(V, C, W, alpha=-1.0, beta=1.0)
+                rem = (C * C).sum(0)  # ||V C_j||_M^2 (V is M-orthonormal): what the projection removed
             ops.apply_M(W, MW)
-            T = _small(_orthonormalizer, ops.device, ops.gram(W, MW, symmetric=True))
+            G = ops.gram(W, MW, symmetric=True)
+            if V is not None and V.shape[1] > 0:
+                G = torch.cat([G, rem[None, :].to(G.dtype)], 0)
+            T, amp = _small(_orthonormalizer_q, ops.device, G)
             ops.mix_inplace(W, T)
+            self.ortho_log.append(amp)
+            # a further pass only repairs what this one lost to rounding: eps * amp in the orthogonality of W
+            if cfg.ortho_tol > 0.0 and eps * amp < cfg.ortho_tol:
+                break
 
     # ------------------------------------------------------------------ main entry
     def solve(self, k: int, X0: Optional[torch.Tensor] = None, tracker: Optional[Callable] = None,

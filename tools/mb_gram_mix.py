@@ -11,13 +11,18 @@ def tm(f, reps=20):
     for _ in range(reps): f()
     torch.cuda.synchronize(); return (time.time() - t) / reps * 1e3
 S = torch.randn((n, 248), device=dev); KS = torch.randn((n, 240), device=dev)
-for p, q, sym in ((160, 72, False), (72, 72, True), (224, 224, True), (240, 240, True), (88, 80, False), (80, 80, True), (64, 64, False)):
+only = os.environ.get('ONLY')
+shapes = ((160, 72, False), (72, 72, True), (224, 224, True), (240, 240, True), (88, 80, False), (80, 80, True), (64, 64, False))
+if only:
+    a_, b_, c_ = only.split(','); shapes = ((int(a_), int(b_), bool(int(c_))),)
+for p, q, sym in shapes:
     A = S[:, 8:8 + p] if sym else S[:, :p]
     B = KS[:, :q]
     ms = tm(lambda: ops.gram(A, B, symmetric=sym))
     fl = 2.0 * n * p * q * (0.5 if sym else 1.0)
     by = n * 4.0 * (p + q)
     print(f"gram {p:3d}x{q:3d} sym={int(sym)}: {ms:.3f} ms  {fl/ms/1e9:6.1f} TF/s(f64)  {by/ms/1e6:6.0f} GB/s min-traffic")
+if only: sys.exit(0)
 out = torch.empty((n, 80), device=dev)
 for p, q in ((160, 72), (72, 72), (224, 72), (240, 80), (80, 80), (80, 64)):
     C = torch.randn((p, q), dtype=torch.float64, device=dev)

@@ -25,7 +25,7 @@ for n in ('apply_K', 'apply_M', 'gram', 'mix', 'mix_inplace', 'residual', 'cheb_
 wrap(ms, '_small', 'host_dense')
 E_ = os.environ.get
 cfg = ms.SolverConfig(block=int(E_('BLOCK', 80)), cheb_degree=int(E_('DEG', 48)), cheb_ratio=float(E_('RATIO', 800)), lmax_cap=10.0,
-                      precond=E_('PRECOND', 'auto'), smooth_degree=int(E_('SD', 3)), smooth_ratio=float(E_('SR', 10)),
+                      precond=E_('PRECOND', 'auto'), ortho_passes=int(E_('OP', 2)), ortho_tol=float(E_('OT', 2e-6)), smooth_degree=int(E_('SD', 3)), smooth_ratio=float(E_('SR', 10)),
                       coarse_degree=int(E_('CD', 24)), coarse_ratio=float(E_('CR', 400)))
 if ops.coarse is not None:
     for n in ('apply_K', 'cheb_init', 'cheb_spmm'):
@@ -39,6 +39,8 @@ for rep in range(2):
     torch.cuda.synchronize(); t_setup = time.time() - t0
     res = solver.solve(64)
     torch.cuda.synchronize(); tot = time.time() - t0
+print("ortho amp", " ".join(f"{a:.1f}" for a in solver.ortho_log))
+print(f"max rerr {float(res.rerr.max()):.2e}" if hasattr(res, "rerr") else "", end=" ")
 print(f"total {tot*1e3:.1f} ms (solver setup incl. lmax power iteration {t_setup*1e3:.1f} ms), iterations {res.iterations}")
 for k, v_ in sorted(acc.items(), key=lambda kv: -kv[1]):
     print(f"  {k:18s} {v_*1e3:8.1f} ms  calls {cnt[k]:5d}  avg {v_/cnt[k]*1e3:7.3f} ms")
