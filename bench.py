@@ -35,7 +35,10 @@ def parse():
     ap.add_argument("--cells", type=int, default=26, help="Kuhn box cells per edge (26 -> 105 456 tets)")
     ap.add_argument("--order", type=int, default=2)
     ap.add_argument("--modes", type=int, default=64)
-    ap.add_argument("--hyp-per-gpu", type=int, default=1)
+    ap.add_argument("--hyp-per-gpu", type=int, default=6, help="material hypotheses per GPU per step")
+    ap.add_argument("--lanes", type=int, default=3,
+                    help="hypotheses in flight at once per GPU (own HIP stream + host thread each), so one lane's "
+                         "host-side Rayleigh-Ritz step overlaps the other lane's kernels")
     ap.add_argument("--cheb-degree", type=int, default=48)
     ap.add_argument("--cheb-ratio", type=float, default=800.0)
     ap.add_argument("--block", type=int, default=80)
@@ -137,8 +140,9 @@ def main():
         pipe.assemble()
         loss_sum = 0.0
         its = []
-        for h in mine:
-            r, res, _ = pipe.run_pass(float(Es[h]), float(nus[h]), warm=warm.get(h) if a.warm_start else None)
+        outs = pipe.run_batch([(float(Es[h]), float(nus[h])) for h in mine], lanes=a.lanes,
+                              warm=[warm.get(h) for h in mine] if a.warm_start else None)
+        for h, (r, res, _) in zip(mine, outs):
             if a.warm_start:
                 warm[h] = res.block_vectors
             loss_sum += r.loss
@@ -220,7 +224,8 @@ def main():
                 "workload": (f"Kuhn box {a.cells}^3 cells = {sysd.T} tets, ord-{a.order} ({sysd.nv} nodes, n={sysd.n}, "
                              f"nnz={sysd.nnzb * 9}), {a.modes} modes, fwd+bwd w.r.t. (E, nu), S=8000 @ 32 kHz"),
                 "hypotheses_per_gpu_per_step": a.hyp_per_gpu,
-                "parallelism": f"dp{world} over material hypotheses, scalar loss all-reduce",
+                "parallelism": (f"dp{world} over material hypotheses, scalar loss all-reduce; {min(a.lanes, a.hyp_per_gpu)} "
+                                "hypotheses in flight per GPU (one HIP stream + host thread each)"),
                 "precision": "fp32 block vectors and SpMM, fp64 Gram accumulation / Rayleigh-Ritz / read-out",
                 "eigensolver": (f"LOBPCG(ortho) block {a.block}, {precond_desc}, "
                                 f"cold start{' (warm)' if a.warm_start else ''}, mean iterations {np.mean(iters):.1f}"),

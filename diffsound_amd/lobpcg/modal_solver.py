@@ -21,6 +21,7 @@ The ``ops`` protocol (see ``diffsound_amd/modal_ops.py`` for the HIP implementat
   n, device, dtype, rigid (n x 6, M-orthonormal), apply_K, apply_M, gram, mix, residual,
   precond, polish_products.
 """
+import threading
 from dataclasses import dataclass, field
 from typing import Callable, Optional
 
@@ -128,15 +129,28 @@ def _orthonormal_columns(Tm):
 
 class _one_thread:
     """LAPACK on <= 3b x 3b matrices is fastest single-threaded (measured on the MI355X host: 240 x 240
-    fp64 eigh 3.2 ms with 1 thread incl. both PCIe hops, 5.7 ms with rocSOLVER's launch-bound syevd,
-    150 ms with the default 128 threads)."""
+    fp64 eigh 2.5 ms with 1 thread, no faster with 2-8, 150 ms with the default 128 threads; rocSOLVER's
+    launch-bound syevd takes 5.7 ms).  Re-entrant across the worker threads of concurrent solves: the
+    process-wide thread count is lowered by the first solve that enters and restored by the last that leaves."""
+
+    _lock = threading.Lock()
+    _depth = 0
+    _saved = 1
 
     def __enter__(self):
-        self.n = torch.get_num_threads()
-        torch.set_num_threads(1)
+        cls = _one_thread
+        with cls._lock:
+            if cls._depth == 0:
+                cls._saved = torch.get_num_threads()
+                torch.set_num_threads(1)
+            cls._depth += 1
 
     def __exit__(self, *a):
-        torch.set_num_threads(self.n)
+        cls = _one_thread
+        with cls._lock:
+            cls._depth -= 1
+            if cls._depth == 0:
+                torch.set_num_threads(cls._saved)
 
 
 def _small(fn, dev, *mats):
@@ -172,8 +186,15 @@ class ChebyshevBlockJacobi:
         self.ops = ops
         self.degree = max(1, int(degree))
         n, dev, dt = ops.n, ops.device, ops.dtype
-        g = torch.Generator(device=dev).manual_seed(seed + 17)  # device-side RNG: no 100 MB host round trip
-        x = torch.randn((n, 8), generator=g, dtype=torch.float32, device=dev).to(dt)
+        # The dominant vectors of T K barely move when the material changes, so an ops object that already went
+        # through a power iteration hands its block over and a quarter of the steps re-converge the bound (the
+        # eigensolve itself still starts cold; only this spectral bound of the preconditioner is warm).
+        x = getattr(ops, "_power_block", None)
+        if x is not None and x.shape == (n, 8) and x.dtype == dt:
+            power_iters = max(6, power_iters // 4)
+        else:
+            g = torch.Generator(device=dev).manual_seed(seed + 17)  # device-side RNG: no 100 MB host round trip
+            x = torch.randn((n, 8), generator=g, dtype=torch.float32, device=dev).to(dt)
         y = torch.empty_like(x)
         z = torch.empty_like(x)
         lm = None
@@ -183,6 +204,10 @@ class ChebyshevBlockJacobi:
             nrm = torch.linalg.vector_norm(x.double(), dim=0)
             lm = nrm.max()
             x = (x / nrm.to(dt)[None, :]).contiguous()
+        try:
+            ops._power_block = x
+        except AttributeError:
+            pass
         # power iteration under-estimates; an under-estimated lmax makes the polynomial blow up on
         # the top of the spectrum (measured: 2% low -> no convergence), an over-estimate costs little
         self.lmax = safety * float(lm)

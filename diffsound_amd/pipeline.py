@@ -70,6 +70,7 @@ class ModalPipeline:
         self.cfg = solver_config or SolverConfig()
         self.system = TetSystem(vertices, tets, order, self.mat.density)
         self.ops = None
+        self._lanes = []
         force = torch.zeros((1, force_frames), device=self.device)
         force[0, 0] = 1  # impulse (reference material_sync_train.py:103-104)
         self.osc = TraditionalDampedOscillator(force, 1, modes, sample_num, sr, self.mat)
@@ -83,20 +84,21 @@ class ModalPipeline:
     def assemble(self):
         self.system.assemble()
 
-    def run_pass(self, youngs, poisson, warm=None, backward=True):
+    def run_pass(self, youngs, poisson, warm=None, backward=True, _lane=None):
         """Steps 2-6 for one hypothesis (step 1 is ``assemble``)."""
         model = DirectLinear(youngs, poisson, self.mat)
         lam, mu = model.lame()
-        if self.ops is None:
-            self.ops = HipModalOps(self.system, float(lam), float(mu))
+        holder = self if _lane is None else _lane
+        if holder.ops is None:
+            holder.ops = HipModalOps(self.system, float(lam), float(mu))
         else:
-            self.ops.set_material(float(lam), float(mu))
-        res = ModalSolver(self.ops, self.cfg).solve(self.modes, X0=warm)
+            holder.ops.set_material(float(lam), float(mu))
+        res = ModalSolver(holder.ops, self.cfg).solve(self.modes, X0=warm)
         ev = res.eigenvalues
         dev = ev.device
         pred = ev + (lam.to(dev) * res.a_lambda + mu.to(dev) * res.b_mu) - ev * res.m_diag
         freqs = (torch.sqrt(pred) / 2 / np.pi).float().unsqueeze(1)
-        audio = self.osc(freqs)
+        audio = holder.osc(freqs)
         if self.target is None:
             loss = (audio ** 2).mean()
         else:
@@ -106,6 +108,66 @@ class ModalPipeline:
             loss.backward()
             gE, gnu = float(model.E.grad), float(model.nu.grad)
         return PassResult(float(loss), gE, gnu, freqs.detach(), res.iterations, ev), res, audio.detach()
+
+
+class _Lane:
+    """Per-stream state of one of the concurrent hypothesis lanes (own material operators and scratch)."""
+
+    def __init__(self, pipe, ops=None):
+        self.ops = ops
+        self.stream = torch.cuda.Stream(device=pipe.device)
+        self.osc = TraditionalDampedOscillator(pipe.osc._force.clone(), 1, pipe.modes, pipe.osc.sample_num, pipe.osc.sr,
+                                               pipe.mat)
+
+
+def _run_batch(pipe, hyps, lanes=2, warm=None, backward=True):
+    """Hypotheses are independent, so ``lanes`` of them are in flight at once, each on its own HIP stream driven
+    by its own host thread: while one lane's small dense Rayleigh-Ritz step runs on the host (the GPU would idle
+    for ~2.5 ms per iteration), the other lane's kernels keep the device busy.  Returns the per-hypothesis
+    ``run_pass`` results in order.  ``warm``: optional list of start blocks."""
+    import threading
+
+    n = len(hyps)
+    if lanes <= 1 or n <= 1:
+        return [pipe.run_pass(E, nu, warm=None if warm is None else warm[i], backward=backward)
+                for i, (E, nu) in enumerate(hyps)]
+    while len(pipe._lanes) < lanes:
+        pipe._lanes.append(_Lane(pipe, ops=pipe.ops if not pipe._lanes else None))
+    main = torch.cuda.current_stream(pipe.device)
+    ready = torch.cuda.Event()
+    ready.record(main)
+    out, errs, done = [None] * n, [], []
+
+    def work(li):
+        lane = pipe._lanes[li]
+        try:
+            torch.cuda.set_device(pipe.device)
+            with torch.cuda.stream(lane.stream):
+                lane.stream.wait_event(ready)
+                for i in range(li, n, lanes):
+                    E, nu = hyps[i]
+                    out[i] = pipe.run_pass(E, nu, warm=None if warm is None else warm[i], backward=backward, _lane=lane)
+                e = torch.cuda.Event()
+                e.record(lane.stream)
+                done.append(e)
+        except BaseException as ex:  # surfaced in the caller's thread
+            errs.append(ex)
+
+    threads = [threading.Thread(target=work, args=(li,)) for li in range(min(lanes, n))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    if errs:
+        raise errs[0]
+    for e in done:
+        main.wait_event(e)
+    if pipe.ops is None:
+        pipe.ops = pipe._lanes[0].ops
+    return out
+
+
+ModalPipeline.run_batch = _run_batch
 
 
 def all_reduce_loss(loss_sum, device):

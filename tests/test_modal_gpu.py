@@ -73,3 +73,29 @@ def test_cube_ord2_vs_oracle(dev):
     err = np.abs(res.eigenvalues.cpu().numpy() - ev_ref) / ev_ref
     print("cube6 ord2 iters", res.iterations, "err", err.max())
     assert err.max() < EIG_TOL
+
+
+def test_concurrent_hypothesis_lanes_match_sequential(dev):
+    """ModalPipeline.run_batch with two hypotheses in flight (two HIP streams + host threads) returns what the
+    sequential passes return: same eigenvalues, losses and (E, nu) gradients (hypotheses are independent)."""
+    from diffsound_amd import meshgen
+    from diffsound_amd.diffelastic.mesh import TetMesh
+    from diffsound_amd.lobpcg.modal_solver import SolverConfig
+    from diffsound_amd.pipeline import ModalPipeline
+
+    mat = (2700.0, 5e10, 0.25, 6.0, 1e-7)
+    v, t = meshgen.kuhn_box(6)
+    mesh = TetMesh(torch.from_numpy(v).to(dev), torch.from_numpy(t).long().to(dev)).to_high_order(2)
+    pipe = ModalPipeline(mesh.vertices, mesh.tets, 2, 16, mat, solver_config=SolverConfig(block=24, lmax_cap=10.0))
+    pipe.assemble()
+    _, _, audio0 = pipe.run_pass(mat[1], mat[2], backward=False)
+    pipe.set_target(audio0)
+    hyps = [(4e10, 0.2), (7e10, 0.3), (5.5e10, 0.27), (9e10, 0.15), (3e10, 0.35)]
+    seq = pipe.run_batch(hyps, lanes=1)
+    par = pipe.run_batch(hyps, lanes=2)
+    assert len(par) == len(hyps) and len(pipe._lanes) == 2
+    for (rs, ress, as_), (rp, resp, ap) in zip(seq, par):
+        assert np.abs(resp.eigenvalues.cpu().numpy() / ress.eigenvalues.cpu().numpy() - 1).max() < 1e-6
+        assert abs(rp.loss / rs.loss - 1) < 1e-3
+        assert abs(rp.grad_E / rs.grad_E - 1) < 1e-2 and abs(rp.grad_nu / rs.grad_nu - 1) < 1e-2
+        assert float((ap - as_).norm() / as_.norm()) < 1e-3
