@@ -138,7 +138,17 @@ def test_c3_mass_conservation_and_rigid_null_space(c3):
 
 
 def test_c3_reproducible(c3):
+    """Same state in -> same spectrum out.  A solve leaves the power-iteration block of the preconditioner's
+    spectral bound on the ops object (the next hypothesis re-converges it in fewer steps), so a repeat from the
+    SAME state means dropping that block first; a repeat that keeps it takes a slightly different polynomial and
+    must still agree to the accuracy of the fp64 polish on fp32 iterates."""
     from diffsound_amd.lobpcg.modal_solver import ModalSolver
 
-    res2 = ModalSolver(c3["ops"], c3["cfg"]).solve(64)
-    assert float((res2.eigenvalues / c3["res"].eigenvalues - 1).abs().max()) < 1e-9
+    ops, ref = c3["ops"], c3["res"].eigenvalues
+    warm = ModalSolver(ops, c3["cfg"]).solve(64)
+    assert float((warm.eigenvalues / ref - 1).abs().max()) < 5e-8
+    for o in (ops, ops.coarse):
+        if o is not None and hasattr(o, "_power_block"):
+            del o._power_block
+    cold = ModalSolver(ops, c3["cfg"]).solve(64)
+    assert float((cold.eigenvalues / ref - 1).abs().max()) < 1e-9
