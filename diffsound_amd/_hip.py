@@ -50,6 +50,9 @@ _SIGNATURES = {
     "ds_groups_free": (None, [_P]),
     "ds_pack_groups": (_I, [_P, _P, _I64, _P, _P]),
     "ds_spmm_grouped": (_I, [_I, _P, _P, _P, _P, _I64, _P, _I64, _P, _I64, _P, _I64, _P, _I, _F, _F, _I, _P]),
+    "ds_spmm_batch_limits": (None, [ctypes.POINTER(_I), ctypes.POINTER(_I)]),
+    "ds_spmm_batched": (_I, [_I, _I, _P, _I64, _P, _P, _P, _I64, _I64, _P, _I64, _P, _I64, _P, _I64, _P, _I, _F, _F,
+                            _I, _P]),
     "ds_geometry_grad": (_I, [_P, _I64, _I, _I64, _P, _P, _I64, _I, _P, _P, _D, _D, _P, _P, _I, _P, _P, _P]),
     "ds_mix": (_I, [_P, _I64, _I, _P, _I, _P, _I64, _I64, _F, _F, _P]),
     "ds_osc_bank_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _D, _P, _P]),
@@ -163,3 +166,30 @@ class Groups:
                   "ds_groups_export")
         finally:
             lib().ds_groups_free(handle)
+
+
+def build_batches(rowptr_cpu):
+    """Batch table of the batched SpMM (ds_spmm_batched): consecutive nodes packed greedily into batches of at
+    most ``cap`` blocks and ``max_nodes`` nodes (ds_spmm_batch_limits).  Returns an (nbatch, 4) int32 CPU tensor
+    of rows (n0, n1, kb0, ke0), or None when the pattern does not qualify (an empty row, or a row longer than
+    a batch) - the caller then keeps the wave-per-node kernels."""
+    import numpy as np
+
+    cap, mx = _I(), _I()
+    lib().ds_spmm_batch_limits(ctypes.byref(cap), ctypes.byref(mx))
+    cap, mx = cap.value, mx.value
+    rp = rowptr_cpu.numpy().astype(np.int64)
+    nv = rp.shape[0] - 1
+    lens = np.diff(rp)
+    if nv == 0 or lens.min() < 1 or lens.max() > cap:
+        return None
+    # greedy: the batch starting at n0 ends at the last node whose row still ends within cap blocks
+    ends = np.searchsorted(rp, rp[:-1] + cap, side="right") - 1  # candidate n1 for every possible n0
+    ends = np.minimum(ends, np.arange(nv) + mx)
+    rows = []
+    n0 = 0
+    while n0 < nv:
+        n1 = int(ends[n0])
+        rows.append((n0, n1, rp[n0], rp[n1]))
+        n0 = n1
+    return torch.from_numpy(np.asarray(rows, dtype=np.int32))

@@ -55,6 +55,12 @@ class SolverConfig:
     smooth_ratio: float = 10.0  # the smoother damps [lmax/ratio, lmax] of T K
     coarse_degree: int = 24
     coarse_ratio: float = 400.0
+    # Rayleigh-Ritz by recurrence: K X and K P of the new basis are the same linear combinations of
+    # K [X P W] as X and P themselves, and X^T K X, X^T K P, P^T K P follow from the small Ritz algebra, so
+    # an iteration multiplies only the b new columns W by K and forms only the [X P W]^T (K W) block of
+    # the Gram matrix (a third of the SpMM columns, half of the Gram flops).  Every ``rr_refresh``-th
+    # iteration recomputes K [X P W] and the whole Gram matrix from the vectors (0 = every iteration).
+    rr_refresh: int = 8
 
 
 @dataclass
@@ -422,16 +428,23 @@ class ModalSolver:
         state.fvars.update(A_norm=float(A_norm), B_norm=float(B_norm))
         tol = cfg.tol or (2e-6 if dt == torch.float32 else 1e-10)
         self._orthonormalize(X, S[:, :ny], MW)
+        KS2 = torch.empty((n, 3 * b), dtype=dt, device=dev)
         ops.apply_K(X, KS[:, :b])
         lam, Z = _small(lambda G: torch.linalg.eigh(_sym(G)), dev, ops.gram(X, KS[:, :b], symmetric=True))
         lam = lam.clone()
         ops.mix(X, Z, S2[:, ny:ny + b])
         S, S2 = S2, S
-        ops.mix(KS[:, :b], Z, R)  # R holds K X for the first residual
+        ops.mix(KS[:, :b], Z, KS2[:, :b])  # K X of the rotated block
+        KS, KS2 = KS2, KS
+        R.copy_(KS[:, :b])  # the residual kernel works in place on a copy of K X
         history = []
         it = 0
         ncl = 0  # locked (converged) leading columns, kept a multiple of 4 for 16-byte aligned slices
         npc = 0  # columns of P
+        k0 = 0  # first column of K X_active inside KS (columns locked since the last Ritz step are skipped)
+        # Gram blocks of the part of the basis that the last Ritz step produced: [X_a P]^T K [X_a P] (host, fp64)
+        Gxp = torch.diag(lam.detach().to(torch.float64).cpu()) if dev.type == "cuda" else torch.diag(lam.to(torch.float64))
+        since_refresh = 0
         rel = torch.full((b,), float("inf"), dtype=torch.float64, device=dev)
         for it in range(cfg.maxit + 1):
             na = b - ncl
@@ -459,6 +472,8 @@ class ModalSolver:
             if new_ncl > ncl:
                 shift = new_ncl - ncl
                 R[:, :na - shift].copy_(R[:, shift:na].clone())
+                Gxp = Gxp[shift:, shift:]
+                k0 += shift
                 ncl = new_ncl
                 na = b - ncl
             w0 = ny + b + npc
@@ -467,15 +482,49 @@ class ModalSolver:
             self._orthonormalize(W, S[:, :w0], MW[:, :na])
             sz = na + npc + na
             Sa = S[:, ny + ncl:ny + ncl + sz]
-            ops.apply_K(Sa, KS[:, :sz])
-            Ea, Z1, Zp = _small(lambda G: _rr_step(G, na), dev, ops.gram(Sa, KS[:, :sz], symmetric=True))
+            KSa = KS[:, k0:k0 + sz]
+            full = cfg.rr_refresh <= 0 or since_refresh >= cfg.rr_refresh
+            if full:
+                ops.apply_K(Sa, KSa)
+                GA = ops.gram(Sa, KSa, symmetric=True)
+                since_refresh = 0
+            else:
+                # only the new columns meet K; the Gram blocks among X and P come from the last Ritz step
+                ops.apply_K(W, KSa[:, na + npc:])
+                GA = ops.gram(Sa, KSa[:, na + npc:])  # (sz x na) = [X P W]^T K W
+                since_refresh += 1
+
+            def ritz(GA_, Gxp_=Gxp, full_=full, na_=na, nxp=na + npc):
+                if full_:
+                    G = _sym(GA_)
+                else:
+                    G = torch.empty((GA_.shape[0], GA_.shape[0]), dtype=GA_.dtype)
+                    G[:nxp, :nxp] = Gxp_
+                    G[:, nxp:] = GA_
+                    G[nxp:, :nxp] = GA_[:nxp].transpose(0, 1)
+                    G = _sym(G)
+                E_, Z1_, Zp_ = _rr_step(G, na_)
+                ZZ = torch.cat([Z1_, Zp_], 1)
+                return E_, Z1_, Zp_, _sym(ZZ.transpose(0, 1) @ G @ ZZ)  # [X' P']^T K [X' P'] of the new basis
+
+            if dev.type == "cuda":
+                host = GA.cpu()
+                with _one_thread():
+                    Ea, Z1, Zp, Gxp = ritz(host)
+                Ea, Z1, Zp = (t_.to(dev, non_blocking=True) for t_ in (Ea, Z1, Zp))
+            else:
+                Ea, Z1, Zp, Gxp = ritz(GA)
             lam[ncl:] = Ea
             if ncl:
                 S2[:, ny:ny + ncl].copy_(S[:, ny:ny + ncl])
             ops.mix(Sa, Z1, S2[:, ny + ncl:ny + b])
             ops.mix(Sa, Zp, S2[:, ny + b:ny + b + na])
-            ops.mix(KS[:, :sz], Z1, R[:, :na])  # K X_new for the next residual
+            ops.mix(KSa, Z1, KS2[:, :na])  # K X_new
+            ops.mix(KSa, Zp, KS2[:, na:2 * na])  # K P_new
             S, S2 = S2, S
+            KS, KS2 = KS2, KS
+            k0 = 0
+            R[:, :na].copy_(KS[:, :na])
             npc = na
 
         X = S[:, ny:ny + b]

@@ -102,6 +102,14 @@ class TetSystem:
             gr = _hip.Groups(pat.rowptr, pat.colidx, self.nv)
             self.groups = dict(ne=gr.ne, gptr=gr.gptr.to(dev), gent=gr.gent.to(dev), goff=gr.goff.to(dev),
                                kperm=gr.kperm.to(dev))
+        # batch table of the batched SpMM (one wave per run of consecutive nodes).  EXPERIMENTAL, opt-in
+        # (DS_SPMM_BATCHED=1): same speed as the wave-per-node kernels (the product is bound by the CU's gather
+        # rate) and NOT yet reliable - the first nodes of a batch intermittently come out zero
+        # (tools/dbg_small.py); kept as the base of the neighbour-union kernel that would cut the gathered bytes.
+        self.batches = None
+        if os.environ.get("DS_SPMM_BATCHED", "0") == "1":
+            bt = _hip.build_batches(pat.rowptr)
+            self.batches = None if bt is None else bt.to(dev)
         self._coarse = None
         self.assemble()
 
@@ -251,8 +259,33 @@ class _HipBlockOps:
                 e1.record()
                 self.spmm_events.append((e0, e1))
 
+    batches = None  # (nbatch, 4) int32 device table for the batched SpMM (<= 84 columns), or None
+    batch_ops = os.environ.get("DS_SPMM_BATCH_OPS", "KMCR")  # which products use it: K X, M X, Chebyshev term, residual
+
+    def _batched_ok(self, X, op="K"):
+        return (self.batches is not None and op in self.batch_ops and X.shape[1] <= 84 and X.shape[1] % 4 == 0
+                and 12 * self.nv * _ld(X) < 0x7F000000 and X.data_ptr() % 16 == 0 and (_ld(X) * 4) % 16 == 0)
+
+    def _batched(self, kind, epilogue, vals, X, Y, R0=None, c1=0.0, c2=0.0, first=False):
+        pp = _hip.ptr
+        bt = self.batches
+        _hip.check(self._L.ds_spmm_batched(kind, epilogue, pp(bt), bt.shape[0], pp(self.rowptr), pp(self.colidx),
+                                           pp(vals), vals.shape[0], self.nv, pp(X), _ld(X), pp(Y), _ld(Y), pp(R0),
+                                           0 if R0 is None else _ld(R0), pp(self.dinv) if epilogue == 1 else None,
+                                           X.shape[1], float(c1), float(c2), int(bool(first)), _hip.stream_ptr()),
+                   "ds_spmm_batched")
+
     def apply_K(self, X, out):
-        if self._has_tiles(X.shape[1]) and X.shape[1] % 4 == 0 and X.shape[1] >= 16:
+        if self._batched_ok(X) and not self._has_tiles(X.shape[1]) and not self._has_groups(X.shape[1]):
+            timed = self.spmm_events is not None and X.shape[1] == self.spmm_event_cols
+            if timed:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            self._batched(0, 0, self.k32t, X, out)
+            if timed:
+                e1.record()
+                self.spmm_events.append((e0, e1))
+        elif self._has_tiles(X.shape[1]) and X.shape[1] % 4 == 0 and X.shape[1] >= 16:
             self._tiled(0, X, out, None, 0.0, 0.0, False)
         elif self._has_groups(X.shape[1]) and X.shape[1] >= 16:
             self._grouped(0, X, out, None, 0.0, 0.0, False)
@@ -261,7 +294,10 @@ class _HipBlockOps:
         self.counts["apply_K_cols"] += X.shape[1]
 
     def apply_M(self, X, out):
-        self._spmm(self.m_kind, self.ms32, X, out)
+        if self.m_kind == 1 and self._batched_ok(X, "M"):
+            self._batched(1, 0, self.ms32, X, out)
+        else:
+            self._spmm(self.m_kind, self.ms32, X, out)
         self.counts["apply_M_cols"] += X.shape[1]
 
     # ------------------------------------------------------------------ tall-skinny dense
@@ -337,6 +373,10 @@ class _HipBlockOps:
     def spmm_residual(self, X, R0, Y):
         """Y <- R0 - K X (<= 84 columns, one fused launch)."""
         pp = _hip.ptr
+        if self._batched_ok(X, "R"):
+            self._batched(0, 2, self.k32t, X, Y, R0)
+            self.counts["apply_K_cols"] += X.shape[1]
+            return
         _hip.check(self._L.ds_spmm_residual(pp(self.rowptr), pp(self.colidx), pp(self.k32), self.nv, pp(X), _ld(X),
                                             pp(R0), _ld(R0), pp(Y), _ld(Y), X.shape[1], _hip.stream_ptr()),
                    "ds_spmm_residual")
@@ -391,6 +431,10 @@ class _HipBlockOps:
             self.counts["apply_K_cols"] += Wk.shape[1]
             return
         pp = _hip.ptr
+        if self._batched_ok(Wk, "C"):
+            self._batched(0, 1, self.k32t, Wk, Wprev, R0, c1, c2, first)
+            self.counts["apply_K_cols"] += Wk.shape[1]
+            return
         _hip.check(self._L.ds_cheb_spmm(pp(self.rowptr), pp(self.colidx), pp(self.k32), self.nv, pp(Wk), _ld(Wk),
                                         pp(Wprev), _ld(Wprev), pp(R0), _ld(R0), pp(self.dinv), Wk.shape[1],
                                         float(c1), float(c2), int(bool(first)), _hip.stream_ptr()), "ds_cheb_spmm")
@@ -419,6 +463,7 @@ class HipModalOps(_HipBlockOps):
         ``DS_TWOLEVEL=0`` turns it off)."""
         self.sys = system
         self._init_common(system.rowptr, system.colidx, system.nv, system.device)
+        self.batches = system.batches
         dev = self.device
         self.k32 = torch.empty((system.nnzb, 9), dtype=torch.float32, device=dev)
         self.k32t = torch.empty((system.nnzb, 9), dtype=torch.float32, device=dev)  # blocks transposed
@@ -517,6 +562,9 @@ class HipSparseOps(_HipBlockOps):
         rowptr = torch.zeros(nv + 1, dtype=torch.int64, device=dev)
         rowptr[1:] = torch.cumsum(torch.bincount(rows, minlength=nv), 0)
         self._init_common(rowptr.to(torch.int32), (keys % nv).to(torch.int32), nv, dev)
+        if os.environ.get("DS_SPMM_BATCHED", "0") == "1":
+            bt = _hip.build_batches(self.rowptr.cpu())
+            self.batches = None if bt is None else bt.to(dev)
         self.k32 = self.a64.float().contiguous()
         self.k32t = self.k32.reshape(-1, 3, 3).transpose(1, 2).reshape(-1, 9).contiguous()
         self.ms32 = self.b64.float().contiguous()

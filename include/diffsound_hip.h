@@ -178,6 +178,22 @@ int ds_pack_groups(const float* vals_t, const int32_t* kperm, int64_t nnzb, floa
 int ds_spmm_grouped(int epilogue, const int32_t* gptr, const int32_t* gent, const int32_t* goff, const float* kgrp,
                     int64_t nv, const float* X, int64_t ldx, float* Y, int64_t ldy, const float* R0, int64_t ldr,
                     const float* dinv, int ncols, float c1, float c2, int first, ds_stream_t stream);
+/* Batched form of ds_spmm_bsr3 / ds_cheb_spmm / ds_spmm_residual for ncols <= 84 (the default path of the
+ * eigensolver's b-column products and of every preconditioner term): one wavefront per batch of consecutive
+ * nodes stages the ids and values of all its rows in LDS with a few coalesced loads and streams their blocks
+ * through one rolling window of neighbour-panel loads.  btab: (nbatch x 4) int32 rows (n0, n1, kb0 = rowptr[n0],
+ * ke0 = rowptr[n1]), consecutive, covering [0, nv), each with at most cap_blocks blocks and max_nodes nodes
+ * (ds_spmm_batch_limits); every row of the pattern non-empty and no longer than cap_blocks.
+ * kind 0: vals (nnzb x 9) f32 = the 3x3 blocks TRANSPOSED (the k32t output of ds_combine_material: [block][col][row]);
+ * kind 1: vals (nnzb) f32 scalars (x I3), epilogue 0 only.
+ * epilogue 0: Y <- A X ; 1: Y (= W_prev) <- X + c1 (X - Y) + c2 T (R0 - A X) (first != 0: Y not read) ;
+ * 2: Y <- R0 - A X.  X and Y distinct, 16-byte aligned rows; 3 nv ldx 4 < 0x7f000000 bytes.
+ * (reference: torch.sparse.mm in src/lobpcg/_linalg_utils.py:36-37 and the iK callable of _lobpcg.py:441) */
+void ds_spmm_batch_limits(int* cap_blocks, int* max_nodes);
+int ds_spmm_batched(int kind, int epilogue, const int32_t* btab, int64_t nbatch, const int32_t* rowptr,
+                    const int32_t* colidx, const float* vals, int64_t nnzb, int64_t nv, const float* X, int64_t ldx,
+                    float* Y, int64_t ldy, const float* R0, int64_t ldr, const float* dinv, int ncols, float c1,
+                    float c2, int first, ds_stream_t stream);
 /* Out <- alpha * A C + beta * Out,  A (n x p) f32, C (p x q) f32 row-major device, Out (n x q) f32.
  * Out must not alias A.  (reference: X <- S Z etc., _lobpcg.py:463-466) */
 int ds_mix(const float* A, int64_t lda, int p, const float* C, int q, float* Out, int64_t ldo,
