@@ -50,13 +50,17 @@ _SIGNATURES = {
     "ds_groups_free": (None, [_P]),
     "ds_pack_groups": (_I, [_P, _P, _I64, _P, _P]),
     "ds_spmm_grouped": (_I, [_I, _P, _P, _P, _P, _I64, _P, _I64, _P, _I64, _P, _I64, _P, _I, _F, _F, _I, _P]),
-    "ds_spmm_batch_limits": (None, [ctypes.POINTER(_I), ctypes.POINTER(_I)]),
-    "ds_spmm_batched": (_I, [_I, _I, _P, _I64, _P, _P, _P, _I64, _I64, _P, _I64, _P, _I64, _P, _I64, _P, _I, _F, _F,
-                            _I, _P]),
     "ds_geometry_grad": (_I, [_P, _I64, _I, _I64, _P, _P, _I64, _I, _P, _P, _D, _D, _P, _P, _I, _P, _P, _P]),
     "ds_mix": (_I, [_P, _I64, _I, _P, _I, _P, _I64, _I64, _F, _F, _P]),
     "ds_osc_bank_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _D, _P, _P]),
     "ds_osc_bank_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _D, _P, _P, _P, _P, _P]),
+}
+
+# only in a library built with `make EXPERIMENTAL=1` (declared under DS_EXPERIMENTAL in the header)
+_EXPERIMENTAL_SIGNATURES = {
+    "ds_spmm_batch_limits": (None, [ctypes.POINTER(_I), ctypes.POINTER(_I)]),
+    "ds_spmm_batched": (_I, [_I, _I, _P, _I64, _P, _P, _P, _I64, _I64, _P, _I64, _P, _I64, _P, _I64, _P, _I, _F, _F,
+                            _I, _P]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
@@ -77,6 +81,11 @@ def lib():
             fn = getattr(handle, name)
             fn.restype = res
             fn.argtypes = args
+        for name, (res, args) in _EXPERIMENTAL_SIGNATURES.items():
+            fn = getattr(handle, name, None)
+            if fn is not None:
+                fn.restype = res
+                fn.argtypes = args
         _lib = handle
     return _lib
 
@@ -175,6 +184,8 @@ def build_batches(rowptr_cpu):
     a batch) - the caller then keeps the wave-per-node kernels."""
     import numpy as np
 
+    if not hasattr(lib(), "ds_spmm_batched"):
+        raise RuntimeError("the batched SpMM is an experiment: rebuild with `make -C diffsound_amd/csrc EXPERIMENTAL=1`")
     cap, mx = _I(), _I()
     lib().ds_spmm_batch_limits(ctypes.byref(cap), ctypes.byref(mx))
     cap, mx = cap.value, mx.value

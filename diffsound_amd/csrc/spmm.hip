@@ -360,619 +360,15 @@ int launch_wn(const int32_t* rowptr, const int32_t* colidx, const void* vals, co
     return DS_OK;
 }
 
-// ------------------------------------------------------------------------------------------------
-// Software-pipelined wave-per-node kernel for <= 84 columns (the solver's b-column products and every
-// preconditioner term).  Same lane layout as RS = 3 above (lane (r, cl) owns 16 bytes of input row r of
-// each neighbour panel), but what bounded the kernel above was the NUMBER OF DEPENDENT ROUND TRIPS per
-// node, not bytes: batches of 8 panel loads drained with vmcnt(0), a one-load-at-a-time tail for the
-// rows' last cnt mod 8 blocks (3.5 more serial round trips on a 28-block row), and the epilogue's R0 /
-// W_prev loads issued only after the last block.  Here
-//   * the panel loads form a rolling window: UX loads are always in flight, the oldest is consumed and
-//     its registers immediately re-issued for block u + UX (counted vmcnt(UX-1) waits, no drain);
-//   * the row is padded to a multiple of UX without touching memory: a padded load gets a byte offset
-//     beyond the buffer descriptor's num_records, which the hardware range check answers with zeros and
-//     no memory request, and its coefficients are zero (slab filled through a per-row descriptor whose
-//     range check zero-fills the padding) - no tail loop, no branches inside the window;
-//   * the epilogue's R0 / W_prev / own-W rows and the block-Jacobi row are requested BEFORE the window,
-//     one 16-byte piece per lane in the same (r, cl) layout, so they travel with the metadata round trip;
-//   * the three row groups are merged by a reduce-scatter (lane group g ends up with output row g:
-//     8 ds_bpermute instead of 24) and every lane stores 16 bytes of its own row.
-// Needs 3 nv ldx 4 < 0x7f000000 (out-of-range marker + offset stay below 2^32); larger blocks keep the
-// kernel above.
-constexpr int PIPE_UX = 8;
-constexpr int PIPE_OOB = 0x7f000000;
-
-template <int KIND, int LPN_CT, int EPI, int DBG = 0, int UXT = PIPE_UX>
-__global__ void __launch_bounds__(256)
-    spmm_node_pipe_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx,
-                          const float* __restrict__ vals, int64_t nv, const float* __restrict__ X, int64_t ldx,
-                          float* __restrict__ Y, int64_t ldy, int lpn_rt, unsigned nblk, ChebEpilogue epi) {
-    using f4 = __attribute__((ext_vector_type(4))) float;
-    constexpr int UX = UXT;
-    __shared__ float s_vals[4][KIND == 0 ? WN_CHUNK * 9 : 1];
-    const int lpn = LPN_CT ? LPN_CT : lpn_rt;
-    const unsigned bid = ds::xcd_remap(blockIdx.x, nblk);
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int64_t node = (int64_t)bid * 4 + wave;
-    if (node >= nv) return;  // wave-uniform
-    const int g = lane / lpn;  // row group: input row of the panels, output row after the merge
-    const int cl = lane - g * lpn;
-    const bool active = g < 3;
-    const int c0 = cl * 4;
-    const __amdgpu_buffer_rsrc_t xrsrc =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(X), 0, (int)(3 * nv * ldx * 4), 0x00020000);
-    // idle lanes (lane >= 3 lpn) carry the out-of-range offset for good: they never touch memory
-    const unsigned xvoff = active ? (unsigned)(((int64_t)g * ldx + c0) * 4) : (unsigned)PIPE_OOB;
-    const int panel_bytes = (int)(ldx * 12);
-    const int kb = rowptr[node], ke = rowptr[node + 1];
-
-    // epilogue operands: requested now, consumed after the window
-    const int64_t myrow = node * 3 + (active ? g : 0);
-    f4 r0v = {0.f, 0.f, 0.f, 0.f}, pv = r0v, wv = r0v;
-    float d0 = 0.f, d1 = 0.f, d2 = 0.f;
-    if (EPI != 0 && active) r0v = *reinterpret_cast<const f4*>(epi.r0 + myrow * epi.ldr + c0);
-    if (EPI == 1 && active) {
-        if (!epi.first) pv = *reinterpret_cast<const f4*>(Y + myrow * ldy + c0);
-        wv = *reinterpret_cast<const f4*>(X + myrow * ldx + c0);
-        const float* d = epi.dinv + node * 9 + g * 3;  // row g of the inverse diagonal block, rotated to start at g
-        d0 = d[g];
-        d1 = d[g == 2 ? 0 : g + 1];
-        d2 = d[g == 0 ? 2 : g - 1];
-    }
-
-    float* sv = s_vals[wave];
-    const float* svr = sv + (active ? g : 0);
-    f4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0, acc2 = acc0;
-    for (int kc = kb; kc < ke; kc += WN_CHUNK) {
-        const int cnt = min(WN_CHUNK, ke - kc);  // wave-uniform
-        const int colreg = lane < cnt ? colidx[kc + lane] : 0;
-        float mreg = 0.f;
-        auto issue = [&](int idx) -> f4 {  // idx wave-uniform; idx >= cnt -> zeros, no memory request
-            // (colreg is 0 in lanes >= cnt, and any id keeps PIPE_OOB + offset below 2^32: no select needed for j)
-            const int j = __builtin_amdgcn_readlane(colreg, idx & 63);
-            if (DBG == 1) return f4{1.f, 2.f, 3.f, (float)j};  // experiment: no panel loads
-            return buf_load4(xrsrc, (int)(xvoff + (idx < cnt ? 0u : (unsigned)PIPE_OOB)), j * panel_bytes);
-        };
-        f4 x[UX];
-        if (KIND == 1) {
-            mreg = lane < cnt ? vals[kc + lane] : 0.f;
-#pragma unroll
-            for (int q = 0; q < UX; ++q) x[q] = issue(q);
-        } else {
-            // the row's 3x3 values -> per-wave LDS slab, zero-padded to a multiple of UX blocks by the range
-            // check of a descriptor that covers exactly this row chunk
-            const __amdgpu_buffer_rsrc_t vrsrc = __builtin_amdgcn_make_buffer_rsrc(
-                const_cast<float*>(vals + (int64_t)kc * 9), 0, cnt * 36, 0x00020000);
-            const int npad = ((cnt + UX - 1) / UX) * UX * 9;  // <= WN_CHUNK * 9
-            float stage[9];
-#pragma unroll
-            for (int i = 0; i < 9; ++i)
-                stage[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(vrsrc, (lane + 64 * i) * 4, 0, 0));
-#pragma unroll
-            for (int q = 0; q < UX; ++q) x[q] = issue(q);
-#pragma unroll
-            for (int i = 0; i < 9; ++i)
-                if (64 * i < npad) sv[lane + 64 * i] = stage[i];  // wave-uniform guard
-            // same-wave LDS write -> read: the LDS queue is in order, only the compiler needs the fence
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        }
-        // coefficients of block i: column g of the 3x3 block, read two blocks ahead of their use so that the
-        // LDS latency hides behind the FMAs of the blocks in between (the slab has >= 1 spare padded block)
-        float ca[4][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};  // ring: block i in slot i % 4
-        auto coef = [&](int i, float (&c)[3]) {
-            const float* a = svr + i * 9;
-            c[0] = a[0];
-            c[1] = a[3];
-            c[2] = a[6];
-        };
-        if (KIND == 0) {
-            coef(0, ca[0]);
-            coef(1, ca[1]);
-        }
-        for (int u = 0; u < cnt; u += UX) {
-#pragma unroll
-            for (int q = 0; q < UX; ++q) {
-                const f4 xv = x[q];
-                if (KIND == 1) {
-                    const float m = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mreg), (u + q) & 63));
-                    acc0 += m * xv;
-                } else {
-                    if (DBG != 3) coef(min(u + q + 2, WN_CHUNK - 1), ca[(q + 2) % 4]);
-                    if (DBG == 2) {  // experiment: no FMAs
-                        acc0 += xv;
-                    } else {
-                        acc0 += ca[q % 4][0] * xv;
-                        acc1 += ca[q % 4][1] * xv;
-                        acc2 += ca[q % 4][2] * xv;
-                    }
-                }
-                x[q] = issue(u + UX + q);
-                // keep "consume the oldest, re-issue into its registers" in program order: left alone, the
-                // scheduler hoists the eight re-issues above the FMAs into fresh registers and drains them
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-        if (KIND == 0 && kc + WN_CHUNK < ke) {  // the slab is rewritten by the next pass
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-        }
-    }
-    f4 tot = acc0;
-    // pulls come from the lanes lpn and 2 lpn further on (cyclically over the 3 lpn active lanes)
-    int s1 = lane + lpn, s2 = lane + 2 * lpn;
-    if (s1 >= 3 * lpn) s1 -= 3 * lpn;
-    if (s2 >= 3 * lpn) s2 -= 3 * lpn;
-    if (!active) s1 = s2 = lane;
-    auto pull = [&](const f4& v, int src) -> f4 {
-        f4 o;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const float e = v[c];  // (bit_cast straight from the vector-element lvalue reads element 0 every time)
-            o[c] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src * 4, __builtin_bit_cast(int, e)));
-        }
-        return o;
-    };
-    if (KIND == 0) {
-        // reduce-scatter: group g wants sum over groups of acc_g.  A lane of group gs publishes, for the
-        // puller s groups behind it, acc_{(gs - s) mod 3}.
-        const f4 own = g == 0 ? acc0 : (g == 1 ? acc1 : acc2);
-        const f4 pub1 = g == 0 ? acc2 : (g == 1 ? acc0 : acc1);
-        const f4 pub2 = g == 0 ? acc1 : (g == 1 ? acc2 : acc0);
-        tot = own + pull(pub1, s1) + pull(pub2, s2);
-    }
-    if (!active) return;  // the pulls below only read active lanes
-    float* yp = Y + myrow * ldy + c0;
-    if (EPI == 1) {
-        const f4 q0 = r0v - tot;
-        const f4 q1 = pull(q0, s1), q2 = pull(q0, s2);  // rows g+1, g+2 (cyclic)
-        const f4 t = d0 * q0 + d1 * q1 + d2 * q2;
-        f4 o = wv + epi.c2 * t;
-        o += epi.first ? epi.c1 * wv : epi.c1 * (wv - pv);
-        *reinterpret_cast<f4*>(yp) = o;
-    } else if (EPI == 2) {
-        *reinterpret_cast<f4*>(yp) = r0v - tot;
-    } else {
-        *reinterpret_cast<f4*>(yp) = tot;
-    }
-}
-
-template <int KIND, int LPN_CT, int EPI = 0>
-int launch_pipe(const int32_t* rowptr, const int32_t* colidx, const void* vals, int64_t nv, const void* X, int64_t ldx,
-                void* Y, int64_t ldy, int lpn, hipStream_t st,
-                ChebEpilogue epi = ChebEpilogue{nullptr, 0, nullptr, 0.f, 0.f, 0}) {
-    const int64_t nblk = ds::ceil_div(nv, 4);
-    static const int dbg = getenv("DS_SPMM_DBG") ? atoi(getenv("DS_SPMM_DBG")) : 0;  // timing experiments only
-    if (dbg && KIND == 0 && EPI == 0 && LPN_CT == 20) {
-#define DS_DBG_LAUNCH(D, U)                                                                                    \
-    spmm_node_pipe_kernel<0, 20, 0, D, U><<<(unsigned)nblk, 256, 0, st>>>(                                      \
-        rowptr, colidx, static_cast<const float*>(vals), nv, static_cast<const float*>(X), ldx,                 \
-        static_cast<float*>(Y), ldy, lpn, (unsigned)nblk, epi)
-        if (dbg == 1) DS_DBG_LAUNCH(1, 8);
-        else if (dbg == 2) DS_DBG_LAUNCH(2, 8);
-        else if (dbg == 3) DS_DBG_LAUNCH(3, 8);
-        else if (dbg == 4) DS_DBG_LAUNCH(0, 4);
-        else DS_DBG_LAUNCH(0, 16);
-#undef DS_DBG_LAUNCH
-        DS_LAUNCH_CHECK("spmm_node_pipe_kernel(dbg)");
-        return DS_OK;
-    }
-    spmm_node_pipe_kernel<KIND, LPN_CT, EPI><<<(unsigned)nblk, 256, 0, st>>>(
-        rowptr, colidx, static_cast<const float*>(vals), nv, static_cast<const float*>(X), ldx,
-        static_cast<float*>(Y), ldy, lpn, (unsigned)nblk, epi);
-    DS_LAUNCH_CHECK("spmm_node_pipe_kernel");
-    return DS_OK;
-}
-
-// ------------------------------------------------------------------------------------------------
-// Batched kernel for <= 84 columns: ONE WAVE PER BATCH OF CONSECUTIVE NODES.
-// Timing experiments on the wave-per-node kernels (tools/mb_kx_time.py, DS_SPMM_DBG) showed where their
-// time goes: with the neighbour-panel loads REMOVED the 80-column product still took 168 of 301 us -
-// every node pays a chain of dependent round trips (row pointers -> ids and values from HBM -> first
-// panels) that 20-28 resident waves per CU cannot hide, and a wave cannot prefetch the next node's
-// metadata under its own panel loads because vmcnt retires in order.  Here the chain is paid once per
-// batch: consecutive nodes own one contiguous range of colidx / vals, so a wave
-//   A. stages the ids and 3x3 values of ALL its nodes in LDS with a handful of fully coalesced 16-byte
-//      loads (host table btab: n0, n1, kb0, ke0 per batch, at most BT_CAP blocks / BT_MAXNODES nodes),
-//      and touches the R0 / W_prev lines its epilogues will read (so those loads hit L2 later);
-//   B. streams every block of the batch through ONE rolling window of UX panel loads that never drains:
-//      rows are padded to a multiple of UX with out-of-range loads (zeros, no memory request), the issue
-//      cursor runs one group ahead of the consume cursor ACROSS node boundaries, ids come from LDS one
-//      group ahead, and when a node's last group retires the row groups are merged (reduce-scatter) and
-//      the epilogue runs while the next node's panels are already in flight.
-// Lane layout, merge and epilogues as in the pipelined kernel above.
-constexpr int BT_CAP = 128;      // blocks of a batch (LDS image)
-constexpr int BT_PAD = 20;       // readable blocks behind the image (>= UX + 2; never contribute)
-constexpr int BT_MAXNODES = 48;  // nodes per batch: their row pointers live in one VGPR
-
-// Phase B issues its loads through inline asm and waits with explicit counted s_waitcnt: left to the
-// compiler, the FMAs sink below the re-issued loads, the window is renamed into fresh registers and copied
-// back behind a vmcnt(0) at the loop latch (seen in the ISA of the first version of this kernel).  The loaded
-// registers are tied in/out operands ("+v"): uses of the old value cannot move past the load, the new value
-// cannot be read before the wait that carries it.  vmcnt retires in order, so "at most N younger operations
-// outstanding" proves a load complete whatever else (stores, the other waves' traffic) is in the queue -
-// PROVIDED every load of the phase is a buffer_load: global_load_* operand loads mixed into the window were
-// overtaken by younger buffer loads on gfx950 (first nodes of a batch read stale operands; found with
-// tools/dbg_cheb1.py), so the epilogue operands go through descriptors as well.
-using i4s = __attribute__((ext_vector_type(4))) int;
-using f3v = __attribute__((ext_vector_type(3))) float;
-__device__ __forceinline__ i4s make_rsrc_words(const void* p, unsigned bytes) {
-    const uint64_t a = reinterpret_cast<uint64_t>(p);
-    i4s r;
-    r.x = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
-    r.y = __builtin_amdgcn_readfirstlane((int)((unsigned)(a >> 32) & 0xffffu));  // stride 0
-    r.z = __builtin_amdgcn_readfirstlane((int)bytes);
-    r.w = 0x00020000;
-    return r;
-}
-#define DS_BUF_LOAD4(dst, voff, rsrc, soff) \
-    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "+v"(dst) : "v"(voff), "s"(rsrc), "s"(soff) : "memory")
-// the same with the accumulators as (unused) inputs: the FMAs that consumed the old value of dst produce them,
-// so they cannot sink below the load (which would keep the old value alive in a COPY made before our wait)
-#define DS_BUF_LOAD4_AFTER(dst, voff, rsrc, soff, a0, a1, a2)                    \
-    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen"                       \
-                 : "+v"(dst)                                                      \
-                 : "v"(voff), "s"(rsrc), "s"(soff), "v"(a0), "v"(a1), "v"(a2)     \
-                 : "memory")
-#define DS_WAIT_VM(n, reg) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(reg) : "n"(n) : "memory")
-
-template <int KIND, int LPN_CT, int EPI, int UX, int DBG = 0>
-__global__ void __launch_bounds__(256)
-    spmm_batch_kernel(const int4* __restrict__ btab, unsigned nbatch, const int32_t* __restrict__ rowptr,
-                      const int32_t* __restrict__ colidx, const float* __restrict__ vals, int64_t nnzb, int64_t nv,
-                      const float* __restrict__ X, int64_t ldx, float* __restrict__ Y, int64_t ldy, int lpn_rt,
-                      unsigned nwg, ChebEpilogue epi) {
-    using f4 = __attribute__((ext_vector_type(4))) float;
-    static_assert(BT_PAD >= UX + 2 && (UX & (UX - 1)) == 0 && UX % 4 == 0, "window must fit the padding");
-    constexpr int NIMG = BT_CAP + BT_PAD;
-    constexpr int NV16 = NIMG * 3;  // value image (KIND 0): one 16-byte slot (A[0][g], A[1][g], A[2][g], 0) per (block, g)
-    constexpr int NCI = (NIMG + 63) / 64;
-    constexpr int NVI = (NV16 + 63) / 64;
-    __shared__ int s_col[4][NIMG];
-    __shared__ __attribute__((aligned(16))) float s_val[4][KIND == 0 ? NV16 * 4 : NIMG];
-    const int lpn = LPN_CT ? LPN_CT : lpn_rt;
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const unsigned batch = ds::xcd_remap(blockIdx.x, nwg) * 4 + wave;
-    if (batch >= nbatch) return;  // wave-uniform
-    const int4 bt = btab[batch];
-    const int n0 = __builtin_amdgcn_readfirstlane(bt.x);
-    const int nn = __builtin_amdgcn_readfirstlane(bt.y) - n0;
-    const int kb0 = __builtin_amdgcn_readfirstlane(bt.z);
-    const int nb = __builtin_amdgcn_readfirstlane(bt.w) - kb0;
-    const int g = lane / lpn;
-    const int cl = lane - g * lpn;
-    const bool active = g < 3;
-    const int ga = active ? g : 0;
-    const int c0 = cl * 4;
-    const i4s xrsrc = make_rsrc_words(X, (unsigned)(3 * nv * ldx * 4));
-    // idle lanes (lane >= 3 lpn) carry the out-of-range offset for good: they never touch memory
-    const unsigned xvoff = active ? (unsigned)(((int64_t)g * ldx + c0) * 4) : (unsigned)PIPE_OOB;
-    const int panel_bytes = (int)(ldx * 12);
-    // epilogue operands go through descriptors too (rows of R0 / Y / dinv of node i at i * panel bytes)
-    const i4s rrsrc = make_rsrc_words(epi.r0, EPI != 0 ? (unsigned)(3 * nv * epi.ldr * 4) : 0u);
-    const i4s yrsrc = make_rsrc_words(Y, (unsigned)(3 * nv * ldy * 4));
-    const i4s drsrc = make_rsrc_words(epi.dinv, EPI == 1 ? (unsigned)(nv * 36) : 0u);
-    const unsigned rvoff = active ? (unsigned)(((int64_t)g * epi.ldr + c0) * 4) : (unsigned)PIPE_OOB;
-    const unsigned yvoff = active ? (unsigned)(((int64_t)g * ldy + c0) * 4) : (unsigned)PIPE_OOB;
-    const unsigned dvoff = active ? (unsigned)(g * 12) : (unsigned)PIPE_OOB;
-    const int rpanel_bytes = (int)(epi.ldr * 12), ypanel_bytes = (int)(ldy * 12);
-    int* sc = s_col[wave];
-    float* svl = s_val[wave];
-
-    // ---------------- phase A: metadata of the whole batch -> LDS
-    // row starts relative to kb0: lane l <-> node n0 + l (l <= nn)
-    const int rpreg = (lane <= nn ? rowptr[n0 + lane] : kb0 + nb) - kb0;
-    auto rp = [&](int i) { return __builtin_amdgcn_readlane(rpreg, i); };
-    int cs[NCI];
-#pragma unroll
-    for (int i = 0; i < NCI; ++i) {
-        const int t = lane + 64 * i;
-        cs[i] = t < nb ? colidx[kb0 + t] : 0;
-    }
-    if (KIND == 0) {
-        // vals holds the TRANSPOSED blocks ([block][g][i] = A[i][g]): item t = (block, g) is 12 contiguous bytes,
-        // consecutive items are consecutive in memory (coalesced 12-byte loads); each lands in its own 16-byte
-        // LDS slot so that a lane later fetches its three coefficients of a block with ONE ds_read_b128.
-        // The descriptor ends with the batch (+ padding) or the array: everything beyond reads as zeros.
-        const int64_t vb = (int64_t)kb0 * 36;
-        const int64_t avail = nnzb * 36 - vb;
-        const int want = (nb + BT_PAD) * 36;
-        const i4s vw = make_rsrc_words(reinterpret_cast<const char*>(vals) + vb, (unsigned)(avail < want ? avail : want));
-        f3v st[NVI];
-#pragma unroll
-        for (int i = 0; i < NVI; ++i) {
-            const int vo = (lane + 64 * i) * 12;
-            asm volatile("buffer_load_dwordx3 %0, %1, %2, 0 offen" : "=v"(st[i]) : "v"(vo), "s"(vw) : "memory");
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-        for (int i = 0; i < NVI; ++i) asm volatile("" : "+v"(st[i]));  // uses stay behind the wait
-#pragma unroll
-        for (int i = 0; i < NVI; ++i)
-            if (lane + 64 * i < NV16) reinterpret_cast<f4*>(svl)[lane + 64 * i] = f4{st[i][0], st[i][1], st[i][2], 0.f};
-    } else {
-#pragma unroll
-        for (int i = 0; i < NCI; ++i) {
-            const int t = lane + 64 * i;
-            const float m = t < nb ? vals[kb0 + t] : 0.f;
-            if (t < NIMG) svl[t] = m;
-        }
-    }
-    if (EPI != 0) {
-        // touch the epilogue operands of every node of the batch (one lane per 64-byte line): the per-node
-        // 16-byte loads below then come from L2 instead of paying an HBM round trip in the in-order queue
-        const int lpr = (lpn * 16 + 63) / 64 + 1;  // lines a row segment can straddle
-        const int total = 3 * nn * lpr;
-        for (int t0 = 0; t0 < total; t0 += 64) {
-            const int t = t0 + lane;
-            if (t < total) {
-                const int row = t / lpr, ln = t - row * lpr;
-                const int64_t r = (int64_t)n0 * 3 + row;
-                const int off = min(ln * 16, lpn * 4 - 1);  // floats
-                float a = epi.r0[r * epi.ldr + off];
-                if (EPI == 1 && !epi.first) a += Y[r * ldy + off];
-                asm volatile("" ::"v"(a));
-            }
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < NCI; ++i)
-        if (lane + 64 * i < NIMG) sc[lane + 64 * i] = cs[i];
-    // every phase-A load has landed (the compiler waited for the LDS stores' data; make it explicit for the
-    // touches) and the LDS image is visible to this wave: the LDS queue is in order
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-
-    unsigned long long dbg_t0 = 0, dbg_r0 = 0;
-    if (DBG == 7) {  // diagnostic build only: in-kernel clock = d(s_memtime) / d(s_memrealtime) x 100 MHz
-        dbg_t0 = __builtin_amdgcn_s_memtime();
-        dbg_r0 = __builtin_amdgcn_s_memrealtime();
-    }
-    // ---------------- phase B: one rolling window over all blocks of the batch
-    // ids cursor: enumerates the groups (node, UX blocks) in consume order, two groups ahead of the consumer
-    int ii = 0, irs = rp(0), icnt = rp(1) - irs, iu = 0;
-    auto load_ids = [&]() { return sc[irs + iu + (lane & (UX - 1))]; };
-    auto advance = [&]() {
-        iu += UX;
-        if (iu >= icnt) {
-            ++ii;
-            iu = 0;
-            irs = rp(min(ii, nn));
-            icnt = ii < nn ? rp(ii + 1) - irs : 0;
-        }
-    };
-    int idA = load_ids(), limA = icnt - iu;
-    advance();
-    int idB = load_ids(), limB = icnt - iu;
-    advance();
-    f4 x[UX];
-#pragma unroll
-    for (int q = 0; q < UX; ++q) x[q] = f4{0.f, 0.f, 0.f, 0.f};
-    // q >= lim: padding.  A load whose lanes are ALL out of range retires at once, out of order (the counted
-    // waits then pass while older real loads are still in flight: stale panels on the first nodes of a batch,
-    // tools/dbg_applyk.py), so a padding load keeps ONE lane in range (16 bytes of panel 0) and stays in the
-    // in-order stream; its value is never used (the FMAs of padding blocks are skipped).
-    const unsigned padvoff = lane == 0 ? 0u : (unsigned)PIPE_OOB;
-#define DS_ISSUE(q)                                                                        \
-    do {                                                                                   \
-        const bool real_ = (q) < limA;                                                     \
-        const int j_ = (DBG == 3 || !real_) ? 0 : __builtin_amdgcn_readlane(idA, q) * panel_bytes; \
-        const unsigned vo_ = real_ ? xvoff : padvoff;                                      \
-        DS_BUF_LOAD4_AFTER(x[q], vo_, xrsrc, j_, acc0, acc1, acc2);                        \
-    } while (0)
-    f4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0, acc2 = acc0;
-#pragma unroll
-    for (int q = 0; q < UX; ++q)
-        if (DBG == 0 || DBG == 3 || DBG >= 7 || (DBG == 2 && q % 2 == 0)) DS_ISSUE(q);
-    idA = idB;
-    limA = limB;
-    idB = load_ids();
-    limB = icnt - iu;
-    advance();
-
-    int s1 = lane + lpn, s2 = lane + 2 * lpn;
-    if (s1 >= 3 * lpn) s1 -= 3 * lpn;
-    if (s2 >= 3 * lpn) s2 -= 3 * lpn;
-    if (!active) s1 = s2 = lane;
-    auto pull = [&](const f4& v, int src) -> f4 {
-        f4 o;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const float e = v[c];
-            o[c] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src * 4, __builtin_bit_cast(int, e)));
-        }
-        return o;
-    };
-    const f4* svr = reinterpret_cast<const f4*>(svl) + ga;
-
-    for (int ci = 0; ci < nn; ++ci) {
-        const int crs = rp(ci), ccnt = rp(ci + 1) - crs;
-        const int64_t node = (int64_t)n0 + ci;
-        const int64_t myrow = node * 3 + ga;
-        // epilogue operands of this node: requested now (L2 hits after the touches), used when the node retires
-        f4 r0v = {0.f, 0.f, 0.f, 0.f}, pv = r0v, wv = r0v;
-        f3v drow = {0.f, 0.f, 0.f};
-        // (all of them buffer loads, like the panels: one in-order stream for the counted waits below)
-        if (EPI != 0) {
-            const int so = (int)node * rpanel_bytes;
-            DS_BUF_LOAD4(r0v, rvoff, rrsrc, so);
-        }
-        if (EPI == 1) {
-            if (!epi.first) {
-                const int so = (int)node * ypanel_bytes;
-                DS_BUF_LOAD4(pv, yvoff, yrsrc, so);
-            }
-            const int so = (int)node * panel_bytes;
-            DS_BUF_LOAD4(wv, xvoff, xrsrc, so);
-            const int sd = (int)node * 36;  // row g of the inverse diagonal block
-            asm volatile("buffer_load_dwordx3 %0, %1, %2, %3 offen" : "+v"(drow) : "v"(dvoff), "s"(drsrc), "s"(sd) : "memory");
-        }
-        acc0 = acc1 = acc2 = f4{0.f, 0.f, 0.f, 0.f};
-        float ca[4][3] = {{1.f, 2.f, 3.f}, {1.f, 2.f, 3.f}, {1.f, 2.f, 3.f}, {1.f, 2.f, 3.f}};  // coefficient ring (KIND 0): block i of the node in slot i % 4, read two blocks ahead
-        auto coef = [&](int i, float (&c)[3]) {
-            const f4 a = svr[(crs + i) * 3];
-            c[0] = a[0];
-            c[1] = a[1];
-            c[2] = a[2];
-        };
-        float mcur = 0.f;
-        if (KIND == 0) {
-            coef(0, ca[0]);
-            coef(1, ca[1]);
-        }
-        for (int cu = 0; cu < ccnt; cu += UX) {
-            if (KIND == 1) mcur = svl[crs + cu + (lane & (UX - 1))];
-#pragma unroll
-            for (int q = 0; q < UX; ++q) {
-                if (KIND == 0 && DBG != 6) coef(cu + q + 2, ca[(q + 2) % 4]);  // (reads at most UX + 1 blocks into the padding)
-                // the oldest load of the window: UX - 1 younger panel loads (the node's epilogue operands, if
-                // still in flight, only make the wait stricter)
-                if (DBG == 0 || DBG == 3 || DBG == 7) DS_WAIT_VM(UX - 1, x[q]);
-                if (DBG == 8) DS_WAIT_VM(0, x[q]);
-                if (DBG == 2 && q % 2 == 0) DS_WAIT_VM(UX / 2 - 1, x[q]);
-                const f4 xv = (DBG == 2 && q % 2 == 1) ? x[q - 1] + x[q] : x[q];
-                if (cu + q < ccnt) {  // wave-uniform: padding blocks contribute nothing
-                    if (KIND == 1) {
-                        const float m = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mcur), q));
-                        acc0 += m * xv;
-                    } else if (DBG == 5) {
-                        acc0 += xv;
-                    } else {
-                        acc0 += ca[q % 4][0] * xv;
-                        acc1 += ca[q % 4][1] * xv;
-                        acc2 += ca[q % 4][2] * xv;
-                    }
-                }
-                if (DBG == 0 || DBG == 3 || DBG >= 7 || (DBG == 2 && q % 2 == 1)) {
-                    if (DBG == 2) {
-                        DS_ISSUE(q - 1);
-                    } else {
-                        DS_ISSUE(q);
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            idA = idB;
-            limA = limB;
-            idB = load_ids();
-            limB = icnt - iu;
-            advance();
-        }
-        // ---- node finished: merge the row groups, epilogue, store (the next node's panels are in flight)
-        f4 tot = acc0;
-        if (KIND == 0) {
-            const f4 own = g == 0 ? acc0 : (g == 1 ? acc1 : acc2);
-            const f4 pub1 = g == 0 ? acc2 : (g == 1 ? acc0 : acc1);
-            const f4 pub2 = g == 0 ? acc1 : (g == 1 ? acc2 : acc0);
-            tot = own + pull(pub1, s1) + pull(pub2, s2);
-        }
-        float* yp = Y + myrow * ldy + c0;
-        if (EPI != 0) {
-            // the operand loads are older than the >= UX panel loads issued since
-            DS_WAIT_VM(UX, r0v);
-            if (EPI == 1) {
-                asm volatile("" : "+v"(pv), "+v"(wv), "+v"(drow));  // ordered behind the wait above
-            }
-        }
-        if (EPI == 1) {
-            const float d0 = g == 0 ? drow[0] : (g == 1 ? drow[1] : drow[2]);  // D[g][g], D[g][g+1], D[g][g+2] (cyclic)
-            const float d1 = g == 0 ? drow[1] : (g == 1 ? drow[2] : drow[0]);
-            const float d2 = g == 0 ? drow[2] : (g == 1 ? drow[0] : drow[1]);
-            const f4 q0 = r0v - tot;
-            const f4 q1 = pull(q0, s1), q2 = pull(q0, s2);  // rows g+1, g+2 (cyclic)
-            const f4 t = d0 * q0 + d1 * q1 + d2 * q2;
-            f4 o = wv + epi.c2 * t;
-            o += epi.first ? epi.c1 * wv : epi.c1 * (wv - pv);
-            if (active) *reinterpret_cast<f4*>(yp) = o;
-        } else if (EPI == 2) {
-            if (active) *reinterpret_cast<f4*>(yp) = r0v - tot;
-        } else {
-            if (active) *reinterpret_cast<f4*>(yp) = tot;
-        }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the window's trailing (padding) loads
-    if (DBG == 7 && lane == 0) {
-        unsigned long long* dbgbuf = reinterpret_cast<unsigned long long*>(const_cast<float*>(epi.dinv));
-        dbgbuf[2 * (size_t)batch] = __builtin_amdgcn_s_memtime() - dbg_t0;
-        dbgbuf[2 * (size_t)batch + 1] = __builtin_amdgcn_s_memrealtime() - dbg_r0;
-    }
-#undef DS_ISSUE
-}
-
-template <int KIND, int LPN_CT, int EPI>
-int launch_batch(const int32_t* btab, int64_t nbatch, const int32_t* rowptr, const int32_t* colidx, const float* vals,
-                 int64_t nnzb, int64_t nv, const float* X, int64_t ldx, float* Y, int64_t ldy, int lpn, hipStream_t st,
-                 ChebEpilogue epi) {
-    const int64_t nwg = ds::ceil_div(nbatch, 4);
-    static const int ux = getenv("DS_SPMM_UX") ? atoi(getenv("DS_SPMM_UX")) : 8;  // window depth (tuning)
-    static const int dbg = getenv("DS_SPMM_DBG") ? atoi(getenv("DS_SPMM_DBG")) : 0;  // timing experiments only
-    if (dbg == 1 && KIND == 0 && EPI == 0)
-        spmm_batch_kernel<KIND, LPN_CT, EPI, 8, 1><<<(unsigned)nwg, 256, 0, st>>>(
-            reinterpret_cast<const int4*>(btab), (unsigned)nbatch, rowptr, colidx, vals, nnzb, nv, X, ldx, Y, ldy, lpn,
-            (unsigned)nwg, epi);
-    else if (dbg == 2 && KIND == 0 && EPI == 0)
-        spmm_batch_kernel<KIND, LPN_CT, EPI, 8, 2><<<(unsigned)nwg, 256, 0, st>>>(
-            reinterpret_cast<const int4*>(btab), (unsigned)nbatch, rowptr, colidx, vals, nnzb, nv, X, ldx, Y, ldy, lpn,
-            (unsigned)nwg, epi);
-    else if (dbg == 3 && KIND == 0 && EPI == 0)
-        spmm_batch_kernel<KIND, LPN_CT, EPI, 8, 3><<<(unsigned)nwg, 256, 0, st>>>(
-            reinterpret_cast<const int4*>(btab), (unsigned)nbatch, rowptr, colidx, vals, nnzb, nv, X, ldx, Y, ldy, lpn,
-            (unsigned)nwg, epi);
-    else if (dbg == 7 && KIND == 0 && EPI == 0 && epi.dinv)
-        spmm_batch_kernel<KIND, LPN_CT, EPI, 8, 7><<<(unsigned)nwg, 256, 0, st>>>(
-            reinterpret_cast<const int4*>(btab), (unsigned)nbatch, rowptr, colidx, vals, nnzb, nv, X, ldx, Y, ldy, lpn,
-            (unsigned)nwg, epi);
-    else if (dbg == 8 && KIND == 0 && EPI == 0)
-        spmm_batch_kernel<KIND, LPN_CT, EPI, 8, 8><<<(unsigned)nwg, 256, 0, st>>>(
-            reinterpret_cast<const int4*>(btab), (unsigned)nbatch, rowptr, colidx, vals, nnzb, nv, X, ldx, Y, ldy, lpn,
-            (unsigned)nwg, epi);
-    else if (dbg == 5 && KIND == 0 && EPI == 0)
-        spmm_batch_kernel<KIND, LPN_CT, EPI, 8, 5><<<(unsigned)nwg, 256, 0, st>>>(
-            reinterpret_cast<const int4*>(btab), (unsigned)nbatch, rowptr, colidx, vals, nnzb, nv, X, ldx, Y, ldy, lpn,
-            (unsigned)nwg, epi);
-    else if (dbg == 6 && KIND == 0 && EPI == 0)
-        spmm_batch_kernel<KIND, LPN_CT, EPI, 8, 6><<<(unsigned)nwg, 256, 0, st>>>(
-            reinterpret_cast<const int4*>(btab), (unsigned)nbatch, rowptr, colidx, vals, nnzb, nv, X, ldx, Y, ldy, lpn,
-            (unsigned)nwg, epi);
-    else if (ux == 16)
-        spmm_batch_kernel<KIND, LPN_CT, EPI, 16><<<(unsigned)nwg, 256, 0, st>>>(
-            reinterpret_cast<const int4*>(btab), (unsigned)nbatch, rowptr, colidx, vals, nnzb, nv, X, ldx, Y, ldy, lpn,
-            (unsigned)nwg, epi);
-    else
-        spmm_batch_kernel<KIND, LPN_CT, EPI, 8><<<(unsigned)nwg, 256, 0, st>>>(
-            reinterpret_cast<const int4*>(btab), (unsigned)nbatch, rowptr, colidx, vals, nnzb, nv, X, ldx, Y, ldy, lpn,
-            (unsigned)nwg, epi);
-    DS_LAUNCH_CHECK("spmm_batch_kernel");
-    return DS_OK;
-}
-
-template <int KIND, int EPI>
-int launch_batch_lpn(const int32_t* btab, int64_t nbatch, const int32_t* rowptr, const int32_t* colidx,
-                     const float* vals, int64_t nnzb, int64_t nv, const float* X, int64_t ldx, float* Y, int64_t ldy,
-                     int lpn, hipStream_t st, ChebEpilogue epi) {
-    if (lpn == 20)
-        return launch_batch<KIND, 20, EPI>(btab, nbatch, rowptr, colidx, vals, nnzb, nv, X, ldx, Y, ldy, lpn, st, epi);
-    return launch_batch<KIND, 0, EPI>(btab, nbatch, rowptr, colidx, vals, nnzb, nv, X, ldx, Y, ldy, lpn, st, epi);
-}
-
-// the pipelined kernel addresses the block through one descriptor and marks padding with PIPE_OOB
-inline bool pipe_ok(int64_t nv, int64_t ldx) {
-    // EXPERIMENTAL, opt-in (DS_SPMM_PIPE=1): no faster than the kernel above - the product is bound by the rate at
-    // which a CU's texture path gathers panels, not by per-wave latency - and its padding loads
-    // (all lanes out of range) are suspected of retiring out of order.
-    static const bool on = getenv("DS_SPMM_PIPE") != nullptr;
-    return on && 3 * nv * ldx * 4 < (int64_t)PIPE_OOB;
-}
+#ifdef DS_EXPERIMENTAL
+#include "spmm_experimental.inc"
+#endif
 
 template <int KIND>
 int launch_fast(const int32_t* rowptr, const int32_t* colidx, const void* vals, const void* vals_t, int64_t nv,
                 const void* X, int64_t ldx, void* Y, int64_t ldy, int ncols, hipStream_t st) {
     const int lpn = ncols / 4;
+#ifdef DS_EXPERIMENTAL
     if (lpn <= 21 && pipe_ok(nv, ldx)) {
         switch (lpn) {
             case 18: return launch_pipe<KIND, 18>(rowptr, colidx, vals, nv, X, ldx, Y, ldy, lpn, st);
@@ -980,6 +376,7 @@ int launch_fast(const int32_t* rowptr, const int32_t* colidx, const void* vals, 
             default: return launch_pipe<KIND, 0>(rowptr, colidx, vals, nv, X, ldx, Y, ldy, lpn, st);
         }
     }
+#endif
     if (lpn <= 21) {
         switch (lpn) {  // the solver's block widths get compile-time lane splits and their own kernel names
             case 18: return launch_wn<KIND, 3, 18>(rowptr, colidx, vals, vals_t, nv, X, ldx, Y, ldy, lpn, st);
@@ -1455,6 +852,7 @@ extern "C" int ds_cheb_spmm(const int32_t* rowptr, const int32_t* colidx, const 
     hipStream_t st = ds::as_stream(stream);
     const ChebEpilogue epi{R0, ldr, dinv, c1, c2, first};
     const int lpn = ncols / 4;
+#ifdef DS_EXPERIMENTAL
     if (pipe_ok(nv, ldw)) {
         switch (lpn) {
             case 18: return launch_pipe<0, 18, 1>(rowptr, colidx, vals, nv, W, ldw, Wprev, ldp, lpn, st, epi);
@@ -1462,6 +860,7 @@ extern "C" int ds_cheb_spmm(const int32_t* rowptr, const int32_t* colidx, const 
             default: return launch_pipe<0, 0, 1>(rowptr, colidx, vals, nv, W, ldw, Wprev, ldp, lpn, st, epi);
         }
     }
+#endif
     switch (lpn) {
         case 18: return launch_wn<0, 3, 18, 1>(rowptr, colidx, vals, nullptr, nv, W, ldw, Wprev, ldp, lpn, st, epi);
         case 20: return launch_wn<0, 3, 20, 1>(rowptr, colidx, vals, nullptr, nv, W, ldw, Wprev, ldp, lpn, st, epi);
@@ -1485,18 +884,21 @@ extern "C" int ds_spmm_residual(const int32_t* rowptr, const int32_t* colidx, co
     hipStream_t st = ds::as_stream(stream);
     const ChebEpilogue epi{R0, ldr, nullptr, 0.f, 0.f, 0};
     const int lpn = ncols / 4;
+#ifdef DS_EXPERIMENTAL
     if (pipe_ok(nv, ldx)) {
         switch (lpn) {
             case 20: return launch_pipe<0, 20, 2>(rowptr, colidx, vals, nv, X, ldx, Y, ldy, lpn, st, epi);
             default: return launch_pipe<0, 0, 2>(rowptr, colidx, vals, nv, X, ldx, Y, ldy, lpn, st, epi);
         }
     }
+#endif
     switch (lpn) {
         case 20: return launch_wn<0, 3, 20, 2>(rowptr, colidx, vals, nullptr, nv, X, ldx, Y, ldy, lpn, st, epi);
         default: return launch_wn<0, 3, 0, 2>(rowptr, colidx, vals, nullptr, nv, X, ldx, Y, ldy, lpn, st, epi);
     }
 }
 
+#ifdef DS_EXPERIMENTAL
 extern "C" void ds_spmm_batch_limits(int* cap_blocks, int* max_nodes) {
     if (cap_blocks) *cap_blocks = BT_CAP;
     if (max_nodes) *max_nodes = BT_MAXNODES;
@@ -1532,3 +934,4 @@ extern "C" int ds_spmm_batched(int kind, int epilogue, const int32_t* btab, int6
     if (epilogue == 2) return launch_batch_lpn<0, 2>(btab, nbatch, rowptr, colidx, vals, nnzb, nv, X, ldx, Y, ldy, lpn, st, epi);
     return launch_batch_lpn<0, 0>(btab, nbatch, rowptr, colidx, vals, nnzb, nv, X, ldx, Y, ldy, lpn, st, epi);
 }
+#endif  // DS_EXPERIMENTAL

@@ -358,24 +358,44 @@ class ModalSolver:
             self.precond_apply = self.precond.apply
 
     # ------------------------------------------------------------------ helpers
-    def _orthonormalize(self, W, V, MW):
+    def _orthonormalize(self, W, V, MW, VW=None):
         """Make W M-orthogonal to the block V (may be None) and M-orthonormal (reference _get_ortho,
-        _lobpcg.py:587-679, with a fixed number of passes instead of host-synchronising norms)."""
+        _lobpcg.py:587-679, with a fixed number of passes instead of host-synchronising norms).
+
+        VW: the contiguous block [V | W] when W directly follows V in memory (it does in the solver's basis
+        buffer).  V is M-orthonormal, so ONE product M W and ONE Gram launch [V W]^T (M W) give both the
+        projection coefficients C = V^T M W and, as G0 - C^T C, the Gram matrix of the projected block; the
+        projection and the Cholesky-QR transform are then one update W <- [V W] [-C T; T]."""
         ops, cfg = self.ops, self.cfg
         eps = 6e-8 if ops.dtype == torch.float32 else 1.1e-16
+        nv_ = 0 if V is None else V.shape[1]
         for ip in range(cfg.ortho_passes):
-            G = None
-            if V is not None and V.shape[1] > 0:
-                ops.apply_M(W, MW)
-                C = ops.gram(V, MW)
-                ops.mix(V, C, W, alpha=-1.0, beta=1.0)
-                rem = (C * C).sum(0)  # ||V C_j||_M^2 (V is M-orthonormal): what the projection removed
             ops.apply_M(W, MW)
-            G = ops.gram(W, MW, symmetric=True)
-            if V is not None and V.shape[1] > 0:
-                G = torch.cat([G, rem[None, :].to(G.dtype)], 0)
-            T, amp = _small(_orthonormalizer_q, ops.device, G)
-            ops.mix_inplace(W, T)
+            if nv_ > 0 and VW is not None:
+                G = ops.gram(VW, MW)  # rows :nv_ = V^T M W, rows nv_: = W^T M W
+
+                def transform(G_, nv=nv_):
+                    C = G_[:nv]
+                    CtC = C.transpose(0, 1) @ C
+                    Gp = torch.cat([_sym(G_[nv:]) - CtC, CtC.diagonal()[None, :]], 0)
+                    T, amp = _orthonormalizer_q(Gp)
+                    return torch.cat([-(C @ T), T], 0).contiguous(), amp
+
+                coef, amp = _small(transform, ops.device, G)
+                tmp = ops._scratch("ortho", W.shape, W.dtype) if hasattr(ops, "_scratch") else torch.empty_like(W)
+                ops.mix(VW, coef, tmp)
+                W.copy_(tmp)
+            else:
+                if nv_ > 0:
+                    C = ops.gram(V, MW)
+                    ops.mix(V, C, W, alpha=-1.0, beta=1.0)
+                    rem = (C * C).sum(0)  # ||V C_j||_M^2 (V is M-orthonormal): what the projection removed
+                    ops.apply_M(W, MW)
+                G = ops.gram(W, MW, symmetric=True)
+                if nv_ > 0:
+                    G = torch.cat([G, rem[None, :].to(G.dtype)], 0)
+                T, amp = _small(_orthonormalizer_q, ops.device, G)
+                ops.mix_inplace(W, T)
             self.ortho_log.append(amp)
             # a further pass only repairs what this one lost to rounding: eps * amp in the orthogonality of W
             if cfg.ortho_tol > 0.0 and eps * amp < cfg.ortho_tol:
@@ -427,7 +447,7 @@ class ModalSolver:
         B_norm = torch.linalg.vector_norm(G1.double()) / gn
         state.fvars.update(A_norm=float(A_norm), B_norm=float(B_norm))
         tol = cfg.tol or (2e-6 if dt == torch.float32 else 1e-10)
-        self._orthonormalize(X, S[:, :ny], MW)
+        self._orthonormalize(X, S[:, :ny], MW, VW=S[:, :ny + b] if ny else None)
         KS2 = torch.empty((n, 3 * b), dtype=dt, device=dev)
         ops.apply_K(X, KS[:, :b])
         lam, Z = _small(lambda G: torch.linalg.eigh(_sym(G)), dev, ops.gram(X, KS[:, :b], symmetric=True))
@@ -479,7 +499,7 @@ class ModalSolver:
             w0 = ny + b + npc
             W = S[:, w0:w0 + na]
             self.precond_apply(R[:, :na], W)
-            self._orthonormalize(W, S[:, :w0], MW[:, :na])
+            self._orthonormalize(W, S[:, :w0], MW[:, :na], VW=S[:, :w0 + na])
             sz = na + npc + na
             Sa = S[:, ny + ncl:ny + ncl + sz]
             KSa = KS[:, k0:k0 + sz]
@@ -504,23 +524,22 @@ class ModalSolver:
                     G[nxp:, :nxp] = GA_[:nxp].transpose(0, 1)
                     G = _sym(G)
                 E_, Z1_, Zp_ = _rr_step(G, na_)
-                ZZ = torch.cat([Z1_, Zp_], 1)
-                return E_, Z1_, Zp_, _sym(ZZ.transpose(0, 1) @ G @ ZZ)  # [X' P']^T K [X' P'] of the new basis
+                ZZ = torch.cat([Z1_, Zp_], 1).contiguous()
+                return E_, ZZ, _sym(ZZ.transpose(0, 1) @ G @ ZZ)  # [X' P']^T K [X' P'] of the new basis
 
             if dev.type == "cuda":
                 host = GA.cpu()
                 with _one_thread():
-                    Ea, Z1, Zp, Gxp = ritz(host)
-                Ea, Z1, Zp = (t_.to(dev, non_blocking=True) for t_ in (Ea, Z1, Zp))
+                    Ea, ZZ, Gxp = ritz(host)
+                Ea, ZZ = Ea.to(dev, non_blocking=True), ZZ.to(dev, non_blocking=True)
             else:
-                Ea, Z1, Zp, Gxp = ritz(GA)
+                Ea, ZZ, Gxp = ritz(GA)
             lam[ncl:] = Ea
             if ncl:
                 S2[:, ny:ny + ncl].copy_(S[:, ny:ny + ncl])
-            ops.mix(Sa, Z1, S2[:, ny + ncl:ny + b])
-            ops.mix(Sa, Zp, S2[:, ny + b:ny + b + na])
-            ops.mix(KSa, Z1, KS2[:, :na])  # K X_new
-            ops.mix(KSa, Zp, KS2[:, na:2 * na])  # K P_new
+            # X_new | P_new are adjacent in S (and K X_new | K P_new in KS): one launch each, reading the basis once
+            ops.mix(Sa, ZZ, S2[:, ny + ncl:ny + b + na])
+            ops.mix(KSa, ZZ, KS2[:, :2 * na])
             S, S2 = S2, S
             KS, KS2 = KS2, KS
             k0 = 0

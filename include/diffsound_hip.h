@@ -178,6 +178,7 @@ int ds_pack_groups(const float* vals_t, const int32_t* kperm, int64_t nnzb, floa
 int ds_spmm_grouped(int epilogue, const int32_t* gptr, const int32_t* gent, const int32_t* goff, const float* kgrp,
                     int64_t nv, const float* X, int64_t ldx, float* Y, int64_t ldy, const float* R0, int64_t ldr,
                     const float* dinv, int ncols, float c1, float c2, int first, ds_stream_t stream);
+#ifdef DS_EXPERIMENTAL /* not in the default library: make -C diffsound_amd/csrc EXPERIMENTAL=1 */
 /* Batched form of ds_spmm_bsr3 / ds_cheb_spmm / ds_spmm_residual for ncols <= 84 (the default path of the
  * eigensolver's b-column products and of every preconditioner term): one wavefront per batch of consecutive
  * nodes stages the ids and values of all its rows in LDS with a few coalesced loads and streams their blocks
@@ -194,6 +195,7 @@ int ds_spmm_batched(int kind, int epilogue, const int32_t* btab, int64_t nbatch,
                     const int32_t* colidx, const float* vals, int64_t nnzb, int64_t nv, const float* X, int64_t ldx,
                     float* Y, int64_t ldy, const float* R0, int64_t ldr, const float* dinv, int ncols, float c1,
                     float c2, int first, ds_stream_t stream);
+#endif
 /* Out <- alpha * A C + beta * Out,  A (n x p) f32, C (p x q) f32 row-major device, Out (n x q) f32.
  * Out must not alias A.  (reference: X <- S Z etc., _lobpcg.py:463-466) */
 int ds_mix(const float* A, int64_t lda, int p, const float* C, int q, float* Out, int64_t ldo,
