@@ -84,13 +84,16 @@ class ModalPipeline:
     def assemble(self):
         self.system.assemble()
 
-    def run_pass(self, youngs, poisson, warm=None, backward=True, _lane=None):
-        """Steps 2-6 for one hypothesis (step 1 is ``assemble``)."""
+    def run_pass(self, youngs, poisson, warm=None, backward=True, _lane=None, assemble=True):
+        """One complete pass for one hypothesis: numeric assembly (step 1; ``assemble=False`` skips it when the
+        caller has just run ``assemble()``), then steps 2-6."""
         model = DirectLinear(youngs, poisson, self.mat)
         lam, mu = model.lame()
         holder = self if _lane is None else _lane
+        if assemble:
+            holder.system.assemble()
         if holder.ops is None:
-            holder.ops = HipModalOps(self.system, float(lam), float(mu))
+            holder.ops = HipModalOps(holder.system, float(lam), float(mu))
         else:
             holder.ops.set_material(float(lam), float(mu))
         res = ModalSolver(holder.ops, self.cfg).solve(self.modes, X0=warm)
@@ -115,6 +118,8 @@ class _Lane:
 
     def __init__(self, pipe, ops=None):
         self.ops = ops
+        # the first lane adopts the pipeline's system (and operators); the others assemble into their own arrays
+        self.system = pipe.system if ops is not None or not pipe._lanes else pipe.system.with_own_values()
         self.stream = torch.cuda.Stream(device=pipe.device)
         self.osc = TraditionalDampedOscillator(pipe.osc._force.clone(), 1, pipe.modes, pipe.osc.sample_num, pipe.osc.sr,
                                                pipe.mat)
