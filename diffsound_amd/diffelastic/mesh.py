@@ -94,6 +94,33 @@ def write_gmsh22(path, vertices, tets):
         f.write(b"\n$EndElements\n")
 
 
+def largest_connected_component(vertices, tets):
+    """Keep the largest node-connected component of a tet mesh: (vertices', tets') with nodes renumbered in
+    their original order and every element of other components dropped (reference
+    src/dmtet/geometry/dmtet_thickness.py:254-285, which round-trips through scipy.sparse.csgraph on the host;
+    callers need it because rigid-mode removal assumes ONE free body).  Runs on the tensors'
+    device: min-label propagation over the elements with pointer jumping, O(log diameter) sweeps."""
+    nv = vertices.shape[0]
+    dev = vertices.device
+    t = tets.long()
+    label = torch.arange(nv, device=dev)
+    while True:
+        m = label[t].amin(dim=1, keepdim=True).expand_as(t)  # smallest label met in each element
+        new = label.scatter_reduce(0, t.reshape(-1), m.reshape(-1), reduce="amin", include_self=True)
+        new = new[new]  # pointer jumping: labels are node ids, follow them
+        if bool((new == label).all()):
+            break
+        label = new
+    counts = torch.bincount(label, minlength=nv)
+    if int((counts > 0).sum()) == 1:
+        return vertices, tets
+    keep = label == torch.argmax(counts)  # ties: the component with the lowest node id, like the reference's loop
+    new_index = torch.full((nv,), -1, dtype=torch.long, device=dev)
+    new_index[keep] = torch.arange(int(keep.sum()), device=dev)
+    nt = new_index[t]
+    return vertices[keep], nt[(nt >= 0).all(dim=1)].to(tets.dtype)
+
+
 class TetMesh:
     """A tetrahedral mesh: ``vertices`` (nv,3) float tensor and ``tets`` (T,4|10) long tensor."""
 

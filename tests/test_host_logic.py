@@ -80,3 +80,33 @@ def test_shard_hypotheses_partitions():
         parts = [shard_hypotheses(num, r, world) for r in range(world)]
         assert sorted(sum(parts, [])) == list(range(num))
         assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
+
+
+def test_largest_connected_component_matches_scipy():
+    """Device-agnostic label propagation vs the reference's scipy.sparse.csgraph route
+    (reference src/dmtet/geometry/dmtet_thickness.py:254-285)."""
+    import scipy.sparse as sp
+    import scipy.sparse.csgraph as csgraph
+
+    from diffsound_amd import meshgen
+    from diffsound_amd.diffelastic.mesh import largest_connected_component
+
+    v1, t1 = meshgen.kuhn_box(3)
+    v2, t2 = meshgen.kuhn_box(2)
+    v = np.concatenate([v2 + 10.0, v1, v2 - 10.0])  # three bodies, the middle one is the largest
+    t = np.concatenate([t2, t1 + len(v2), t2 + len(v2) + len(v1)])
+    rng = np.random.default_rng(0)
+    perm = rng.permutation(len(v))  # scramble node numbering
+    inv = np.empty_like(perm); inv[perm] = np.arange(len(v))
+    v, t = v[perm], inv[t]
+    vo, to = largest_connected_component(torch.from_numpy(v), torch.from_numpy(t))
+    rows = np.concatenate([t[:, i] for i in range(4)]); cols = np.concatenate([t[:, (i + 1) % 4] for i in range(4)])
+    A = sp.coo_matrix((np.ones(len(rows)), (rows, cols)), shape=(len(v), len(v))).tocsr()
+    _, labels = csgraph.connected_components(A, directed=False)
+    big = np.argmax(np.bincount(labels))
+    assert np.array_equal(vo.numpy(), v[labels == big])
+    assert to.shape[0] == len(t1) and int(to.max()) == len(v1) - 1
+    assert np.allclose(vo.numpy()[to.numpy()], v[t[(labels[t] == big).all(1)]])
+    # a single body comes back untouched
+    a, b = largest_connected_component(torch.from_numpy(v1), torch.from_numpy(t1))
+    assert a.shape[0] == len(v1) and b.shape[0] == len(t1)
