@@ -537,9 +537,13 @@ class ModalSolver:
             lam[ncl:] = Ea
             if ncl:
                 S2[:, ny:ny + ncl].copy_(S[:, ny:ny + ncl])
-            # X_new | P_new are adjacent in S (and K X_new | K P_new in KS): one launch each, reading the basis once
-            ops.mix(Sa, ZZ, S2[:, ny + ncl:ny + b + na])
-            ops.mix(KSa, ZZ, KS2[:, :2 * na])
+            # (one 2na-column launch per product was measured SLOWER than two na-column ones: 909 us against
+            # 2 x 284 us at na = 80 - ten accumulator tiles per wave cost the update kernel its occupancy)
+            Z1, Zp = ZZ[:, :na], ZZ[:, na:]
+            ops.mix(Sa, Z1, S2[:, ny + ncl:ny + b])
+            ops.mix(Sa, Zp, S2[:, ny + b:ny + b + na])
+            ops.mix(KSa, Z1, KS2[:, :na])  # K X_new
+            ops.mix(KSa, Zp, KS2[:, na:2 * na])  # K P_new
             S, S2 = S2, S
             KS, KS2 = KS2, KS
             k0 = 0
