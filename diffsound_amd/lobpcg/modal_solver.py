@@ -365,27 +365,40 @@ class ModalSolver:
         VW: the contiguous block [V | W] when W directly follows V in memory (it does in the solver's basis
         buffer).  V is M-orthonormal, so ONE product M W and ONE Gram launch [V W]^T (M W) give both the
         projection coefficients C = V^T M W and, as G0 - C^T C, the Gram matrix of the projected block; the
-        projection and the Cholesky-QR transform are then one update W <- [V W] [-C T; T]."""
+        projection and the Cholesky-QR transform are then one update W <- [V W] [-C T; T].  The closed form is used
+        for the first sweep only and abandoned when a column turns out to lie (numerically) in span(V); the repair
+        sweep, when one is needed, is the explicit project / re-multiply / Cholesky-QR sequence."""
         ops, cfg = self.ops, self.cfg
         eps = 6e-8 if ops.dtype == torch.float32 else 1.1e-16
         nv_ = 0 if V is None else V.shape[1]
         for ip in range(cfg.ortho_passes):
             ops.apply_M(W, MW)
-            if nv_ > 0 and VW is not None:
+            done = False
+            if nv_ > 0 and VW is not None and ip == 0:
                 G = ops.gram(VW, MW)  # rows :nv_ = V^T M W, rows nv_: = W^T M W
 
                 def transform(G_, nv=nv_):
                     C = G_[:nv]
                     CtC = C.transpose(0, 1) @ C
-                    Gp = torch.cat([_sym(G_[nv:]) - CtC, CtC.diagonal()[None, :]], 0)
-                    T, amp = _orthonormalizer_q(Gp)
+                    G0 = _sym(G_[nv:])
+                    Gp = G0 - CtC
+                    # a column (numerically) inside span(V) leaves nothing of itself in G0 - C^T C but cancellation
+                    # noise: the closed form has broken down, take the explicit route for this sweep
+                    if bool((Gp.diagonal() <= 1e-9 * G0.diagonal().abs()).any()) or not bool(torch.isfinite(Gp).all()):
+                        return None, float("inf")
+                    L, info = torch.linalg.cholesky_ex(Gp)
+                    if int(info) != 0:
+                        return None, float("inf")
+                    T, amp = _orthonormalizer_q(torch.cat([Gp, CtC.diagonal()[None, :]], 0))
                     return torch.cat([-(C @ T), T], 0).contiguous(), amp
 
                 coef, amp = _small(transform, ops.device, G)
-                tmp = ops._scratch("ortho", W.shape, W.dtype) if hasattr(ops, "_scratch") else torch.empty_like(W)
-                ops.mix(VW, coef, tmp)
-                W.copy_(tmp)
-            else:
+                if coef is not None:
+                    tmp = ops._scratch("ortho", W.shape, W.dtype) if hasattr(ops, "_scratch") else torch.empty_like(W)
+                    ops.mix(VW, coef, tmp)
+                    W.copy_(tmp)
+                    done = True
+            if not done:
                 if nv_ > 0:
                     C = ops.gram(V, MW)
                     ops.mix(V, C, W, alpha=-1.0, beta=1.0)
