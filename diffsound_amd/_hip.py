@@ -61,6 +61,7 @@ _EXPERIMENTAL_SIGNATURES = {
     "ds_spmm_batch_limits": (None, [ctypes.POINTER(_I), ctypes.POINTER(_I)]),
     "ds_spmm_batched": (_I, [_I, _I, _P, _I64, _P, _P, _P, _I64, _I64, _P, _I64, _P, _I64, _P, _I64, _P, _I, _F, _F,
                             _I, _P]),
+    "ds_spmm_union": (_I, [_I, _P, _P, _I64, _I, _P, _P, _I64, _I64, _P, _I64, _P, _I64, _P, _I64, _P, _I, _F, _F, _I, _P]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

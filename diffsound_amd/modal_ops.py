@@ -98,14 +98,37 @@ class TetSystem:
         # panel loads).  EXPERIMENTAL, opt-in: correct, but no faster than the wave-per-node kernel, which PMC
         # counters show to be bound by fp32 FMA issue + load latency rather than by gathered bytes.
         self.groups = None
-        if os.environ.get("DS_SPMM_GROUPED", "0") == "1":
+        union = os.environ.get("DS_SPMM_UNION", "0") == "1" and hasattr(_hip.lib(), "ds_spmm_union")
+        if os.environ.get("DS_SPMM_GROUPED", "0") == "1" or union:
             gr = _hip.Groups(pat.rowptr, pat.colidx, self.nv)
             self.groups = dict(ne=gr.ne, gptr=gr.gptr.to(dev), gent=gr.gent.to(dev), goff=gr.goff.to(dev),
-                               kperm=gr.kperm.to(dev))
-        # batch table of the batched SpMM (one wave per run of consecutive nodes).  EXPERIMENTAL, opt-in
+                               kperm=gr.kperm.to(dev), union=None)
+            if union:
+                # neighbour-union kernel (EXPERIMENTAL build): every group is cut into chunks of whole entries that fit
+                # the kernel's LDS images (cap entries / blocks; almost always ONE chunk): ctab rows (e0, e1, b0, b1),
+                # utab rows (first chunk, end chunk) per group
+                import numpy as np
+                cap = int(os.environ.get("DS_UNION_CAP", "116"))
+                gp, go = gr.gptr.numpy().astype(np.int64), gr.goff.numpy().astype(np.int64)
+                crow, urow = [], []
+                for gi in range(len(gp) - 1):
+                    e, e_end = gp[gi], gp[gi + 1]
+                    first = len(crow)
+                    while e < e_end:
+                        # furthest entry end with <= cap blocks and <= cap entries
+                        lim = min(e_end, e + cap)
+                        e1 = int(np.searchsorted(go[e:lim + 1], go[e] + cap, side="right")) - 1 + e
+                        e1 = max(e1, e + 1)
+                        crow.append((e, e1, go[e], go[e1]))
+                        e = e1
+                    urow.append((first, len(crow)))
+                ct = torch.from_numpy(np.asarray(crow, dtype=np.int32))
+                if int((ct[:, 3] - ct[:, 2]).max()) <= cap:
+                    self.groups["union"] = dict(utab=torch.from_numpy(np.asarray(urow, dtype=np.int32)).to(dev),
+                                                ctab=ct.to(dev), capb=cap, ngroups=len(urow))
+        # batch table of the batched SpMM (one wave per run of consecutive nodes).  EXPERIMENTAL build, opt-in
         # (DS_SPMM_BATCHED=1): same speed as the wave-per-node kernels (the product is bound by the CU's gather
-        # rate) and NOT yet reliable - the first nodes of a batch intermittently come out zero
-        # (tools/dbg_small.py); kept as the base of the neighbour-union kernel that would cut the gathered bytes.
+        # rate); kept as the base of the neighbour-union kernel.
         self.batches = None
         if os.environ.get("DS_SPMM_BATCHED", "0") == "1":
             bt = _hip.build_batches(pat.rowptr)
@@ -277,6 +300,22 @@ class _HipBlockOps:
     batches = None  # (nbatch, 4) int32 device table for the batched SpMM (<= 84 columns), or None
     batch_ops = os.environ.get("DS_SPMM_BATCH_OPS", "KMCR")  # which products use it: K X, M X, Chebyshev term, residual
 
+    def _union_ok(self, X):
+        g = getattr(getattr(self, "sys", None), "groups", None)
+        return (g is not None and g.get("union") is not None and self.kgrp is not None and X.shape[1] <= 84
+                and X.shape[1] % 4 == 0 and 12 * self.nv * _ld(X) < 0x7F000000 and X.data_ptr() % 16 == 0
+                and (_ld(X) * 4) % 16 == 0)
+
+    def _union(self, epilogue, X, Y, R0=None, c1=0.0, c2=0.0, first=False):
+        pp = _hip.ptr
+        g = self.sys.groups
+        u = g["union"]
+        _hip.check(self._L.ds_spmm_union(epilogue, pp(u["utab"]), pp(u["ctab"]), u["ngroups"], u["capb"], pp(g["gent"]), pp(self.kgrp),
+                                         self.kgrp.shape[0], self.nv, pp(X), _ld(X), pp(Y), _ld(Y), pp(R0),
+                                         0 if R0 is None else _ld(R0), pp(self.dinv) if epilogue == 1 else None,
+                                         X.shape[1], float(c1), float(c2), int(bool(first)), _hip.stream_ptr()),
+                   "ds_spmm_union")
+
     def _batched_ok(self, X, op="K"):
         return (self.batches is not None and op in self.batch_ops and X.shape[1] <= 84 and X.shape[1] % 4 == 0
                 and 12 * self.nv * _ld(X) < 0x7F000000 and X.data_ptr() % 16 == 0 and (_ld(X) * 4) % 16 == 0)
@@ -291,7 +330,9 @@ class _HipBlockOps:
                    "ds_spmm_batched")
 
     def apply_K(self, X, out):
-        if self._batched_ok(X) and not self._has_tiles(X.shape[1]) and not self._has_groups(X.shape[1]):
+        if self._union_ok(X):
+            self._union(0, X, out)
+        elif self._batched_ok(X) and not self._has_tiles(X.shape[1]) and not self._has_groups(X.shape[1]):
             timed = self.spmm_events is not None and X.shape[1] == self.spmm_event_cols
             if timed:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -393,6 +434,10 @@ class _HipBlockOps:
     def spmm_residual(self, X, R0, Y):
         """Y <- R0 - K X (<= 84 columns, one fused launch)."""
         pp = _hip.ptr
+        if self._union_ok(X):
+            self._union(2, X, Y, R0)
+            self.counts["apply_K_cols"] += X.shape[1]
+            return
         if self._batched_ok(X, "R"):
             self._batched(0, 2, self.k32t, X, Y, R0)
             self.counts["apply_K_cols"] += X.shape[1]
@@ -435,13 +480,17 @@ class _HipBlockOps:
                                            _hip.stream_ptr()), "ds_spmm_grouped")
 
     def _has_groups(self, ncols):
-        return (self.kgrp is not None and getattr(getattr(self, "sys", None), "groups", None) is not None
-                and ncols <= 84 and ncols % 4 == 0)
+        g = getattr(getattr(self, "sys", None), "groups", None)
+        return (self.kgrp is not None and g is not None and g.get("union") is None and ncols <= 84 and ncols % 4 == 0)
 
     def _has_tiles(self, ncols):
         return getattr(getattr(self, "sys", None), "tiles", None) is not None and ncols <= 84
 
     def _cheb_spmm_launch(self, Wk, Wprev, R0, c1, c2, first):
+        if self._union_ok(Wk):
+            self._union(1, Wk, Wprev, R0, c1, c2, first)
+            self.counts["apply_K_cols"] += Wk.shape[1]
+            return
         if self._has_groups(Wk.shape[1]) and not self._has_tiles(Wk.shape[1]):
             self._grouped(1, Wk, Wprev, R0, c1, c2, first)
             self.counts["apply_K_cols"] += Wk.shape[1]

@@ -195,6 +195,15 @@ int ds_spmm_batched(int kind, int epilogue, const int32_t* btab, int64_t nbatch,
                     const int32_t* colidx, const float* vals, int64_t nnzb, int64_t nv, const float* X, int64_t ldx,
                     float* Y, int64_t ldy, const float* R0, int64_t ldr, const float* dinv, int ncols, float c1,
                     float c2, int first, ds_stream_t stream);
+/* Neighbour-union form (one wavefront per group of 4 consecutive nodes walks the UNION of their neighbours, so a
+ * shared neighbour panel is gathered once): tables from ds_groups_build - gent (union entries col | mask << 28),
+ * kgrp (transposed blocks in group order, ds_pack_groups) - cut into chunks of whole entries with at most
+ * cap_blocks blocks: ctab (nchunks x 4) = (e0, e1, b0, b1), utab (ngroups x 2) = chunk range of each group.
+ * Epilogues as above.  Correct, measured, and not faster than ds_cheb_spmm yet. */
+int ds_spmm_union(int epilogue, const int32_t* utab, const int32_t* ctab, int64_t ngroups, int cap_blocks,
+                  const int32_t* gent, const float* kgrp, int64_t nnzb, int64_t nv, const float* X, int64_t ldx,
+                  float* Y, int64_t ldy, const float* R0, int64_t ldr, const float* dinv, int ncols, float c1, float c2,
+                  int first, ds_stream_t stream);
 #endif
 /* Out <- alpha * A C + beta * Out,  A (n x p) f32, C (p x q) f32 row-major device, Out (n x q) f32.
  * Out must not alias A.  (reference: X <- S Z etc., _lobpcg.py:463-466) */
