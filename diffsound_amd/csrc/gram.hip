@@ -20,6 +20,7 @@
 // order: deterministic, no atomics.  With `symmetric`, only workgroup tiles on or above the
 // diagonal are computed and the reduction mirrors them (A^T (K A) for symmetric K).
 #include <algorithm>
+#include <cstdlib>
 
 #include "ds_common.h"
 
@@ -203,7 +204,11 @@ Plan make_plan(int64_t n, int p, int q, int symmetric) {
     pl.ntj = (int)ds::ceil_div(q, WT);
     pl.ntiles = symmetric ? nti * (nti + 1) / 2 : nti * pl.ntj;
     pl.groups = (int)ds::ceil_div(pl.ntiles, 4);
-    int64_t nsplit = ds::ceil_div(1024, pl.groups);             // ~4 workgroups per CU
+    // The kernel holds 152 VGPRs: 3 workgroups per CU, 768 resident on the chip.  The grid is sized to fill the
+    // chip an integer number of times - a 1026-workgroup grid ran one full round and a second one at a third of
+    // the occupancy, i.e. in the time of two (DS_GRAM_WGS overrides the target for experiments).
+    static const int64_t target = getenv("DS_GRAM_WGS") ? atoll(getenv("DS_GRAM_WGS")) : 768;
+    int64_t nsplit = std::max<int64_t>(1, target / pl.groups);
     nsplit = std::min<int64_t>(nsplit, ds::ceil_div(n, 512));   // at least 512 rows per split
     nsplit = std::max<int64_t>(nsplit, 1);
     int64_t rps = ds::ceil_div(n, nsplit);

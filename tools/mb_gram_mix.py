@@ -12,7 +12,7 @@ def tm(f, reps=20):
     torch.cuda.synchronize(); return (time.time() - t) / reps * 1e3
 S = torch.randn((n, 248), device=dev); KS = torch.randn((n, 240), device=dev)
 only = os.environ.get('ONLY')
-shapes = ((160, 72, False), (72, 72, True), (224, 224, True), (240, 240, True), (88, 80, False), (80, 80, True), (64, 64, False))
+shapes = ((248, 80, False), (240, 80, False), (240, 240, True), (168, 80, False), (88, 80, False), (80, 80, True))
 if only:
     a_, b_, c_ = only.split(','); shapes = ((int(a_), int(b_), bool(int(c_))),)
 for p, q, sym in shapes:
