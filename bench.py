@@ -48,6 +48,8 @@ def parse():
     ap.add_argument("--smooth-ratio", type=float, default=10.0)
     ap.add_argument("--coarse-degree", type=int, default=24)
     ap.add_argument("--coarse-ratio", type=float, default=400.0)
+    ap.add_argument("--rr-refresh", type=int, default=-1,
+                    help="recompute K [X P W] and the whole Gram matrix every this many iterations (-1 = solver default)")
     ap.add_argument("--warm-start", action="store_true", help="amortised variant: reuse the previous block")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-cells", type=int, default=5)
@@ -122,6 +124,8 @@ def main():
     cfg = SolverConfig(block=a.block, cheb_degree=a.cheb_degree, cheb_ratio=a.cheb_ratio,
                        lmax_cap=float({1: 4, 2: 10}[a.order]), precond=a.precond, smooth_degree=a.smooth_degree,
                        smooth_ratio=a.smooth_ratio, coarse_degree=a.coarse_degree, coarse_ratio=a.coarse_ratio)
+    if a.rr_refresh >= 0:
+        cfg.rr_refresh = a.rr_refresh
     t_sym = time.time()
     pipe = ModalPipeline(mesh.vertices, mesh.tets, a.order, a.modes, MAT, solver_config=cfg)
     torch.cuda.synchronize()
