@@ -3,7 +3,8 @@
 configs[1] (10k-tet ord-1 mesh, 32 modes, forward only) is small enough for the CPU oracle, so it is a
 direct parity test; configs[2] (100k-tet ord-2, 64 modes) is checked through size-independent properties:
 residuals recomputed in fp64 by an independent kernel path, M-orthonormality, exact scaling of the spectrum
-with Young's modulus, mass conservation, rigid-body null space, run-to-run reproducibility.  pytest -m gpu."""
+with Young's modulus, mass conservation, rigid-body null space, run-to-run reproducibility; configs[4] (1M-tet
+ord-2, 128 modes) runs the same fp64 residual / Rayleigh-quotient / mass checks.  pytest -m gpu."""
 import numpy as np
 import pytest
 import torch
@@ -152,3 +153,66 @@ def test_c3_reproducible(c3):
             del o._power_block
     cold = ModalSolver(ops, c3["cfg"]).solve(64)
     assert float((cold.eigenvalues / ref - 1).abs().max()) < 1e-9
+
+
+@pytest.fixture(scope="module")
+def c5(dev):
+    """BASELINE.json configs[4]: 1M-tet ord-2 mesh (55^3 Kuhn cells = 998 250 tets, n = 4.1 M), 128 modes."""
+    from diffsound_amd import meshgen
+    from diffsound_amd.diffelastic.mesh import TetMesh
+    from diffsound_amd.lobpcg.modal_solver import ModalSolver, SolverConfig
+    from diffsound_amd.modal_ops import HipModalOps, TetSystem
+
+    v, t = meshgen.kuhn_box(55)
+    mesh = TetMesh(torch.from_numpy(v).to(dev), torch.from_numpy(t).long().to(dev)).to_high_order(2)
+    sysd = TetSystem(mesh.vertices, mesh.tets, 2, MAT[0])
+    lam, mu = fem.lame(MAT[1], MAT[2])
+    ops = HipModalOps(sysd, lam, mu)
+    cfg = SolverConfig(block=136, lmax_cap=10.0)
+    res = ModalSolver(ops, cfg).solve(128)
+    return dict(sys=sysd, ops=ops, res=res, lam=lam, mu=mu)
+
+
+def test_c5_sizes_and_convergence(c5):
+    s, res = c5["sys"], c5["res"]
+    assert s.T == 998250 and s.nv == 1367631 and s.n == 4102893
+    assert res.iterations < 60
+    assert float(res.rerr.max()) < 2e-6  # the solver's own backward-error test, fp32 iterates
+    ev = res.eigenvalues
+    assert ev.dtype == torch.float64 and bool((ev[1:] >= ev[:-1]).all()) and float(ev[0]) > 0
+
+
+def test_c5_fp64_residuals_and_rayleigh_quotients(c5):
+    """The same independent fp64 check as at C3, on the first 32 of the 128 modes (fp64 blocks of n x 32)."""
+    s, ops, res = c5["sys"], c5["ops"], c5["res"]
+    k = 32
+    U = res.vectors[:, :k].contiguous()
+    n = U.shape[0]
+    KU = torch.zeros((n, k), dtype=torch.float64, device=U.device)
+    tmp = torch.empty_like(KU)
+    for vals, c in ((s.klam, c5["lam"]), (s.kmu, c5["mu"])):
+        ops._spmm(2, vals, U, tmp)
+        KU += c * tmp
+    MU = torch.empty_like(KU)
+    ops._spmm(3, s.ms, U, MU)
+    ev = res.eigenvalues[:k]
+    Ud = U.double()
+    rq = (Ud * KU).sum(0) / (Ud * MU).sum(0)
+    assert float((rq / ev - 1).abs().max()) < 1e-7  # fp64 eigenvalues from the Rayleigh-Ritz polish
+    R = KU - MU * ev[None, :]
+    # backward error of the pairs, ||K u - lambda M u|| / (||u|| (||K|| + lambda ||M||)), norms from a random probe
+    g = torch.Generator(device=U.device).manual_seed(1)
+    P = torch.randn((n, 8), generator=g, device=U.device)
+    KP = torch.zeros((n, 8), dtype=torch.float64, device=U.device)
+    t2 = torch.empty_like(KP)
+    for vals, c in ((s.klam, c5["lam"]), (s.kmu, c5["mu"])):
+        ops._spmm(2, vals, P, t2)
+        KP += c * t2
+    MP = torch.empty_like(KP)
+    ops._spmm(3, s.ms, P, MP)
+    An, Bn = float(KP.norm() / P.double().norm()), float(MP.norm() / P.double().norm())
+    assert float((R.norm(dim=0) / (Ud.norm(dim=0) * (An + ev * Bn))).max()) < 1e-5
+    G = Ud.T @ MU
+    assert float((G - torch.eye(k, device=U.device, dtype=torch.float64)).abs().max()) < 1e-4
+    # mass conservation at this size: sum(M_s) = rho * volume
+    assert abs(float(s.ms.sum()) / (MAT[0] * 0.10 * 0.08 * 0.06) - 1) < 1e-5
