@@ -268,6 +268,7 @@ class _HipBlockOps:
         self.device = device
         self._L = _hip.lib()
         self._gram_ws = None
+        self.gram_exact = False
         self._tmp = {}
         self._nrm = torch.empty((2, 1024), dtype=torch.float64, device=device)
         self.counts = dict(apply_K_cols=0, apply_M_cols=0, gram=0, mix=0)
@@ -357,7 +358,10 @@ class _HipBlockOps:
         self.counts["apply_M_cols"] += X.shape[1]
 
     # ------------------------------------------------------------------ tall-skinny dense
-    def gram(self, A, B, symmetric=False):
+    def gram(self, A, B, symmetric=False, exact=False):
+        """G = A^T B in fp64.  exact=False: fp32 MFMA folded into fp64 every 48 rows (~1e-9 of |A_i||B_j| at the
+        benchmark's row count, ~1e-7 on a few hundred rows); ops with gram_exact set always take the fp64 MFMA."""
+        exact = exact or self.gram_exact
         p, q = A.shape[1], B.shape[1]
         need = self._L.ds_gram_workspace_bytes(self.n, p, q)
         if self._gram_ws is None or self._gram_ws.numel() < need:
@@ -365,7 +369,7 @@ class _HipBlockOps:
         G = torch.empty((p, q), dtype=torch.float64, device=self.device)
         bdt = DS_F64 if B.dtype == torch.float64 else DS_F32
         pp = _hip.ptr
-        _hip.check(self._L.ds_gram(pp(A), _ld(A), p, pp(B), bdt, _ld(B), q, self.n, int(bool(symmetric)), pp(G),
+        _hip.check(self._L.ds_gram(pp(A), _ld(A), p, pp(B), bdt, _ld(B), q, self.n, int(bool(symmetric)) | (2 if exact else 0), pp(G),
                                    pp(self._gram_ws), self._gram_ws.numel(), _hip.stream_ptr()), "ds_gram")
         self.counts["gram"] += 1
         return G
@@ -631,6 +635,8 @@ class HipSparseOps(_HipBlockOps):
         rowptr = torch.zeros(nv + 1, dtype=torch.int64, device=dev)
         rowptr[1:] = torch.cumsum(torch.bincount(rows, minlength=nv), 0)
         self._init_common(rowptr.to(torch.int32), (keys % nv).to(torch.int32), nv, dev)
+        # arbitrary pencils (no deflation, possibly -A for the largest end, no preconditioner): keep the Gram exact
+        self.gram_exact = True
         if os.environ.get("DS_SPMM_BATCHED", "0") == "1":
             bt = _hip.build_batches(self.rowptr.cpu())
             self.batches = None if bt is None else bt.to(dev)

@@ -121,17 +121,22 @@ int ds_spmm_bsr3(int kind, const int32_t* rowptr, const int32_t* colidx, const v
                  ds_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
- * Tall-skinny Gram  G = A^T B  (p x q, fp64, row-major, ld = q) with MFMA, fp64 accumulation.
+ * Tall-skinny Gram  G = A^T B  (p x q, fp64, row-major, ld = q) with MFMA.
  * Replaces the dense (k x n)(n x k) products of Rayleigh-Ritz / svqb / ortho in the reference
  * (src/lobpcg/_linalg_utils.py:64-73 via torch.matmul).
  *   A: (n x p) f32, lda ;  B: (n x q) f32 or f64 (b_dtype), ldb
- *   symmetric != 0 (needs p == q): the caller asserts G is symmetric (e.g. S^T (K S)); only the
+ *   flags: DS_GRAM_SYMMETRIC (needs p == q): the caller asserts G is symmetric (e.g. S^T (K S)); only the
  *     block-upper part is computed and mirrored.
+ *     DS_GRAM_EXACT: exact products, fp64 accumulation throughout (fp64 MFMA).  Without it an f32 x f32 product
+ *     runs on the fp32 MFMA with the accumulators folded into fp64 every 64 rows (error ~1e-8 |A_i||B_j|, far
+ *     below the operands' own fp32 rounding) at twice the rate; an f64 B always takes the exact path.
  *   work: device scratch of ds_gram_workspace_bytes(n, p, q) bytes.
  * ---------------------------------------------------------------------------------------------- */
 int64_t ds_gram_workspace_bytes(int64_t n, int p, int q);
+#define DS_GRAM_SYMMETRIC 1
+#define DS_GRAM_EXACT 2
 int ds_gram(const float* A, int64_t lda, int p, const void* B, int b_dtype, int64_t ldb, int q,
-            int64_t n, int symmetric, double* G, void* work, int64_t work_bytes, ds_stream_t stream);
+            int64_t n, int flags, double* G, void* work, int64_t work_bytes, ds_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Fused block-vector updates of the eigensolver (all (n x ncols) f32 with leading dimensions).

@@ -65,6 +65,25 @@ def c3(dev):
     return dict(sys=sysd, ops=ops, res=res, cfg=cfg, mesh=mesh, lam=lam, mu=mu, v=v, t=t)
 
 
+@pytest.mark.parametrize("p,q,sym", [(240, 80, False), (168, 80, False), (240, 240, True), (136, 72, False)])
+def test_c3_gram_folded_fp32_accuracy(c3, dev, p, q, sym):
+    """The fast Gram (fp32 MFMA folded into fp64 every 48 rows) at the benchmark's row count against fp64:
+    each element within 1e-8 |A_i||B_j| - below the fp32 rounding of the operands themselves; the exact path
+    (fp64 MFMA) to 1e-14."""
+    ops = c3["ops"]
+    g = torch.Generator().manual_seed(p + q)
+    S = torch.randn((ops.n, 248), generator=g).to(dev)
+    A = S[:, 4:4 + p]
+    B = (A * 1.5) if sym else torch.randn((ops.n, 88), generator=g).to(dev)[:, 8:8 + q]
+    ref = (A.double().T @ B.double()).cpu().numpy()
+    scale = np.sqrt(np.outer((A.double() ** 2).sum(0).cpu().numpy(), (B.double() ** 2).sum(0).cpu().numpy()))
+    G = ops.gram(A, B, symmetric=sym).cpu().numpy()
+    assert (np.abs(G - ref) / scale).max() < 1e-8
+    Ge = ops.gram(A, B, symmetric=sym, exact=True).cpu().numpy()
+    assert (np.abs(Ge - ref) / scale).max() < (1e-9 if sym else 1e-14)  # 1.5 A is rounded: not exactly symmetric
+    assert np.array_equal(ops.gram(A, B, symmetric=sym).cpu().numpy(), G)  # deterministic
+
+
 def test_c3_sizes(c3):
     s = c3["sys"]
     assert s.T == 105456 and s.nv == 148877 and s.n == 446631 and s.nnzb * 9 == 37227537

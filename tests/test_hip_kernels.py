@@ -199,14 +199,26 @@ def test_spmm(case, dev, ncols):
         assert float(outb[:, :8].abs().max()) == 0.0 and float(outb[:, 8 + ncols:].abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("p,q", [(8, 40), (40, 40), (80, 80), (240, 240), (104, 56)])
+@pytest.mark.parametrize("p,q", [(8, 40), (40, 40), (80, 80), (240, 240), (104, 56), (240, 80), (88, 80), (33, 47)])
 def test_gram(case, dev, p, q):
     h = case["hops"]
     g = torch.Generator().manual_seed(p * 1000 + q)
     A = torch.randn((h.n, p), generator=g)
     B = torch.randn((h.n, q), generator=g)
-    G = h.gram(A.to(dev), B.to(dev)).cpu()
     ref = A.double().T @ B.double()
+    scale = np.sqrt(np.outer((A.double() ** 2).sum(0).numpy(), (B.double() ** 2).sum(0).numpy()))
+    # default: fp32 MFMA folded into fp64 every 48 rows - elementwise error against |A_i||B_j|.  The error is
+    # relative to the 48-row partials and averages out over the folds: ~5e-8 on this mesh of a few hundred rows,
+    # 1e-9 at the 4.5e5 rows of the benchmark (tests/test_fullsize_gpu.py checks that)
+    G = h.gram(A.to(dev), B.to(dev)).cpu()
+    assert (np.abs(G.numpy() - ref.numpy()) / scale).max() < 2e-7
+    # strided views of wider buffers whose neighbouring columns hold junk (how the solver calls it)
+    wa, wb = torch.full((h.n, p + 24), float("nan")), torch.full((h.n, q + 24), float("nan"))
+    wa[:, 8:8 + p], wb[:, 16:16 + q] = A, B
+    Gv = h.gram(wa.to(dev)[:, 8:8 + p], wb.to(dev)[:, 16:16 + q]).cpu()
+    assert torch.equal(Gv, G)
+    # exact products, fp64 accumulation
+    G = h.gram(A.to(dev), B.to(dev), exact=True).cpu()
     assert rel(G.numpy(), ref.numpy()) < 1e-13
     G64 = h.gram(A.to(dev), B.double().to(dev)).cpu()
     assert rel(G64.numpy(), ref.numpy()) < 1e-13
