@@ -229,7 +229,7 @@ def main():
                 traffic = None
         roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "kernel": (f"spmm_wave_node_kernel<0,3,{a.block // 4},1>: W' = W + c1(W - W_prev) + c2 T(R0 - K W) on a "
+                "kernel": (f"spmm_union_kernel<{a.block // 4},1,*>: W' = W + c1(W - W_prev) + c2 T(R0 - K W) on a "
                            f"{a.block}-column block (fine and corner-node level launches)"),
                 "algorithmic_bytes_per_launch": float(nbytes.mean()), "avg_launch_ms": float(ms.mean()),
                 "launches_timed": int(len(ms)), "levels": levels,

@@ -51,6 +51,7 @@ _SIGNATURES = {
     "ds_pack_groups": (_I, [_P, _P, _I64, _P, _P]),
     "ds_spmm_grouped": (_I, [_I, _P, _P, _P, _P, _I64, _P, _I64, _P, _I64, _P, _I64, _P, _I, _F, _F, _I, _P]),
     "ds_geometry_grad": (_I, [_P, _I64, _I, _I64, _P, _P, _I64, _I, _P, _P, _D, _D, _P, _P, _I, _P, _P, _P]),
+    "ds_spmm_union": (_I, [_I, _P, _P, _I64, _I, _P, _P, _I64, _I64, _P, _I64, _P, _I64, _P, _I64, _P, _I, _F, _F, _I, _P]),
     "ds_mix": (_I, [_P, _I64, _I, _P, _I, _P, _I64, _I64, _F, _F, _P]),
     "ds_osc_bank_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _D, _P, _P]),
     "ds_osc_bank_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _D, _P, _P, _P, _P, _P]),
@@ -61,7 +62,6 @@ _EXPERIMENTAL_SIGNATURES = {
     "ds_spmm_batch_limits": (None, [ctypes.POINTER(_I), ctypes.POINTER(_I)]),
     "ds_spmm_batched": (_I, [_I, _I, _P, _I64, _P, _P, _P, _I64, _I64, _P, _I64, _P, _I64, _P, _I64, _P, _I, _F, _F,
                             _I, _P]),
-    "ds_spmm_union": (_I, [_I, _P, _P, _I64, _I, _P, _P, _I64, _I64, _P, _I64, _P, _I64, _P, _I64, _P, _I, _F, _F, _I, _P]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
@@ -176,6 +176,40 @@ class Groups:
                   "ds_groups_export")
         finally:
             lib().ds_groups_free(handle)
+
+
+def union_chunks(gptr_cpu, goff_cpu, cap):
+    """Chunk tables of the neighbour-union SpMM (ds_spmm_union): every group of 4 nodes (entries gptr[g]..gptr[g+1],
+    blocks goff[e]..) is cut into chunks of whole entries with at most ``cap`` entries and ``cap`` blocks.  Returns
+    (utab (ngroups, 2) int32 = chunk range of each group, ctab (nchunks, 4) int32 = (e0, e1, b0, b1)) as CPU tensors,
+    or (None, None) if a single entry does not fit."""
+    import numpy as np
+
+    gp, go = gptr_cpu.numpy().astype(np.int64), goff_cpu.numpy().astype(np.int64)
+    ng = gp.shape[0] - 1
+    e0, e1 = gp[:-1], gp[1:]
+    single = ((e1 - e0) <= cap) & ((go[e1] - go[e0]) <= cap)
+    per_group = [None] * ng if not single.all() else None
+    counts = np.ones(ng, dtype=np.int64)
+    for gi in np.nonzero(~single)[0]:  # rare: a group whose union or block count exceeds the image
+        e, rows = int(e0[gi]), []
+        while e < e1[gi]:
+            lim = min(int(e1[gi]), e + cap)  # furthest entry end with <= cap blocks and <= cap entries
+            nxt = max(int(np.searchsorted(go[e:lim + 1], go[e] + cap, side="right")) - 1 + e, e + 1)
+            rows.append((e, nxt, go[e], go[nxt]))
+            e = nxt
+        per_group[gi] = rows
+        counts[gi] = len(rows)
+    start = np.concatenate([[0], np.cumsum(counts)])
+    ctab = np.empty((int(start[-1]), 4), dtype=np.int64)
+    s_idx = start[:-1][single]
+    ctab[s_idx] = np.stack([e0[single], e1[single], go[e0[single]], go[e1[single]]], 1)
+    for gi in np.nonzero(~single)[0]:
+        ctab[start[gi]:start[gi + 1]] = np.asarray(per_group[gi], dtype=np.int64)
+    if ctab.shape[0] == 0 or int((ctab[:, 3] - ctab[:, 2]).max()) > cap:
+        return None, None
+    utab = np.stack([start[:-1], start[1:]], 1)
+    return torch.from_numpy(utab.astype(np.int32)), torch.from_numpy(ctab.astype(np.int32))
 
 
 def build_batches(rowptr_cpu):

@@ -202,33 +202,50 @@ int launch_mix(const float* A, int64_t lda, int p, const float* C, int q, float*
 
 // Out <- alpha A C + beta Out for the eigensolver's shapes (p <= 256, q <= 80, 16-byte aligned rows of A): the
 // coefficient matrix C (<= 80 KB) is staged ONCE per workgroup in LDS and the workgroups are persistent over row
-// tiles (2 per CU), so the MFMA B operands come from LDS (conflict-free: a ds_read_b32 fetches 4 rows x 16
-// consecutive floats) instead of twenty 4-byte global loads per 16-deep k-step; A is prefetched one k-step ahead.
-// The generic kernel above ran at 54 TFLOP/s on (n x 240)(240 x 80); its floor is the 0.57 GB it has to move.
-__host__ __device__ inline int mix_ldc(int q) { return q + ((4 - q % 8) + 8) % 8; }
+// tiles (2 per CU), so the MFMA B operands come from LDS instead of twenty 4-byte global loads per 16-deep k-step.
+//
+// LDS layout [k / 4][position][k % 4]: the four k values a lane feeds to four consecutive MFMAs are one
+// ds_read_b128 (five per k-step; the first version issued twenty predicated ds_read_b32, each followed by a wait
+// and two MFMAs: 73 TF/s).  "position" j * 16 + li holds column JT * li + j: an MFMA does not care which column its
+// index stands for, and with this interleave a lane ends up owning JT CONSECUTIVE output columns per row, so the
+// result is stored (and, for beta != 0, read) as 16-lane x 20-byte = 320-byte row segments instead of 64-byte ones.
+// A and the B operands of the next k-step are fetched before the current step's 40 MFMAs issue.
+// The generic kernel above ran at 54 TFLOP/s on (n x 240)(240 x 80); the floor is the 0.57 GB it has to move.
+// nothing moves across: neither in the IR (memory clobber) nor in the machine scheduler
+#define DS_PIN_ORDER()                      \
+    do {                                    \
+        asm volatile("" ::: "memory");        \
+        __builtin_amdgcn_sched_barrier(0);  \
+    } while (0)
+
 constexpr int MIX_NW = 8;  // waves per workgroup sharing one LDS copy of C (2 workgroups per CU -> 4 waves per SIMD)
+
+using u4 = __attribute__((ext_vector_type(4))) unsigned;
+
+template <int N>
+struct alignas(4) FloatPack {
+    float v[N];
+};
 
 template <int JT>
 __global__ void __launch_bounds__(64 * MIX_NW)
     mix_lds_kernel(const float* __restrict__ A, int64_t lda, int p, const float* __restrict__ C, int q,
                    float* __restrict__ Out, int64_t ldo, int64_t n, float alpha, float beta) {
-    extern __shared__ __attribute__((aligned(16))) float s_c[];  // [p16][ldc], rows >= p zero
+    extern __shared__ __attribute__((aligned(16))) float s_c[];  // [p16 / 4][JT * 16][4], rows >= p and columns >= q zero
+    constexpr int W = JT * 16;
     const int p16 = (p + 15) & ~15;
-    // a wave's B read covers rows k, k+4, k+8, k+12 (16 consecutive floats each): with ldc % 8 == 4 the four
-    // row segments fall into four different bank groups of 16 (ldc = q put rows k and k+4 on the same banks)
-    const int ldc = mix_ldc(q);
-    for (int t = threadIdx.x; t < p16 * q; t += 64 * MIX_NW) {
-        const int r = t / q, c = t - r * q;
-        s_c[r * ldc + c] = r < p ? C[t] : 0.f;
+    for (int t = threadIdx.x; t < p16 * W; t += 64 * MIX_NW) {
+        const int kq = t / (W * 4), rem = t - kq * (W * 4), pos = rem >> 2;
+        const int r = kq * 4 + (rem & 3), c = (pos & 15) * JT + (pos >> 4);
+        s_c[t] = (r < p && c < q) ? C[r * q + c] : 0.f;
     }
     __syncthreads();
+    const f4* sc4 = reinterpret_cast<const f4*>(s_c);
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int li = lane & 15, lq = lane >> 4;
     const int64_t ntile = (n + RT * 16 - 1) / (RT * 16);
-    bool jv[JT];
-#pragma unroll
-    for (int j = 0; j < JT; ++j) jv[j] = (j * 16 + li) < q;
+    const int nstep = p16 >> 4;
     for (int64_t tile = (int64_t)blockIdx.x * MIX_NW + wave; tile < ntile; tile += (int64_t)gridDim.x * MIX_NW) {
         const int64_t row0 = tile * (RT * 16);
         f4acc acc[RT][JT];
@@ -236,49 +253,84 @@ __global__ void __launch_bounds__(64 * MIX_NW)
         for (int t = 0; t < RT; ++t)
 #pragma unroll
             for (int j = 0; j < JT; ++j) acc[t][j] = f4acc{0.f, 0.f, 0.f, 0.f};
-        const float* ap[RT];
-        bool rv[RT];
+        // A through a per-tile buffer descriptor that ends after column p of the tile's last row: rows past n read
+        // zeros without a branch; a k-step past p (only the last one can be partial; p % 4 == 0) reads the
+        // neighbouring block's columns, which may hold anything, and is replaced by zeros
+        const int64_t trows = min((int64_t)(RT * 16), n - row0);
+        const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A + row0 * lda), 0,
+                                                          (int)(((trows - 1) * lda + p) * 4), 0x00020000);
+        unsigned voff[RT];
 #pragma unroll
-        for (int t = 0; t < RT; ++t) {
-            const int64_t r = row0 + t * 16 + li;
-            rv[t] = r < n;
-            ap[t] = A + (rv[t] ? r : 0) * lda + 4 * lq;
-        }
-        f4 a[RT], an[RT];
+        for (int t = 0; t < RT; ++t) voff[t] = (unsigned)((t * 16 + li) * lda + 4 * lq) * 4u;
+        auto fetch = [&](f4 (&a)[RT], f4 (&b)[JT], int step) {
 #pragma unroll
-        for (int t = 0; t < RT; ++t) a[t] = (rv[t] && 4 * lq < p) ? ld4(ap[t]) : f4{0.f, 0.f, 0.f, 0.f};
-        for (int k0 = 0; k0 < p16; k0 += 16) {
-            const int kn = k0 + 16 + 4 * lq;
+            for (int t = 0; t < RT; ++t) {
+                const u4 raw = __builtin_amdgcn_raw_buffer_load_b128(rs, voff[t] + (unsigned)step * 64u, 0, 0);
+                a[t] = __builtin_bit_cast(f4, raw);
+            }
+            const int sb = min(step, nstep - 1);  // the fetch past the last step re-reads it (never used)
 #pragma unroll
-            for (int t = 0; t < RT; ++t) an[t] = (rv[t] && kn < p) ? ld4(ap[t] + k0 + 16) : f4{0.f, 0.f, 0.f, 0.f};
-            const float* cp = s_c + (k0 + 4 * lq) * ldc + li;
+            for (int j = 0; j < JT; ++j) b[j] = sc4[(sb * 4 + lq) * W + j * 16 + li];
+        };
+        // the zeroing of a partial last k-step happens here, at the use: done at the fetch it put a wait for the
+        // prefetched operands in front of the current step's MFMAs
+        auto mfma = [&](const f4 (&a)[RT], const f4 (&b)[JT], int step) {
+            const bool kv = step * 16 + 4 * lq < p;
+            f4 am[RT];
 #pragma unroll
-            for (int s_ = 0; s_ < 4; ++s_) {
+            for (int t = 0; t < RT; ++t) am[t] = kv ? a[t] : f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int j = 0; j < JT; ++j) {
-                    const float b = jv[j] ? cp[s_ * ldc + j * 16] : 0.f;
+            for (int s_ = 0; s_ < 4; ++s_)
+#pragma unroll
+                for (int j = 0; j < JT; ++j)
 #pragma unroll
                     for (int t = 0; t < RT; ++t)
-                        acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t][s_], b, acc[t][j], 0, 0, 0);
-                }
-            }
-#pragma unroll
-            for (int t = 0; t < RT; ++t) a[t] = an[t];
+                        acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(am[t][s_], b[j][s_], acc[t][j], 0, 0, 0);
+        };
+        f4 a0[RT], a1[RT], b0[JT], b1[JT];
+        fetch(a0, b0, 0);
+        // scheduling barriers: the operands of step + 1 are requested BEFORE the MFMAs of step issue and waited
+        // for after them (left alone, the compiler gathered the requests of two steps behind the MFMAs and met
+        // them with vmcnt(0) at the loop head)
+        DS_PIN_ORDER();
+        for (int step = 0; step + 1 < nstep; step += 2) {  // both halves unconditional: a fetch whose use sits
+            fetch(a1, b1, step + 1);                       // under a condition is sunk to that use
+            DS_PIN_ORDER();
+            mfma(a0, b0, step);
+            DS_PIN_ORDER();
+            fetch(a0, b0, step + 2);
+            DS_PIN_ORDER();
+            mfma(a1, b1, step + 1);
+            DS_PIN_ORDER();
         }
+        if (nstep & 1) mfma(a0, b0, nstep - 1);
+        // lane (li, lq) owns rows 4 lq + g and the JT consecutive columns JT li .. JT li + JT - 1
 #pragma unroll
         for (int t = 0; t < RT; ++t)
 #pragma unroll
-            for (int j = 0; j < JT; ++j)
+            for (int g = 0; g < 4; ++g) {
+                const int64_t r = row0 + t * 16 + lq * 4 + g;
+                const int c0 = JT * li;
+                if (r >= n || c0 >= q) continue;
+                float* o = Out + r * ldo + c0;
+                FloatPack<JT> v;
+                if (c0 + JT <= q) {
+                    if (beta != 0.f) v = *reinterpret_cast<const FloatPack<JT>*>(o);
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int64_t r = row0 + t * 16 + lq * 4 + g;
-                    const int col = j * 16 + li;
-                    if (r < n && col < q) {
-                        float* o = Out + r * ldo + col;
-                        const float v = alpha * acc[t][j][g];
-                        *o = (beta == 0.f) ? v : fmaf(beta, *o, v);
+                    for (int j = 0; j < JT; ++j) {
+                        const float x = alpha * acc[t][j][g];
+                        v.v[j] = (beta == 0.f) ? x : fmaf(beta, v.v[j], x);
                     }
+                    *reinterpret_cast<FloatPack<JT>*>(o) = v;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < JT; ++j)
+                        if (c0 + j < q) {
+                            const float x = alpha * acc[t][j][g];
+                            o[j] = (beta == 0.f) ? x : fmaf(beta, o[j], x);
+                        }
                 }
+            }
     }
 }
 
@@ -286,7 +338,7 @@ template <int JT>
 int launch_mix_lds(const float* A, int64_t lda, int p, const float* C, int q, float* Out, int64_t ldo, int64_t n,
                    float alpha, float beta, hipStream_t st) {
     const int p16 = (p + 15) & ~15;
-    const size_t lds = (size_t)p16 * mix_ldc(q) * sizeof(float);
+    const size_t lds = (size_t)p16 * JT * 16 * sizeof(float);
     static size_t attr_bytes = 0;
     if (lds > 48 * 1024 && lds > attr_bytes) {  // opt in to large dynamic LDS (per instantiation, grows only)
         int rc = ds::check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&mix_lds_kernel<JT>),

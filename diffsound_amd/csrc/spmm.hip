@@ -360,6 +360,7 @@ int launch_wn(const int32_t* rowptr, const int32_t* colidx, const void* vals, co
     return DS_OK;
 }
 
+#include "spmm_union.inc"
 #ifdef DS_EXPERIMENTAL
 #include "spmm_experimental.inc"
 #endif
@@ -935,6 +936,8 @@ extern "C" int ds_spmm_batched(int kind, int epilogue, const int32_t* btab, int6
     return launch_batch_lpn<0, 0>(btab, nbatch, rowptr, colidx, vals, nnzb, nv, X, ldx, Y, ldy, lpn, st, epi);
 }
 
+#endif  // DS_EXPERIMENTAL
+
 extern "C" int ds_spmm_union(int epilogue, const int32_t* utab, const int32_t* ctab, int64_t ngroups, int cap_blocks,
                              const int32_t* gent,
                              const float* kgrp, int64_t nnzb, int64_t nv, const float* X, int64_t ldx, float* Y,
@@ -972,4 +975,4 @@ extern "C" int ds_spmm_union(int epilogue, const int32_t* utab, const int32_t* c
     DS_U(0, 0);
 #undef DS_U
 }
-#endif  // DS_EXPERIMENTAL
+

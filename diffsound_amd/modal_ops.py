@@ -41,7 +41,7 @@ def morton_order(vertices, bits=10):
 
 
 class TetSystem:
-    def __init__(self, vertices, tets, order, density, reorder=True):
+    def __init__(self, vertices, tets, order, density, reorder=True, level=0):
         """vertices (nv,3) float32 HIP tensor, tets (T,N) integer HIP tensor in the reference's local
         node order, N = 4 / 10.  With ``reorder`` the nodes are renumbered internally along a Morton
         curve; ``perm`` / ``inv_perm`` map between the caller's node ids and the internal ones and
@@ -94,38 +94,26 @@ class TetSystem:
                                   ulist=tl.ulist.to(dev), lidx=tl.lidx.to(dev))
             except RuntimeError:
                 self.tiles = None  # a row with more neighbours than a tile holds: keep the untiled kernels
-        # Node groups for the register-blocked SpMM (4 nodes per wave share their neighbour loads: 1.7x fewer
-        # panel loads).  EXPERIMENTAL, opt-in: correct, but no faster than the wave-per-node kernel, which PMC
-        # counters show to be bound by fp32 FMA issue + load latency rather than by gathered bytes.
+        # Node groups of the neighbour-union SpMM (ds_spmm_union, the default for blocks of <= 84 columns): one
+        # wavefront per 4 consecutive nodes walks the union of their neighbours (with the Morton numbering 0.58 x
+        # as many panel loads as one wavefront per node).  Every group is cut into chunks of whole entries that fit
+        # the kernel's LDS images (cap entries / blocks; almost always ONE chunk): ctab rows (e0, e1, b0, b1),
+        # utab rows (first chunk, end chunk) per group.  DS_SPMM_UNION=0 keeps the wave-per-node kernels
+        # (DS_SPMM_UNION_COARSE=0: on the corner-node level only); DS_SPMM_GROUPED=1 is the older
+        # register-blocked experiment on the same tables.
         self.groups = None
-        union = os.environ.get("DS_SPMM_UNION", "0") == "1" and hasattr(_hip.lib(), "ds_spmm_union")
+        union = os.environ.get("DS_SPMM_UNION", "1") != "0" and self.nv >= 8
+        if level == 1 and os.environ.get("DS_SPMM_UNION_COARSE", "1") == "0":
+            union = False
         if os.environ.get("DS_SPMM_GROUPED", "0") == "1" or union:
             gr = _hip.Groups(pat.rowptr, pat.colidx, self.nv)
             self.groups = dict(ne=gr.ne, gptr=gr.gptr.to(dev), gent=gr.gent.to(dev), goff=gr.goff.to(dev),
                                kperm=gr.kperm.to(dev), union=None)
             if union:
-                # neighbour-union kernel (EXPERIMENTAL build): every group is cut into chunks of whole entries that fit
-                # the kernel's LDS images (cap entries / blocks; almost always ONE chunk): ctab rows (e0, e1, b0, b1),
-                # utab rows (first chunk, end chunk) per group
-                import numpy as np
                 cap = int(os.environ.get("DS_UNION_CAP", "116"))
-                gp, go = gr.gptr.numpy().astype(np.int64), gr.goff.numpy().astype(np.int64)
-                crow, urow = [], []
-                for gi in range(len(gp) - 1):
-                    e, e_end = gp[gi], gp[gi + 1]
-                    first = len(crow)
-                    while e < e_end:
-                        # furthest entry end with <= cap blocks and <= cap entries
-                        lim = min(e_end, e + cap)
-                        e1 = int(np.searchsorted(go[e:lim + 1], go[e] + cap, side="right")) - 1 + e
-                        e1 = max(e1, e + 1)
-                        crow.append((e, e1, go[e], go[e1]))
-                        e = e1
-                    urow.append((first, len(crow)))
-                ct = torch.from_numpy(np.asarray(crow, dtype=np.int32))
-                if int((ct[:, 3] - ct[:, 2]).max()) <= cap:
-                    self.groups["union"] = dict(utab=torch.from_numpy(np.asarray(urow, dtype=np.int32)).to(dev),
-                                                ctab=ct.to(dev), capb=cap, ngroups=len(urow))
+                ut, ct = _hip.union_chunks(gr.gptr, gr.goff, cap)
+                if ct is not None:
+                    self.groups["union"] = dict(utab=ut.to(dev), ctab=ct.to(dev), capb=cap, ngroups=ut.shape[0])
         # batch table of the batched SpMM (one wave per run of consecutive nodes).  EXPERIMENTAL build, opt-in
         # (DS_SPMM_BATCHED=1): same speed as the wave-per-node kernels (the product is bound by the CU's gather
         # rate); kept as the base of the neighbour-union kernel.
@@ -172,7 +160,7 @@ class TetSystem:
         if bool((pa < 0).any()) or bool((pb < 0).any()):
             return None
         nvc = corners.numel()
-        csys = TetSystem(self.vertices[corners], cid[tets[:, list(cs)]], 1, self.density, reorder=False)
+        csys = TetSystem(self.vertices[corners], cid[tets[:, list(cs)]], 1, self.density, reorder=False, level=1)
         i32 = lambda t: t.to(torch.int32).contiguous()
         fine = torch.arange(self.nv, device=dev)
         mid = pa != pb
@@ -301,11 +289,13 @@ class _HipBlockOps:
     batches = None  # (nbatch, 4) int32 device table for the batched SpMM (<= 84 columns), or None
     batch_ops = os.environ.get("DS_SPMM_BATCH_OPS", "KMCR")  # which products use it: K X, M X, Chebyshev term, residual
 
-    def _union_ok(self, X):
+    def _union_ok(self, X, *others):
         g = getattr(getattr(self, "sys", None), "groups", None)
-        return (g is not None and g.get("union") is not None and self.kgrp is not None and X.shape[1] <= 84
-                and X.shape[1] % 4 == 0 and 12 * self.nv * _ld(X) < 0x7F000000 and X.data_ptr() % 16 == 0
-                and (_ld(X) * 4) % 16 == 0)
+        if g is None or g.get("union") is None or self.kgrp is None or X.shape[1] > 84 or X.shape[1] % 4:
+            return False
+        # every operand is addressed through a 32-bit buffer descriptor offset and read / written 16 bytes at a time
+        return all(12 * self.nv * _ld(T) < 0x7F000000 and T.data_ptr() % 16 == 0 and (_ld(T) * 4) % 16 == 0
+                   for T in (X,) + others if T is not None)
 
     def _union(self, epilogue, X, Y, R0=None, c1=0.0, c2=0.0, first=False):
         pp = _hip.ptr
@@ -331,7 +321,7 @@ class _HipBlockOps:
                    "ds_spmm_batched")
 
     def apply_K(self, X, out):
-        if self._union_ok(X):
+        if self._union_ok(X, out):
             self._union(0, X, out)
         elif self._batched_ok(X) and not self._has_tiles(X.shape[1]) and not self._has_groups(X.shape[1]):
             timed = self.spmm_events is not None and X.shape[1] == self.spmm_event_cols
@@ -438,7 +428,7 @@ class _HipBlockOps:
     def spmm_residual(self, X, R0, Y):
         """Y <- R0 - K X (<= 84 columns, one fused launch)."""
         pp = _hip.ptr
-        if self._union_ok(X):
+        if self._union_ok(X, Y, R0):
             self._union(2, X, Y, R0)
             self.counts["apply_K_cols"] += X.shape[1]
             return
@@ -491,7 +481,7 @@ class _HipBlockOps:
         return getattr(getattr(self, "sys", None), "tiles", None) is not None and ncols <= 84
 
     def _cheb_spmm_launch(self, Wk, Wprev, R0, c1, c2, first):
-        if self._union_ok(Wk):
+        if self._union_ok(Wk, Wprev, R0):
             self._union(1, Wk, Wprev, R0, c1, c2, first)
             self.counts["apply_K_cols"] += Wk.shape[1]
             return

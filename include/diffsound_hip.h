@@ -183,6 +183,21 @@ int ds_pack_groups(const float* vals_t, const int32_t* kperm, int64_t nnzb, floa
 int ds_spmm_grouped(int epilogue, const int32_t* gptr, const int32_t* gent, const int32_t* goff, const float* kgrp,
                     int64_t nv, const float* X, int64_t ldx, float* Y, int64_t ldy, const float* R0, int64_t ldr,
                     const float* dinv, int ncols, float c1, float c2, int first, ds_stream_t stream);
+/* Neighbour-union form of ds_spmm_bsr3 / ds_cheb_spmm / ds_spmm_residual for ncols <= 84 (the eigensolver's
+ * b-column products and every preconditioner term): one wavefront per group of 4 consecutive nodes walks the UNION
+ * of their neighbours, so a neighbour panel shared inside the group is gathered once (Morton order: 0.58 x the
+ * panel loads of one wavefront per node).  Tables from ds_groups_build - gent (union entries col | mask << 28),
+ * kgrp (TRANSPOSED 3x3 blocks in group order, ds_pack_groups) - cut into chunks of whole entries with at most
+ * cap_blocks (<= 276) blocks: ctab (nchunks x 4) = (e0, e1, b0, b1), utab (ngroups x 2) = chunk range of each
+ * group, ngroups = ceil(nv / 4).
+ * epilogue 0: Y <- A X ; 1: Y (= W_prev) <- X + c1 (X - Y) + c2 T (R0 - A X) (first != 0: Y not read) ;
+ * 2: Y <- R0 - A X.  X and Y distinct, 16-byte aligned rows; every operand block 3 nv ld 4 < 0x7f000000 bytes
+ * (larger problems use ds_cheb_spmm / ds_spmm_residual / ds_spmm_bsr3).
+ * (reference: torch.sparse.mm in src/lobpcg/_linalg_utils.py:36-37 and the iK callable of _lobpcg.py:441) */
+int ds_spmm_union(int epilogue, const int32_t* utab, const int32_t* ctab, int64_t ngroups, int cap_blocks,
+                  const int32_t* gent, const float* kgrp, int64_t nnzb, int64_t nv, const float* X, int64_t ldx,
+                  float* Y, int64_t ldy, const float* R0, int64_t ldr, const float* dinv, int ncols, float c1, float c2,
+                  int first, ds_stream_t stream);
 #ifdef DS_EXPERIMENTAL /* not in the default library: make -C diffsound_amd/csrc EXPERIMENTAL=1 */
 /* Batched form of ds_spmm_bsr3 / ds_cheb_spmm / ds_spmm_residual for ncols <= 84 (the default path of the
  * eigensolver's b-column products and of every preconditioner term): one wavefront per batch of consecutive
@@ -200,15 +215,6 @@ int ds_spmm_batched(int kind, int epilogue, const int32_t* btab, int64_t nbatch,
                     const int32_t* colidx, const float* vals, int64_t nnzb, int64_t nv, const float* X, int64_t ldx,
                     float* Y, int64_t ldy, const float* R0, int64_t ldr, const float* dinv, int ncols, float c1,
                     float c2, int first, ds_stream_t stream);
-/* Neighbour-union form (one wavefront per group of 4 consecutive nodes walks the UNION of their neighbours, so a
- * shared neighbour panel is gathered once): tables from ds_groups_build - gent (union entries col | mask << 28),
- * kgrp (transposed blocks in group order, ds_pack_groups) - cut into chunks of whole entries with at most
- * cap_blocks blocks: ctab (nchunks x 4) = (e0, e1, b0, b1), utab (ngroups x 2) = chunk range of each group.
- * Epilogues as above.  Correct, measured, and not faster than ds_cheb_spmm yet. */
-int ds_spmm_union(int epilogue, const int32_t* utab, const int32_t* ctab, int64_t ngroups, int cap_blocks,
-                  const int32_t* gent, const float* kgrp, int64_t nnzb, int64_t nv, const float* X, int64_t ldx,
-                  float* Y, int64_t ldy, const float* R0, int64_t ldr, const float* dinv, int ncols, float c1, float c2,
-                  int first, ds_stream_t stream);
 #endif
 /* Out <- alpha * A C + beta * Out,  A (n x p) f32, C (p x q) f32 row-major device, Out (n x q) f32.
  * Out must not alias A.  (reference: X <- S Z etc., _lobpcg.py:463-466) */

@@ -1,4 +1,5 @@
-"""Parked SpMM experiments (diffsound_amd/csrc/spmm_experimental.inc): parity with the production kernels.
+"""Parked SpMM experiment (the batched kernel of diffsound_amd/csrc/spmm_experimental.inc): parity with the
+wave-per-node kernels.
 Only runs against a library built with `make -C diffsound_amd/csrc EXPERIMENTAL=1` (skipped otherwise)."""
 import numpy as np
 import pytest
@@ -17,19 +18,19 @@ def dev():
         pytest.skip("no HIP device")
     from diffsound_amd import _hip
 
-    if not hasattr(_hip.lib(), "ds_spmm_union"):
+    if not hasattr(_hip.lib(), "ds_spmm_batched"):
         pytest.skip("library built without EXPERIMENTAL=1")
     return torch.device("cuda:0")
 
 
 @pytest.mark.parametrize("mesh,order,ncols", [("3", 1, 8), ("bowl", 1, 40), ("6", 2, 72), ("6", 2, 80)])
-@pytest.mark.parametrize("variant", ["union", "batched"])
-def test_experimental_spmm_matches_production(dev, monkeypatch, mesh, order, ncols, variant):
+def test_experimental_spmm_matches_production(dev, monkeypatch, mesh, order, ncols):
     from diffsound_amd import meshgen
     from diffsound_amd.diffelastic.mesh import TetMesh
     from diffsound_amd.modal_ops import HipModalOps, TetSystem
 
-    monkeypatch.setenv("DS_SPMM_UNION" if variant == "union" else "DS_SPMM_BATCHED", "1")
+    monkeypatch.setenv("DS_SPMM_BATCHED", "1")
+    monkeypatch.setenv("DS_SPMM_UNION", "0")  # the batched kernel is compared with the wave-per-node kernels
     if mesh == "bowl":
         m = np.load("tests/golden/g0_bowl_mesh.npz")
         v, t = m["verts"], m["tets"]
@@ -38,10 +39,7 @@ def test_experimental_spmm_matches_production(dev, monkeypatch, mesh, order, nco
     tm = TetMesh(torch.from_numpy(v).to(dev), torch.from_numpy(t).long().to(dev)).to_high_order(order)
     sysd = TetSystem(tm.vertices, tm.tets, order, 2700.0)
     ops = HipModalOps(sysd, 2e10, 2e10, two_level=False)
-    if variant == "union":
-        assert sysd.groups is not None and sysd.groups["union"] is not None
-    else:
-        assert ops.batches is not None
+    assert ops.batches is not None
     g = torch.Generator(device=dev).manual_seed(ncols)
     big = torch.randn((sysd.n, ncols + 16), generator=g, device=dev)
     X = big[:, 8:8 + ncols]  # a strided view, as in the solver
@@ -61,13 +59,9 @@ def test_experimental_spmm_matches_production(dev, monkeypatch, mesh, order, nco
 
     for _ in range(3):  # the bugs found while building these kernels were intermittent
         got = run()
-        saved = (sysd.groups["union"] if variant == "union" else None), ops.batches
-        if variant == "union":
-            sysd.groups["union"] = None
+        saved = ops.batches
         ops.batches = None
         ref = run()
-        if variant == "union":
-            sysd.groups["union"] = saved[0]
-        ops.batches = saved[1]
+        ops.batches = saved
         for x, y in zip(got, ref):
             assert rel(x, y) < 5e-6

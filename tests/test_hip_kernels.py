@@ -423,3 +423,56 @@ def test_errors_are_loud(dev):
         from diffsound_amd.modal_ops import TetSystem
 
         TetSystem(torch.zeros((4, 3)), torch.zeros((1, 4), dtype=torch.int64), 1, 1000.0)  # CPU tensors
+
+
+@pytest.mark.parametrize("mesh,order,ncols", [("2", 1, 8), ("3", 1, 8), ("bowl", 1, 40), ("bowl", 2, 24), ("6", 2, 72),
+                                              ("6", 2, 80), ("6", 2, 84), ("5", 2, 4)])
+def test_union_spmm_matches_wave_per_node(dev, mesh, order, ncols):
+    """ds_spmm_union (one wavefront per 4 nodes, shared neighbour panels gathered once; the default for <= 84
+    columns) against the wave-per-node kernels on the same operands: K X, both Chebyshev-term epilogues and the
+    residual epilogue, on strided views.  Repeated: the bugs met while building this kernel were intermittent
+    (a stale descriptor word read 5 wait states too early).  The oracle comparisons of this file (test_spmm,
+    test_fused_chebyshev_spmm, test_residual_and_cheb, the two-level tests) run through the same kernel."""
+    from diffsound_amd import meshgen
+    from diffsound_amd.diffelastic.mesh import TetMesh
+    from diffsound_amd.modal_ops import HipModalOps, TetSystem
+
+    if mesh == "bowl":
+        m = np.load("tests/golden/g0_bowl_mesh.npz")
+        v, t = m["verts"], m["tets"]
+    else:
+        v, t = meshgen.kuhn_box(int(mesh))
+    tm = TetMesh(torch.from_numpy(v).to(dev), torch.from_numpy(t).long().to(dev)).to_high_order(order)
+    sysd = TetSystem(tm.vertices, tm.tets, order, 2700.0)
+    ops = HipModalOps(sysd, 2e10, 2e10, two_level=False)
+    assert sysd.groups is not None and sysd.groups["union"] is not None
+    u = sysd.groups["union"]
+    ct, ut = u["ctab"].cpu().numpy(), u["utab"].cpu().numpy()
+    assert ut.shape == ((sysd.nv + 3) // 4, 2) and ut[0, 0] == 0 and ut[-1, 1] == ct.shape[0]
+    assert (ct[:, 3] - ct[:, 2]).max() <= u["capb"] and ct[-1, 3] == sysd.nnzb
+    g = torch.Generator(device=dev).manual_seed(ncols)
+    big = torch.randn((sysd.n, ncols + 16), generator=g, device=dev)
+    X = big[:, 8:8 + ncols]
+    Wp = torch.randn((sysd.n, ncols), generator=g, device=dev)
+    R0 = torch.randn((sysd.n, ncols), generator=g, device=dev) * 1e10
+
+    def run():
+        Y = torch.zeros((sysd.n, ncols), device=dev)
+        ops.apply_K(X, Y)
+        a = Wp.clone()
+        ops.cheb_spmm(X, a, R0, 0.31, 0.77, False)
+        b = Wp.clone()
+        ops.cheb_spmm(X, b, R0, 0.0, 0.5, True)
+        c = torch.zeros((sysd.n, ncols), device=dev)
+        ops.spmm_residual(X, R0, c)
+        return Y, a, b, c
+
+    assert ops._union_ok(X, Wp, R0)
+    for _ in range(3):
+        got = run()
+        sysd.groups["union"] = None
+        assert not ops._union_ok(X, Wp, R0)
+        ref = run()
+        sysd.groups["union"] = u
+        for x, y in zip(got, ref):
+            assert rel(x.cpu().numpy(), y.cpu().numpy()) < 5e-6
