@@ -1,0 +1,17 @@
+"""Launch the fused Chebyshev-term SpMM on an 80-column block a few times (for rocprofv3 --pmc runs)."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from diffsound_amd import meshgen
+from diffsound_amd.diffelastic.mesh import TetMesh
+from diffsound_amd.modal_ops import TetSystem, HipModalOps
+dev = torch.device('cuda')
+v, t = meshgen.kuhn_box(26)
+mesh = TetMesh(torch.from_numpy(v).to(dev), torch.from_numpy(t).long().to(dev)).to_high_order(2)
+sysd = TetSystem(mesh.vertices, mesh.tets, 2, 2700.0)
+ops = HipModalOps(sysd, 2e10, 2e10, two_level=False)
+X = torch.randn(sysd.n, 80, device=dev); W = torch.randn(sysd.n, 80, device=dev); R0 = torch.randn(sysd.n, 80, device=dev)
+for _ in range(int(sys.argv[1]) if len(sys.argv) > 1 else 4):
+    ops.cheb_spmm(X, W, R0, 0.3, 0.7, False)
+torch.cuda.synchronize()
+print("done", flush=True)
