@@ -77,12 +77,12 @@ __global__ void __launch_bounds__(256) assemble_blocks_kernel(const int32_t* __r
     for (int i = threadIdx.x; i < N * 4 * N * 4; i += blockDim.x) sD[i] = dtab[i];
     for (int i = threadIdx.x; i < N * N; i += blockDim.x) sM[i] = mtab[i];
     __syncthreads();
-    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= nnzb) return;
+    const int64_t s0 = (int64_t)blockIdx.x * blockDim.x;
+    const int64_t s = s0 + threadIdx.x;
     double H[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
     double msum = 0.0;
-    const int c_end = cptr[s + 1];
-    for (int c = cptr[s]; c < c_end; ++c) {
+    const int c_end = s < nnzb ? cptr[s + 1] : 0;
+    for (int c = s < nnzb ? cptr[s] : 0; c < c_end; ++c) {
         const int cid = clist[c];
         const int t = cid / (N * N);
         const int ab = cid - t * (N * N);
@@ -120,17 +120,26 @@ __global__ void __launch_bounds__(256) assemble_blocks_kernel(const int32_t* __r
             for (int j = 0; j < 3; ++j) H[i][j] = fma(J, h[i][j], H[i][j]);
         msum = fma(J, sM[a * N + b], msum);
     }
+    // The 9 doubles of a slot are contiguous in memory, the slots of neighbouring lanes 72 bytes apart: written
+    // straight from the registers every store instruction covered 8 of every 72 bytes (1.9 ms for 0.63 GB on the
+    // benchmark mesh).  The workgroup's 256 x 9 values go through LDS instead and leave as whole rows.
+    __shared__ double sOut[256 * 9];
     const double tr = H[0][0] + H[1][1] + H[2][2];
-    double* kl = klam + s * 9;
-    double* km = kmu + s * 9;
+    const int64_t nslot = min<int64_t>(256, nnzb - s0);
+    const int nval = (int)nslot * 9;
 #pragma unroll
-    for (int i = 0; i < 3; ++i)
+    for (int pass = 0; pass < 2; ++pass) {
+        __syncthreads();  // (pass 0: the tables are no longer read; pass 1: sOut has been drained)
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            kl[i * 3 + j] = H[i][j];
-            km[i * 3 + j] = H[j][i] + (i == j ? tr : 0.0);
-        }
-    ms[s] = msum;
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+                sOut[threadIdx.x * 9 + i * 3 + j] = pass == 0 ? H[i][j] : H[j][i] + (i == j ? tr : 0.0);
+        __syncthreads();
+        double* dst = (pass == 0 ? klam : kmu) + s0 * 9;
+        for (int e = threadIdx.x; e < nval; e += 256) dst[e] = sOut[e];
+    }
+    if (s < nnzb) ms[s] = msum;
 }
 
 __global__ void combine_values_kernel(const double* __restrict__ klam, const double* __restrict__ kmu,
