@@ -394,6 +394,84 @@ int launch_fast(const int32_t* rowptr, const int32_t* colidx, const void* vals, 
 
 }  // namespace
 
+// ------------------------------------------------------------------------------------------------
+// fp64-value products of the read-out (X^T K_lambda X, X^T K_mu X, X^T M X on the converged block: kinds 2 / 3,
+// fp64 values and result, fp32 X) for <= 84 columns: ONE WAVEFRONT PER NODE in the lane layout of the fp32
+// kernels above - lane (g, cl) loads 16 bytes of row g of every neighbour panel and, for 3x3 blocks, column g of
+// the block (3 doubles), accumulates its share of all three output rows in fp64 and the three lane groups are
+// merged at the end.  The generic kernel above gives a lane 2 columns of one node and makes it load all 9 values
+// of every block itself: 12 dependent-address loads per block and lane, 1.17 ms per 64-column product on the
+// benchmark mesh; this one issues 4.
+template <int KIND>
+__global__ void __launch_bounds__(256)
+    spmm_f64_node_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx,
+                         const double* __restrict__ vals, int64_t nv, const float* __restrict__ X, int64_t ldx,
+                         double* __restrict__ Y, int64_t ldy, int lpn, unsigned nblk) {
+    using f4 = __attribute__((ext_vector_type(4))) float;
+    using d2 = __attribute__((ext_vector_type(2))) double;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t node = (int64_t)ds::xcd_remap(blockIdx.x, nblk) * 4 + wave;
+    if (node >= nv) return;  // wave-uniform
+    const int g = lane / lpn, cl = lane - g * lpn;
+    const bool active = g < 3;
+    const int ga = active ? g : 0;
+    const int kb = __builtin_amdgcn_readfirstlane(rowptr[node]), ke = __builtin_amdgcn_readfirstlane(rowptr[node + 1]);
+    const float* xb = X + (int64_t)ga * ldx + cl * 4;
+    double acc[3][4];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) acc[r][v] = 0.0;
+#pragma unroll 4
+    for (int k = kb; k < ke; ++k) {
+        const int64_t col = colidx[k];
+        const f4 x = *reinterpret_cast<const f4*>(xb + col * 3 * ldx);
+        if (KIND == 0) {
+            const double* a = vals + (int64_t)k * 9 + ga;  // column g of the block
+            const double a0 = a[0], a1 = a[3], a2 = a[6];
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const double xv = (double)x[v];
+                acc[0][v] = fma(a0, xv, acc[0][v]);
+                acc[1][v] = fma(a1, xv, acc[1][v]);
+                acc[2][v] = fma(a2, xv, acc[2][v]);
+            }
+        } else {
+            const double m = vals[k];
+#pragma unroll
+            for (int v = 0; v < 4; ++v) acc[0][v] = fma(m, (double)x[v], acc[0][v]);  // m I3: row g feeds row g only
+        }
+    }
+    double out[4];
+    if (KIND == 0) {
+        // lane (g, cl) ends with output row g: its own share plus the shares of the two other groups, which send
+        // their row (g_src + s) mod 3 to the group s steps ahead
+#pragma unroll
+        for (int v = 0; v < 4; ++v) out[v] = ga == 0 ? acc[0][v] : (ga == 1 ? acc[1][v] : acc[2][v]);
+#pragma unroll
+        for (int s_ = 1; s_ <= 2; ++s_) {
+            const int to_row = (ga + s_) % 3;
+            int src_g = ga - s_;
+            if (src_g < 0) src_g += 3;
+            const int src_lane = active ? src_g * lpn + cl : lane;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const double send = to_row == 0 ? acc[0][v] : (to_row == 1 ? acc[1][v] : acc[2][v]);
+                out[v] += __shfl(send, src_lane, 64);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) out[v] = acc[0][v];
+    }
+    if (active) {
+        double* yp = Y + (node * 3 + g) * ldy + cl * 4;
+        *reinterpret_cast<d2*>(yp) = d2{out[0], out[1]};
+        *reinterpret_cast<d2*>(yp + 2) = d2{out[2], out[3]};
+    }
+}
+
 extern "C" int ds_spmm_bsr3(int kind, const int32_t* rowptr, const int32_t* colidx, const void* vals,
                             const void* vals_t, int64_t nv, const void* X, int64_t ldx, void* Y, int64_t ldy,
                             int ncols, ds_stream_t stream) {
@@ -425,6 +503,20 @@ extern "C" int ds_spmm_bsr3(int kind, const int32_t* rowptr, const int32_t* coli
     }
     DS_REQUIRE(ncols % 2 == 0 && ncols <= 128 && (xalign & 7) == 0 && (yalign & 15) == 0,
                "ds_spmm_bsr3: f64-output blocks need an even column count <= 128 and aligned rows (ncols=%d)", ncols);
+    static const bool generic64 = getenv("DS_SPMM_F64_GENERIC") != nullptr;  // A/B switch for benchmarking
+    if (ncols % 4 == 0 && ncols <= 84 && (xalign & 15) == 0 && !generic64) {
+        const unsigned nblk = (unsigned)ds::ceil_div(nv, 4);
+        if (kind == 2)
+            spmm_f64_node_kernel<0><<<nblk, 256, 0, st>>>(rowptr, colidx, static_cast<const double*>(vals), nv,
+                                                          static_cast<const float*>(X), ldx, static_cast<double*>(Y),
+                                                          ldy, ncols / 4, nblk);
+        else
+            spmm_f64_node_kernel<1><<<nblk, 256, 0, st>>>(rowptr, colidx, static_cast<const double*>(vals), nv,
+                                                          static_cast<const float*>(X), ldx, static_cast<double*>(Y),
+                                                          ldy, ncols / 4, nblk);
+        DS_LAUNCH_CHECK("spmm_f64_node_kernel");
+        return DS_OK;
+    }
     return kind == 2 ? launch<0, double, float, double, 2>(rowptr, colidx, vals, nv, X, ldx, Y, ldy, ncols, st)
                      : launch<1, double, float, double, 2>(rowptr, colidx, vals, nv, X, ldx, Y, ldy, ncols, st);
 }

@@ -364,6 +364,29 @@ def test_polish_products(case, dev):
         assert rel(a.cpu().numpy(), b.numpy()) < 2e-6  # assembly tolerance; the products themselves are fp64
 
 
+@pytest.mark.parametrize("ncols", [4, 16, 64, 84, 86, 128])
+def test_f64_value_spmm(case, dev, ncols):
+    """fp64-value products (kinds 2 / 3: K_lambda, K_mu blocks and the mass scalars in fp64, fp32 X, fp64 result) against
+    a dense fp64 product with the HIP-assembled values; <= 84 columns take the wave-per-node kernel, wider or
+    odd-multiple blocks the generic one; strided views."""
+    h = case["hops"]
+    s_ = h.sys
+    g = torch.Generator().manual_seed(ncols)
+    big = torch.randn((h.n, ncols + 8), generator=g).to(dev)
+    X = big[:, 4:4 + ncols]
+    rp, ci = s_.rowptr.cpu().numpy(), s_.colidx.cpu().numpy()
+    rows = np.repeat(np.arange(s_.nv), np.diff(rp))
+    Xd = X.double().cpu().numpy()
+    for kind, vals in ((2, s_.klam), (2, s_.kmu), (3, s_.ms)):
+        Y = torch.full((h.n, ncols + 2), float("nan"), dtype=torch.float64, device=dev)[:, :ncols]
+        h._spmm(kind, vals, X, Y)
+        blocks = vals.cpu().numpy().reshape(-1, 3, 3) if kind == 2 else vals.cpu().numpy()[:, None, None] * np.eye(3)
+        A = sp.bsr_matrix((blocks, ci, rp), shape=(h.n, h.n))
+        ref = A @ Xd
+        assert rel(Y.cpu().numpy(), ref) < 1e-13
+        assert rows.shape[0] == ci.shape[0]
+
+
 def test_rigid_basis(case):
     h = case["hops"]
     Y = h.rigid[:, :6].double().cpu().numpy()
