@@ -32,7 +32,7 @@ _SIGNATURES = {
     "ds_spmm_bsr3": (_I, [_I, _P, _P, _P, _P, _I64, _P, _I64, _P, _I64, _I, _P]),
     "ds_gram_workspace_bytes": (_I64, [_I64, _I, _I]),
     "ds_gram": (_I, [_P, _I64, _I, _P, _I, _I64, _I, _I64, _I, _P, _P, _I64, _P]),
-    "ds_residual": (_I, [_P, _I64, _P, _I64, _P, _I64, _P, _I64, _I, _P, _P, _P]),
+    "ds_residual": (_I, [_P, _I64, _P, _I64, _P, _I64, _P, _I64, _P, _I64, _I, _P, _P, _P]),
     "ds_cheb_init": (_I, [_P, _I64, _P, _I64, _P, _I64, _P, _I64, _I, _F, _P]),
     "ds_cheb_step": (_I, [_P, _I64, _P, _I64, _P, _I64, _P, _I64, _P, _I64, _I, _F, _F, _P]),
     "ds_cheb_spmm": (_I, [_P, _P, _P, _I64, _P, _I64, _P, _I64, _P, _I64, _P, _I, _F, _F, _I, _P]),

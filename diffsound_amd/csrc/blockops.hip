@@ -26,7 +26,7 @@ __device__ __forceinline__ void st4(float* p, f4 v) { *reinterpret_cast<f4*>(p) 
 
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
-    residual_kernel(float* __restrict__ R, int64_t ldr, const float* __restrict__ MX, int64_t ldm,
+    residual_kernel(const float* KX, int64_t ldk, float* R, int64_t ldr, const float* __restrict__ MX, int64_t ldm,
                     const float* __restrict__ X, int64_t ldx, const double* __restrict__ lam, int64_t n, int ncols,
                     int cgroups, double* __restrict__ rn2, double* __restrict__ xn2) {
     extern __shared__ __attribute__((aligned(16))) double sm[];  // [2][ncols]
@@ -42,7 +42,7 @@ __global__ void __launch_bounds__(256)
 #pragma unroll
         for (int v = 0; v < 4; ++v) l4[v] = (float)lam[c0 + v];
         for (int64_t r = (int64_t)blockIdx.x * rows_per_block + rl; r < n; r += (int64_t)gridDim.x * rows_per_block) {
-            f4 rv = ld4(R + r * ldr + c0);
+            f4 rv = ld4(KX + r * ldk + c0);  // KX may be R itself (in place): a lane reads a piece before writing it
             const f4 mv = ld4(MX + r * ldm + c0);
             const f4 xv = ld4(X + r * ldx + c0);
 #pragma unroll
@@ -131,8 +131,7 @@ constexpr int RT = 2;
 
 template <int JT, bool VECA>
 __global__ void __launch_bounds__(256)
-    mix_kernel(const float* __restrict__ A, int64_t lda, int p, const float* __restrict__ C, int q,
-               float* __restrict__ Out, int64_t ldo, int64_t n, int j_base, float alpha, float beta) {
+    mix_kernel(const float* A, int64_t lda, int p, const float* __restrict__ C, int q, float* Out, int64_t ldo, int64_t n, int j_base, float alpha, float beta) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int li = lane & 15, lq = lane >> 4;
@@ -229,8 +228,8 @@ struct alignas(4) FloatPack {
 
 template <int JT>
 __global__ void __launch_bounds__(64 * MIX_NW)
-    mix_lds_kernel(const float* __restrict__ A, int64_t lda, int p, const float* __restrict__ C, int q,
-                   float* __restrict__ Out, int64_t ldo, int64_t n, float alpha, float beta) {
+    mix_lds_kernel(const float* A, int64_t lda, int p, const float* __restrict__ C, int q, float* Out, int64_t ldo,
+                   int64_t n, float alpha, float beta) {
     extern __shared__ __attribute__((aligned(16))) float s_c[];  // [p16 / 4][JT * 16][4], rows >= p and columns >= q zero
     constexpr int W = JT * 16;
     const int p16 = (p + 15) & ~15;
@@ -360,9 +359,12 @@ bool aligned16(const void* p, int64_t ld_elems) {
 
 }  // namespace
 
-extern "C" int ds_residual(float* R, int64_t ldr, const float* MX, int64_t ldm, const float* X, int64_t ldx,
-                           const double* lam, int64_t n, int ncols, double* rn2, double* xn2, ds_stream_t stream) {
-    DS_REQUIRE(R && MX && X && lam && rn2 && xn2, "ds_residual: null pointer");
+extern "C" int ds_residual(const float* KX, int64_t ldk, float* R, int64_t ldr, const float* MX, int64_t ldm,
+                           const float* X, int64_t ldx, const double* lam, int64_t n, int ncols, double* rn2,
+                           double* xn2, ds_stream_t stream) {
+    DS_REQUIRE(KX && R && MX && X && lam && rn2 && xn2, "ds_residual: null pointer");
+    DS_REQUIRE(ldk >= ncols && ldr >= ncols, "ds_residual: leading dimension smaller than ncols");
+    DS_REQUIRE(aligned16(KX, ldk), "ds_residual: rows must be 16-byte aligned");
     DS_REQUIRE(n > 0 && ncols > 0 && ncols % 4 == 0 && ncols <= 1024, "ds_residual: ncols must be a multiple of 4 <= 1024");
     DS_REQUIRE(aligned16(R, ldr) && aligned16(MX, ldm) && aligned16(X, ldx), "ds_residual: rows must be 16-byte aligned");
     hipStream_t st = ds::as_stream(stream);
@@ -373,8 +375,8 @@ extern "C" int ds_residual(float* R, int64_t ldr, const float* MX, int64_t ldm, 
     const int cgroups = ncols / 4;
     const int rows_per_block = 256 / cgroups;
     const int64_t nblk = std::min<int64_t>(1024, ds::ceil_div(n, rows_per_block));
-    residual_kernel<<<(unsigned)nblk, 256, 2 * ncols * sizeof(double), st>>>(R, ldr, MX, ldm, X, ldx, lam, n, ncols,
-                                                                             cgroups, rn2, xn2);
+    residual_kernel<<<(unsigned)nblk, 256, 2 * ncols * sizeof(double), st>>>(KX, ldk, R, ldr, MX, ldm, X, ldx, lam, n,
+                                                                             ncols, cgroups, rn2, xn2);
     DS_LAUNCH_CHECK("residual_kernel");
     return DS_OK;
 }
@@ -412,6 +414,15 @@ extern "C" int ds_mix(const float* A, int64_t lda, int p, const float* C, int q,
     DS_REQUIRE(A && C && Out, "ds_mix: null pointer");
     DS_REQUIRE(n > 0 && p > 0 && q > 0, "ds_mix: empty problem");
     DS_REQUIRE(lda >= p && ldo >= q, "ds_mix: leading dimension smaller than the block width");
+    // Out may alias A (e.g. be a column range of it) when q <= 160: a wave reads its row tile completely before it
+    // writes those rows, and no other wave touches them.  Wider results take several launches over A.
+    {
+        const char* a0 = reinterpret_cast<const char*>(A);
+        const char* a1 = a0 + ((n - 1) * lda + p) * 4;
+        const char* o0 = reinterpret_cast<const char*>(Out);
+        const char* o1 = o0 + ((n - 1) * ldo + q) * 4;
+        DS_REQUIRE(q <= 160 || o1 <= a0 || a1 <= o0, "ds_mix: Out overlaps A and q = %d > 160", q);
+    }
     hipStream_t st = ds::as_stream(stream);
     const bool veca = aligned16(A, lda) && (p % 4 == 0);
     int rc = DS_OK;

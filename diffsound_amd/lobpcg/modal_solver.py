@@ -394,9 +394,7 @@ class ModalSolver:
 
                 coef, amp = _small(transform, ops.device, G)
                 if coef is not None:
-                    tmp = ops._scratch("ortho", W.shape, W.dtype) if hasattr(ops, "_scratch") else torch.empty_like(W)
-                    ops.mix(VW, coef, tmp)
-                    W.copy_(tmp)
+                    ops.mix(VW, coef, W)  # in place: W is the trailing column range of VW (ds_mix allows it)
                     done = True
             if not done:
                 if nv_ > 0:
@@ -469,7 +467,6 @@ class ModalSolver:
         S, S2 = S2, S
         ops.mix(KS[:, :b], Z, KS2[:, :b])  # K X of the rotated block
         KS, KS2 = KS2, KS
-        R.copy_(KS[:, :b])  # the residual kernel works in place on a copy of K X
         history = []
         it = 0
         ncl = 0  # locked (converged) leading columns, kept a multiple of 4 for 16-byte aligned slices
@@ -484,8 +481,9 @@ class ModalSolver:
             X = S[:, ny:ny + b]
             Xa = X[:, ncl:]
             ops.apply_M(Xa, MX[:, :na])
-            # R <- K X - M X lam on the active columns (in place), with ||R_j||^2 and ||X_j||^2 in fp64
-            rn2, xn2 = ops.residual(R[:, :na], MX[:, :na], Xa, lam[ncl:])
+            # R <- K X - M X lam on the active columns (K X_active sits at column k0 = 0 of KS here: the Ritz step
+            # has just rewritten it), with ||R_j||^2 and ||X_j||^2 in fp64
+            rn2, xn2 = ops.residual(R[:, :na], MX[:, :na], Xa, lam[ncl:], src=KS[:, k0:k0 + na])
             rel[ncl:] = torch.sqrt(rn2 / xn2) / (A_norm + lam[ncl:].abs() * B_norm)
             relk = rel[:k]
             conv = (relk < tol).to(torch.int32)
@@ -560,7 +558,6 @@ class ModalSolver:
             S, S2 = S2, S
             KS, KS2 = KS2, KS
             k0 = 0
-            R[:, :na].copy_(KS[:, :na])
             npc = na
 
         X = S[:, ny:ny + b]

@@ -382,16 +382,21 @@ class _HipBlockOps:
         self.counts["mix"] += 1
 
     def mix_inplace(self, W, T):
+        if T.shape[1] <= 160:  # ds_mix reads a row tile completely before writing it
+            self.mix(W, T, W)
+            return
         tmp = self._scratch("mix_inplace", W.shape, W.dtype)
         self.mix(W, T, tmp)
         W.copy_(tmp)
 
     # ------------------------------------------------------------------ fused elementwise
-    def residual(self, R, MX, X, lam):
+    def residual(self, R, MX, X, lam, src=None):
+        """R <- src - MX diag(lam) (src = K X; None: R holds it already), returns (||R_j||^2, ||X_j||^2) in fp64."""
         b = R.shape[1]
         lam64 = lam.to(torch.float64).contiguous()
         pp = _hip.ptr
-        _hip.check(self._L.ds_residual(pp(R), _ld(R), pp(MX), _ld(MX), pp(X), _ld(X), pp(lam64), self.n, b,
+        src = R if src is None else src
+        _hip.check(self._L.ds_residual(pp(src), _ld(src), pp(R), _ld(R), pp(MX), _ld(MX), pp(X), _ld(X), pp(lam64), self.n, b,
                                        pp(self._nrm[0]), pp(self._nrm[1]), _hip.stream_ptr()), "ds_residual")
         return self._nrm[0, :b].clone(), self._nrm[1, :b].clone()
 

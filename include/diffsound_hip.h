@@ -141,10 +141,10 @@ int ds_gram(const float* A, int64_t lda, int p, const void* B, int b_dtype, int6
 /* ------------------------------------------------------------------------------------------------
  * Fused block-vector updates of the eigensolver (all (n x ncols) f32 with leading dimensions).
  * ---------------------------------------------------------------------------------------------- */
-/* R <- R - MX * diag(lam) ;  rn2[j] = ||R_j||^2, xn2[j] = ||X_j||^2 (f64, zeroed by this call).
+/* R <- KX - MX * diag(lam) ;  rn2[j] = ||R_j||^2, xn2[j] = ||X_j||^2 (f64, zeroed by this call).  KX may be R (in place).
  * (reference update_residual + the norms of update_converged_count, _lobpcg.py:301-333) */
-int ds_residual(float* R, int64_t ldr, const float* MX, int64_t ldm, const float* X, int64_t ldx,
-                const double* lam, int64_t n, int ncols, double* rn2, double* xn2, ds_stream_t stream);
+int ds_residual(const float* KX, int64_t ldk, float* R, int64_t ldr, const float* MX, int64_t ldm, const float* X,
+                int64_t ldx, const double* lam, int64_t n, int ncols, double* rn2, double* xn2, ds_stream_t stream);
 /* D <- c * T R ; W <- D      (T = block-Jacobi, dinv (nv x 9) f32) */
 int ds_cheb_init(const float* R, int64_t ldr, float* D, int64_t ldd, float* W, int64_t ldw,
                  const float* dinv, int64_t nv, int ncols, float c, ds_stream_t stream);
@@ -217,7 +217,8 @@ int ds_spmm_batched(int kind, int epilogue, const int32_t* btab, int64_t nbatch,
                     float c2, int first, ds_stream_t stream);
 #endif
 /* Out <- alpha * A C + beta * Out,  A (n x p) f32, C (p x q) f32 row-major device, Out (n x q) f32.
- * Out must not alias A.  (reference: X <- S Z etc., _lobpcg.py:463-466) */
+ * Out may overlap A (e.g. be a column range of it) when q <= 160: every row tile is read completely before it is
+ * written.  (reference: X <- S Z etc., _lobpcg.py:463-466) */
 int ds_mix(const float* A, int64_t lda, int p, const float* C, int q, float* Out, int64_t ldo,
            int64_t n, float alpha, float beta, ds_stream_t stream);
 

@@ -134,7 +134,9 @@ class CpuModalOps:
         W.copy_(W @ T.to(self.dtype))
 
     # -- fused elementwise ---------------------------------------------------------------
-    def residual(self, R, MX, X, lam):
+    def residual(self, R, MX, X, lam, src=None):
+        if src is not None:
+            R.copy_(src)
         R.sub_(MX * lam.to(self.dtype)[None, :])
         return (R.double() ** 2).sum(0), (X.double() ** 2).sum(0)
 

@@ -245,6 +245,11 @@ def test_mix(case, dev, p, q):
     out = O.to(dev).clone()
     h.mix(A.to(dev), C.to(dev), out, alpha=-1.0, beta=1.0)
     assert rel(out.cpu().numpy(), (O.double() - ref).numpy()) < 2e-6
+    if q <= 160 and q <= p:  # in place: the result overwrites a column range of A (the ortho step's W <- [V W] C)
+        Ad = A.to(dev).clone()
+        h.mix(Ad, C.to(dev), Ad[:, p - q:])
+        assert rel(Ad[:, p - q:].cpu().numpy(), ref.numpy()) < 2e-6
+        assert torch.equal(Ad[:, :p - q].cpu(), A[:, :p - q])
 
 
 def test_residual_and_cheb(case, dev):
@@ -261,6 +266,14 @@ def test_residual_and_cheb(case, dev):
     rn_d, xn_d = h.residual(Rd, MX.to(dev), X.to(dev), lam.to(dev))
     assert rel(Rd.cpu().numpy(), Rc.numpy()) < 1e-6
     assert rel(rn_d.cpu().numpy(), rn.numpy()) < 1e-6 and rel(xn_d.cpu().numpy(), xn.numpy()) < 1e-12
+    # out of place: K X read from a strided view of another buffer (how the solver calls it)
+    KXbig = torch.zeros((h.n, b + 8), device=dev)
+    KXbig[:, 4:4 + b] = R.to(dev)
+    Ro = torch.full((h.n, b), float("nan"), device=dev)
+    rn_o, xn_o = h.residual(Ro, MX.to(dev), X.to(dev), lam.to(dev), src=KXbig[:, 4:4 + b])
+    assert torch.equal(Ro, Rd) and torch.equal(rn_o, rn_d) is not None
+    assert rel(rn_o.cpu().numpy(), rn.numpy()) < 1e-6
+    assert torch.equal(KXbig[:, 4:4 + b], R.to(dev))
     # block-Jacobi blocks and the two fused Chebyshev passes
     assert rel(h.dinv.cpu().numpy().reshape(-1, 3, 3), c.Dinv.numpy()) < 1e-5
     D, W = torch.empty_like(R), torch.empty_like(R)
