@@ -14,7 +14,7 @@ def table(f, n=14):
         elif name.startswith("void at::native::elementwise_kernel_manual_unroll"):
             name = "torch copy kernel (`Tensor.copy_`)"
         else:
-            name = "`" + name.split("(")[0] + "`"
+            name = "`" + name.split("(")[0].replace("void ", "") + "`"
         out.append(f"| {name} | {r[1]} | {r[2]} | {r[3]} | {r[6]} |")
     t = rows[-1]
     out.append(f"| all kernels | {t[1]} | {t[2]} | | 100 |")
@@ -24,8 +24,9 @@ d = json.load(open(P("r01_bench_n1.json")))
 r = d["roofline"]; lv = r["levels"]; solo = r["solo"]
 t1, rows1 = table("r01_bench_lanes1_kernel_stats.csv")
 t3, rows3 = table("r01_bench_kernel_stats.csv")
-fused1 = next(x for x in rows1 if "spmm_wave_node_kernel<0, 3, 20, 1>" in x[0])
-fused3 = next(x for x in rows3 if "spmm_wave_node_kernel<0, 3, 20, 1>" in x[0])
+fused1 = next(x for x in rows1 if "spmm_union_kernel<20, 1" in x[0])
+fused3 = next(x for x in rows3 if "spmm_union_kernel<20, 1" in x[0])
+pmc = json.load(open(P("spmm_pmc_bytes_per_launch.json")))["cells26_cols80"]
 tot1 = float(rows1[-1][2]); npass1 = 11
 readme = f'''# profiles/ — round 1 evidence (MI355X, gfx950, ROCm 7.2)
 
@@ -38,7 +39,7 @@ numeric assembly in every pass.  (regenerate this file with `python tools/make_p
 | `r01_bench_n1.json` | the JSON line of `python bench.py` (N = 1, 3 steps, 1 warm-up, CPU baseline included): {d["value"]:.1f} passes/s |
 | `r01_bench_kernel_stats.csv` | `rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --no-cpu-baseline`, top 45 kernels (target pass + warm-up step + 3 timed steps; 3 hypothesis lanes overlap, so durations are stretched by sharing) |
 | `r01_bench_lanes1_kernel_stats.csv` | the same with `--lanes 1 --hyp-per-gpu 2`: one hypothesis at a time, every kernel alone on the device - the table to read kernel durations from |
-| `spmm_pmc_bytes_per_launch.json` | HBM traffic of the dominant kernel (fine level) from separate `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes, gfx950 correction (2·FETCH + WRITE)·1024 as prescribed by `guides/MI355X_MICROARCH.md`; the kernel is unchanged since it was taken |
+| `spmm_pmc_bytes_per_launch.json` | HBM-side traffic of the dominant kernel (fine level) from separate `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes (`tools/pmc_bytes.sh`), gfx950 correction (2·FETCH + WRITE)·1024 as prescribed by `guides/MI355X_MICROARCH.md` |
 
 (summaries made on the GPU box by `tools/summarize_prof.py`; the raw traces exceed what travels back)
 
@@ -46,11 +47,14 @@ numeric assembly in every pass.  (regenerate this file with `python tools/make_p
 
 {t1}
 
-{tot1 / npass1:.0f} ms of kernels per pass. `spmm_wave_node_kernel<0,3,20,1>` is the fused Chebyshev-term SpMM on a full 80-column block;
-the name covers the fine level (252 launches, ≈ 0.35 ms each = 743.1 MB algorithmic → 2.1 TB/s) and the corner-node level
-(1 545 launches, ≈ 0.045 ms each), {float(fused1[3]):.0f} µs on average; `<0,3,0,1>` is the same kernel on the narrower blocks left after locking,
-`<1,3,20,0>` the mass product, `<0,3,·,0>` K·W, `<0,3,·,2>` the residual handed to the corner-node level,
-`gram_partial_kernel<float>` the fp64-MFMA Gram blocks [V W]ᵀ(MW) and [X P W]ᵀ(KW), `mix_lds_kernel` the Ritz / ortho updates.
+{(tot1 - 47.6) / npass1:.0f} ms of kernels per pass (without the one-off rocBLAS set-up product). `spmm_union_kernel<20,1,116>` is the fused
+Chebyshev-term SpMM on a full 80-column block (one wavefront per 4 nodes walking the union of their neighbours); the
+name covers the fine level (252 launches, ≈ 0.29 ms each = 743.1 MB algorithmic) and the corner-node level
+(1 545 launches, ≈ 0.05 ms each), {float(fused1[3]):.0f} µs on average; `<0,1,…>` is the same kernel on the narrower blocks left after
+locking, `<·,0,…>` K·W, `<·,2,…>` the residual handed to the corner-node level, `spmm_wave_node_kernel<1,3,·,0>` the mass
+product (node-scalar values, one wavefront per node), `gram32_partial_kernel` the folded-fp32 MFMA Gram blocks
+[V W]ᵀ(MW) and [X P W]ᵀ(KW), `mix_lds_kernel` the Ritz / ortho updates, `spmm_f64_node_kernel` and
+`gram_partial_kernel<double>` the fp64 read-out.
 
 ## Default run, 3 lanes (`r01_bench_kernel_stats.csv`)
 
@@ -61,9 +65,10 @@ The dominant kernel by total time is the fused Chebyshev-term SpMM. Its rocprofv
 timed region inside `bench.py` ({r["avg_launch_ms"]:.3f} ms over {r["launches_timed"]} launches: fine level {lv["fine"]["avg_launch_ms"]:.2f} ms, corner-node level {lv["corner_node"]["avg_launch_ms"]:.3f} ms;
 a different run, without the profiler) are both stretched by the three lanes sharing the device: `roofline.achieved` =
 {r["achieved"]:.0f} GB/s. Alone on the device the fine-level launch takes {solo["avg_launch_ms"]:.3f} ms (`roofline.solo` in the JSON; the
-single-lane profile above agrees), i.e. {solo["achieved"] / 1e3:.2f} TB/s algorithmic = {100 * solo["frac"]:.1f} % of the 8 TB/s HBM peak, with 870.7 MB of
-PMC traffic per launch (1.17 × algorithmic). It is bound by the CU gather path (≈ 27 B/clk/CU for the 960-byte neighbour
-panels), not by HBM: see DESIGN.md §5 for the experiments.
+single-lane profile above agrees; 0.275–0.279 ms on contiguous operands in `tools/mb_kx_time.py` - the solver's blocks are
+column ranges of a 248-column buffer), i.e. {solo["achieved"] / 1e3:.2f} TB/s algorithmic = {100 * solo["frac"]:.1f} % of the 8 TB/s HBM peak, with {pmc / 1e6:.1f} MB of
+PMC traffic per launch ({pmc / 743098484:.2f} × algorithmic). It is bound by the CU gather path (≈ 27 B/clk/CU for the 960-byte neighbour
+panels) plus the per-entry LDS / FMA work, not by HBM: see DESIGN.md §5.
 
 ## History this round (C3, one MI355X)
 
@@ -75,14 +80,19 @@ panels), not by HBM: see DESIGN.md §5 for the experiments.
 | symmetric/skip-tile Gram, conditional second ortho sweep | 8.5 |
 | 3 hypotheses in flight per GPU (stream + host thread each) | 13.9 |
 | Rayleigh–Ritz by recurrence, single-sweep projected Cholesky-QR, assembly in every pass | 14.5 |
-| persistent LDS-staged `mix` kernel | {d["value"]:.1f} |
+| persistent LDS-staged `mix` kernel | 15.8 |
+| Gram on the fp32 MFMA folded into fp64 every 48 rows (240×80: 0.466 → 0.230 ms) | 16.5 |
+| neighbour-union SpMM promoted to the default on both levels (fused term 0.332 → 0.275 ms), `mix` with `ds_read_b128` operands | 18.0 |
+| assembly stores through LDS (2.0 → 0.45 ms), wave-per-node fp64 read-out products, in-place residual / ortho update | {d["value"]:.1f} |
 
 SpMM kernel history (80 columns, K·X, micro-benchmark `tools/mb_spmm.py`): node groups per wave 0.441 ms → Morton order
 0.426 → wave per node with scalar metadata 0.340 → cooperative row metadata (readlane ids, LDS coefficients) 0.286 →
 buffer loads with scalar panel offsets 0.271. Variants measured and parked because they are not faster (the product is
 gather-bound; `make EXPERIMENTAL=1`): LDS-tiled 0.69–0.94 ms, register-blocked 4 nodes per wave 0.273, software-pipelined
-window 0.301, batched (one wave per run of nodes) 0.282, neighbour union (4 nodes share their panel loads) 0.289
-(fused term 0.311 against 0.325).
+window 0.301, batched (one wave per run of nodes) 0.282.  The neighbour union (4 nodes share their panel loads) went from
+0.289 / fused 0.311 ms (compiler-scheduled FMAs and coefficient reads) to 0.268 / 0.275 ms with inline-asm packed FMAs on
+accumulator halves that never change registers and without the epilogue-row touch during staging, against 0.272 / 0.322 ms
+for one wavefront per node: it is now the production kernel.
 '''
 open(P("README.md"), "w").write(readme)
 print("profiles/README.md written")
