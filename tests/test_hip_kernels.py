@@ -462,7 +462,7 @@ def test_errors_are_loud(dev):
 
 
 @pytest.mark.parametrize("mesh,order,ncols", [("2", 1, 8), ("3", 1, 8), ("bowl", 1, 40), ("bowl", 2, 24), ("6", 2, 72),
-                                              ("6", 2, 80), ("6", 2, 84), ("5", 2, 4)])
+                                              ("6", 2, 80), ("6", 2, 84), ("5", 2, 4), ("3+unused", 1, 16)])
 def test_union_spmm_matches_wave_per_node(dev, mesh, order, ncols):
     """ds_spmm_union (one wavefront per 4 nodes, shared neighbour panels gathered once; the default for <= 84
     columns) against the wave-per-node kernels on the same operands: K X, both Chebyshev-term epilogues and the
@@ -476,12 +476,17 @@ def test_union_spmm_matches_wave_per_node(dev, mesh, order, ncols):
     if mesh == "bowl":
         m = np.load("tests/golden/g0_bowl_mesh.npz")
         v, t = m["verts"], m["tets"]
+    elif mesh == "3+unused":  # 9 clustered vertices that no tet references: empty rows and one whole empty group
+        v, t = meshgen.kuhn_box(3)
+        v = np.concatenate([v, np.array([[9.0, 9.0, 9.0 + 0.01 * i] for i in range(9)], dtype=v.dtype)], 0)
     else:
         v, t = meshgen.kuhn_box(int(mesh))
     tm = TetMesh(torch.from_numpy(v).to(dev), torch.from_numpy(t).long().to(dev)).to_high_order(order)
     sysd = TetSystem(tm.vertices, tm.tets, order, 2700.0)
     ops = HipModalOps(sysd, 2e10, 2e10, two_level=False)
     assert sysd.groups is not None and sysd.groups["union"] is not None
+    if mesh == "3+unused":
+        assert int((sysd.rowptr[1:] == sysd.rowptr[:-1]).sum()) == 9
     u = sysd.groups["union"]
     ct, ut = u["ctab"].cpu().numpy(), u["utab"].cpu().numpy()
     assert ut.shape == ((sysd.nv + 3) // 4, 2) and ut[0, 0] == 0 and ut[-1, 1] == ct.shape[0]
