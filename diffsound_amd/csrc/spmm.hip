@@ -1036,22 +1036,22 @@ extern "C" int ds_spmm_union(int epilogue, const int32_t* utab, const int32_t* c
                              int64_t ldy, const float* R0, int64_t ldr, const float* dinv, int ncols, float c1, float c2,
                              int first, ds_stream_t stream) {
     DS_REQUIRE(utab && ctab && gent && kgrp && X && Y, "ds_spmm_union: null pointer");
-    DS_REQUIRE(epilogue >= 0 && epilogue <= 2, "ds_spmm_union: bad epilogue %d", epilogue);
-    DS_REQUIRE(epilogue == 0 || R0, "ds_spmm_union: the epilogue needs R0");
+    DS_REQUIRE(epilogue >= 0 && epilogue <= 3, "ds_spmm_union: bad epilogue %d", epilogue);
+    DS_REQUIRE(epilogue == 0 || epilogue == 3 || R0, "ds_spmm_union: the epilogue needs R0");
     DS_REQUIRE(epilogue != 1 || dinv, "ds_spmm_union: the Chebyshev epilogue needs dinv");
     DS_REQUIRE(nv > 0 && ngroups == (nv + 3) / 4 && nnzb > 0 && ncols > 0 && ncols % 4 == 0 && ncols <= 84,
                "ds_spmm_union: ncols must be a multiple of 4 <= 84 and ngroups = ceil(nv / 4)");
     DS_REQUIRE(cap_blocks > 0 && cap_blocks <= 276, "ds_spmm_union: a group of %d blocks exceeds the LDS image", cap_blocks);
-    DS_REQUIRE(ldx >= ncols && ldy >= ncols && (epilogue == 0 || ldr >= ncols),
+    DS_REQUIRE(ldx >= ncols && ldy >= ncols && (epilogue == 0 || epilogue == 3 || ldr >= ncols),
                "ds_spmm_union: leading dimension smaller than ncols");
     DS_REQUIRE(X != Y, "ds_spmm_union: X and Y must be different buffers");
     DS_REQUIRE(3 * nv * ldx * 4 < (int64_t)PIPE_OOB && 3 * nv * ldy * 4 < (int64_t)PIPE_OOB &&
-                   (epilogue == 0 || 3 * nv * ldr * 4 < (int64_t)PIPE_OOB),
+                   (epilogue == 0 || epilogue == 3 || 3 * nv * ldr * 4 < (int64_t)PIPE_OOB),
                "ds_spmm_union: block of %lld bytes exceeds the descriptor range", (long long)(3 * nv * ldx * 4));
     DS_REQUIRE(nnzb * 36 < ((int64_t)1 << 32), "ds_spmm_union: value array exceeds the descriptor range");
     uintptr_t al = reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(Y) | (uintptr_t)(ldx * 4) |
                    (uintptr_t)(ldy * 4) | reinterpret_cast<uintptr_t>(kgrp) | reinterpret_cast<uintptr_t>(ctab);
-    if (epilogue) al |= reinterpret_cast<uintptr_t>(R0) | (uintptr_t)(ldr * 4);
+    if (epilogue == 1 || epilogue == 2) al |= reinterpret_cast<uintptr_t>(R0) | (uintptr_t)(ldr * 4);
     DS_REQUIRE((al & 15) == 0, "ds_spmm_union: rows, kgrp and ctab must be 16-byte aligned");
     hipStream_t st = ds::as_stream(stream);
     const ChebEpilogue epi{R0, ldr, dinv, c1, c2, first};
@@ -1060,10 +1060,12 @@ extern "C" int ds_spmm_union(int epilogue, const int32_t* utab, const int32_t* c
     if (lpn == 20) {
         if (epilogue == 1) DS_U(20, 1);
         if (epilogue == 2) DS_U(20, 2);
+        if (epilogue == 3) DS_U(20, 3);
         DS_U(20, 0);
     }
     if (epilogue == 1) DS_U(0, 1);
     if (epilogue == 2) DS_U(0, 2);
+    if (epilogue == 3) DS_U(0, 3);
     DS_U(0, 0);
 #undef DS_U
 }

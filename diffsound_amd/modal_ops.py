@@ -40,6 +40,9 @@ def morton_order(vertices, bits=10):
     return torch.argsort(key, stable=True)
 
 
+_UNION_M = os.environ.get("DS_SPMM_UNION_M", "1") != "0"  # A/B switch: mass product on the neighbour-union kernel
+
+
 class TetSystem:
     def __init__(self, vertices, tets, order, density, reorder=True, level=0):
         """vertices (nv,3) float32 HIP tensor, tets (T,N) integer HIP tensor in the reference's local
@@ -248,6 +251,7 @@ class _HipBlockOps:
     m_kind = 1  # 1: M = M_s (x) I3 (one scalar per block), 0: general 3x3 blocks
     k32t = None
     kgrp = None  # transposed blocks in node-group order (register-blocked SpMM)
+    mgrp = None  # node-scalar mass values in node-group order (neighbour-union SpMM, epilogue 3)
 
     def _init_common(self, rowptr, colidx, nv, device):
         self.rowptr, self.colidx = rowptr, colidx
@@ -301,8 +305,9 @@ class _HipBlockOps:
         pp = _hip.ptr
         g = self.sys.groups
         u = g["union"]
-        _hip.check(self._L.ds_spmm_union(epilogue, pp(u["utab"]), pp(u["ctab"]), u["ngroups"], u["capb"], pp(g["gent"]), pp(self.kgrp),
-                                         self.kgrp.shape[0], self.nv, pp(X), _ld(X), pp(Y), _ld(Y), pp(R0),
+        vals = self.mgrp if epilogue == 3 else self.kgrp
+        _hip.check(self._L.ds_spmm_union(epilogue, pp(u["utab"]), pp(u["ctab"]), u["ngroups"], u["capb"], pp(g["gent"]), pp(vals),
+                                         vals.shape[0], self.nv, pp(X), _ld(X), pp(Y), _ld(Y), pp(R0),
                                          0 if R0 is None else _ld(R0), pp(self.dinv) if epilogue == 1 else None,
                                          X.shape[1], float(c1), float(c2), int(bool(first)), _hip.stream_ptr()),
                    "ds_spmm_union")
@@ -341,7 +346,9 @@ class _HipBlockOps:
         self.counts["apply_K_cols"] += X.shape[1]
 
     def apply_M(self, X, out):
-        if self.m_kind == 1 and self._batched_ok(X, "M"):
+        if self.m_kind == 1 and self.mgrp is not None and _UNION_M and self._union_ok(X, out):
+            self._union(3, X, out)
+        elif self.m_kind == 1 and self._batched_ok(X, "M"):
             self._batched(1, 0, self.ms32, X, out)
         else:
             self._spmm(self.m_kind, self.ms32, X, out)
@@ -561,6 +568,10 @@ class HipModalOps(_HipBlockOps):
                 self.kgrp = torch.empty((s.nnzb, 9), dtype=torch.float32, device=self.device)
             _hip.check(self._L.ds_pack_groups(p(self.k32t), p(s.groups["kperm"]), s.nnzb, p(self.kgrp),
                                               _hip.stream_ptr()), "ds_pack_groups")
+            if s.groups.get("union") is not None and self.m_kind == 1:
+                if "kperm64" not in s.groups:
+                    s.groups["kperm64"] = s.groups["kperm"].long()
+                self.mgrp = self.ms32[s.groups["kperm64"]].contiguous()  # node-scalar mass values in group order
 
     def _rigid_basis(self):
         """Translations + rotations about the centroid, M-orthonormalised in fp64; stored (n, 8) fp32 with

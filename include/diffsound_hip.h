@@ -191,7 +191,8 @@ int ds_spmm_grouped(int epilogue, const int32_t* gptr, const int32_t* gent, cons
  * cap_blocks (<= 276) blocks: ctab (nchunks x 4) = (e0, e1, b0, b1), utab (ngroups x 2) = chunk range of each
  * group, ngroups = ceil(nv / 4).
  * epilogue 0: Y <- A X ; 1: Y (= W_prev) <- X + c1 (X - Y) + c2 T (R0 - A X) (first != 0: Y not read) ;
- * 2: Y <- R0 - A X.  X and Y distinct, 16-byte aligned rows; every operand block 3 nv ld 4 < 0x7f000000 bytes
+ * 2: Y <- R0 - A X ; 3: Y <- (A_s (x) I3) X with kgrp = the node-SCALAR values in group order (nnzb floats: the mass
+ * matrix).  X and Y distinct, 16-byte aligned rows; every operand block 3 nv ld 4 < 0x7f000000 bytes
  * (larger problems use ds_cheb_spmm / ds_spmm_residual / ds_spmm_bsr3).
  * (reference: torch.sparse.mm in src/lobpcg/_linalg_utils.py:36-37 and the iK callable of _lobpcg.py:441) */
 int ds_spmm_union(int epilogue, const int32_t* utab, const int32_t* ctab, int64_t ngroups, int cap_blocks,

@@ -506,9 +506,11 @@ def test_union_spmm_matches_wave_per_node(dev, mesh, order, ncols):
         ops.cheb_spmm(X, b, R0, 0.0, 0.5, True)
         c = torch.zeros((sysd.n, ncols), device=dev)
         ops.spmm_residual(X, R0, c)
-        return Y, a, b, c
+        d = torch.full((sysd.n, ncols), float("nan"), device=dev)
+        ops.apply_M(X, d)  # node-scalar values (epilogue 3)
+        return Y, a, b, c, d
 
-    assert ops._union_ok(X, Wp, R0)
+    assert ops._union_ok(X, Wp, R0) and ops.mgrp is not None
     for _ in range(3):
         got = run()
         sysd.groups["union"] = None
