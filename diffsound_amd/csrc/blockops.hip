@@ -347,7 +347,8 @@ int launch_mix_lds(const float* A, int64_t lda, int p, const float* C, int q, fl
         attr_bytes = lds;
     }
     const int64_t ntile = ds::ceil_div(n, RT * 16);
-    const unsigned grid = (unsigned)std::min<int64_t>(ds::ceil_div(ntile, MIX_NW), 512);  // persistent: 2 workgroups per CU
+    // persistent: 2 workgroups per CU while two coefficient images fit its LDS, else 1
+    const unsigned grid = (unsigned)std::min<int64_t>(ds::ceil_div(ntile, MIX_NW), 2 * lds <= 160 * 1024 ? 512 : 256);
     mix_lds_kernel<JT><<<grid, 64 * MIX_NW, lds, st>>>(A, lda, p, C, q, Out, ldo, n, alpha, beta);
     DS_LAUNCH_CHECK("mix_lds_kernel");
     return DS_OK;
@@ -427,13 +428,22 @@ extern "C" int ds_mix(const float* A, int64_t lda, int p, const float* C, int q,
     const bool veca = aligned16(A, lda) && (p % 4 == 0);
     int rc = DS_OK;
     static const bool no_lds = getenv("DS_MIX_GENERIC") != nullptr;  // A/B switch for benchmarking
-    if (veca && q <= 80 && p <= 256 && n >= 4096 && !no_lds) {
-        switch ((q + 15) / 16) {
+    // LDS-staged path: the coefficient image ((p rounded to 16) x (q rounded to 16) floats) has to fit the CU's 160 KB;
+    // up to 80 columns two workgroups share a CU, wider results (the fused [X' P'] = [X P W] [Z1 Zp] update) take it whole
+    const int jt = (q + 15) / 16;
+    const size_t image = (size_t)((p + 15) & ~15) * jt * 16 * sizeof(float);
+    if (veca && q <= 160 && p <= 256 && n >= 4096 && image <= 160 * 1024 && !no_lds) {
+        switch (jt) {
             case 1: return launch_mix_lds<1>(A, lda, p, C, q, Out, ldo, n, alpha, beta, st);
             case 2: return launch_mix_lds<2>(A, lda, p, C, q, Out, ldo, n, alpha, beta, st);
             case 3: return launch_mix_lds<3>(A, lda, p, C, q, Out, ldo, n, alpha, beta, st);
             case 4: return launch_mix_lds<4>(A, lda, p, C, q, Out, ldo, n, alpha, beta, st);
-            default: return launch_mix_lds<5>(A, lda, p, C, q, Out, ldo, n, alpha, beta, st);
+            case 5: return launch_mix_lds<5>(A, lda, p, C, q, Out, ldo, n, alpha, beta, st);
+            case 6: return launch_mix_lds<6>(A, lda, p, C, q, Out, ldo, n, alpha, beta, st);
+            case 7: return launch_mix_lds<7>(A, lda, p, C, q, Out, ldo, n, alpha, beta, st);
+            case 8: return launch_mix_lds<8>(A, lda, p, C, q, Out, ldo, n, alpha, beta, st);
+            case 9: return launch_mix_lds<9>(A, lda, p, C, q, Out, ldo, n, alpha, beta, st);
+            default: return launch_mix_lds<10>(A, lda, p, C, q, Out, ldo, n, alpha, beta, st);
         }
     }
     // column chunks of at most 10 MFMA tiles (160 columns) so the accumulators stay in registers

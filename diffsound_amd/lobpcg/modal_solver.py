@@ -548,13 +548,18 @@ class ModalSolver:
             lam[ncl:] = Ea
             if ncl:
                 S2[:, ny:ny + ncl].copy_(S[:, ny:ny + ncl])
-            # (one 2na-column launch per product was measured SLOWER than two na-column ones: 909 us against
-            # 2 x 284 us at na = 80 - ten accumulator tiles per wave cost the update kernel its occupancy)
-            Z1, Zp = ZZ[:, :na], ZZ[:, na:]
-            ops.mix(Sa, Z1, S2[:, ny + ncl:ny + b])
-            ops.mix(Sa, Zp, S2[:, ny + b:ny + b + na])
-            ops.mix(KSa, Z1, KS2[:, :na])  # K X_new
-            ops.mix(KSa, Zp, KS2[:, na:2 * na])  # K P_new
+            # X_new | P_new (and K X_new | K P_new) are adjacent column ranges: ONE update [X' P'] = [X P W] [Z1 Zp]
+            # per product reads the 240-column operand once instead of twice (the LDS-staged mix kernel holds the
+            # 240 x 160 coefficient image; with the first, register-only kernel one wide launch was slower than two)
+            if getattr(ops, "fused_ritz_mix", True) and 2 * na <= 160:
+                ops.mix(Sa, ZZ, S2[:, ny + ncl:ny + b + na])
+                ops.mix(KSa, ZZ, KS2[:, :2 * na])
+            else:
+                Z1, Zp = ZZ[:, :na], ZZ[:, na:]
+                ops.mix(Sa, Z1, S2[:, ny + ncl:ny + b])
+                ops.mix(Sa, Zp, S2[:, ny + b:ny + b + na])
+                ops.mix(KSa, Z1, KS2[:, :na])  # K X_new
+                ops.mix(KSa, Zp, KS2[:, na:2 * na])  # K P_new
             S, S2 = S2, S
             KS, KS2 = KS2, KS
             k0 = 0

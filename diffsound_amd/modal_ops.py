@@ -252,6 +252,7 @@ class _HipBlockOps:
     k32t = None
     kgrp = None  # transposed blocks in node-group order (register-blocked SpMM)
     mgrp = None  # node-scalar mass values in node-group order (neighbour-union SpMM, epilogue 3)
+    fused_ritz_mix = os.environ.get("DS_FUSED_RITZ_MIX", "1") != "0"  # A/B switch (lobpcg/modal_solver.py)
 
     def _init_common(self, rowptr, colidx, nv, device):
         self.rowptr, self.colidx = rowptr, colidx

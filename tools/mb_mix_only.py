@@ -6,8 +6,8 @@ from diffsound_amd.modal_ops import _HipBlockOps
 dev = torch.device('cuda')
 nv = 148877; n = 3 * nv
 ops = _HipBlockOps(); ops._init_common(None, None, nv, dev)
-S = torch.randn((n, 248), device=dev); out = torch.empty((n, 80), device=dev)
-for p, q in ((240, 80), (160, 80), (80, 80)):
+S = torch.randn((n, 248), device=dev); out = torch.empty((n, 160), device=dev)
+for p, q in ((240, 80), (160, 80), (80, 80), (240, 160), (216, 144), (168, 112)):
     C = torch.randn((p, q), dtype=torch.float64, device=dev)
     A = S[:, :p]; O = out[:, :q]
     f = lambda: ops.mix(A, C, O)
