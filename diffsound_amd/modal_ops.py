@@ -299,8 +299,13 @@ class _HipBlockOps:
         if g is None or g.get("union") is None or self.kgrp is None or X.shape[1] > 84 or X.shape[1] % 4:
             return False
         # every operand is addressed through a 32-bit buffer descriptor offset and read / written 16 bytes at a time
-        return all(12 * self.nv * _ld(T) < 0x7F000000 and T.data_ptr() % 16 == 0 and (_ld(T) * 4) % 16 == 0
-                   for T in (X,) + others if T is not None)
+        lim = 0x7F000000 // (12 * self.nv)
+        for T in (X,) + others:
+            if T is not None:
+                ld = T.stride(0)
+                if ld >= lim or ld % 4 or T.data_ptr() % 16 or T.stride(1) != 1:
+                    return False
+        return True
 
     def _union(self, epilogue, X, Y, R0=None, c1=0.0, c2=0.0, first=False):
         pp = _hip.ptr
