@@ -47,12 +47,12 @@ numeric assembly in every pass.  (regenerate this file with `python tools/make_p
 
 {t1}
 
-{(tot1 - 47.6) / npass1:.0f} ms of kernels per pass (without the one-off rocBLAS set-up product). `spmm_union_kernel<20,1,116>` is the fused
+{(tot1 - 47.7) / npass1:.0f} ms of kernels per pass (without the one-off rocBLAS set-up product). `spmm_union_kernel<20,1,116>` is the fused
 Chebyshev-term SpMM on a full 80-column block (one wavefront per 4 nodes walking the union of their neighbours); the
 name covers the fine level (252 launches, ≈ 0.29 ms each = 743.1 MB algorithmic) and the corner-node level
 (1 545 launches, ≈ 0.05 ms each), {float(fused1[3]):.0f} µs on average; `<0,1,…>` is the same kernel on the narrower blocks left after
-locking, `<·,0,…>` K·W, `<·,2,…>` the residual handed to the corner-node level, `spmm_wave_node_kernel<1,3,·,0>` the mass
-product (node-scalar values, one wavefront per node), `gram32_partial_kernel` the folded-fp32 MFMA Gram blocks
+locking, `<·,0,…>` K·W, `<·,2,…>` the residual handed to the corner-node level, `<·,3,…>` the mass product (node-scalar
+values), `mix_lds_kernel<10>` the fused Ritz updates [X' P'] = [X P W][Z1 Zp], `gram32_partial_kernel` the folded-fp32 MFMA Gram blocks
 [V W]ᵀ(MW) and [X P W]ᵀ(KW), `mix_lds_kernel` the Ritz / ortho updates, `spmm_f64_node_kernel` and
 `gram_partial_kernel<double>` the fp64 read-out.
 
@@ -83,7 +83,8 @@ panels) plus the per-entry LDS / FMA work, not by HBM: see DESIGN.md §5.
 | persistent LDS-staged `mix` kernel | 15.8 |
 | Gram on the fp32 MFMA folded into fp64 every 48 rows (240×80: 0.466 → 0.230 ms) | 16.5 |
 | neighbour-union SpMM promoted to the default on both levels (fused term 0.332 → 0.275 ms), `mix` with `ds_read_b128` operands | 18.0 |
-| assembly stores through LDS (2.0 → 0.45 ms), wave-per-node fp64 read-out products, in-place residual / ortho update | {d["value"]:.1f} |
+| assembly stores through LDS (2.0 → 0.45 ms), wave-per-node fp64 read-out products, in-place residual / ortho update | 18.4 |
+| mass product on the union kernel, fused [X' P'] Ritz updates, leaner launch path | {d["value"]:.1f} |
 
 SpMM kernel history (80 columns, K·X, micro-benchmark `tools/mb_spmm.py`): node groups per wave 0.441 ms → Morton order
 0.426 → wave per node with scalar metadata 0.340 → cooperative row metadata (readlane ids, LDS coefficients) 0.286 →
