@@ -392,8 +392,6 @@ int launch_fast(const int32_t* rowptr, const int32_t* colidx, const void* vals, 
     }
 }
 
-}  // namespace
-
 // ------------------------------------------------------------------------------------------------
 // fp64-value products of the read-out (X^T K_lambda X, X^T K_mu X, X^T M X on the converged block: kinds 2 / 3,
 // fp64 values and result, fp32 X) for <= 84 columns: ONE WAVEFRONT PER NODE in the lane layout of the fp32
@@ -471,6 +469,8 @@ __global__ void __launch_bounds__(256)
         *reinterpret_cast<d2*>(yp + 2) = d2{out[2], out[3]};
     }
 }
+
+}  // namespace
 
 extern "C" int ds_spmm_bsr3(int kind, const int32_t* rowptr, const int32_t* colidx, const void* vals,
                             const void* vals_t, int64_t nv, const void* X, int64_t ldx, void* Y, int64_t ldy,
