@@ -165,9 +165,11 @@ def main():
     # ---- instrument the dominant kernel: every launch of the fused Chebyshev-term SpMM on a full b-column block,
     #      fine and corner-node level alike (they are ONE kernel, rocprofv3 reports them under one name), with HIP
     #      events on the launching stream; narrower blocks (after locking) run another instantiation
+    #      The FIRST lane is instrumented: it issues the terms one by one from the solver loop; the other lanes run the
+    #      whole V-cycle through the native driver (ds_twolevel_apply), which leaves no place for per-launch events.
     events = []
     lane_ops = [ln.ops for ln in pipe._lanes if ln.ops is not None] or [pipe.ops]
-    for o in lane_ops:
+    for o in lane_ops[:1]:
         for lvl in (o, getattr(o, "coarse", None)):
             if lvl is not None:
                 lvl.spmm_event_cols = a.block
@@ -235,6 +237,8 @@ def main():
                 "launches_timed": int(len(ms)), "levels": levels,
                 "note": (f"{nlanes} hypothesis lanes launch concurrently on separate HIP streams, so a launch shares the "
                          "device with the other lanes' kernels and its event-timed duration is stretched accordingly; "
+                         "the launches of the first lane are the ones timed (the other lanes issue the same launches "
+                         "through the native V-cycle driver); "
                          "'solo' is the same kernel, fine level, alone on the device right after the timed region; "
                          "'traffic' is the PMC figure of a fine-level launch"),
                 "solo": {"avg_launch_ms": solo_ms, "algorithmic_bytes_per_launch": fine_bytes,

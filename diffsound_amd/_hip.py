@@ -64,6 +64,24 @@ _EXPERIMENTAL_SIGNATURES = {
                             _I, _P]),
 }
 
+
+
+class LevelDesc(ctypes.Structure):
+    """ds_level_t of include/diffsound_hip.h."""
+    _fields_ = [("utab", _P), ("ctab", _P), ("ngroups", _I64), ("cap_blocks", ctypes.c_int32),
+                ("degree", ctypes.c_int32), ("gent", _P), ("kgrp", _P), ("nnzb", _I64), ("nv", _I64), ("dinv", _P),
+                ("lmax", _D), ("lmin", _D)]
+
+
+class TwoLevelDesc(ctypes.Structure):
+    """ds_twolevel_t of include/diffsound_hip.h."""
+    _fields_ = [("fine", LevelDesc), ("coarse", LevelDesc), ("rptr", _P), ("rcol", _P), ("rw", _P), ("pptr", _P),
+                ("pcol", _P), ("pw", _P), ("R", _P), ("ldr", _I64), ("W", _P), ("ldw", _I64), ("D", _P), ("ldd", _I64),
+                ("AD", _P), ("lda", _I64), ("Rr", _P), ("ldrr", _I64), ("Rc", _P), ("Ec", _P), ("Dc", _P), ("ADc", _P),
+                ("ldc", _I64), ("ncols", ctypes.c_int32)]
+
+
+_SIGNATURES["ds_twolevel_apply"] = (_I, [ctypes.POINTER(TwoLevelDesc), _P])
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 _lib = None
 

@@ -21,6 +21,7 @@ The ``ops`` protocol (see ``diffsound_amd/modal_ops.py`` for the HIP implementat
   n, device, dtype, rigid (n x 6, M-orthonormal), apply_K, apply_M, gram, mix, residual,
   precond, polish_products.
 """
+import os
 import threading
 from dataclasses import dataclass, field
 from typing import Callable, Optional
@@ -312,6 +313,13 @@ class TwoLevelChebyshev:
                 mk = lambda rows: torch.empty((rows, w), dtype=R.dtype, device=R.device)
                 self._buf = (mk(R.shape[0]), mk(nc), mk(nc))
             Rr, Rc, Ec = self._buf
+            native = getattr(ops, "twolevel_apply", None)
+            if native is not None and os.environ.get("DS_NATIVE_VCYCLE", "1") != "0":
+                D, AD = self.smooth._buffers(Rs)
+                Dc, ADc = self.coarse._buffers(Rc)
+                if native((self.smooth.degree, self.smooth.lmax, self.smooth.lmin),
+                          (self.coarse.degree, self.coarse.lmax, self.coarse.lmin), Rs, Ws, D, AD, Rr, Rc, Ec, Dc, ADc):
+                    continue
             self.smooth.apply(Rs, Ws)
             ops.spmm_residual(Ws, Rs, Rr)
             ops.restrict(Rr, Rc)

@@ -307,6 +307,49 @@ class _HipBlockOps:
                     return False
         return True
 
+    def level_desc(self, d, degree, lmax, lmin):
+        """Fill a ds_level_t with this level's neighbour-union tables (None when the level has none)."""
+        g = getattr(getattr(self, "sys", None), "groups", None)
+        if g is None or g.get("union") is None or self.kgrp is None:
+            return None
+        u = g["union"]
+        d.utab, d.ctab, d.ngroups, d.cap_blocks = u["utab"].data_ptr(), u["ctab"].data_ptr(), u["ngroups"], u["capb"]
+        d.gent, d.kgrp, d.nnzb, d.nv, d.dinv = g["gent"].data_ptr(), self.kgrp.data_ptr(), self.kgrp.shape[0], self.nv, self.dinv.data_ptr()
+        d.degree, d.lmax, d.lmin = int(degree), float(lmax), float(lmin)
+        return d
+
+    def twolevel_apply(self, smooth, coarse, R, W, D, AD, Rr, Rc, Ec, Dc, ADc):
+        """The whole two-level V-cycle W = B R through the native driver (ds_twolevel_apply): one call instead of
+        ~45 launches issued one by one.  ``smooth`` / ``coarse``: (degree, lmax, lmin) of the two Chebyshev operators.
+        Returns False (nothing done) when a level or a block does not qualify for the neighbour-union kernels."""
+        co = self.coarse
+        if co is None or self.cheb_events is not None or co.cheb_events is not None:
+            return False  # (the bench times the fused terms launch by launch: that lane keeps the Python path)
+        if not (self._union_ok(R, W, D, AD, Rr) and co._union_ok(Rc, Ec, Dc, ADc)):
+            return False
+        d = self._tl_desc
+        if d is None:
+            d = self._tl_desc = _hip.TwoLevelDesc()
+            t = self._xfer
+            d.rptr, d.rcol, d.rw = t["rptr"].data_ptr(), t["rcol"].data_ptr(), t["rw"].data_ptr()
+            d.pptr, d.pcol, d.pw = t["pptr"].data_ptr(), t["pcol"].data_ptr(), t["pw"].data_ptr()
+        if self.level_desc(d.fine, *smooth) is None or co.level_desc(d.coarse, *coarse) is None:
+            return False
+        if not (Rc.stride(0) == Ec.stride(0) == Dc.stride(0) == ADc.stride(0)):
+            return False
+        d.R, d.ldr, d.W, d.ldw = R.data_ptr(), R.stride(0), W.data_ptr(), W.stride(0)
+        d.D, d.ldd, d.AD, d.lda = D.data_ptr(), D.stride(0), AD.data_ptr(), AD.stride(0)
+        d.Rr, d.ldrr = Rr.data_ptr(), Rr.stride(0)
+        d.Rc, d.Ec, d.Dc, d.ADc, d.ldc = Rc.data_ptr(), Ec.data_ptr(), Dc.data_ptr(), ADc.data_ptr(), Rc.stride(0)
+        d.ncols = R.shape[1]
+        _hip.check(self._L.ds_twolevel_apply(ctypes.byref(d), _hip.stream_ptr()), "ds_twolevel_apply")
+        c = R.shape[1]
+        self.counts["apply_K_cols"] += c * (max(smooth[0] - 1, 0) + 1 + smooth[0])
+        co.counts["apply_K_cols"] += c * (coarse[0] - 1)
+        return True
+
+    _tl_desc = None
+
     def _union(self, epilogue, X, Y, R0=None, c1=0.0, c2=0.0, first=False):
         pp = _hip.ptr
         g = self.sys.groups

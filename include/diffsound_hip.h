@@ -199,6 +199,50 @@ int ds_spmm_union(int epilogue, const int32_t* utab, const int32_t* ctab, int64_
                   const int32_t* gent, const float* kgrp, int64_t nnzb, int64_t nv, const float* X, int64_t ldx,
                   float* Y, int64_t ldy, const float* R0, int64_t ldr, const float* dinv, int ncols, float c1, float c2,
                   int first, ds_stream_t stream);
+/* ------------------------------------------------------------------------------------------------
+ * Two-level V-cycle preconditioner in one call (host-side driver, csrc/vcycle.cpp): issues on `stream` the launch
+ * sequence  W1 = S R ; W2 = W1 + P C P^T (R - K W1) ; W = W2 + S (R - K W2)  out of ds_cheb_init, ds_spmm_union and
+ * ds_scalar_csr_spmm - S: degree-`fine.degree` Chebyshev block-Jacobi smoother for the interval [lmin, lmax] of T K
+ * on the fine level, C: the same on the corner-node level, P / P^T the transfer operators.  The preconditioner of
+ * the reference's LOBPCG is an opaque callable (src/lobpcg/_lobpcg.py:441); this is the one diffsound_amd supplies.
+ * All blocks (rows x ncols) f32 with leading dimensions, 16-byte aligned rows, ncols a multiple of 4 <= 84; R is only
+ * read; D, AD, Rr (fine) and Rc, Ec, Dc, ADc (corner-node level, common leading dimension ldc) are scratch.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+    const int32_t* utab;   /* neighbour-union tables and values of the level, as for ds_spmm_union */
+    const int32_t* ctab;
+    int64_t ngroups;
+    int32_t cap_blocks;
+    int32_t degree;        /* polynomial degree of the level's Chebyshev block-Jacobi operator */
+    const int32_t* gent;
+    const float* kgrp;
+    int64_t nnzb;
+    int64_t nv;
+    const float* dinv;     /* (nv x 9) inverse diagonal blocks */
+    double lmax, lmin;     /* the polynomial targets [lmin, lmax] of T K */
+} ds_level_t;
+typedef struct {
+    ds_level_t fine, coarse;
+    const int32_t *rptr, *rcol;  /* restriction (corner node <- fine nodes) */
+    const float* rw;
+    const int32_t *pptr, *pcol;  /* prolongation (fine node <- corner nodes) */
+    const float* pw;
+    const float* R;
+    int64_t ldr;
+    float* W;
+    int64_t ldw;
+    float* D;
+    int64_t ldd;
+    float* AD;
+    int64_t lda;
+    float* Rr;
+    int64_t ldrr;
+    float *Rc, *Ec, *Dc, *ADc;
+    int64_t ldc;
+    int32_t ncols;
+} ds_twolevel_t;
+int ds_twolevel_apply(const ds_twolevel_t* p, ds_stream_t stream);
+
 #ifdef DS_EXPERIMENTAL /* not in the default library: make -C diffsound_amd/csrc EXPERIMENTAL=1 */
 /* Batched form of ds_spmm_bsr3 / ds_cheb_spmm / ds_spmm_residual for ncols <= 84 (the default path of the
  * eigensolver's b-column products and of every preconditioner term): one wavefront per batch of consecutive

@@ -364,6 +364,24 @@ def test_two_level_cycle_matches_oracle(case, dev):
     Wh = torch.empty((h.n, 96), device=dev)
     ph.apply(R.to(dev), Wh)
     assert rel(Wh.cpu().numpy(), Wc.numpy()) < 2e-4
+    # the native driver (ds_twolevel_apply: the whole cycle in one call) issues the same launches as the Python loop
+    calls = h.counts["apply_K_cols"], h.coarse.counts["apply_K_cols"]
+    import os
+    os.environ["DS_NATIVE_VCYCLE"] = "0"
+    try:
+        Wp = torch.empty((h.n, 96), device=dev)
+        k0 = h.counts["apply_K_cols"], h.coarse.counts["apply_K_cols"]
+        ph.apply(R.to(dev), Wp)
+        k1 = h.counts["apply_K_cols"], h.coarse.counts["apply_K_cols"]
+    finally:
+        os.environ.pop("DS_NATIVE_VCYCLE", None)
+    assert torch.equal(Wp, Wh)
+    Wn = torch.empty((h.n, 96), device=dev)
+    ph.apply(R.to(dev), Wn)
+    k2 = h.counts["apply_K_cols"], h.coarse.counts["apply_K_cols"]
+    assert torch.equal(Wn, Wh)
+    assert (k2[0] - k1[0], k2[1] - k1[1]) == (k1[0] - k0[0], k1[1] - k0[1])  # same product counts either way
+    assert calls[0] > 0
 
 
 def test_polish_products(case, dev):

@@ -22,4 +22,4 @@ for E, nu in ((4e10, 0.2), (7e10, 0.33), (3e10, 0.28)):
 torch.cuda.synchronize(); dt = time.time() - t0
 pr.disable()
 print(f"3 passes: {dt*1e3/3:.1f} ms per pass")
-s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(28); print(s.getvalue()[:6000])
+s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(70); print(s.getvalue()[:14000])
