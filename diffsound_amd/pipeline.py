@@ -158,11 +158,16 @@ def _run_batch(pipe, hyps, lanes=2, warm=None, backward=True):
         except BaseException as ex:  # surfaced in the caller's thread
             errs.append(ex)
 
-    threads = [threading.Thread(target=work, args=(li,)) for li in range(min(lanes, n))]
-    for t in threads:
-        t.start()
-    for t in threads:
-        t.join()
+    # persistent worker threads: starting three threads per batch cost 2-9 ms of interpreter-lock hand-offs before the
+    # first lane reached its first launch (device idle at every step boundary in the kernel trace)
+    pool = getattr(pipe, "_lane_pool", None)
+    if pool is None or pool._max_workers < lanes:
+        from concurrent.futures import ThreadPoolExecutor
+
+        pool = pipe._lane_pool = ThreadPoolExecutor(max_workers=lanes, thread_name_prefix="ds-lane")
+    futures = [pool.submit(work, li) for li in range(min(lanes, n))]
+    for f in futures:
+        f.result()
     if errs:
         raise errs[0]
     for e in done:

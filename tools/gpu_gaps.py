@@ -24,3 +24,18 @@ print("kernel that ENDED before the gap (ms of gap):")
 for k, v in before.most_common(8): print(f"  {v/1e6:7.1f}  {k}")
 print("kernel that STARTED after the gap:")
 for k, v in after.most_common(8): print(f"  {v/1e6:7.1f}  {k}")
+
+# timeline around the three longest gaps: (time since gap start in us, duration, stream, kernel)
+rows2 = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r.get("Stream_Id", "?"), r["Kernel_Name"].split("(")[0][-40:]) for r in rows))
+gaps = []
+cur_end = 0
+for s, e, st, nm in rows2:
+    if e <= lo:
+        cur_end = max(cur_end, e); continue
+    if cur_end and s > cur_end: gaps.append((s - cur_end, cur_end, s))
+    cur_end = max(cur_end, e)
+for g, a, b in sorted(gaps, reverse=True)[3:6]:
+    print(f"--- gap {g/1e3:.0f} us")
+    for s, e, st, nm in rows2:
+        if e > a - 1_500_000 and s < b + 1_500_000:
+            print(f"  {(s - a)/1e3:9.1f} +{(e - s)/1e3:7.1f} us  stream {st}  {nm}")
