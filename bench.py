@@ -35,8 +35,8 @@ def parse():
     ap.add_argument("--cells", type=int, default=26, help="Kuhn box cells per edge (26 -> 105 456 tets)")
     ap.add_argument("--order", type=int, default=2)
     ap.add_argument("--modes", type=int, default=64)
-    ap.add_argument("--hyp-per-gpu", type=int, default=6, help="material hypotheses per GPU per step")
-    ap.add_argument("--lanes", type=int, default=3,
+    ap.add_argument("--hyp-per-gpu", type=int, default=8, help="material hypotheses per GPU per step")
+    ap.add_argument("--lanes", type=int, default=4,
                     help="hypotheses in flight at once per GPU (own HIP stream + host thread each), so one lane's "
                          "host-side Rayleigh-Ritz step overlaps the other lane's kernels")
     ap.add_argument("--cheb-degree", type=int, default=48)
@@ -65,7 +65,10 @@ def cpu_baseline(sample_cells, order, modes, full_tets):
     from oracle import fem, modal
     from oracle import oscillator as oosc
 
-    torch.set_num_threads(os.cpu_count() or 1)
+    # 16 threads = the host share of one GPU on this pool; measured on the MI355X host: 1 thread 3.9 s, 4-64 threads
+    # 2.9 s, all 256 hardware threads 18.2 s (oversubscribed: every small op forks a 256-thread team)
+    nthreads = min(os.cpu_count() or 1, 16)
+    torch.set_num_threads(nthreads)
     v, t = meshgen.kuhn_box(sample_cells)
     t0 = time.time()
     v, t = fem.to_high_order(torch.from_numpy(v), torch.from_numpy(t).long(), order)
@@ -88,7 +91,7 @@ def cpu_baseline(sample_cells, order, modes, full_tets):
     return {
         "value": 1.0 / scaled,
         "unit": "passes/s",
-        "cores": os.cpu_count() or 1,
+        "cores": nthreads,
         "kind": "port",
         "sample": (f"one full fwd+bwd pass of the CPU oracle on a {sample_cells}^3-cell Kuhn box ({ntets} tets, "
                    f"ord-{order}, {modes} modes) took {dt:.1f} s; extrapolated linearly in tets to {full_tets} tets"),

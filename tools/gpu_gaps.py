@@ -34,8 +34,12 @@ for s, e, st, nm in rows2:
         cur_end = max(cur_end, e); continue
     if cur_end and s > cur_end: gaps.append((s - cur_end, cur_end, s))
     cur_end = max(cur_end, e)
-for g, a, b in sorted(gaps, reverse=True)[3:6]:
+import os as _os
+sel = [int(x) for x in _os.environ.get('GAPS', '10,40,90').split(',')]
+sg = sorted(gaps, reverse=True)
+print('gap size ranks (us):', [round(g[0]/1e3) for g in sg[:120:5]])
+for g, a, b in [sg[i] for i in sel if i < len(sg)]:
     print(f"--- gap {g/1e3:.0f} us")
     for s, e, st, nm in rows2:
-        if e > a - 1_500_000 and s < b + 1_500_000:
+        if e > a - 400_000 and s < b + 400_000:
             print(f"  {(s - a)/1e3:9.1f} +{(e - s)/1e3:7.1f} us  stream {st}  {nm}")

@@ -31,13 +31,13 @@ tot1 = float(rows1[-1][2]); npass1 = 11
 readme = f'''# profiles/ — round 1 evidence (MI355X, gfx950, ROCm 7.2)
 
 All runs: `bench.py` defaults = workload C3 (Kuhn box 26³ = 105 456 tets, ord-2, n = 446 631, nnz = 37.2 M, 64 modes,
-block 80, two-level Chebyshev preconditioner), 6 hypotheses per step, 3 in flight per GPU, cold-start eigensolve and
+block 80, two-level Chebyshev preconditioner), 8 hypotheses per step, 4 in flight per GPU, cold-start eigensolve and
 numeric assembly in every pass.  (regenerate this file with `python tools/make_profiles_readme.py`)
 
 | file | what |
 |---|---|
 | `r01_bench_n1.json` | the JSON line of `python bench.py` (N = 1, 3 steps, 1 warm-up, CPU baseline included): {d["value"]:.1f} passes/s |
-| `r01_bench_kernel_stats.csv` | `rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --no-cpu-baseline`, top 45 kernels (target pass + warm-up step + 3 timed steps; 3 hypothesis lanes overlap, so durations are stretched by sharing) |
+| `r01_bench_kernel_stats.csv` | `rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --no-cpu-baseline`, top 45 kernels (target pass + warm-up step + 3 timed steps; 4 hypothesis lanes overlap, so durations are stretched by sharing) |
 | `r01_bench_lanes1_kernel_stats.csv` | the same with `--lanes 1 --hyp-per-gpu 2`: one hypothesis at a time, every kernel alone on the device - the table to read kernel durations from |
 | `spmm_pmc_bytes_per_launch.json` | HBM-side traffic of the dominant kernel (fine level) from separate `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes (`tools/pmc_bytes.sh`), gfx950 correction (2·FETCH + WRITE)·1024 as prescribed by `guides/MI355X_MICROARCH.md` |
 
@@ -56,14 +56,14 @@ values), `mix_lds_kernel<10>` the fused Ritz updates [X' P'] = [X P W][Z1 Zp], `
 [V W]ᵀ(MW) and [X P W]ᵀ(KW), `mix_lds_kernel` the Ritz / ortho updates, `spmm_f64_node_kernel` and
 `gram_partial_kernel<double>` the fp64 read-out.
 
-## Default run, 3 lanes (`r01_bench_kernel_stats.csv`)
+## Default run, 4 lanes (`r01_bench_kernel_stats.csv`)
 
 {t3}
 
 The dominant kernel by total time is the fused Chebyshev-term SpMM. Its rocprofv3 average over this run
 ({float(fused3[3]) / 1e3:.3f} ms over {fused3[1]} launches; includes the single-lane target pass and the warm-up) and the HIP-event average over the
 timed region inside `bench.py` ({r["avg_launch_ms"]:.3f} ms over {r["launches_timed"]} launches: fine level {lv["fine"]["avg_launch_ms"]:.2f} ms, corner-node level {lv["corner_node"]["avg_launch_ms"]:.3f} ms;
-a different run, without the profiler) are both stretched by the three lanes sharing the device: `roofline.achieved` =
+a different run, without the profiler) are both stretched by the four lanes sharing the device: `roofline.achieved` =
 {r["achieved"]:.0f} GB/s. Alone on the device the fine-level launch takes {solo["avg_launch_ms"]:.3f} ms (`roofline.solo` in the JSON; the
 single-lane profile above agrees; 0.275–0.279 ms on contiguous operands in `tools/mb_kx_time.py` - the solver's blocks are
 column ranges of a 248-column buffer), i.e. {solo["achieved"] / 1e3:.2f} TB/s algorithmic = {100 * solo["frac"]:.1f} % of the 8 TB/s HBM peak, with {pmc / 1e6:.1f} MB of
@@ -84,7 +84,8 @@ panels) plus the per-entry LDS / FMA work, not by HBM: see DESIGN.md §5.
 | Gram on the fp32 MFMA folded into fp64 every 48 rows (240×80: 0.466 → 0.230 ms) | 16.5 |
 | neighbour-union SpMM promoted to the default on both levels (fused term 0.332 → 0.275 ms), `mix` with `ds_read_b128` operands | 18.0 |
 | assembly stores through LDS (2.0 → 0.45 ms), wave-per-node fp64 read-out products, in-place residual / ortho update | 18.4 |
-| mass product on the union kernel, fused [X' P'] Ritz updates, leaner launch path | {d["value"]:.1f} |
+| mass product on the union kernel, fused [X' P'] Ritz updates, leaner launch path | 19.2 |
+| persistent lane threads (no 3-13 ms bubble per step), 4 lanes x 2 hypotheses per step | {d["value"]:.1f} |
 
 SpMM kernel history (80 columns, K·X, micro-benchmark `tools/mb_spmm.py`): node groups per wave 0.441 ms → Morton order
 0.426 → wave per node with scalar metadata 0.340 → cooperative row metadata (readlane ids, LDS coefficients) 0.286 →
