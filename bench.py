@@ -44,10 +44,10 @@ def parse():
     ap.add_argument("--block", type=int, default=80)
     ap.add_argument("--precond", default="auto", choices=["auto", "chebyshev", "twolevel"],
                     help="auto = two-level V-cycle on ord-2 meshes, one-level Chebyshev polynomial otherwise")
-    ap.add_argument("--smooth-degree", type=int, default=3)
+    ap.add_argument("--smooth-degree", type=int, default=2)
     ap.add_argument("--smooth-ratio", type=float, default=10.0)
-    ap.add_argument("--coarse-degree", type=int, default=24)
-    ap.add_argument("--coarse-ratio", type=float, default=400.0)
+    ap.add_argument("--coarse-degree", type=int, default=28)
+    ap.add_argument("--coarse-ratio", type=float, default=550.0)
     ap.add_argument("--rr-refresh", type=int, default=-1,
                     help="recompute K [X P W] and the whole Gram matrix every this many iterations (-1 = solver default)")
     ap.add_argument("--warm-start", action="store_true", help="amortised variant: reuse the previous block")

@@ -27,7 +27,7 @@ t3, rows3 = table("r01_bench_kernel_stats.csv")
 fused1 = next(x for x in rows1 if "spmm_union_kernel<20, 1" in x[0])
 fused3 = next(x for x in rows3 if "spmm_union_kernel<20, 1" in x[0])
 pmc = json.load(open(P("spmm_pmc_bytes_per_launch.json")))["cells26_cols80"]
-tot1 = float(rows1[-1][2]); npass1 = 11
+tot1 = float(rows1[-1][2]); npass1 = 11  # target pass + (1 warm-up + 3 timed) steps x 2 hypotheses on one lane + ... see bench.py
 readme = f'''# profiles/ — round 1 evidence (MI355X, gfx950, ROCm 7.2)
 
 All runs: `bench.py` defaults = workload C3 (Kuhn box 26³ = 105 456 tets, ord-2, n = 446 631, nnz = 37.2 M, 64 modes,
@@ -85,7 +85,8 @@ panels) plus the per-entry LDS / FMA work, not by HBM: see DESIGN.md §5.
 | neighbour-union SpMM promoted to the default on both levels (fused term 0.332 → 0.275 ms), `mix` with `ds_read_b128` operands | 18.0 |
 | assembly stores through LDS (2.0 → 0.45 ms), wave-per-node fp64 read-out products, in-place residual / ortho update | 18.4 |
 | mass product on the union kernel, fused [X' P'] Ritz updates, leaner launch path | 19.2 |
-| persistent lane threads (no 3-13 ms bubble per step), 4 lanes x 2 hypotheses per step | {d["value"]:.1f} |
+| persistent lane threads (no 3-13 ms bubble per step), 4 lanes x 2 hypotheses per step | 20.3 |
+| bench preconditioner Chebyshev(2) smoother / Chebyshev(28, ratio 550) corner-node level | {d["value"]:.1f} |
 
 SpMM kernel history (80 columns, K·X, micro-benchmark `tools/mb_spmm.py`): node groups per wave 0.441 ms → Morton order
 0.426 → wave per node with scalar metadata 0.340 → cooperative row metadata (readlane ids, LDS coefficients) 0.286 →
