@@ -49,8 +49,8 @@ numeric assembly in every pass.  (regenerate this file with `python tools/make_p
 
 {(tot1 - 47.7) / npass1:.0f} ms of kernels per pass (without the one-off rocBLAS set-up product). `spmm_union_kernel<20,1,116>` is the fused
 Chebyshev-term SpMM on a full 80-column block (one wavefront per 4 nodes walking the union of their neighbours); the
-name covers the fine level (252 launches, ≈ 0.29 ms each = 743.1 MB algorithmic) and the corner-node level
-(1 545 launches, ≈ 0.05 ms each), {float(fused1[3]):.0f} µs on average; `<0,1,…>` is the same kernel on the narrower blocks left after
+name covers the fine level (≈ 0.29 ms per launch = 743.1 MB algorithmic) and the roughly ten times more numerous launches of
+the corner-node level (≈ 0.05 ms each), {float(fused1[3]):.0f} µs on average; `<0,1,…>` is the same kernel on the narrower blocks left after
 locking, `<·,0,…>` K·W, `<·,2,…>` the residual handed to the corner-node level, `<·,3,…>` the mass product (node-scalar
 values), `mix_lds_kernel<10>` the fused Ritz updates [X' P'] = [X P W][Z1 Zp], `gram32_partial_kernel` the folded-fp32 MFMA Gram blocks
 [V W]ᵀ(MW) and [X P W]ᵀ(KW), `mix_lds_kernel` the Ritz / ortho updates, `spmm_f64_node_kernel` and
