@@ -1035,7 +1035,7 @@ extern "C" int ds_spmm_union(int epilogue, const int32_t* utab, const int32_t* c
                              const float* kgrp, int64_t nnzb, int64_t nv, const float* X, int64_t ldx, float* Y,
                              int64_t ldy, const float* R0, int64_t ldr, const float* dinv, int ncols, float c1, float c2,
                              int first, ds_stream_t stream) {
-    DS_REQUIRE(utab && ctab && gent && kgrp && X && Y, "ds_spmm_union: null pointer");
+    DS_REQUIRE(ctab && gent && kgrp && X && Y, "ds_spmm_union: null pointer");
     DS_REQUIRE(epilogue >= 0 && epilogue <= 3, "ds_spmm_union: bad epilogue %d", epilogue);
     DS_REQUIRE(epilogue == 0 || epilogue == 3 || R0, "ds_spmm_union: the epilogue needs R0");
     DS_REQUIRE(epilogue != 1 || dinv, "ds_spmm_union: the Chebyshev epilogue needs dinv");

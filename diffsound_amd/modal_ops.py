@@ -116,7 +116,8 @@ class TetSystem:
                 cap = int(os.environ.get("DS_UNION_CAP", "116"))
                 ut, ct = _hip.union_chunks(gr.gptr, gr.goff, cap)
                 if ct is not None:
-                    self.groups["union"] = dict(utab=ut.to(dev), ctab=ct.to(dev), capb=cap, ngroups=ut.shape[0])
+                    self.groups["union"] = dict(utab=ut.to(dev), ctab=ct.to(dev), capb=cap, ngroups=ut.shape[0],
+                                                single=bool(ct.shape[0] == ut.shape[0]))  # every group one chunk
         # batch table of the batched SpMM (one wave per run of consecutive nodes).  EXPERIMENTAL build, opt-in
         # (DS_SPMM_BATCHED=1): same speed as the wave-per-node kernels (the product is bound by the CU's gather
         # rate); kept as the base of the neighbour-union kernel.
@@ -313,7 +314,7 @@ class _HipBlockOps:
         if g is None or g.get("union") is None or self.kgrp is None:
             return None
         u = g["union"]
-        d.utab, d.ctab, d.ngroups, d.cap_blocks = u["utab"].data_ptr(), u["ctab"].data_ptr(), u["ngroups"], u["capb"]
+        d.utab, d.ctab, d.ngroups, d.cap_blocks = (None if u.get("single") else u["utab"].data_ptr()), u["ctab"].data_ptr(), u["ngroups"], u["capb"]
         d.gent, d.kgrp, d.nnzb, d.nv, d.dinv = g["gent"].data_ptr(), self.kgrp.data_ptr(), self.kgrp.shape[0], self.nv, self.dinv.data_ptr()
         d.degree, d.lmax, d.lmin = int(degree), float(lmax), float(lmin)
         return d
@@ -355,7 +356,7 @@ class _HipBlockOps:
         g = self.sys.groups
         u = g["union"]
         vals = self.mgrp if epilogue == 3 else self.kgrp
-        _hip.check(self._L.ds_spmm_union(epilogue, pp(u["utab"]), pp(u["ctab"]), u["ngroups"], u["capb"], pp(g["gent"]), pp(vals),
+        _hip.check(self._L.ds_spmm_union(epilogue, None if u.get("single") else pp(u["utab"]), pp(u["ctab"]), u["ngroups"], u["capb"], pp(g["gent"]), pp(vals),
                                          vals.shape[0], self.nv, pp(X), _ld(X), pp(Y), _ld(Y), pp(R0),
                                          0 if R0 is None else _ld(R0), pp(self.dinv) if epilogue == 1 else None,
                                          X.shape[1], float(c1), float(c2), int(bool(first)), _hip.stream_ptr()),

@@ -189,7 +189,7 @@ int ds_spmm_grouped(int epilogue, const int32_t* gptr, const int32_t* gent, cons
  * panel loads of one wavefront per node).  Tables from ds_groups_build - gent (union entries col | mask << 28),
  * kgrp (TRANSPOSED 3x3 blocks in group order, ds_pack_groups) - cut into chunks of whole entries with at most
  * cap_blocks (<= 276) blocks: ctab (nchunks x 4) = (e0, e1, b0, b1), utab (ngroups x 2) = chunk range of each
- * group, ngroups = ceil(nv / 4).
+ * group, ngroups = ceil(nv / 4); utab may be NULL when every group is exactly one chunk (ctab has ngroups rows).
  * epilogue 0: Y <- A X ; 1: Y (= W_prev) <- X + c1 (X - Y) + c2 T (R0 - A X) (first != 0: Y not read) ;
  * 2: Y <- R0 - A X ; 3: Y <- (A_s (x) I3) X with kgrp = the node-SCALAR values in group order (nnzb floats: the mass
  * matrix).  X and Y distinct, 16-byte aligned rows; every operand block 3 nv ld 4 < 0x7f000000 bytes
