@@ -86,7 +86,8 @@ panels) plus the per-entry LDS / FMA work, not by HBM: see DESIGN.md §5.
 | assembly stores through LDS (2.0 → 0.45 ms), wave-per-node fp64 read-out products, in-place residual / ortho update | 18.4 |
 | mass product on the union kernel, fused [X' P'] Ritz updates, leaner launch path | 19.2 |
 | persistent lane threads (no 3-13 ms bubble per step), 4 lanes x 2 hypotheses per step | 20.3 |
-| bench preconditioner Chebyshev(2) smoother / Chebyshev(28, ratio 550) corner-node level | {d["value"]:.1f} |
+| bench preconditioner Chebyshev(2) smoother / Chebyshev(28, ratio 550) corner-node level | 20.7 |
+| union SpMM at five waves per SIMD with a window of four loads (fused term 0.275 -> 0.260 ms, corner-node term 30 -> 25 us) | {d["value"]:.1f} |
 
 SpMM kernel history (80 columns, K·X, micro-benchmark `tools/mb_spmm.py`): node groups per wave 0.441 ms → Morton order
 0.426 → wave per node with scalar metadata 0.340 → cooperative row metadata (readlane ids, LDS coefficients) 0.286 →
@@ -94,8 +95,9 @@ buffer loads with scalar panel offsets 0.271. Variants measured and parked becau
 gather-bound; `make EXPERIMENTAL=1`): LDS-tiled 0.69–0.94 ms, register-blocked 4 nodes per wave 0.273, software-pipelined
 window 0.301, batched (one wave per run of nodes) 0.282.  The neighbour union (4 nodes share their panel loads) went from
 0.289 / fused 0.311 ms (compiler-scheduled FMAs and coefficient reads) to 0.268 / 0.275 ms with inline-asm packed FMAs on
-accumulator halves that never change registers and without the epilogue-row touch during staging, against 0.272 / 0.322 ms
-for one wavefront per node: it is now the production kernel.
+accumulator halves that never change registers and without the epilogue-row touch during staging, then to 0.245 / 0.260 ms
+at five waves per SIMD with a window of four loads, against 0.272 / 0.322 ms for one wavefront per node: it is now the
+production kernel.
 '''
 open(P("README.md"), "w").write(readme)
 print("profiles/README.md written")
