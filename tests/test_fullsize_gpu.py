@@ -84,6 +84,46 @@ def test_c3_gram_folded_fp32_accuracy(c3, dev, p, q, sym):
     assert np.array_equal(ops.gram(A, B, symmetric=sym).cpu().numpy(), G)  # deterministic
 
 
+@pytest.mark.parametrize("ncols", [80, 72])
+def test_c3_union_spmm_matches_wave_per_node(c3, dev, ncols):
+    """The production SpMM of the eigensolver (ds_spmm_union: one wavefront per 4 nodes, five waves per SIMD) against
+    the wave-per-node kernels at the benchmark's size, on column ranges of a 248-column buffer as in the solve:
+    K X, both Chebyshev-term forms, the residual form and the mass product."""
+    ops, sysd = c3["ops"], c3["sys"]
+    assert sysd.groups is not None and sysd.groups["union"] is not None
+    g = torch.Generator(device=dev).manual_seed(ncols)
+    S = torch.randn((ops.n, 248), generator=g, device=dev)
+    X = S[:, 168:168 + ncols]
+    Wp = torch.randn((ops.n, 80), generator=g, device=dev)[:, :ncols]
+    R0 = torch.randn((ops.n, 80), generator=g, device=dev)[:, :ncols] * 1e10
+
+    def run():
+        Y = torch.zeros((ops.n, ncols), device=dev)
+        ops.apply_K(X, Y)
+        a = Wp.clone()
+        ops.cheb_spmm(X, a, R0, 0.31, 0.77, False)
+        b = Wp.clone()
+        ops.cheb_spmm(X, b, R0, 0.0, 0.5, True)
+        c = torch.zeros((ops.n, ncols), device=dev)
+        ops.spmm_residual(X, R0, c)
+        d = torch.zeros((ops.n, ncols), device=dev)
+        ops.apply_M(X, d)
+        return Y, a, b, c, d
+
+    assert ops._union_ok(X, Wp, R0)
+    got = run()
+    u = sysd.groups["union"]
+    sysd.groups["union"] = None
+    try:
+        assert not ops._union_ok(X, Wp, R0)
+        ref = run()
+    finally:
+        sysd.groups["union"] = u
+    for x, y in zip(got, ref):
+        assert float((x - y).abs().max() / y.abs().max()) < 5e-6
+    assert all(torch.equal(x, y) for x, y in zip(run(), got))  # reproducible launch to launch
+
+
 def test_c3_sizes(c3):
     s = c3["sys"]
     assert s.T == 105456 and s.nv == 148877 and s.n == 446631 and s.nnzb * 9 == 37227537
