@@ -63,9 +63,10 @@ values), `mix_lds_kernel<10>` the fused Ritz updates [X' P'] = [X P W][Z1 Zp], `
 The dominant kernel by total time is the fused Chebyshev-term SpMM. Its rocprofv3 average over this run
 ({float(fused3[3]) / 1e3:.3f} ms over {fused3[1]} launches; includes the single-lane target pass and the warm-up) and the HIP-event average over the
 timed region inside `bench.py` ({r["avg_launch_ms"]:.3f} ms over {r["launches_timed"]} launches: fine level {lv["fine"]["avg_launch_ms"]:.2f} ms, corner-node level {lv["corner_node"]["avg_launch_ms"]:.3f} ms;
-a different run, without the profiler) are both stretched by the four lanes sharing the device: `roofline.achieved` =
+a different run, without the profiler, and the launches of the first lane only - the lane that issues them one by one
+from the solver loop) are both stretched by the four lanes sharing the device: `roofline.achieved` =
 {r["achieved"]:.0f} GB/s. Alone on the device the fine-level launch takes {solo["avg_launch_ms"]:.3f} ms (`roofline.solo` in the JSON; the
-single-lane profile above agrees; 0.275–0.279 ms on contiguous operands in `tools/mb_kx_time.py` - the solver's blocks are
+single-lane profile above agrees; 0.260 ms on contiguous operands in `tools/mb_kx_time.py` - the solver's blocks are
 column ranges of a 248-column buffer), i.e. {solo["achieved"] / 1e3:.2f} TB/s algorithmic = {100 * solo["frac"]:.1f} % of the 8 TB/s HBM peak, with {pmc / 1e6:.1f} MB of
 PMC traffic per launch ({pmc / 743098484:.2f} × algorithmic). It is bound by the CU gather path (≈ 27 B/clk/CU for the 960-byte neighbour
 panels) plus the per-entry LDS / FMA work, not by HBM: see DESIGN.md §5.
