@@ -26,7 +26,7 @@ void set_error(const char* fmt, ...) {
 }  // namespace ds
 
 extern "C" const char* ds_last_error(void) { return ds::g_err; }
-extern "C" int ds_abi_version(void) { return 9; }
+extern "C" int ds_abi_version(void) { return 10; }
 
 struct ds_pattern {
     int64_t nv = 0, nnzb = 0, ncontrib = 0;

@@ -33,7 +33,7 @@ def test_header_symbols_exported():
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in include/diffsound_hip.h but not exported"
     assert declared == set(_hip.EXPORTED_SYMBOLS), (declared ^ set(_hip.EXPORTED_SYMBOLS))
-    assert lib.ds_abi_version() == 9
+    assert lib.ds_abi_version() == 10
     assert lib.ds_last_error() is not None
 
 
