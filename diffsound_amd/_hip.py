@@ -51,7 +51,8 @@ _SIGNATURES = {
     "ds_pack_groups": (_I, [_P, _P, _I64, _P, _P]),
     "ds_spmm_grouped": (_I, [_I, _P, _P, _P, _P, _I64, _P, _I64, _P, _I64, _P, _I64, _P, _I, _F, _F, _I, _P]),
     "ds_geometry_grad": (_I, [_P, _I64, _I, _I64, _P, _P, _I64, _I, _P, _P, _D, _D, _P, _P, _I, _P, _P, _P]),
-    "ds_spmm_union": (_I, [_I, _P, _P, _I64, _I, _P, _P, _I64, _I64, _P, _I64, _P, _I64, _P, _I64, _P, _I, _F, _F, _I, _P]),
+    "ds_spmm_union": (_I, [_I, _P, _P, _I64, _I, _P, _P, _I64, _I64, _P, _I64, _P, _I64, _P, _I64, _P, _I, _F, _F, _I, _P,
+                          _I64, _P]),
     "ds_mix": (_I, [_P, _I64, _I, _P, _I, _P, _I64, _I64, _F, _F, _P]),
     "ds_osc_bank_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _D, _P, _P]),
     "ds_osc_bank_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _D, _P, _P, _P, _P, _P]),
@@ -78,7 +79,7 @@ class TwoLevelDesc(ctypes.Structure):
     _fields_ = [("fine", LevelDesc), ("coarse", LevelDesc), ("rptr", _P), ("rcol", _P), ("rw", _P), ("pptr", _P),
                 ("pcol", _P), ("pw", _P), ("R", _P), ("ldr", _I64), ("W", _P), ("ldw", _I64), ("D", _P), ("ldd", _I64),
                 ("AD", _P), ("lda", _I64), ("Rr", _P), ("ldrr", _I64), ("Rc", _P), ("Ec", _P), ("Dc", _P), ("ADc", _P),
-                ("ldc", _I64), ("ncols", ctypes.c_int32)]
+                ("ldc", _I64), ("ncols", ctypes.c_int32), ("Wc", _P), ("ldwc", _I64)]
 
 
 _SIGNATURES["ds_twolevel_apply"] = (_I, [ctypes.POINTER(TwoLevelDesc), _P])

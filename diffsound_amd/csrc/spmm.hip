@@ -169,6 +169,10 @@ struct ChebEpilogue {
     const float* dinv;
     float c1, c2;
     int first;  // W_{k-1} = 0: Y is not read
+    // neighbour-union kernel only: W_{k-1} read from here instead of from Y (nullptr: from Y, the in-place form) - the
+    // last term of a polynomial run on compact scratch blocks can then land in a column range of a wider buffer
+    const float* wprev = nullptr;
+    int64_t ldp = 0;
 };
 
 template <int KIND, int RS, int LPN_CT, int EPI>
@@ -1034,7 +1038,7 @@ extern "C" int ds_spmm_union(int epilogue, const int32_t* utab, const int32_t* c
                              const int32_t* gent,
                              const float* kgrp, int64_t nnzb, int64_t nv, const float* X, int64_t ldx, float* Y,
                              int64_t ldy, const float* R0, int64_t ldr, const float* dinv, int ncols, float c1, float c2,
-                             int first, ds_stream_t stream) {
+                             int first, const float* Wprev, int64_t ldp, ds_stream_t stream) {
     DS_REQUIRE(ctab && gent && kgrp && X && Y, "ds_spmm_union: null pointer");
     DS_REQUIRE(epilogue >= 0 && epilogue <= 3, "ds_spmm_union: bad epilogue %d", epilogue);
     DS_REQUIRE(epilogue == 0 || epilogue == 3 || R0, "ds_spmm_union: the epilogue needs R0");
@@ -1054,7 +1058,13 @@ extern "C" int ds_spmm_union(int epilogue, const int32_t* utab, const int32_t* c
     if (epilogue == 1 || epilogue == 2) al |= reinterpret_cast<uintptr_t>(R0) | (uintptr_t)(ldr * 4);
     DS_REQUIRE((al & 15) == 0, "ds_spmm_union: rows, kgrp and ctab must be 16-byte aligned");
     hipStream_t st = ds::as_stream(stream);
-    const ChebEpilogue epi{R0, ldr, dinv, c1, c2, first};
+    ChebEpilogue epi{R0, ldr, dinv, c1, c2, first};
+    if (Wprev && epilogue == 1) {
+        DS_REQUIRE(ldp >= ncols && 3 * nv * ldp * 4 < (int64_t)PIPE_OOB &&
+                       ((reinterpret_cast<uintptr_t>(Wprev) | (uintptr_t)(ldp * 4)) & 15) == 0 && Wprev != X,
+                   "ds_spmm_union: bad W_prev block");
+        epi.wprev = Wprev, epi.ldp = ldp;
+    }
     const int lpn = ncols / 4;
 #define DS_U(L, E) return launch_union<L, E>(utab, ctab, ngroups, cap_blocks, gent, kgrp, nnzb, nv, X, ldx, Y, ldy, lpn, st, epi)
     if (lpn == 20) {

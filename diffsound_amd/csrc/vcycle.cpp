@@ -12,26 +12,23 @@
 
 namespace {
 
-// W <- p(T K) T R by the three-term Chebyshev recurrence W_{k+1} = W_k + c1 (W_k - W_{k-1}) + c2 T (R - K W_k)
-// (Saad, Iterative Methods, Alg. 12.1), ping-ponging between W and D; from_guess: W holds W_0 and `degree` terms
-// of the ITERATION for K W = R are run from it.  Mirrors ChebyshevBlockJacobi._fused.
-int chebyshev(const ds_level_t& L, const float* R, int64_t ldr, float* W, int64_t ldw, float* D, int64_t ldd,
-              float* AD, int64_t lda, int ncols, bool from_guess, ds_stream_t stream) {
+// Wout <- p(T K) T R by the three-term Chebyshev recurrence W_{k+1} = W_k + c1 (W_k - W_{k-1}) + c2 T (R - K W_k)
+// (Saad, Iterative Methods, Alg. 12.1).  The iterates ping-pong between the COMPACT scratch blocks A and B (a neighbour
+// panel of a compact block is 960 contiguous bytes; the same panel of a column range of the 248-column basis buffer
+// spans a quarter more cache lines: 0.287 against 0.260 ms per fused term), and the LAST term reads its W_{k-1} from
+// scratch but writes into Wout (out-of-place form of ds_spmm_union).  from_guess: A holds W_0 and `degree` terms of
+// the ITERATION for K W = R are run from it.  B doubles as the unused second output of ds_cheb_init.  Mirrors
+// ChebyshevBlockJacobi._fused.
+int chebyshev(const ds_level_t& L, const float* R, int64_t ldr, float* Wout, int64_t ldw, float* A, float* B,
+              int64_t lds, int ncols, bool from_guess, ds_stream_t stream) {
     const double theta = 0.5 * (L.lmax + L.lmin), delta = 0.5 * (L.lmax - L.lmin);
     const double sigma1 = theta / delta;
     double rho = 1.0 / sigma1;
-    int terms;
-    float *cur, *oth;
-    int64_t ldcur, ldoth;
-    if (from_guess) {
-        terms = L.degree;
-        cur = W, ldcur = ldw, oth = D, ldoth = ldd;
-    } else {
-        terms = L.degree - 1;
-        const bool w_first = terms % 2 == 0;  // so that the last term lands in W
-        cur = w_first ? W : D, ldcur = w_first ? ldw : ldd;
-        oth = w_first ? D : W, ldoth = w_first ? ldd : ldw;
-        int rc = ds_cheb_init(R, ldr, AD, lda, cur, ldcur, L.dinv, L.nv, ncols, (float)(1.0 / theta), stream);
+    const int terms = from_guess ? L.degree : L.degree - 1;
+    float *cur = A, *oth = B;
+    if (!from_guess) {  // W_1 = T R / theta (straight into Wout when no term follows)
+        int rc = ds_cheb_init(R, ldr, B, lds, terms == 0 ? Wout : cur, terms == 0 ? ldw : lds, L.dinv, L.nv, ncols,
+                              (float)(1.0 / theta), stream);
         if (rc != DS_OK) return rc;
     }
     for (int k = 0; k < terms; ++k) {
@@ -43,19 +40,14 @@ int chebyshev(const ds_level_t& L, const float* R, int64_t ldr, float* W, int64_
             c1 = (float)(rho_new * rho), c2 = (float)(2.0 * rho_new / delta);
             rho = rho_new;
         }
-        int rc = ds_spmm_union(1, L.utab, L.ctab, L.ngroups, L.cap_blocks, L.gent, L.kgrp, L.nnzb, L.nv, cur, ldcur, oth,
-                               ldoth, R, ldr, L.dinv, ncols, c1, c2, k == 0 ? 1 : 0, stream);
+        const bool last = k == terms - 1;
+        // W_{k+1} overwrites W_{k-1} (oth) - except the last one, which reads oth and lands in Wout
+        int rc = ds_spmm_union(1, L.utab, L.ctab, L.ngroups, L.cap_blocks, L.gent, L.kgrp, L.nnzb, L.nv, cur, lds,
+                               last ? Wout : oth, last ? ldw : lds, R, ldr, L.dinv, ncols, c1, c2, k == 0 ? 1 : 0,
+                               last ? oth : nullptr, last ? lds : 0, stream);
         if (rc != DS_OK) return rc;
         float* t = cur;
         cur = oth, oth = t;
-        const int64_t tl = ldcur;
-        ldcur = ldoth, ldoth = tl;
-    }
-    if (cur != W) {
-        int rc = ds::check_hip(hipMemcpy2DAsync(W, (size_t)ldw * 4, cur, (size_t)ldcur * 4, (size_t)ncols * 4,
-                                                (size_t)(3 * L.nv), hipMemcpyDeviceToDevice, ds::as_stream(stream)),
-                               "ds_twolevel_apply: hipMemcpy2DAsync");
-        if (rc != DS_OK) return rc;
     }
     return DS_OK;
 }
@@ -64,33 +56,30 @@ int chebyshev(const ds_level_t& L, const float* R, int64_t ldr, float* W, int64_
 
 extern "C" int ds_twolevel_apply(const ds_twolevel_t* p, ds_stream_t stream) {
     DS_REQUIRE(p, "ds_twolevel_apply: null descriptor");
-    DS_REQUIRE(p->R && p->W && p->D && p->AD && p->Rr && p->Rc && p->Ec && p->Dc && p->ADc,
+    DS_REQUIRE(p->R && p->W && p->Wc && p->D && p->AD && p->Rr && p->Rc && p->Ec && p->Dc && p->ADc,
                "ds_twolevel_apply: null block pointer");
     DS_REQUIRE(p->rptr && p->rcol && p->rw && p->pptr && p->pcol && p->pw, "ds_twolevel_apply: null transfer operator");
     DS_REQUIRE(p->ncols > 0 && p->ncols % 4 == 0 && p->ncols <= 84, "ds_twolevel_apply: ncols must be a multiple of 4 <= 84");
-    DS_REQUIRE(p->fine.degree >= 1 && p->coarse.degree >= 2 && p->fine.lmax > p->fine.lmin && p->fine.lmin > 0.0 &&
+    DS_REQUIRE(p->ldwc == p->ldd && p->lda == p->ldd, "ds_twolevel_apply: Wc, D and AD must share one leading dimension");
+    DS_REQUIRE(p->fine.degree >= 1 && p->coarse.degree >= 1 && p->fine.lmax > p->fine.lmin && p->fine.lmin > 0.0 &&
                    p->coarse.lmax > p->coarse.lmin && p->coarse.lmin > 0.0,
                "ds_twolevel_apply: bad polynomial degrees / spectral intervals");
     const int c = p->ncols;
-    int rc;
-    // W1 = S R
-    if (p->fine.degree > 1)
-        rc = chebyshev(p->fine, p->R, p->ldr, p->W, p->ldw, p->D, p->ldd, p->AD, p->lda, c, false, stream);
-    else
-        rc = ds_cheb_init(p->R, p->ldr, p->D, p->ldd, p->W, p->ldw, p->fine.dinv, p->fine.nv, c,
-                          (float)(1.0 / (0.5 * (p->fine.lmax + p->fine.lmin))), stream);
+    // fine-level iterates live in the compact blocks Wc / D / AD; W is written once, by the last term of the cycle
+    int rc = chebyshev(p->fine, p->R, p->ldr, p->Wc, p->ldwc, p->D, p->AD, p->ldd, c, false, stream);  // W1 = S R
     if (rc != DS_OK) return rc;
     // Rr = R - K W1 ;  Rc = P^T Rr
     rc = ds_spmm_union(2, p->fine.utab, p->fine.ctab, p->fine.ngroups, p->fine.cap_blocks, p->fine.gent, p->fine.kgrp,
-                       p->fine.nnzb, p->fine.nv, p->W, p->ldw, p->Rr, p->ldrr, p->R, p->ldr, nullptr, c, 0.f, 0.f, 0, stream);
+                       p->fine.nnzb, p->fine.nv, p->Wc, p->ldwc, p->Rr, p->ldrr, p->R, p->ldr, nullptr, c, 0.f, 0.f, 0,
+                       nullptr, 0, stream);
     if (rc != DS_OK) return rc;
     rc = ds_scalar_csr_spmm(p->rptr, p->rcol, p->rw, p->coarse.nv, p->Rr, p->ldrr, p->Rc, p->ldc, c, 0.f, stream);
     if (rc != DS_OK) return rc;
     // Ec = C Rc ;  W2 = W1 + P Ec
-    rc = chebyshev(p->coarse, p->Rc, p->ldc, p->Ec, p->ldc, p->Dc, p->ldc, p->ADc, p->ldc, c, false, stream);
+    rc = chebyshev(p->coarse, p->Rc, p->ldc, p->Ec, p->ldc, p->Dc, p->ADc, p->ldc, c, false, stream);
     if (rc != DS_OK) return rc;
-    rc = ds_scalar_csr_spmm(p->pptr, p->pcol, p->pw, p->fine.nv, p->Ec, p->ldc, p->W, p->ldw, c, 1.f, stream);
+    rc = ds_scalar_csr_spmm(p->pptr, p->pcol, p->pw, p->fine.nv, p->Ec, p->ldc, p->Wc, p->ldwc, c, 1.f, stream);
     if (rc != DS_OK) return rc;
-    // W = W2 + S (R - K W2): the smoother's iteration started from W2
-    return chebyshev(p->fine, p->R, p->ldr, p->W, p->ldw, p->D, p->ldd, p->AD, p->lda, c, true, stream);
+    // W = W2 + S (R - K W2): the smoother's iteration started from W2 (in Wc), its last term lands in W
+    return chebyshev(p->fine, p->R, p->ldr, p->W, p->ldw, p->Wc, p->D, p->ldd, c, true, stream);
 }

@@ -311,14 +311,15 @@ class TwoLevelChebyshev:
             w = Rs.shape[1]
             if self._buf is None or self._buf[0].shape[1] != w:
                 mk = lambda rows: torch.empty((rows, w), dtype=R.dtype, device=R.device)
-                self._buf = (mk(R.shape[0]), mk(nc), mk(nc))
-            Rr, Rc, Ec = self._buf
+                self._buf = (mk(R.shape[0]), mk(nc), mk(nc), mk(R.shape[0]))
+            Rr, Rc, Ec, Wc = self._buf
             native = getattr(ops, "twolevel_apply", None)
             if native is not None and os.environ.get("DS_NATIVE_VCYCLE", "1") != "0":
                 D, AD = self.smooth._buffers(Rs)
                 Dc, ADc = self.coarse._buffers(Rc)
                 if native((self.smooth.degree, self.smooth.lmax, self.smooth.lmin),
-                          (self.coarse.degree, self.coarse.lmax, self.coarse.lmin), Rs, Ws, D, AD, Rr, Rc, Ec, Dc, ADc):
+                          (self.coarse.degree, self.coarse.lmax, self.coarse.lmin), Rs, Ws, D, AD, Rr, Rc, Ec, Dc, ADc,
+                          Wc):
                     continue
             self.smooth.apply(Rs, Ws)
             ops.spmm_residual(Ws, Rs, Rr)

@@ -319,14 +319,14 @@ class _HipBlockOps:
         d.degree, d.lmax, d.lmin = int(degree), float(lmax), float(lmin)
         return d
 
-    def twolevel_apply(self, smooth, coarse, R, W, D, AD, Rr, Rc, Ec, Dc, ADc):
+    def twolevel_apply(self, smooth, coarse, R, W, D, AD, Rr, Rc, Ec, Dc, ADc, Wc):
         """The whole two-level V-cycle W = B R through the native driver (ds_twolevel_apply): one call instead of
         ~45 launches issued one by one.  ``smooth`` / ``coarse``: (degree, lmax, lmin) of the two Chebyshev operators.
         Returns False (nothing done) when a level or a block does not qualify for the neighbour-union kernels."""
         co = self.coarse
         if co is None or self.cheb_events is not None or co.cheb_events is not None:
             return False  # (the bench times the fused terms launch by launch: that lane keeps the Python path)
-        if not (self._union_ok(R, W, D, AD, Rr) and co._union_ok(Rc, Ec, Dc, ADc)):
+        if not (self._union_ok(R, W, D, AD, Rr, Wc) and co._union_ok(Rc, Ec, Dc, ADc)):
             return False
         d = self._tl_desc
         if d is None:
@@ -336,13 +336,15 @@ class _HipBlockOps:
             d.pptr, d.pcol, d.pw = t["pptr"].data_ptr(), t["pcol"].data_ptr(), t["pw"].data_ptr()
         if self.level_desc(d.fine, *smooth) is None or co.level_desc(d.coarse, *coarse) is None:
             return False
-        if not (Rc.stride(0) == Ec.stride(0) == Dc.stride(0) == ADc.stride(0)):
+        if not (Rc.stride(0) == Ec.stride(0) == Dc.stride(0) == ADc.stride(0) and
+                Wc.stride(0) == D.stride(0) == AD.stride(0)):
             return False
         d.R, d.ldr, d.W, d.ldw = R.data_ptr(), R.stride(0), W.data_ptr(), W.stride(0)
         d.D, d.ldd, d.AD, d.lda = D.data_ptr(), D.stride(0), AD.data_ptr(), AD.stride(0)
         d.Rr, d.ldrr = Rr.data_ptr(), Rr.stride(0)
         d.Rc, d.Ec, d.Dc, d.ADc, d.ldc = Rc.data_ptr(), Ec.data_ptr(), Dc.data_ptr(), ADc.data_ptr(), Rc.stride(0)
         d.ncols = R.shape[1]
+        d.Wc, d.ldwc = Wc.data_ptr(), Wc.stride(0)
         _hip.check(self._L.ds_twolevel_apply(ctypes.byref(d), _hip.stream_ptr()), "ds_twolevel_apply")
         c = R.shape[1]
         self.counts["apply_K_cols"] += c * (max(smooth[0] - 1, 0) + 1 + smooth[0])
@@ -351,7 +353,7 @@ class _HipBlockOps:
 
     _tl_desc = None
 
-    def _union(self, epilogue, X, Y, R0=None, c1=0.0, c2=0.0, first=False):
+    def _union(self, epilogue, X, Y, R0=None, c1=0.0, c2=0.0, first=False, Wprev=None):
         pp = _hip.ptr
         g = self.sys.groups
         u = g["union"]
@@ -359,7 +361,8 @@ class _HipBlockOps:
         _hip.check(self._L.ds_spmm_union(epilogue, None if u.get("single") else pp(u["utab"]), pp(u["ctab"]), u["ngroups"], u["capb"], pp(g["gent"]), pp(vals),
                                          vals.shape[0], self.nv, pp(X), _ld(X), pp(Y), _ld(Y), pp(R0),
                                          0 if R0 is None else _ld(R0), pp(self.dinv) if epilogue == 1 else None,
-                                         X.shape[1], float(c1), float(c2), int(bool(first)), _hip.stream_ptr()),
+                                         X.shape[1], float(c1), float(c2), int(bool(first)), pp(Wprev),
+                                         0 if Wprev is None else _ld(Wprev), _hip.stream_ptr()),
                    "ds_spmm_union")
 
     def _batched_ok(self, X, op="K"):

@@ -191,6 +191,7 @@ int ds_spmm_grouped(int epilogue, const int32_t* gptr, const int32_t* gent, cons
  * cap_blocks (<= 276) blocks: ctab (nchunks x 4) = (e0, e1, b0, b1), utab (ngroups x 2) = chunk range of each
  * group, ngroups = ceil(nv / 4); utab may be NULL when every group is exactly one chunk (ctab has ngroups rows).
  * epilogue 0: Y <- A X ; 1: Y (= W_prev) <- X + c1 (X - Y) + c2 T (R0 - A X) (first != 0: Y not read) ;
+ * (Wprev != NULL, epilogue 1 only: W_prev is read from there and Y is only written - out-of-place form) ;
  * 2: Y <- R0 - A X ; 3: Y <- (A_s (x) I3) X with kgrp = the node-SCALAR values in group order (nnzb floats: the mass
  * matrix).  X and Y distinct, 16-byte aligned rows; every operand block 3 nv ld 4 < 0x7f000000 bytes
  * (larger problems use ds_cheb_spmm / ds_spmm_residual / ds_spmm_bsr3).
@@ -198,7 +199,7 @@ int ds_spmm_grouped(int epilogue, const int32_t* gptr, const int32_t* gent, cons
 int ds_spmm_union(int epilogue, const int32_t* utab, const int32_t* ctab, int64_t ngroups, int cap_blocks,
                   const int32_t* gent, const float* kgrp, int64_t nnzb, int64_t nv, const float* X, int64_t ldx,
                   float* Y, int64_t ldy, const float* R0, int64_t ldr, const float* dinv, int ncols, float c1, float c2,
-                  int first, ds_stream_t stream);
+                  int first, const float* Wprev, int64_t ldp, ds_stream_t stream);
 /* ------------------------------------------------------------------------------------------------
  * Two-level V-cycle preconditioner in one call (host-side driver, csrc/vcycle.cpp): issues on `stream` the launch
  * sequence  W1 = S R ; W2 = W1 + P C P^T (R - K W1) ; W = W2 + S (R - K W2)  out of ds_cheb_init, ds_spmm_union and
@@ -206,7 +207,8 @@ int ds_spmm_union(int epilogue, const int32_t* utab, const int32_t* ctab, int64_
  * on the fine level, C: the same on the corner-node level, P / P^T the transfer operators.  The preconditioner of
  * the reference's LOBPCG is an opaque callable (src/lobpcg/_lobpcg.py:441); this is the one diffsound_amd supplies.
  * All blocks (rows x ncols) f32 with leading dimensions, 16-byte aligned rows, ncols a multiple of 4 <= 84; R is only
- * read; D, AD, Rr (fine) and Rc, Ec, Dc, ADc (corner-node level, common leading dimension ldc) are scratch.
+ * read; Wc, D, AD (one common leading dimension), Rr (fine) and Rc, Ec, Dc, ADc (corner-node level, common leading
+ * dimension ldc) are scratch.
  * ---------------------------------------------------------------------------------------------- */
 typedef struct {
     const int32_t* utab;   /* neighbour-union tables and values of the level, as for ds_spmm_union */
@@ -240,6 +242,8 @@ typedef struct {
     float *Rc, *Ec, *Dc, *ADc;
     int64_t ldc;
     int32_t ncols;
+    float* Wc;       /* fine scratch: the cycle's iterate (compact), W itself is written once at the end */
+    int64_t ldwc;    /* = ldd = lda */
 } ds_twolevel_t;
 int ds_twolevel_apply(const ds_twolevel_t* p, ds_stream_t stream);
 

@@ -529,6 +529,13 @@ def test_union_spmm_matches_wave_per_node(dev, mesh, order, ncols):
         return Y, a, b, c, d
 
     assert ops._union_ok(X, Wp, R0) and ops.mgrp is not None
+    # out-of-place form of the fused term: W_prev read from one block, the result written to a column range of another
+    wide = torch.full((sysd.n, ncols + 8), float("nan"), device=dev)
+    ops._union(1, X, wide[:, 4:4 + ncols], R0, 0.31, 0.77, False, Wprev=Wp)
+    inplace = Wp.clone()
+    ops._union(1, X, inplace, R0, 0.31, 0.77, False)
+    assert torch.equal(wide[:, 4:4 + ncols], inplace)
+    assert bool(torch.isnan(wide[:, :4]).all()) and bool(torch.isnan(wide[:, 4 + ncols:]).all())
     for _ in range(3):
         got = run()
         sysd.groups["union"] = None
