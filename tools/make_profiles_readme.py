@@ -88,7 +88,8 @@ panels) plus the per-entry LDS / FMA work, not by HBM: see DESIGN.md §5.
 | mass product on the union kernel, fused [X' P'] Ritz updates, leaner launch path | 19.2 |
 | persistent lane threads (no 3-13 ms bubble per step), 4 lanes x 2 hypotheses per step | 20.3 |
 | bench preconditioner Chebyshev(2) smoother / Chebyshev(28, ratio 550) corner-node level | 20.7 |
-| union SpMM at five waves per SIMD with a window of four loads (fused term 0.275 -> 0.260 ms, corner-node term 30 -> 25 us) | {d["value"]:.1f} |
+| union SpMM at five waves per SIMD with a window of four loads (fused term 0.275 -> 0.260 ms, corner-node term 30 -> 25 us) | 21.5 |
+| V-cycle on compact iterates (out-of-place last term) | {d["value"]:.1f} |
 
 SpMM kernel history (80 columns, K·X, micro-benchmark `tools/mb_spmm.py`): node groups per wave 0.441 ms → Morton order
 0.426 → wave per node with scalar metadata 0.340 → cooperative row metadata (readlane ids, LDS coefficients) 0.286 →
