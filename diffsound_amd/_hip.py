@@ -12,6 +12,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libdiffsound_hip.so")
+ABI_VERSION = 11  # DS_ABI_VERSION of include/diffsound_hip.h
 
 c_i32p = ctypes.POINTER(ctypes.c_int32)
 _P = ctypes.c_void_p
@@ -38,18 +39,11 @@ _SIGNATURES = {
     "ds_cheb_spmm": (_I, [_P, _P, _P, _I64, _P, _I64, _P, _I64, _P, _I64, _P, _I, _F, _F, _I, _P]),
     "ds_spmm_residual": (_I, [_P, _P, _P, _I64, _P, _I64, _P, _I64, _P, _I64, _I, _P]),
     "ds_scalar_csr_spmm": (_I, [_P, _P, _P, _I64, _P, _I64, _P, _I64, _I, _F, _P]),
-    "ds_tiles_build": (_I, [_P, _P, _I64, _I, _I, ctypes.POINTER(_P)]),
-    "ds_tiles_sizes": (_I, [_P, ctypes.POINTER(_I64), ctypes.POINTER(_I64)]),
-    "ds_tiles_export": (_I, [_P, _P, _P, _P, _P]),
-    "ds_tiles_free": (None, [_P]),
-    "ds_spmm_tiled": (_I, [_I, _P, _P, _I64, _P, _P, _P, _P, _I64, _I, _P, _I64, _P, _I64, _P, _I64, _P, _I, _F, _F,
-                           _I, _P]),
     "ds_groups_build": (_I, [_P, _P, _I64, ctypes.POINTER(_P)]),
     "ds_groups_sizes": (_I, [_P, ctypes.POINTER(_I64), ctypes.POINTER(_I64)]),
     "ds_groups_export": (_I, [_P, _P, _P, _P, _P]),
     "ds_groups_free": (None, [_P]),
     "ds_pack_groups": (_I, [_P, _P, _I64, _P, _P]),
-    "ds_spmm_grouped": (_I, [_I, _P, _P, _P, _P, _I64, _P, _I64, _P, _I64, _P, _I64, _P, _I, _F, _F, _I, _P]),
     "ds_geometry_grad": (_I, [_P, _I64, _I, _I64, _P, _P, _I64, _I, _P, _P, _D, _D, _P, _P, _I, _P, _P, _P]),
     "ds_spmm_union": (_I, [_I, _P, _P, _I64, _I, _P, _P, _I64, _I64, _P, _I64, _P, _I64, _P, _I64, _P, _I, _F, _F, _I, _P,
                           _I64, _P]),
@@ -57,15 +51,6 @@ _SIGNATURES = {
     "ds_osc_bank_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _D, _P, _P]),
     "ds_osc_bank_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _D, _P, _P, _P, _P, _P]),
 }
-
-# only in a library built with `make EXPERIMENTAL=1` (declared under DS_EXPERIMENTAL in the header)
-_EXPERIMENTAL_SIGNATURES = {
-    "ds_spmm_batch_limits": (None, [ctypes.POINTER(_I), ctypes.POINTER(_I)]),
-    "ds_spmm_batched": (_I, [_I, _I, _P, _I64, _P, _P, _P, _I64, _I64, _P, _I64, _P, _I64, _P, _I64, _P, _I, _F, _F,
-                            _I, _P]),
-}
-
-
 
 class LevelDesc(ctypes.Structure):
     """ds_level_t of include/diffsound_hip.h."""
@@ -97,15 +82,15 @@ def lib():
                 "`python -c 'import __graft_entry__ as g; g.build()'` or `make -C diffsound_amd/csrc`. "
                 "There is no CPU fallback.")
         handle = ctypes.CDLL(LIB_PATH)
+        handle.ds_abi_version.restype = _I
+        got = handle.ds_abi_version()
+        if got != ABI_VERSION:  # a stale build resolves every symbol and would be called with shifted arguments
+            raise RuntimeError(f"diffsound_amd: {LIB_PATH} has ABI version {got}, this package needs {ABI_VERSION} - "
+                               "rebuild it with `make -C diffsound_amd/csrc`")
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(handle, name)
             fn.restype = res
             fn.argtypes = args
-        for name, (res, args) in _EXPERIMENTAL_SIGNATURES.items():
-            fn = getattr(handle, name, None)
-            if fn is not None:
-                fn.restype = res
-                fn.argtypes = args
         _lib = handle
     return _lib
 
@@ -164,29 +149,8 @@ class Pattern:
             lib().ds_pattern_free(handle)
 
 
-class Tiles:
-    """Row tiles for the LDS-tiled SpMM (ds_tiles_build): host arrays tnode, tuptr, ulist (int32), lidx (int16 bits)."""
-
-    def __init__(self, rowptr_cpu, colidx_cpu, nv, nu_max=80, nb_max=8):
-        handle = ctypes.c_void_p()
-        check(lib().ds_tiles_build(ptr(rowptr_cpu), ptr(colidx_cpu), nv, nu_max, nb_max, ctypes.byref(handle)),
-              "ds_tiles_build")
-        try:
-            a, b = _I64(), _I64()
-            check(lib().ds_tiles_sizes(handle, ctypes.byref(a), ctypes.byref(b)), "ds_tiles_sizes")
-            self.ntiles, self.nu_total, self.nu_max = a.value, b.value, nu_max
-            self.tnode = torch.empty(self.ntiles + 1, dtype=torch.int32)
-            self.tuptr = torch.empty(self.ntiles + 1, dtype=torch.int32)
-            self.ulist = torch.empty(self.nu_total, dtype=torch.int32)
-            self.lidx = torch.empty(colidx_cpu.numel(), dtype=torch.int16)  # uint16 payload
-            check(lib().ds_tiles_export(handle, ptr(self.tnode), ptr(self.tuptr), ptr(self.ulist), ptr(self.lidx)),
-                  "ds_tiles_export")
-        finally:
-            lib().ds_tiles_free(handle)
-
-
 class Groups:
-    """Node groups for the register-blocked SpMM (ds_groups_build): host arrays gptr, gent, goff, kperm (int32)."""
+    """Node groups of the neighbour-union SpMM (ds_groups_build): host arrays gptr, gent, goff, kperm (int32)."""
 
     def __init__(self, rowptr_cpu, colidx_cpu, nv):
         handle = ctypes.c_void_p()
@@ -237,32 +201,3 @@ def union_chunks(gptr_cpu, goff_cpu, cap):
         return None, None
     utab = np.stack([start[:-1], start[1:]], 1)
     return torch.from_numpy(utab.astype(np.int32)), torch.from_numpy(ctab.astype(np.int32))
-
-
-def build_batches(rowptr_cpu):
-    """Batch table of the batched SpMM (ds_spmm_batched): consecutive nodes packed greedily into batches of at
-    most ``cap`` blocks and ``max_nodes`` nodes (ds_spmm_batch_limits).  Returns an (nbatch, 4) int32 CPU tensor
-    of rows (n0, n1, kb0, ke0), or None when the pattern does not qualify (an empty row, or a row longer than
-    a batch) - the caller then keeps the wave-per-node kernels."""
-    import numpy as np
-
-    if not hasattr(lib(), "ds_spmm_batched"):
-        raise RuntimeError("the batched SpMM is an experiment: rebuild with `make -C diffsound_amd/csrc EXPERIMENTAL=1`")
-    cap, mx = _I(), _I()
-    lib().ds_spmm_batch_limits(ctypes.byref(cap), ctypes.byref(mx))
-    cap, mx = cap.value, mx.value
-    rp = rowptr_cpu.numpy().astype(np.int64)
-    nv = rp.shape[0] - 1
-    lens = np.diff(rp)
-    if nv == 0 or lens.min() < 1 or lens.max() > cap:
-        return None
-    # greedy: the batch starting at n0 ends at the last node whose row still ends within cap blocks
-    ends = np.searchsorted(rp, rp[:-1] + cap, side="right") - 1  # candidate n1 for every possible n0
-    ends = np.minimum(ends, np.arange(nv) + mx)
-    rows = []
-    n0 = 0
-    while n0 < nv:
-        n1 = int(ends[n0])
-        rows.append((n0, n1, rp[n0], rp[n1]))
-        n0 = n1
-    return torch.from_numpy(np.asarray(rows, dtype=np.int32))

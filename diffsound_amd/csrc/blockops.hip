@@ -427,12 +427,11 @@ extern "C" int ds_mix(const float* A, int64_t lda, int p, const float* C, int q,
     hipStream_t st = ds::as_stream(stream);
     const bool veca = aligned16(A, lda) && (p % 4 == 0);
     int rc = DS_OK;
-    static const bool no_lds = getenv("DS_MIX_GENERIC") != nullptr;  // A/B switch for benchmarking
     // LDS-staged path: the coefficient image ((p rounded to 16) x (q rounded to 16) floats) has to fit the CU's 160 KB;
     // up to 80 columns two workgroups share a CU, wider results (the fused [X' P'] = [X P W] [Z1 Zp] update) take it whole
     const int jt = (q + 15) / 16;
     const size_t image = (size_t)((p + 15) & ~15) * jt * 16 * sizeof(float);
-    if (veca && q <= 160 && p <= 256 && n >= 4096 && image <= 160 * 1024 && !no_lds) {
+    if (veca && q <= 160 && p <= 256 && n >= 4096 && image <= 160 * 1024) {
         switch (jt) {
             case 1: return launch_mix_lds<1>(A, lda, p, C, q, Out, ldo, n, alpha, beta, st);
             case 2: return launch_mix_lds<2>(A, lda, p, C, q, Out, ldo, n, alpha, beta, st);

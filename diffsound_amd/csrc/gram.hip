@@ -433,11 +433,10 @@ Plan make_plan(int64_t n, int p, int q, int symmetric, bool fast) {
     pl.groups = (int)ds::ceil_div(pl.ntiles, 4);
     // The grid is sized to fill the chip an integer number of times: the fp64 kernel holds 152 VGPRs = 3 workgroups
     // per CU, 768 on the chip, and a 1026-workgroup grid ran one full round and a second one at a third of the
-    // occupancy, i.e. in the time of two (DS_GRAM_WGS overrides the target for experiments).
-    static const int64_t forced = getenv("DS_GRAM_WGS") ? atoll(getenv("DS_GRAM_WGS")) : 0;
+    // occupancy, i.e. in the time of two.
     static const int64_t res64 = resident_workgroups(gram_partial_kernel<float>);
     static const int64_t res32 = resident_workgroups(gram32_partial_kernel);
-    const int64_t target = forced ? forced : (fast ? res32 : res64);
+    const int64_t target = fast ? res32 : res64;
     int64_t nsplit = std::max<int64_t>(1, target / pl.groups);
     nsplit = std::min<int64_t>(nsplit, ds::ceil_div(n, 512));   // at least 512 rows per split
     nsplit = std::max<int64_t>(nsplit, 1);
@@ -467,8 +466,7 @@ extern "C" int ds_gram(const float* A, int64_t lda, int p, const void* B, int b_
     DS_REQUIRE((flags & ~(DS_GRAM_SYMMETRIC | DS_GRAM_EXACT)) == 0, "ds_gram: unknown flag bits %d", flags);
     const int symmetric = (flags & DS_GRAM_SYMMETRIC) ? 1 : 0;
     DS_REQUIRE(!symmetric || p == q, "ds_gram: symmetric needs p == q");
-    static const bool force_exact = getenv("DS_GRAM_EXACT") != nullptr;
-    const bool fast = b_dtype == DS_F32 && !(flags & DS_GRAM_EXACT) && !force_exact;
+    const bool fast = b_dtype == DS_F32 && !(flags & DS_GRAM_EXACT);
     const Plan pl = make_plan(n, p, q, symmetric, fast);
     DS_REQUIRE(work_bytes >= (int64_t)pl.nsplit * p * q * (int64_t)sizeof(double),
                "ds_gram: workspace too small (%lld bytes given)", (long long)work_bytes);

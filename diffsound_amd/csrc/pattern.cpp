@@ -26,7 +26,7 @@ void set_error(const char* fmt, ...) {
 }  // namespace ds
 
 extern "C" const char* ds_last_error(void) { return ds::g_err; }
-extern "C" int ds_abi_version(void) { return 10; }
+extern "C" int ds_abi_version(void) { return DS_ABI_VERSION; }
 
 struct ds_pattern {
     int64_t nv = 0, nnzb = 0, ncontrib = 0;
@@ -178,91 +178,6 @@ extern "C" int ds_pattern_export(const ds_pattern_t* p, int32_t* rowptr, int32_t
 extern "C" void ds_pattern_free(ds_pattern_t* p) { delete p; }
 
 // ------------------------------------------------------------------------------------------------
-// Row tiles for the LDS-tiled SpMM: consecutive (Morton-ordered) nodes are grouped greedily so that the
-// union of their neighbour sets has at most nu_max members; each block then carries a 16-bit index into
-// its tile's unique-neighbour list, and the kernel stages every neighbour panel ONCE per tile in LDS.
-struct ds_tiles {
-    int64_t ntiles = 0, nu_total = 0, nnzb = 0;
-    std::vector<int32_t> tnode, tuptr, ulist;
-    std::vector<uint16_t> lidx;
-};
-
-extern "C" int ds_tiles_build(const int32_t* rowptr, const int32_t* colidx, int64_t nv, int nu_max, int nb_max,
-                              ds_tiles_t** out) {
-    DS_REQUIRE(rowptr && colidx && out, "ds_tiles_build: null argument");
-    DS_REQUIRE(nv > 0 && nu_max > 0 && nu_max <= 65535 && nb_max > 0, "ds_tiles_build: bad parameters");
-    auto* t = new (std::nothrow) ds_tiles;
-    if (!t) {
-        ds::set_error("ds_tiles_build: out of memory");
-        return DS_ERR_NOMEM;
-    }
-    t->nnzb = rowptr[nv];
-    t->lidx.resize(t->nnzb);
-    std::vector<int32_t> stamp(nv, -1);  // tile id that last saw a column
-    t->tnode.push_back(0);
-    t->tuptr.push_back(0);
-    std::vector<int32_t> cur;  // unique columns of the open tile
-    int64_t start = 0;
-    auto close_tile = [&](int64_t end) {
-        std::sort(cur.begin(), cur.end());
-        for (int64_t k = rowptr[start]; k < rowptr[end]; ++k) {
-            const auto it = std::lower_bound(cur.begin(), cur.end(), colidx[k]);
-            t->lidx[k] = (uint16_t)(it - cur.begin());
-        }
-        t->ulist.insert(t->ulist.end(), cur.begin(), cur.end());
-        t->tnode.push_back((int32_t)end);
-        t->tuptr.push_back((int32_t)t->ulist.size());
-        cur.clear();
-        start = end;
-    };
-    int32_t tile_id = 0;
-    for (int64_t i = 0; i < nv; ++i) {
-        int added = 0;
-        for (int64_t k = rowptr[i]; k < rowptr[i + 1]; ++k)
-            if (stamp[colidx[k]] != tile_id) ++added;
-        if (i > start && ((int64_t)cur.size() + added > nu_max || i - start >= nb_max)) {
-            close_tile(i);
-            ++tile_id;
-        }
-        for (int64_t k = rowptr[i]; k < rowptr[i + 1]; ++k) {
-            const int32_t c = colidx[k];
-            if (stamp[c] != tile_id) {
-                stamp[c] = tile_id;
-                cur.push_back(c);
-            }
-        }
-        if ((int64_t)cur.size() > nu_max) {
-            delete t;
-            ds::set_error("ds_tiles_build: node %lld has %lld neighbours > nu_max=%d", (long long)i,
-                          (long long)cur.size(), nu_max);
-            return DS_ERR_ARG;
-        }
-    }
-    close_tile(nv);
-    t->ntiles = (int64_t)t->tnode.size() - 1;
-    t->nu_total = (int64_t)t->ulist.size();
-    *out = t;
-    return DS_OK;
-}
-
-extern "C" int ds_tiles_sizes(const ds_tiles_t* t, int64_t* ntiles, int64_t* nu_total) {
-    DS_REQUIRE(t != nullptr, "ds_tiles_sizes: null handle");
-    if (ntiles) *ntiles = t->ntiles;
-    if (nu_total) *nu_total = t->nu_total;
-    return DS_OK;
-}
-
-extern "C" int ds_tiles_export(const ds_tiles_t* t, int32_t* tnode, int32_t* tuptr, int32_t* ulist, uint16_t* lidx) {
-    DS_REQUIRE(t != nullptr, "ds_tiles_export: null handle");
-    if (tnode) std::memcpy(tnode, t->tnode.data(), sizeof(int32_t) * (t->ntiles + 1));
-    if (tuptr) std::memcpy(tuptr, t->tuptr.data(), sizeof(int32_t) * (t->ntiles + 1));
-    if (ulist) std::memcpy(ulist, t->ulist.data(), sizeof(int32_t) * t->nu_total);
-    if (lidx) std::memcpy(lidx, t->lidx.data(), sizeof(uint16_t) * t->nnzb);
-    return DS_OK;
-}
-
-extern "C" void ds_tiles_free(ds_tiles_t* t) { delete t; }
-
 // ------------------------------------------------------------------------------------------------
 // Node groups for the register-blocked SpMM: G = 4 consecutive (Morton-ordered) nodes share one wave.
 // Their neighbour sets overlap (~1.7x on P2 meshes), so the wave walks the UNION of the four column

@@ -365,23 +365,11 @@ int launch_wn(const int32_t* rowptr, const int32_t* colidx, const void* vals, co
 }
 
 #include "spmm_union.inc"
-#ifdef DS_EXPERIMENTAL
-#include "spmm_experimental.inc"
-#endif
 
 template <int KIND>
 int launch_fast(const int32_t* rowptr, const int32_t* colidx, const void* vals, const void* vals_t, int64_t nv,
                 const void* X, int64_t ldx, void* Y, int64_t ldy, int ncols, hipStream_t st) {
     const int lpn = ncols / 4;
-#ifdef DS_EXPERIMENTAL
-    if (lpn <= 21 && pipe_ok(nv, ldx)) {
-        switch (lpn) {
-            case 18: return launch_pipe<KIND, 18>(rowptr, colidx, vals, nv, X, ldx, Y, ldy, lpn, st);
-            case 20: return launch_pipe<KIND, 20>(rowptr, colidx, vals, nv, X, ldx, Y, ldy, lpn, st);
-            default: return launch_pipe<KIND, 0>(rowptr, colidx, vals, nv, X, ldx, Y, ldy, lpn, st);
-        }
-    }
-#endif
     if (lpn <= 21) {
         switch (lpn) {  // the solver's block widths get compile-time lane splits and their own kernel names
             case 18: return launch_wn<KIND, 3, 18>(rowptr, colidx, vals, vals_t, nv, X, ldx, Y, ldy, lpn, st);
@@ -490,13 +478,9 @@ extern "C" int ds_spmm_bsr3(int kind, const int32_t* rowptr, const int32_t* coli
     if (!f64out) {
         // float4 path needs 16-byte aligned rows; float2 path 8-byte
         if (ncols % 4 == 0 && ncols <= 256 && (xalign & 15) == 0 && (yalign & 15) == 0) {
-            static const bool legacy = getenv("DS_SPMM_LEGACY") != nullptr;  // A/B switch for benchmarking
-            // the fast path addresses X through one buffer descriptor (32-bit byte offsets)
-            if (!legacy)
-                return kind == 0 ? launch_fast<0>(rowptr, colidx, vals, vals_t, nv, X, ldx, Y, ldy, ncols, st)
-                                 : launch_fast<1>(rowptr, colidx, vals, vals_t, nv, X, ldx, Y, ldy, ncols, st);
-            return kind == 0 ? launch<0, float, float, float, 4>(rowptr, colidx, vals, nv, X, ldx, Y, ldy, ncols, st)
-                             : launch<1, float, float, float, 4>(rowptr, colidx, vals, nv, X, ldx, Y, ldy, ncols, st);
+            // (the fast path addresses X through one buffer descriptor: 32-bit byte offsets)
+            return kind == 0 ? launch_fast<0>(rowptr, colidx, vals, vals_t, nv, X, ldx, Y, ldy, ncols, st)
+                             : launch_fast<1>(rowptr, colidx, vals, vals_t, nv, X, ldx, Y, ldy, ncols, st);
         }
         DS_REQUIRE(ncols % 2 == 0 && ncols <= 128 && (xalign & 7) == 0 && (yalign & 7) == 0,
                    "ds_spmm_bsr3: f32 blocks need an even column count <= 256 (multiple of 4 above 128) and "
@@ -507,8 +491,7 @@ extern "C" int ds_spmm_bsr3(int kind, const int32_t* rowptr, const int32_t* coli
     }
     DS_REQUIRE(ncols % 2 == 0 && ncols <= 128 && (xalign & 7) == 0 && (yalign & 15) == 0,
                "ds_spmm_bsr3: f64-output blocks need an even column count <= 128 and aligned rows (ncols=%d)", ncols);
-    static const bool generic64 = getenv("DS_SPMM_F64_GENERIC") != nullptr;  // A/B switch for benchmarking
-    if (ncols % 4 == 0 && ncols <= 84 && (xalign & 15) == 0 && !generic64) {
+    if (ncols % 4 == 0 && ncols <= 84 && (xalign & 15) == 0) {
         const unsigned nblk = (unsigned)ds::ceil_div(nv, 4);
         if (kind == 2)
             spmm_f64_node_kernel<0><<<nblk, 256, 0, st>>>(rowptr, colidx, static_cast<const double*>(vals), nv,
@@ -526,380 +509,13 @@ extern "C" int ds_spmm_bsr3(int kind, const int32_t* rowptr, const int32_t* coli
 }
 
 // ------------------------------------------------------------------------------------------------
-// LDS-tiled variant for <= 84 columns.  The wave-per-node kernel above fetches every neighbour panel
-// once per block: 27.8 panels per node, 4.0 GB through L2 per 80-column product on the benchmark mesh,
-// which pins it at the ~70 GB/s per CU that a CU can gather from L2 (guides/MI355X_MICROARCH.md,
-// "Indexed rows").  Here a workgroup owns a tile of consecutive (Morton-ordered) nodes whose neighbour
-// sets overlap heavily; it stages the tile's UNIQUE neighbour panels once in LDS (coalesced 16-byte
-// loads), and the per-block loads become LDS reads.  L2 -> CU traffic drops by the reuse factor of the
-// tiling (about 2x at 80 panels per tile), HBM traffic is unchanged (compulsory).
-// NW waves per workgroup; MAXIT staging items per thread: nu_max * 3 * lpn <= MAXIT * 64 * NW (checked on the host)
-
-// Persistent form: the grid is sized to the chip (2 workgroups per CU), every workgroup walks a contiguous
-// range of tiles, and the staging is software-pipelined through registers two tiles deep:
-//   ids(t+2) -> panels(t+1) in flight in VGPRs while the rows of tile t are computed out of LDS.
-// (One workgroup per tile spent more time in dispatch - 31k launches with 80 KB of LDS each - than in work.)
-template <int EPI, int LPN_CT, int NW, int MAXIT>
-__global__ void __launch_bounds__(64 * NW)
-    spmm_tile_kernel(const int32_t* __restrict__ rowptr, const float* __restrict__ vals, int64_t nv,
-                     const int32_t* __restrict__ tnode, const int32_t* __restrict__ tuptr,
-                     const int32_t* __restrict__ ulist, const uint16_t* __restrict__ lidx,
-                     const float* __restrict__ X, int64_t ldx, float* __restrict__ Y, int64_t ldy, int lpn_rt,
-                     unsigned ntiles, ChebEpilogue epi) {
-    using f4 = __attribute__((ext_vector_type(4))) float;
-    extern __shared__ __attribute__((aligned(16))) float s_dyn[];  // [nu][3][lpn] float4 panels
-    constexpr int TCH = NW > 4 ? 16 : 32;  // blocks of a row staged per pass (small per-wave slab)
-    constexpr int NT = 64 * NW;
-    __shared__ float s_vals[NW][TCH * 9];
-    const int lpn = LPN_CT ? LPN_CT : lpn_rt;
-    const int row_items = 3 * lpn;
-    const unsigned G = gridDim.x;
-    const unsigned wg = ds::xcd_remap(blockIdx.x, G);
-    const unsigned t_begin = (unsigned)(((uint64_t)wg * ntiles) / G);
-    const unsigned t_end = (unsigned)(((uint64_t)(wg + 1) * ntiles) / G);
-    if (t_begin >= t_end) return;
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    f4* panels = reinterpret_cast<f4*>(s_dyn);
-    const int r_raw = lane / lpn;
-    const int cl_raw = lane - r_raw * lpn;
-    const bool active = r_raw < 3 && cl_raw < lpn;
-    const int r = active ? r_raw : 0;
-    const int cl = active ? cl_raw : 0;
-    const int c0 = cl * 4;
-    float* sv = s_vals[wave];
-    const f4* prow = panels + r * lpn + cl;  // + lid * row_items
-
-    // staging item it = threadIdx.x + 256 j  ->  (panel u, row rr, 16-byte chunk q); recomputed where needed
-    auto load_ids = [&](unsigned tile, int (&ids)[MAXIT]) {
-        const int u0 = tuptr[tile], nu = tuptr[tile + 1] - u0;
-#pragma unroll
-        for (int j = 0; j < MAXIT; ++j) {
-            const int u = (threadIdx.x + NT * j) / row_items;
-            ids[j] = ulist[u0 + (u < nu ? u : 0)];
-        }
-    };
-    auto load_panels = [&](const int (&ids)[MAXIT], f4 (&st)[MAXIT]) {
-#pragma unroll
-        for (int j = 0; j < MAXIT; ++j) {
-            const int it = threadIdx.x + NT * j;
-            const int rem = it - (it / row_items) * row_items;  // = rr * lpn + q
-            const int rr = rem / lpn, q = rem - rr * lpn;
-            st[j] = *reinterpret_cast<const f4*>(X + ((int64_t)ids[j] * 3 + rr) * ldx + q * 4);
-        }
-    };
-
-    int ids[MAXIT];
-    f4 stage[MAXIT];
-    load_ids(t_begin, ids);
-    load_panels(ids, stage);
-    if (t_begin + 1 < t_end) load_ids(t_begin + 1, ids);
-
-    for (unsigned tile = t_begin; tile < t_end; ++tile) {
-        const int n0 = tnode[tile], n1 = tnode[tile + 1];
-        const int total = (tuptr[tile + 1] - tuptr[tile]) * row_items;
-        __syncthreads();  // every wave is done reading the previous tile's panels
-#pragma unroll
-        for (int j = 0; j < MAXIT; ++j) {
-            const int it = threadIdx.x + NT * j;
-            if (it < total) panels[it] = stage[j];
-        }
-        __syncthreads();
-        // keep the pipeline full: panels of tile+1 (ids already here), ids of tile+2
-        if (tile + 1 < t_end) {
-            load_panels(ids, stage);
-            if (tile + 2 < t_end) load_ids(tile + 2, ids);
-        }
-        // ---- rows of the tile: wave w takes nodes n0 + w, n0 + w + 4, ...
-        for (int64_t node = n0 + wave; node < n1; node += NW) {
-            const int kb = rowptr[node], ke = rowptr[node + 1];
-            f4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0, acc2 = acc0;
-            for (int kc = kb; kc < ke; kc += TCH) {
-                const int cnt = min(TCH, ke - kc);
-                const int lidreg = lane < cnt ? (int)lidx[kc + lane] : 0;
-                const float* vsrc = vals + (int64_t)kc * 9;
-                for (int t = lane; t < cnt * 9; t += 64) sv[t] = vsrc[t];
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll 4
-                for (int u = 0; u < cnt; ++u) {
-                    const int lid = __builtin_amdgcn_readlane(lidreg, u);
-                    const f4 x = prow[lid * row_items];
-                    const float* a = sv + u * 9 + r;  // column r of the block
-                    acc0 += a[0] * x;
-                    acc1 += a[3] * x;
-                    acc2 += a[6] * x;
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-            }
-#pragma unroll
-            for (int v = 0; v < 4; ++v) {
-                acc0[v] += __shfl(acc0[v], lane + lpn) + __shfl(acc0[v], lane + 2 * lpn);
-                acc1[v] += __shfl(acc1[v], lane + lpn) + __shfl(acc1[v], lane + 2 * lpn);
-                acc2[v] += __shfl(acc2[v], lane + lpn) + __shfl(acc2[v], lane + 2 * lpn);
-            }
-            float* yp = Y + (node * 3) * ldy + c0;
-            if (active && r_raw == 0) {
-                if (EPI == 1) {
-                    const float* rp = epi.r0 + (node * 3) * epi.ldr + c0;
-                    const float* xp = X + (node * 3) * ldx + c0;
-                    const float* d = epi.dinv + node * 9;
-                    const f4 q0 = *reinterpret_cast<const f4*>(rp) - acc0;
-                    const f4 q1 = *reinterpret_cast<const f4*>(rp + epi.ldr) - acc1;
-                    const f4 q2 = *reinterpret_cast<const f4*>(rp + 2 * epi.ldr) - acc2;
-                    const f4 t0 = d[0] * q0 + d[1] * q1 + d[2] * q2;
-                    const f4 t1 = d[3] * q0 + d[4] * q1 + d[5] * q2;
-                    const f4 t2 = d[6] * q0 + d[7] * q1 + d[8] * q2;
-                    const f4 w0 = *reinterpret_cast<const f4*>(xp);
-                    const f4 w1 = *reinterpret_cast<const f4*>(xp + ldx);
-                    const f4 w2 = *reinterpret_cast<const f4*>(xp + 2 * ldx);
-                    f4 o0 = w0 + epi.c2 * t0, o1 = w1 + epi.c2 * t1, o2 = w2 + epi.c2 * t2;
-                    if (!epi.first) {
-                        o0 += epi.c1 * (w0 - *reinterpret_cast<const f4*>(yp));
-                        o1 += epi.c1 * (w1 - *reinterpret_cast<const f4*>(yp + ldy));
-                        o2 += epi.c1 * (w2 - *reinterpret_cast<const f4*>(yp + 2 * ldy));
-                    } else {  // W_prev = 0 (not read)
-                        o0 += epi.c1 * w0;
-                        o1 += epi.c1 * w1;
-                        o2 += epi.c1 * w2;
-                    }
-                    *reinterpret_cast<f4*>(yp) = o0;
-                    *reinterpret_cast<f4*>(yp + ldy) = o1;
-                    *reinterpret_cast<f4*>(yp + 2 * ldy) = o2;
-                } else {
-                    *reinterpret_cast<f4*>(yp) = acc0;
-                    *reinterpret_cast<f4*>(yp + ldy) = acc1;
-                    *reinterpret_cast<f4*>(yp + 2 * ldy) = acc2;
-                }
-            }
-        }
-    }
-}
-
-template <int EPI, int LPN_CT, int NW, int MAXIT>
-int launch_tile_nw(const int32_t* rowptr, const float* vals, int64_t nv, const int32_t* tnode, const int32_t* tuptr,
-                const int32_t* ulist, const uint16_t* lidx, int64_t ntiles, int nu_max, const float* X, int64_t ldx,
-                float* Y, int64_t ldy, int lpn, hipStream_t st, ChebEpilogue epi) {
-    const size_t lds = (size_t)nu_max * 3 * lpn * 16;
-    static size_t attr_bytes = 0;
-    if (lds > 48 * 1024 && lds > attr_bytes) {  // opt in to large dynamic LDS (per instantiation, grows only)
-        int rc = ds::check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&spmm_tile_kernel<EPI, LPN_CT, NW, MAXIT>),
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
-                               "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
-        if (rc != DS_OK) return rc;
-        attr_bytes = lds;
-    }
-    static const int wg_per_cu = getenv("DS_TILE_WGPCU") ? atoi(getenv("DS_TILE_WGPCU")) : (NW > 4 ? 1 : 2);
-    const unsigned grid = (unsigned)std::min<int64_t>(ntiles, 256 * (int64_t)std::max(1, wg_per_cu));
-    spmm_tile_kernel<EPI, LPN_CT, NW, MAXIT><<<grid, 64 * NW, lds, st>>>(rowptr, vals, nv, tnode, tuptr, ulist, lidx, X, ldx, Y, ldy,
-                                                          lpn, (unsigned)ntiles, epi);
-    DS_LAUNCH_CHECK("spmm_tile_kernel");
-    return DS_OK;
-}
-
-template <int EPI, int LPN_CT>
-int launch_tile(const int32_t* rowptr, const float* vals, int64_t nv, const int32_t* tnode, const int32_t* tuptr,
-                const int32_t* ulist, const uint16_t* lidx, int64_t ntiles, int nu_max, const float* X, int64_t ldx,
-                float* Y, int64_t ldy, int lpn, hipStream_t st, ChebEpilogue epi) {
-    // small tiles: 4 waves, two workgroups per CU; large tiles (more reuse): 16 waves, one workgroup per CU
-    if ((size_t)nu_max * 3 * lpn <= 20 * 256 && nu_max <= 80)
-        return launch_tile_nw<EPI, LPN_CT, 4, 20>(rowptr, vals, nv, tnode, tuptr, ulist, lidx, ntiles, nu_max, X, ldx, Y,
-                                                  ldy, lpn, st, epi);
-    return launch_tile_nw<EPI, LPN_CT, 16, 9>(rowptr, vals, nv, tnode, tuptr, ulist, lidx, ntiles, nu_max, X, ldx, Y, ldy,
-                                              lpn, st, epi);
-}
-
-extern "C" int ds_spmm_tiled(int epilogue, const int32_t* rowptr, const float* vals, int64_t nv, const int32_t* tnode,
-                             const int32_t* tuptr, const int32_t* ulist, const uint16_t* lidx, int64_t ntiles,
-                             int nu_max, const float* X, int64_t ldx, float* Y, int64_t ldy, const float* R0,
-                             int64_t ldr, const float* dinv, int ncols, float c1, float c2, int first,
-                             ds_stream_t stream) {
-    DS_REQUIRE(rowptr && vals && tnode && tuptr && ulist && lidx && X && Y, "ds_spmm_tiled: null pointer");
-    DS_REQUIRE(epilogue == 0 || (R0 && dinv), "ds_spmm_tiled: the Chebyshev epilogue needs R0 and dinv");
-    DS_REQUIRE(nv > 0 && ntiles > 0 && ncols > 0 && ncols % 4 == 0 && ncols <= 84,
-               "ds_spmm_tiled: ncols must be a multiple of 4 <= 84");
-    DS_REQUIRE(ldx >= ncols && ldy >= ncols, "ds_spmm_tiled: leading dimension smaller than ncols");
-    DS_REQUIRE(X != Y, "ds_spmm_tiled: X and Y must be different buffers");
-    const int lpn = ncols / 4;
-    DS_REQUIRE(nu_max > 0 && (size_t)nu_max * 3 * lpn <= 9 * 1024 && (size_t)nu_max * 3 * lpn * 16 <= 142 * 1024,
-               "ds_spmm_tiled: nu_max * 3 * ncols/4 must be <= 9088 (staging registers / LDS)");
-    uintptr_t al = reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(Y) | (uintptr_t)(ldx * 4) |
-                   (uintptr_t)(ldy * 4);
-    if (epilogue) al |= reinterpret_cast<uintptr_t>(R0) | (uintptr_t)(ldr * 4);
-    DS_REQUIRE((al & 15) == 0, "ds_spmm_tiled: rows must be 16-byte aligned");
-    hipStream_t st = ds::as_stream(stream);
-    const ChebEpilogue epi{R0, ldr, dinv, c1, c2, first};
-    if (epilogue) {
-        if (lpn == 20)
-            return launch_tile<1, 20>(rowptr, vals, nv, tnode, tuptr, ulist, lidx, ntiles, nu_max, X, ldx, Y, ldy, lpn, st, epi);
-        return launch_tile<1, 0>(rowptr, vals, nv, tnode, tuptr, ulist, lidx, ntiles, nu_max, X, ldx, Y, ldy, lpn, st, epi);
-    }
-    if (lpn == 20)
-        return launch_tile<0, 20>(rowptr, vals, nv, tnode, tuptr, ulist, lidx, ntiles, nu_max, X, ldx, Y, ldy, lpn, st, epi);
-    return launch_tile<0, 0>(rowptr, vals, nv, tnode, tuptr, ulist, lidx, ntiles, nu_max, X, ldx, Y, ldy, lpn, st, epi);
-}
-
-// ------------------------------------------------------------------------------------------------
-// Register-blocked variant for <= 84 columns: FOUR consecutive nodes per wave, union column list.
-// The wave-per-node kernel is pinned at the rate a CU can gather rows from L2 (4.0 GB of neighbour
-// panels per 80-column product).  Neighbouring (Morton-ordered) nodes share ~40 % of their neighbours,
-// so walking the union of four rows loads each shared panel once: 64 panel loads per group instead
-// of 111.  Block values come in group order (contiguous per chunk of the union list), staged in a
-// per-wave LDS slab; presence masks and value offsets travel with v_readlane, all wave-uniform.
-constexpr int GR_CH = 24;  // union entries staged per pass (<= 63: goff needs cnt + 1 lanes)
-
-template <int EPI, int LPN_CT>
-__global__ void __launch_bounds__(256)
-    spmm_group_kernel(const int32_t* __restrict__ gptr, const int32_t* __restrict__ gent,
-                      const int32_t* __restrict__ goff, const float* __restrict__ kgrp, int64_t nv,
-                      const float* __restrict__ X, int64_t ldx, float* __restrict__ Y, int64_t ldy, int lpn_rt,
-                      unsigned nblk, ChebEpilogue epi) {
-    using f4 = __attribute__((ext_vector_type(4))) float;
-    __shared__ float s_k[4][GR_CH * 4 * 9];
-    const int lpn = LPN_CT ? LPN_CT : lpn_rt;
-    const unsigned bid = ds::xcd_remap(blockIdx.x, nblk);
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int64_t grp = (int64_t)bid * 4 + wave;
-    const int64_t n0 = grp * 4;
-    if (n0 >= nv) return;  // wave-uniform
-    const int r_raw = lane / lpn;
-    const int cl_raw = lane - r_raw * lpn;
-    const bool active = r_raw < 3 && cl_raw < lpn;
-    const int r = active ? r_raw : 0;
-    const int cl = active ? cl_raw : 0;
-    const int c0 = cl * 4;
-    const float* xbase = X + (int64_t)r * ldx + c0;
-    const int64_t ldx3 = 3 * ldx;
-    float* sk = s_k[wave];
-    const float* skr = sk + r * 3;  // column r of a (transposed) block: 3 contiguous floats
-    f4 acc[4][3];
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int i = 0; i < 3; ++i) acc[q][i] = f4{0.f, 0.f, 0.f, 0.f};
-    const int e0 = gptr[grp], e1 = gptr[grp + 1];
-    for (int ec = e0; ec < e1; ec += GR_CH) {
-        const int cnt = min(GR_CH, e1 - ec);  // wave-uniform
-        const int entreg = lane < cnt ? gent[ec + lane] : 0;
-        const int offreg = lane <= cnt ? goff[ec + lane] : 0;
-        const int b0 = __builtin_amdgcn_readlane(offreg, 0);
-        const int nb = __builtin_amdgcn_readlane(offreg, cnt) - b0;  // blocks in this chunk
-        const float* ksrc = kgrp + (int64_t)b0 * 9;
-        for (int t = lane; t < nb * 9; t += 64) sk[t] = ksrc[t];
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        int u = 0;
-        for (; u + 4 <= cnt; u += 4) {
-            int ent[4], bo[4];
-            f4 x[4];
-#pragma unroll
-            for (int v = 0; v < 4; ++v) {
-                ent[v] = __builtin_amdgcn_readlane(entreg, u + v);
-                bo[v] = __builtin_amdgcn_readlane(offreg, u + v) - b0;
-                x[v] = *reinterpret_cast<const f4*>(xbase + (int64_t)(ent[v] & 0x0fffffff) * ldx3);
-            }
-#pragma unroll
-            for (int v = 0; v < 4; ++v) {
-                const unsigned mask = (unsigned)ent[v] >> 28;
-                int p = bo[v];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    if (mask & (1u << q)) {  // wave-uniform
-                        const float* a = skr + p * 9;
-                        acc[q][0] += a[0] * x[v];
-                        acc[q][1] += a[1] * x[v];
-                        acc[q][2] += a[2] * x[v];
-                        ++p;
-                    }
-                }
-            }
-        }
-        for (; u < cnt; ++u) {
-            const int ent = __builtin_amdgcn_readlane(entreg, u);
-            int p = __builtin_amdgcn_readlane(offreg, u) - b0;
-            const f4 x = *reinterpret_cast<const f4*>(xbase + (int64_t)(ent & 0x0fffffff) * ldx3);
-            const unsigned mask = (unsigned)ent >> 28;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                if (mask & (1u << q)) {
-                    const float* a = skr + p * 9;
-                    acc[q][0] += a[0] * x;
-                    acc[q][1] += a[1] * x;
-                    acc[q][2] += a[2] * x;
-                    ++p;
-                }
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-    }
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int64_t node = n0 + q;
-        if (node >= nv) break;  // wave-uniform
-#pragma unroll
-        for (int i = 0; i < 3; ++i)
-#pragma unroll
-            for (int v = 0; v < 4; ++v)
-                acc[q][i][v] += __shfl(acc[q][i][v], lane + lpn) + __shfl(acc[q][i][v], lane + 2 * lpn);
-        float* yp = Y + (node * 3) * ldy + c0;
-        if (active && r_raw == 0) {
-            if (EPI == 1) {
-                const float* rp = epi.r0 + (node * 3) * epi.ldr + c0;
-                const float* xp = X + (node * 3) * ldx + c0;
-                const float* d = epi.dinv + node * 9;
-                const f4 q0 = *reinterpret_cast<const f4*>(rp) - acc[q][0];
-                const f4 q1 = *reinterpret_cast<const f4*>(rp + epi.ldr) - acc[q][1];
-                const f4 q2 = *reinterpret_cast<const f4*>(rp + 2 * epi.ldr) - acc[q][2];
-                const f4 t0 = d[0] * q0 + d[1] * q1 + d[2] * q2;
-                const f4 t1 = d[3] * q0 + d[4] * q1 + d[5] * q2;
-                const f4 t2 = d[6] * q0 + d[7] * q1 + d[8] * q2;
-                const f4 w0 = *reinterpret_cast<const f4*>(xp);
-                const f4 w1 = *reinterpret_cast<const f4*>(xp + ldx);
-                const f4 w2 = *reinterpret_cast<const f4*>(xp + 2 * ldx);
-                f4 o0 = w0 + epi.c2 * t0, o1 = w1 + epi.c2 * t1, o2 = w2 + epi.c2 * t2;
-                if (!epi.first) {
-                    o0 += epi.c1 * (w0 - *reinterpret_cast<const f4*>(yp));
-                    o1 += epi.c1 * (w1 - *reinterpret_cast<const f4*>(yp + ldy));
-                    o2 += epi.c1 * (w2 - *reinterpret_cast<const f4*>(yp + 2 * ldy));
-                } else {  // W_prev = 0 (not read)
-                    o0 += epi.c1 * w0;
-                    o1 += epi.c1 * w1;
-                    o2 += epi.c1 * w2;
-                }
-                *reinterpret_cast<f4*>(yp) = o0;
-                *reinterpret_cast<f4*>(yp + ldy) = o1;
-                *reinterpret_cast<f4*>(yp + 2 * ldy) = o2;
-            } else {
-                *reinterpret_cast<f4*>(yp) = acc[q][0];
-                *reinterpret_cast<f4*>(yp + ldy) = acc[q][1];
-                *reinterpret_cast<f4*>(yp + 2 * ldy) = acc[q][2];
-            }
-        }
-    }
-}
-
+// Pack the (transposed) blocks into the entry-major / node-minor order of the neighbour-union tables.
 __global__ void pack_groups_kernel(const float* __restrict__ vals_t, const int32_t* __restrict__ kperm, int64_t nnzb,
                                    float* __restrict__ kgrp) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nnzb * 9) return;
     const int64_t p = i / 9;
     kgrp[i] = vals_t[(int64_t)kperm[p] * 9 + (i - p * 9)];
-}
-
-template <int EPI, int LPN_CT>
-int launch_group(const int32_t* gptr, const int32_t* gent, const int32_t* goff, const float* kgrp, int64_t nv,
-                 const float* X, int64_t ldx, float* Y, int64_t ldy, int lpn, hipStream_t st, ChebEpilogue epi) {
-    const int64_t ngroups = ds::ceil_div(nv, 4);
-    const int64_t nblk = ds::ceil_div(ngroups, 4);
-    spmm_group_kernel<EPI, LPN_CT><<<(unsigned)nblk, 256, 0, st>>>(gptr, gent, goff, kgrp, nv, X, ldx, Y, ldy, lpn,
-                                                                   (unsigned)nblk, epi);
-    DS_LAUNCH_CHECK("spmm_group_kernel");
-    return DS_OK;
 }
 
 extern "C" int ds_pack_groups(const float* vals_t, const int32_t* kperm, int64_t nnzb, float* kgrp,
@@ -909,30 +525,6 @@ extern "C" int ds_pack_groups(const float* vals_t, const int32_t* kperm, int64_t
                                                                                                 kgrp);
     DS_LAUNCH_CHECK("pack_groups_kernel");
     return DS_OK;
-}
-
-extern "C" int ds_spmm_grouped(int epilogue, const int32_t* gptr, const int32_t* gent, const int32_t* goff,
-                               const float* kgrp, int64_t nv, const float* X, int64_t ldx, float* Y, int64_t ldy,
-                               const float* R0, int64_t ldr, const float* dinv, int ncols, float c1, float c2,
-                               int first, ds_stream_t stream) {
-    DS_REQUIRE(gptr && gent && goff && kgrp && X && Y, "ds_spmm_grouped: null pointer");
-    DS_REQUIRE(epilogue == 0 || (R0 && dinv), "ds_spmm_grouped: the Chebyshev epilogue needs R0 and dinv");
-    DS_REQUIRE(nv > 0 && ncols > 0 && ncols % 4 == 0 && ncols <= 84, "ds_spmm_grouped: ncols must be a multiple of 4 <= 84");
-    DS_REQUIRE(ldx >= ncols && ldy >= ncols, "ds_spmm_grouped: leading dimension smaller than ncols");
-    DS_REQUIRE(X != Y, "ds_spmm_grouped: X and Y must be different buffers");
-    uintptr_t al = reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(Y) | (uintptr_t)(ldx * 4) |
-                   (uintptr_t)(ldy * 4);
-    if (epilogue) al |= reinterpret_cast<uintptr_t>(R0) | (uintptr_t)(ldr * 4);
-    DS_REQUIRE((al & 15) == 0, "ds_spmm_grouped: rows must be 16-byte aligned");
-    hipStream_t st = ds::as_stream(stream);
-    const ChebEpilogue epi{R0, ldr, dinv, c1, c2, first};
-    const int lpn = ncols / 4;
-    if (epilogue) {
-        if (lpn == 20) return launch_group<1, 20>(gptr, gent, goff, kgrp, nv, X, ldx, Y, ldy, lpn, st, epi);
-        return launch_group<1, 0>(gptr, gent, goff, kgrp, nv, X, ldx, Y, ldy, lpn, st, epi);
-    }
-    if (lpn == 20) return launch_group<0, 20>(gptr, gent, goff, kgrp, nv, X, ldx, Y, ldy, lpn, st, epi);
-    return launch_group<0, 0>(gptr, gent, goff, kgrp, nv, X, ldx, Y, ldy, lpn, st, epi);
 }
 
 extern "C" int ds_cheb_spmm(const int32_t* rowptr, const int32_t* colidx, const float* vals, int64_t nv, const float* W,
@@ -949,15 +541,6 @@ extern "C" int ds_cheb_spmm(const int32_t* rowptr, const int32_t* colidx, const 
     hipStream_t st = ds::as_stream(stream);
     const ChebEpilogue epi{R0, ldr, dinv, c1, c2, first};
     const int lpn = ncols / 4;
-#ifdef DS_EXPERIMENTAL
-    if (pipe_ok(nv, ldw)) {
-        switch (lpn) {
-            case 18: return launch_pipe<0, 18, 1>(rowptr, colidx, vals, nv, W, ldw, Wprev, ldp, lpn, st, epi);
-            case 20: return launch_pipe<0, 20, 1>(rowptr, colidx, vals, nv, W, ldw, Wprev, ldp, lpn, st, epi);
-            default: return launch_pipe<0, 0, 1>(rowptr, colidx, vals, nv, W, ldw, Wprev, ldp, lpn, st, epi);
-        }
-    }
-#endif
     switch (lpn) {
         case 18: return launch_wn<0, 3, 18, 1>(rowptr, colidx, vals, nullptr, nv, W, ldw, Wprev, ldp, lpn, st, epi);
         case 20: return launch_wn<0, 3, 20, 1>(rowptr, colidx, vals, nullptr, nv, W, ldw, Wprev, ldp, lpn, st, epi);
@@ -981,58 +564,12 @@ extern "C" int ds_spmm_residual(const int32_t* rowptr, const int32_t* colidx, co
     hipStream_t st = ds::as_stream(stream);
     const ChebEpilogue epi{R0, ldr, nullptr, 0.f, 0.f, 0};
     const int lpn = ncols / 4;
-#ifdef DS_EXPERIMENTAL
-    if (pipe_ok(nv, ldx)) {
-        switch (lpn) {
-            case 20: return launch_pipe<0, 20, 2>(rowptr, colidx, vals, nv, X, ldx, Y, ldy, lpn, st, epi);
-            default: return launch_pipe<0, 0, 2>(rowptr, colidx, vals, nv, X, ldx, Y, ldy, lpn, st, epi);
-        }
-    }
-#endif
     switch (lpn) {
         case 20: return launch_wn<0, 3, 20, 2>(rowptr, colidx, vals, nullptr, nv, X, ldx, Y, ldy, lpn, st, epi);
         default: return launch_wn<0, 3, 0, 2>(rowptr, colidx, vals, nullptr, nv, X, ldx, Y, ldy, lpn, st, epi);
     }
 }
 
-#ifdef DS_EXPERIMENTAL
-extern "C" void ds_spmm_batch_limits(int* cap_blocks, int* max_nodes) {
-    if (cap_blocks) *cap_blocks = BT_CAP;
-    if (max_nodes) *max_nodes = BT_MAXNODES;
-}
-
-extern "C" int ds_spmm_batched(int kind, int epilogue, const int32_t* btab, int64_t nbatch, const int32_t* rowptr,
-                               const int32_t* colidx, const float* vals, int64_t nnzb, int64_t nv, const float* X,
-                               int64_t ldx, float* Y, int64_t ldy, const float* R0, int64_t ldr, const float* dinv,
-                               int ncols, float c1, float c2, int first, ds_stream_t stream) {
-    DS_REQUIRE(btab && rowptr && colidx && vals && X && Y, "ds_spmm_batched: null pointer");
-    DS_REQUIRE(kind == 0 || kind == 1, "ds_spmm_batched: kind must be 0 (3x3 blocks) or 1 (scalar x I3)");
-    DS_REQUIRE(epilogue >= 0 && epilogue <= 2 && (epilogue == 0 || kind == 0), "ds_spmm_batched: bad epilogue %d", epilogue);
-    DS_REQUIRE(epilogue == 0 || R0, "ds_spmm_batched: the epilogue needs R0");
-    DS_REQUIRE(epilogue != 1 || dinv, "ds_spmm_batched: the Chebyshev epilogue needs dinv");
-    DS_REQUIRE(nv > 0 && nbatch > 0 && nnzb > 0 && ncols > 0 && ncols % 4 == 0 && ncols <= 84,
-               "ds_spmm_batched: ncols must be a multiple of 4 <= 84");
-    DS_REQUIRE(ldx >= ncols && ldy >= ncols && (epilogue == 0 || ldr >= ncols),
-               "ds_spmm_batched: leading dimension smaller than ncols");
-    DS_REQUIRE(X != Y, "ds_spmm_batched: X and Y must be different buffers");
-    DS_REQUIRE(3 * nv * ldx * 4 < (int64_t)PIPE_OOB && 3 * nv * ldy * 4 < (int64_t)PIPE_OOB &&
-                   (epilogue == 0 || 3 * nv * ldr * 4 < (int64_t)PIPE_OOB),
-               "ds_spmm_batched: block of %lld bytes exceeds the descriptor range", (long long)(3 * nv * ldx * 4));
-    DS_REQUIRE(nnzb * 36 < ((int64_t)1 << 32), "ds_spmm_batched: value array exceeds the descriptor range");
-    uintptr_t al = reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(Y) | (uintptr_t)(ldx * 4) |
-                   (uintptr_t)(ldy * 4) | reinterpret_cast<uintptr_t>(vals) | reinterpret_cast<uintptr_t>(btab);
-    if (epilogue) al |= reinterpret_cast<uintptr_t>(R0) | (uintptr_t)(ldr * 4);
-    DS_REQUIRE((al & 15) == 0, "ds_spmm_batched: rows, vals and btab must be 16-byte aligned");
-    hipStream_t st = ds::as_stream(stream);
-    const ChebEpilogue epi{R0, ldr, dinv, c1, c2, first};
-    const int lpn = ncols / 4;
-    if (kind == 1) return launch_batch_lpn<1, 0>(btab, nbatch, rowptr, colidx, vals, nnzb, nv, X, ldx, Y, ldy, lpn, st, epi);
-    if (epilogue == 1) return launch_batch_lpn<0, 1>(btab, nbatch, rowptr, colidx, vals, nnzb, nv, X, ldx, Y, ldy, lpn, st, epi);
-    if (epilogue == 2) return launch_batch_lpn<0, 2>(btab, nbatch, rowptr, colidx, vals, nnzb, nv, X, ldx, Y, ldy, lpn, st, epi);
-    return launch_batch_lpn<0, 0>(btab, nbatch, rowptr, colidx, vals, nnzb, nv, X, ldx, Y, ldy, lpn, st, epi);
-}
-
-#endif  // DS_EXPERIMENTAL
 
 extern "C" int ds_spmm_union(int epilogue, const int32_t* utab, const int32_t* ctab, int64_t ngroups, int cap_blocks,
                              const int32_t* gent,
@@ -1045,7 +582,7 @@ extern "C" int ds_spmm_union(int epilogue, const int32_t* utab, const int32_t* c
     DS_REQUIRE(epilogue != 1 || dinv, "ds_spmm_union: the Chebyshev epilogue needs dinv");
     DS_REQUIRE(nv > 0 && ngroups == (nv + 3) / 4 && nnzb > 0 && ncols > 0 && ncols % 4 == 0 && ncols <= 84,
                "ds_spmm_union: ncols must be a multiple of 4 <= 84 and ngroups = ceil(nv / 4)");
-    DS_REQUIRE(cap_blocks > 0 && cap_blocks <= 276, "ds_spmm_union: a group of %d blocks exceeds the LDS image", cap_blocks);
+    DS_REQUIRE(cap_blocks > 0 && cap_blocks <= UN_CAPB, "ds_spmm_union: a chunk of %d blocks exceeds the LDS image (116)", cap_blocks);
     DS_REQUIRE(ldx >= ncols && ldy >= ncols && (epilogue == 0 || epilogue == 3 || ldr >= ncols),
                "ds_spmm_union: leading dimension smaller than ncols");
     DS_REQUIRE(X != Y, "ds_spmm_union: X and Y must be different buffers");

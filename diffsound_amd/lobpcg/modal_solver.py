@@ -21,7 +21,6 @@ The ``ops`` protocol (see ``diffsound_amd/modal_ops.py`` for the HIP implementat
   n, device, dtype, rigid (n x 6, M-orthonormal), apply_K, apply_M, gram, mix, residual,
   precond, polish_products.
 """
-import os
 import threading
 from dataclasses import dataclass, field
 from typing import Callable, Optional
@@ -293,6 +292,8 @@ class TwoLevelChebyshev:
     degree for are handled on the cheap level: ~6 fine SpMMs per application instead of ~48 at the same
     outer iteration count.  Fixed, symmetric positive definite, as LOBPCG requires."""
 
+    use_native = True  # run the cycle through ops.twolevel_apply (one native call) when the ops offer it
+
     def __init__(self, ops, cfg):
         self.ops = ops
         args = (cfg.power_iters, cfg.seed, cfg.lmax_safety)
@@ -314,7 +315,7 @@ class TwoLevelChebyshev:
                 self._buf = (mk(R.shape[0]), mk(nc), mk(nc), mk(R.shape[0]))
             Rr, Rc, Ec, Wc = self._buf
             native = getattr(ops, "twolevel_apply", None)
-            if native is not None and os.environ.get("DS_NATIVE_VCYCLE", "1") != "0":
+            if native is not None and self.use_native:
                 D, AD = self.smooth._buffers(Rs)
                 Dc, ADc = self.coarse._buffers(Rc)
                 if native((self.smooth.degree, self.smooth.lmax, self.smooth.lmin),
@@ -560,7 +561,7 @@ class ModalSolver:
             # X_new | P_new (and K X_new | K P_new) are adjacent column ranges: ONE update [X' P'] = [X P W] [Z1 Zp]
             # per product reads the 240-column operand once instead of twice (the LDS-staged mix kernel holds the
             # 240 x 160 coefficient image; with the first, register-only kernel one wide launch was slower than two)
-            if getattr(ops, "fused_ritz_mix", True) and 2 * na <= 160:
+            if 2 * na <= 160:
                 ops.mix(Sa, ZZ, S2[:, ny + ncl:ny + b + na])
                 ops.mix(KSa, ZZ, KS2[:, :2 * na])
             else:

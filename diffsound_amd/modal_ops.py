@@ -17,6 +17,7 @@ import torch
 from . import _hip, fem_tables
 
 DS_F32, DS_F64 = 0, 1
+UNION_CAP = 116  # blocks per chunk of the neighbour-union tables (the kernel's smallest LDS image)
 
 
 def _ld(t):
@@ -40,11 +41,8 @@ def morton_order(vertices, bits=10):
     return torch.argsort(key, stable=True)
 
 
-_UNION_M = os.environ.get("DS_SPMM_UNION_M", "1") != "0"  # A/B switch: mass product on the neighbour-union kernel
-
-
 class TetSystem:
-    def __init__(self, vertices, tets, order, density, reorder=True, level=0):
+    def __init__(self, vertices, tets, order, density, reorder=True):
         """vertices (nv,3) float32 HIP tensor, tets (T,N) integer HIP tensor in the reference's local
         node order, N = 4 / 10.  With ``reorder`` the nodes are renumbered internally along a Morton
         curve; ``perm`` / ``inv_perm`` map between the caller's node ids and the internal ones and
@@ -85,46 +83,20 @@ class TetSystem:
         self.kmu = torch.empty((self.nnzb, 9), dtype=torch.float64, device=dev)
         self.ms = torch.empty((self.nnzb,), dtype=torch.float64, device=dev)
         self._tetgeo = torch.empty((self.T, 13), dtype=torch.float64, device=dev)
-        # Row tiles for the LDS-tiled SpMM (needs the Morton numbering).  EXPERIMENTAL and off by default:
-        # correct (tests/test_hip_kernels.py::test_tiled_spmm_matches_untiled) but, at 8 waves per CU, still
-        # 2x slower than the wave-per-node kernel - every per-node global latency is exposed.
-        self.tiles = None
-        if reorder and os.environ.get("DS_SPMM_TILED", "0") == "1":
-            try:
-                tl = _hip.Tiles(pat.rowptr, pat.colidx, self.nv, nu_max=int(os.environ.get("DS_TILE_NU", "76")),
-                                nb_max=int(os.environ.get("DS_TILE_NB", "8")))
-                self.tiles = dict(ntiles=tl.ntiles, nu_max=tl.nu_max, tnode=tl.tnode.to(dev), tuptr=tl.tuptr.to(dev),
-                                  ulist=tl.ulist.to(dev), lidx=tl.lidx.to(dev))
-            except RuntimeError:
-                self.tiles = None  # a row with more neighbours than a tile holds: keep the untiled kernels
-        # Node groups of the neighbour-union SpMM (ds_spmm_union, the default for blocks of <= 84 columns): one
-        # wavefront per 4 consecutive nodes walks the union of their neighbours (with the Morton numbering 0.58 x
-        # as many panel loads as one wavefront per node).  Every group is cut into chunks of whole entries that fit
-        # the kernel's LDS images (cap entries / blocks; almost always ONE chunk): ctab rows (e0, e1, b0, b1),
-        # utab rows (first chunk, end chunk) per group.  DS_SPMM_UNION=0 keeps the wave-per-node kernels
-        # (DS_SPMM_UNION_COARSE=0: on the corner-node level only); DS_SPMM_GROUPED=1 is the older
-        # register-blocked experiment on the same tables.
+        # Node groups of the neighbour-union SpMM (ds_spmm_union, the kernel of every product on blocks of <= 84
+        # columns): one wavefront per 4 consecutive nodes walks the union of their neighbours (with the Morton
+        # numbering 0.58 x as many panel loads as one wavefront per node).  Every group is cut into chunks of whole
+        # entries that fit the kernel's LDS images (cap entries / blocks; almost always ONE chunk): ctab rows
+        # (e0, e1, b0, b1), utab rows (first chunk, end chunk) per group.
         self.groups = None
-        union = os.environ.get("DS_SPMM_UNION", "1") != "0" and self.nv >= 8
-        if level == 1 and os.environ.get("DS_SPMM_UNION_COARSE", "1") == "0":
-            union = False
-        if os.environ.get("DS_SPMM_GROUPED", "0") == "1" or union:
+        if self.nv >= 8:
             gr = _hip.Groups(pat.rowptr, pat.colidx, self.nv)
-            self.groups = dict(ne=gr.ne, gptr=gr.gptr.to(dev), gent=gr.gent.to(dev), goff=gr.goff.to(dev),
-                               kperm=gr.kperm.to(dev), union=None)
-            if union:
-                cap = int(os.environ.get("DS_UNION_CAP", "116"))
-                ut, ct = _hip.union_chunks(gr.gptr, gr.goff, cap)
-                if ct is not None:
-                    self.groups["union"] = dict(utab=ut.to(dev), ctab=ct.to(dev), capb=cap, ngroups=ut.shape[0],
-                                                single=bool(ct.shape[0] == ut.shape[0]))  # every group one chunk
-        # batch table of the batched SpMM (one wave per run of consecutive nodes).  EXPERIMENTAL build, opt-in
-        # (DS_SPMM_BATCHED=1): same speed as the wave-per-node kernels (the product is bound by the CU's gather
-        # rate); kept as the base of the neighbour-union kernel.
-        self.batches = None
-        if os.environ.get("DS_SPMM_BATCHED", "0") == "1":
-            bt = _hip.build_batches(pat.rowptr)
-            self.batches = None if bt is None else bt.to(dev)
+            ut, ct = _hip.union_chunks(gr.gptr, gr.goff, UNION_CAP)
+            if ct is not None:
+                kperm = gr.kperm.to(dev)
+                self.groups = dict(ne=gr.ne, gent=gr.gent.to(dev), kperm=kperm, kperm64=kperm.long(),
+                                   union=dict(utab=ut.to(dev), ctab=ct.to(dev), capb=UNION_CAP, ngroups=ut.shape[0],
+                                              single=bool(ct.shape[0] == ut.shape[0])))  # every group one chunk
         self._coarse = None
         self.assemble()
 
@@ -164,7 +136,7 @@ class TetSystem:
         if bool((pa < 0).any()) or bool((pb < 0).any()):
             return None
         nvc = corners.numel()
-        csys = TetSystem(self.vertices[corners], cid[tets[:, list(cs)]], 1, self.density, reorder=False, level=1)
+        csys = TetSystem(self.vertices[corners], cid[tets[:, list(cs)]], 1, self.density, reorder=False)
         i32 = lambda t: t.to(torch.int32).contiguous()
         fine = torch.arange(self.nv, device=dev)
         mid = pa != pb
@@ -251,9 +223,8 @@ class _HipBlockOps:
     dtype = torch.float32
     m_kind = 1  # 1: M = M_s (x) I3 (one scalar per block), 0: general 3x3 blocks
     k32t = None
-    kgrp = None  # transposed blocks in node-group order (register-blocked SpMM)
+    kgrp = None  # transposed blocks in node-group order (neighbour-union SpMM)
     mgrp = None  # node-scalar mass values in node-group order (neighbour-union SpMM, epilogue 3)
-    fused_ritz_mix = os.environ.get("DS_FUSED_RITZ_MIX", "1") != "0"  # A/B switch (lobpcg/modal_solver.py)
 
     def _init_common(self, rowptr, colidx, nv, device):
         self.rowptr, self.colidx = rowptr, colidx
@@ -291,9 +262,6 @@ class _HipBlockOps:
             if timed:
                 e1.record()
                 self.spmm_events.append((e0, e1))
-
-    batches = None  # (nbatch, 4) int32 device table for the batched SpMM (<= 84 columns), or None
-    batch_ops = os.environ.get("DS_SPMM_BATCH_OPS", "KMCR")  # which products use it: K X, M X, Chebyshev term, residual
 
     def _union_ok(self, X, *others):
         g = getattr(getattr(self, "sys", None), "groups", None)
@@ -365,44 +333,16 @@ class _HipBlockOps:
                                          0 if Wprev is None else _ld(Wprev), _hip.stream_ptr()),
                    "ds_spmm_union")
 
-    def _batched_ok(self, X, op="K"):
-        return (self.batches is not None and op in self.batch_ops and X.shape[1] <= 84 and X.shape[1] % 4 == 0
-                and 12 * self.nv * _ld(X) < 0x7F000000 and X.data_ptr() % 16 == 0 and (_ld(X) * 4) % 16 == 0)
-
-    def _batched(self, kind, epilogue, vals, X, Y, R0=None, c1=0.0, c2=0.0, first=False):
-        pp = _hip.ptr
-        bt = self.batches
-        _hip.check(self._L.ds_spmm_batched(kind, epilogue, pp(bt), bt.shape[0], pp(self.rowptr), pp(self.colidx),
-                                           pp(vals), vals.shape[0], self.nv, pp(X), _ld(X), pp(Y), _ld(Y), pp(R0),
-                                           0 if R0 is None else _ld(R0), pp(self.dinv) if epilogue == 1 else None,
-                                           X.shape[1], float(c1), float(c2), int(bool(first)), _hip.stream_ptr()),
-                   "ds_spmm_batched")
-
     def apply_K(self, X, out):
         if self._union_ok(X, out):
             self._union(0, X, out)
-        elif self._batched_ok(X) and not self._has_tiles(X.shape[1]) and not self._has_groups(X.shape[1]):
-            timed = self.spmm_events is not None and X.shape[1] == self.spmm_event_cols
-            if timed:
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-            self._batched(0, 0, self.k32t, X, out)
-            if timed:
-                e1.record()
-                self.spmm_events.append((e0, e1))
-        elif self._has_tiles(X.shape[1]) and X.shape[1] % 4 == 0 and X.shape[1] >= 16:
-            self._tiled(0, X, out, None, 0.0, 0.0, False)
-        elif self._has_groups(X.shape[1]) and X.shape[1] >= 16:
-            self._grouped(0, X, out, None, 0.0, 0.0, False)
         else:
             self._spmm(0, self.k32, X, out)
         self.counts["apply_K_cols"] += X.shape[1]
 
     def apply_M(self, X, out):
-        if self.m_kind == 1 and self.mgrp is not None and _UNION_M and self._union_ok(X, out):
+        if self.m_kind == 1 and self.mgrp is not None and self._union_ok(X, out):
             self._union(3, X, out)
-        elif self.m_kind == 1 and self._batched_ok(X, "M"):
-            self._batched(1, 0, self.ms32, X, out)
         else:
             self._spmm(self.m_kind, self.ms32, X, out)
         self.counts["apply_M_cols"] += X.shape[1]
@@ -497,10 +437,6 @@ class _HipBlockOps:
             self._union(2, X, Y, R0)
             self.counts["apply_K_cols"] += X.shape[1]
             return
-        if self._batched_ok(X, "R"):
-            self._batched(0, 2, self.k32t, X, Y, R0)
-            self.counts["apply_K_cols"] += X.shape[1]
-            return
         _hip.check(self._L.ds_spmm_residual(pp(self.rowptr), pp(self.colidx), pp(self.k32), self.nv, pp(X), _ld(X),
                                             pp(R0), _ld(R0), pp(Y), _ld(Y), X.shape[1], _hip.stream_ptr()),
                    "ds_spmm_residual")
@@ -521,48 +457,12 @@ class _HipBlockOps:
         t = self._xfer
         self._transfer(t["pptr"], t["pcol"], t["pw"], self.nv, Ec, Wf, 1.0)
 
-    def _tiled(self, epilogue, X, Y, R0, c1, c2, first):
-        t = self.sys.tiles
-        pp = _hip.ptr
-        _hip.check(self._L.ds_spmm_tiled(epilogue, pp(self.rowptr), pp(self.k32), self.nv, pp(t["tnode"]),
-                                         pp(t["tuptr"]), pp(t["ulist"]), pp(t["lidx"]), t["ntiles"], t["nu_max"],
-                                         pp(X), _ld(X), pp(Y), _ld(Y), pp(R0), 0 if R0 is None else _ld(R0),
-                                         pp(self.dinv), X.shape[1], float(c1), float(c2), int(bool(first)),
-                                         _hip.stream_ptr()), "ds_spmm_tiled")
-
-    def _grouped(self, epilogue, X, Y, R0, c1, c2, first):
-        g = self.sys.groups
-        pp = _hip.ptr
-        _hip.check(self._L.ds_spmm_grouped(epilogue, pp(g["gptr"]), pp(g["gent"]), pp(g["goff"]), pp(self.kgrp), self.nv,
-                                           pp(X), _ld(X), pp(Y), _ld(Y), pp(R0), 0 if R0 is None else _ld(R0),
-                                           pp(self.dinv), X.shape[1], float(c1), float(c2), int(bool(first)),
-                                           _hip.stream_ptr()), "ds_spmm_grouped")
-
-    def _has_groups(self, ncols):
-        g = getattr(getattr(self, "sys", None), "groups", None)
-        return (self.kgrp is not None and g is not None and g.get("union") is None and ncols <= 84 and ncols % 4 == 0)
-
-    def _has_tiles(self, ncols):
-        return getattr(getattr(self, "sys", None), "tiles", None) is not None and ncols <= 84
-
     def _cheb_spmm_launch(self, Wk, Wprev, R0, c1, c2, first):
         if self._union_ok(Wk, Wprev, R0):
             self._union(1, Wk, Wprev, R0, c1, c2, first)
             self.counts["apply_K_cols"] += Wk.shape[1]
             return
-        if self._has_groups(Wk.shape[1]) and not self._has_tiles(Wk.shape[1]):
-            self._grouped(1, Wk, Wprev, R0, c1, c2, first)
-            self.counts["apply_K_cols"] += Wk.shape[1]
-            return
-        if self._has_tiles(Wk.shape[1]):
-            self._tiled(1, Wk, Wprev, R0, c1, c2, first)
-            self.counts["apply_K_cols"] += Wk.shape[1]
-            return
         pp = _hip.ptr
-        if self._batched_ok(Wk, "C"):
-            self._batched(0, 1, self.k32t, Wk, Wprev, R0, c1, c2, first)
-            self.counts["apply_K_cols"] += Wk.shape[1]
-            return
         _hip.check(self._L.ds_cheb_spmm(pp(self.rowptr), pp(self.colidx), pp(self.k32), self.nv, pp(Wk), _ld(Wk),
                                         pp(Wprev), _ld(Wprev), pp(R0), _ld(R0), pp(self.dinv), Wk.shape[1],
                                         float(c1), float(c2), int(bool(first)), _hip.stream_ptr()), "ds_cheb_spmm")
@@ -587,18 +487,16 @@ class HipModalOps(_HipBlockOps):
     """One material hypothesis (lam, mu) on a TetSystem."""
 
     def __init__(self, system: TetSystem, lam, mu, two_level=None, _level=0):
-        """two_level: build the corner-node level for the two-level preconditioner (ord-2 meshes; default on,
-        ``DS_TWOLEVEL=0`` turns it off)."""
+        """two_level: build the corner-node level for the two-level preconditioner (ord-2 meshes; default on)."""
         self.sys = system
         self._init_common(system.rowptr, system.colidx, system.nv, system.device)
-        self.batches = system.batches
         dev = self.device
         self.k32 = torch.empty((system.nnzb, 9), dtype=torch.float32, device=dev)
         self.k32t = torch.empty((system.nnzb, 9), dtype=torch.float32, device=dev)  # blocks transposed
         self.ms32 = torch.empty((system.nnzb,), dtype=torch.float32, device=dev)
         self.dinv = torch.empty((system.nv, 9), dtype=torch.float32, device=dev)
         if two_level is None:
-            two_level = os.environ.get("DS_TWOLEVEL", "1") != "0"
+            two_level = True
         if two_level and _level == 0 and system.order == 2:
             lvl = system.coarse_level()
             if lvl is not None:
@@ -621,9 +519,7 @@ class HipModalOps(_HipBlockOps):
                 self.kgrp = torch.empty((s.nnzb, 9), dtype=torch.float32, device=self.device)
             _hip.check(self._L.ds_pack_groups(p(self.k32t), p(s.groups["kperm"]), s.nnzb, p(self.kgrp),
                                               _hip.stream_ptr()), "ds_pack_groups")
-            if s.groups.get("union") is not None and self.m_kind == 1:
-                if "kperm64" not in s.groups:
-                    s.groups["kperm64"] = s.groups["kperm"].long()
+            if self.m_kind == 1:
                 self.mgrp = self.ms32[s.groups["kperm64"]].contiguous()  # node-scalar mass values in group order
 
     def _rigid_basis(self):
@@ -696,9 +592,6 @@ class HipSparseOps(_HipBlockOps):
         self._init_common(rowptr.to(torch.int32), (keys % nv).to(torch.int32), nv, dev)
         # arbitrary pencils (no deflation, possibly -A for the largest end, no preconditioner): keep the Gram exact
         self.gram_exact = True
-        if os.environ.get("DS_SPMM_BATCHED", "0") == "1":
-            bt = _hip.build_batches(self.rowptr.cpu())
-            self.batches = None if bt is None else bt.to(dev)
         self.k32 = self.a64.float().contiguous()
         self.k32t = self.k32.reshape(-1, 3, 3).transpose(1, 2).reshape(-1, 9).contiguous()
         self.ms32 = self.b64.float().contiguous()

@@ -39,7 +39,8 @@ enum { DS_OK = 0, DS_ERR_ARG = 1, DS_ERR_HIP = 2, DS_ERR_NOMEM = 3 };
 
 /* Thread-local text of the last error returned on this thread ("" if none). */
 const char* ds_last_error(void);
-/* Library ABI version (bumped on any signature change). */
+/* Library ABI version (bumped on any signature change); ds_abi_version() returns the value the library was built with. */
+#define DS_ABI_VERSION 11
 int ds_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------------
@@ -59,18 +60,7 @@ int ds_pattern_export(const ds_pattern_t* p, int32_t* rowptr, int32_t* colidx, i
                       int32_t* cptr, int32_t* clist);
 void ds_pattern_free(ds_pattern_t* p);
 
-/* Row tiles for the LDS-tiled SpMM (HOST): consecutive nodes are grouped greedily so that the union of
- * their neighbour sets has <= nu_max members and a tile has <= nb_max nodes.  Exports tnode[ntiles+1]
- * (node ranges), tuptr[ntiles+1] + ulist[nu_total] (unique neighbour ids per tile, ascending) and
- * lidx[nnzb] (uint16: position of colidx[k] in its tile's list).  Fails if one row alone exceeds nu_max. */
-typedef struct ds_tiles ds_tiles_t;
-int ds_tiles_build(const int32_t* rowptr, const int32_t* colidx, int64_t nv, int nu_max, int nb_max,
-                   ds_tiles_t** out);
-int ds_tiles_sizes(const ds_tiles_t* t, int64_t* ntiles, int64_t* nu_total);
-int ds_tiles_export(const ds_tiles_t* t, int32_t* tnode, int32_t* tuptr, int32_t* ulist, uint16_t* lidx);
-void ds_tiles_free(ds_tiles_t* t);
-
-/* Node groups for the register-blocked SpMM (HOST): 4 consecutive nodes share one wave and walk the union of
+/* Node groups of the neighbour-union SpMM (HOST): 4 consecutive nodes share one wave and walk the union of
  * their column lists.  Exports gptr[ngroups+1], gent[ne] (column id | presence mask << 28), goff[ne+1] (block
  * offsets into the group-ordered value copy) and kperm[nnzb] (group-ordered position -> BSR slot). */
 typedef struct ds_groups ds_groups_t;
@@ -128,7 +118,7 @@ int ds_spmm_bsr3(int kind, const int32_t* rowptr, const int32_t* colidx, const v
  *   flags: DS_GRAM_SYMMETRIC (needs p == q): the caller asserts G is symmetric (e.g. S^T (K S)); only the
  *     block-upper part is computed and mirrored.
  *     DS_GRAM_EXACT: exact products, fp64 accumulation throughout (fp64 MFMA).  Without it an f32 x f32 product
- *     runs on the fp32 MFMA with the accumulators folded into fp64 every 64 rows (error ~1e-8 |A_i||B_j|, far
+ *     runs on the fp32 MFMA with the accumulators folded into fp64 every 48 rows (error ~1e-9 |A_i||B_j|, far
  *     below the operands' own fp32 rounding) at twice the rate; an f64 B always takes the exact path.
  *   work: device scratch of ds_gram_workspace_bytes(n, p, q) bytes.
  * ---------------------------------------------------------------------------------------------- */
@@ -170,25 +160,14 @@ int ds_spmm_residual(const int32_t* rowptr, const int32_t* colidx, const float* 
 int ds_scalar_csr_spmm(const int32_t* rowptr, const int32_t* colidx, const float* w, int64_t nrows,
                        const float* X, int64_t ldx, float* Y, int64_t ldy, int ncols, float beta,
                        ds_stream_t stream);
-/* LDS-tiled form of the two above for ncols <= 84 on the row tiles of ds_tiles_build (nu_max as given there):
- * epilogue 0: Y <- K X ; epilogue 1: Y (= W_prev) <- X + c1 (X - Y) + c2 T (R0 - K X). */
-int ds_spmm_tiled(int epilogue, const int32_t* rowptr, const float* vals, int64_t nv, const int32_t* tnode,
-                  const int32_t* tuptr, const int32_t* ulist, const uint16_t* lidx, int64_t ntiles, int nu_max,
-                  const float* X, int64_t ldx, float* Y, int64_t ldy, const float* R0, int64_t ldr,
-                  const float* dinv, int ncols, float c1, float c2, int first, ds_stream_t stream);
-/* Register-blocked form (4 nodes per wave, union column list; see ds_groups_build) for ncols <= 84.
- * kgrp: (nnzb x 9) f32 = the TRANSPOSED blocks in group order, kgrp[p] = vals_t[kperm[p]] (ds_pack_groups).
- * epilogue 0: Y <- K X ; epilogue 1: Y (= W_prev) <- X + c1 (X - Y) + c2 T (R0 - K X). */
+/* kgrp: (nnzb x 9) f32 = the TRANSPOSED blocks in group order, kgrp[p] = vals_t[kperm[p]] (tables of ds_groups_build). */
 int ds_pack_groups(const float* vals_t, const int32_t* kperm, int64_t nnzb, float* kgrp, ds_stream_t stream);
-int ds_spmm_grouped(int epilogue, const int32_t* gptr, const int32_t* gent, const int32_t* goff, const float* kgrp,
-                    int64_t nv, const float* X, int64_t ldx, float* Y, int64_t ldy, const float* R0, int64_t ldr,
-                    const float* dinv, int ncols, float c1, float c2, int first, ds_stream_t stream);
 /* Neighbour-union form of ds_spmm_bsr3 / ds_cheb_spmm / ds_spmm_residual for ncols <= 84 (the eigensolver's
  * b-column products and every preconditioner term): one wavefront per group of 4 consecutive nodes walks the UNION
  * of their neighbours, so a neighbour panel shared inside the group is gathered once (Morton order: 0.58 x the
  * panel loads of one wavefront per node).  Tables from ds_groups_build - gent (union entries col | mask << 28),
  * kgrp (TRANSPOSED 3x3 blocks in group order, ds_pack_groups) - cut into chunks of whole entries with at most
- * cap_blocks (<= 276) blocks: ctab (nchunks x 4) = (e0, e1, b0, b1), utab (ngroups x 2) = chunk range of each
+ * cap_blocks (<= 116) blocks: ctab (nchunks x 4) = (e0, e1, b0, b1), utab (ngroups x 2) = chunk range of each
  * group, ngroups = ceil(nv / 4); utab may be NULL when every group is exactly one chunk (ctab has ngroups rows).
  * epilogue 0: Y <- A X ; 1: Y (= W_prev) <- X + c1 (X - Y) + c2 T (R0 - A X) (first != 0: Y not read) ;
  * (Wprev != NULL, epilogue 1 only: W_prev is read from there and Y is only written - out-of-place form) ;
@@ -247,24 +226,6 @@ typedef struct {
 } ds_twolevel_t;
 int ds_twolevel_apply(const ds_twolevel_t* p, ds_stream_t stream);
 
-#ifdef DS_EXPERIMENTAL /* not in the default library: make -C diffsound_amd/csrc EXPERIMENTAL=1 */
-/* Batched form of ds_spmm_bsr3 / ds_cheb_spmm / ds_spmm_residual for ncols <= 84 (the default path of the
- * eigensolver's b-column products and of every preconditioner term): one wavefront per batch of consecutive
- * nodes stages the ids and values of all its rows in LDS with a few coalesced loads and streams their blocks
- * through one rolling window of neighbour-panel loads.  btab: (nbatch x 4) int32 rows (n0, n1, kb0 = rowptr[n0],
- * ke0 = rowptr[n1]), consecutive, covering [0, nv), each with at most cap_blocks blocks and max_nodes nodes
- * (ds_spmm_batch_limits); every row of the pattern non-empty and no longer than cap_blocks.
- * kind 0: vals (nnzb x 9) f32 = the 3x3 blocks TRANSPOSED (the k32t output of ds_combine_material: [block][col][row]);
- * kind 1: vals (nnzb) f32 scalars (x I3), epilogue 0 only.
- * epilogue 0: Y <- A X ; 1: Y (= W_prev) <- X + c1 (X - Y) + c2 T (R0 - A X) (first != 0: Y not read) ;
- * 2: Y <- R0 - A X.  X and Y distinct, 16-byte aligned rows; 3 nv ldx 4 < 0x7f000000 bytes.
- * (reference: torch.sparse.mm in src/lobpcg/_linalg_utils.py:36-37 and the iK callable of _lobpcg.py:441) */
-void ds_spmm_batch_limits(int* cap_blocks, int* max_nodes);
-int ds_spmm_batched(int kind, int epilogue, const int32_t* btab, int64_t nbatch, const int32_t* rowptr,
-                    const int32_t* colidx, const float* vals, int64_t nnzb, int64_t nv, const float* X, int64_t ldx,
-                    float* Y, int64_t ldy, const float* R0, int64_t ldr, const float* dinv, int ncols, float c1,
-                    float c2, int first, ds_stream_t stream);
-#endif
 /* Out <- alpha * A C + beta * Out,  A (n x p) f32, C (p x q) f32 row-major device, Out (n x q) f32.
  * Out may overlap A (e.g. be a column range of it) when q <= 160: every row tile is read completely before it is
  * written.  (reference: X <- S Z etc., _lobpcg.py:463-466) */

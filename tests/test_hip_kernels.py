@@ -100,72 +100,6 @@ def test_morton_reordering_is_transparent(case, dev):
     assert torch.equal(s1.rows_to_external(s1.rows_to_internal(X)), X)
 
 
-@pytest.mark.parametrize("ncols", [80, 72, 40, 16])
-def test_tiled_spmm_matches_untiled(case, dev, ncols):
-    """LDS-tiled kernels (plain product and fused Chebyshev term) on the Morton-ordered system."""
-    from diffsound_amd.modal_ops import HipModalOps, TetSystem
-
-    import os
-
-    os.environ["DS_SPMM_TILED"] = "1"
-    try:
-        s1 = TetSystem(case["v"].to(dev), case["t"].to(dev), case["order"], MAT[0], reorder=True)
-    finally:
-        os.environ.pop("DS_SPMM_TILED", None)
-    if s1.tiles is None:
-        pytest.skip("a row exceeds the tile capacity")
-    h1 = HipModalOps(s1, case["lam"], case["mu"])
-    g = torch.Generator().manual_seed(ncols)
-    X = torch.randn((s1.n, ncols), generator=g).to(dev)
-    Wp = torch.randn((s1.n, ncols), generator=g).to(dev)
-    R0 = (torch.randn((s1.n, ncols), generator=g) * 1e10).to(dev)
-    Yt = torch.empty_like(X)
-    h1._tiled(0, X, Yt, None, 0.0, 0.0, False)
-    Yu = torch.empty_like(X)
-    h1._spmm(0, h1.k32, X, Yu)
-    assert rel(Yt.cpu().numpy(), Yu.cpu().numpy()) < 2e-6
-    for first in (True, False):
-        a, b = Wp.clone(), Wp.clone()
-        h1._tiled(1, X, a, R0, 0.31, 0.77, first)
-        tiles, s1.tiles = s1.tiles, None
-        h1._cheb_spmm_launch(X, b, R0, 0.31, 0.77, first)
-        s1.tiles = tiles
-        assert rel(a.cpu().numpy(), b.cpu().numpy()) < 2e-6
-
-
-@pytest.mark.parametrize("ncols", [80, 72, 40, 16])
-def test_grouped_spmm_matches_untiled(case, dev, ncols):
-    """Register-blocked kernels (4 nodes per wave) on both node orderings."""
-    from diffsound_amd.modal_ops import HipModalOps, TetSystem
-
-    import os
-
-    for reorder in (False, True):
-        os.environ["DS_SPMM_GROUPED"] = "1"
-        try:
-            s1 = TetSystem(case["v"].to(dev), case["t"].to(dev), case["order"], MAT[0], reorder=reorder)
-        finally:
-            os.environ.pop("DS_SPMM_GROUPED", None)
-        assert s1.groups is not None
-        h1 = HipModalOps(s1, case["lam"], case["mu"])
-        g = torch.Generator().manual_seed(ncols)
-        X = torch.randn((s1.n, ncols), generator=g).to(dev)
-        Wp = torch.randn((s1.n, ncols), generator=g).to(dev)
-        R0 = (torch.randn((s1.n, ncols), generator=g) * 1e10).to(dev)
-        Yg = torch.empty_like(X)
-        h1._grouped(0, X, Yg, None, 0.0, 0.0, False)
-        Yu = torch.empty_like(X)
-        h1._spmm(0, h1.k32, X, Yu)
-        assert rel(Yg.cpu().numpy(), Yu.cpu().numpy()) < 2e-6
-        for first in (True, False):
-            a, b = Wp.clone(), Wp.clone()
-            h1._grouped(1, X, a, R0, 0.31, 0.77, first)
-            groups, s1.groups = s1.groups, None
-            h1._cheb_spmm_launch(X, b, R0, 0.31, 0.77, first)
-            s1.groups = groups
-            assert rel(a.cpu().numpy(), b.cpu().numpy()) < 2e-6
-
-
 def test_assembly_deterministic(case):
     s = case["sys"]
     a = s.klam.clone(), s.kmu.clone(), s.ms.clone()
@@ -366,15 +300,14 @@ def test_two_level_cycle_matches_oracle(case, dev):
     assert rel(Wh.cpu().numpy(), Wc.numpy()) < 2e-4
     # the native driver (ds_twolevel_apply: the whole cycle in one call) issues the same launches as the Python loop
     calls = h.counts["apply_K_cols"], h.coarse.counts["apply_K_cols"]
-    import os
-    os.environ["DS_NATIVE_VCYCLE"] = "0"
+    ph.use_native = False
     try:
         Wp = torch.empty((h.n, 96), device=dev)
         k0 = h.counts["apply_K_cols"], h.coarse.counts["apply_K_cols"]
         ph.apply(R.to(dev), Wp)
         k1 = h.counts["apply_K_cols"], h.coarse.counts["apply_K_cols"]
     finally:
-        os.environ.pop("DS_NATIVE_VCYCLE", None)
+        ph.use_native = True
     assert torch.equal(Wp, Wh)
     Wn = torch.empty((h.n, 96), device=dev)
     ph.apply(R.to(dev), Wn)
