@@ -2,7 +2,9 @@
 """Headline benchmark: forward+backward modal-analysis passes/sec on the 100k-tet ord-2 mesh, 64 modes.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+    (N > 1 without WORLD_SIZE in the environment: the script re-launches itself as
+     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...,
+     one rank per GPU over RCCL, and exits with that job's status; fewer than N visible devices is an error)
 
 One *step* = every rank runs ``--hyp-per-gpu`` complete passes (numeric assembly of K_lambda / K_mu / M, cold-start
 block eigensolve for 64 elastic modes, differentiable frequency read-out, oscillator render, MSE loss,
@@ -13,6 +15,8 @@ Inputs are synthetic (Kuhn box mesh) and resident in HBM before 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -24,7 +28,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 MAT = (2700.0, 5e10, 0.25, 6.0, 1e-7)
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md); ~6300 GB/s achievable
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md); the STREAM triad below is MEASURED in the run
 
 
 def parse():
@@ -52,60 +56,116 @@ def parse():
                     help="recompute K [X P W] and the whole Gram matrix every this many iterations (-1 = solver default)")
     ap.add_argument("--warm-start", action="store_true", help="amortised variant: reuse the previous block")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-cells", type=int, default=5)
+    ap.add_argument("--cpu-sample-cells", type=int, default=8,
+                    help="the CPU oracle runs ONE full pass on a Kuhn box of this many cells per edge (8 -> 3072 tets, the "
+                         "smallest ord-2 size of BASELINE.md section 3; 12 takes several minutes)")
     return ap.parse_args()
 
 
+def relaunch_as_ranks(a):
+    """``--gpus N`` with N > 1 and no WORLD_SIZE: start N ranks (one per GPU) under torch.distributed.run as a CHILD
+    process and exit with its status.  Runs before anything touches the GPU (``device_count`` does not initialise it).
+    Never falls back to fewer ranks."""
+    if "WORLD_SIZE" in os.environ:
+        world = int(os.environ["WORLD_SIZE"])
+        if world != a.gpus:
+            raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}; launch with "
+                             f"`python bench.py --gpus {a.gpus}` or torch.distributed.run --nproc-per-node {a.gpus}")
+        return
+    if a.gpus <= 1:
+        return
+    ndev = torch.cuda.device_count()
+    if ndev < a.gpus:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but only {ndev} HIP device(s) are visible")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // a.gpus)))
+    sys.exit(subprocess.call(cmd, env=env))
+
+
 def cpu_baseline(sample_cells, order, modes, full_tets):
-    """The CPU oracle (faithful restatement of the reference loop body) timed on a bounded sample:
-    one full pass on a small Kuhn box of the same kind, extrapolated LINEARLY in the number of tets
-    to the benchmark mesh (optimistic for the CPU: the reference's assembly and ARPACK's LU are
+    """The CPU oracle (faithful restatement of the reference loop body) MEASURED on one full
+    fwd+bwd pass at a stated size, with per-stage times.  ``value`` is passes/s AT THAT SIZE; the linear extrapolation
+    to the benchmark mesh is reported separately (optimistic for the CPU: the reference's assembly and ARPACK's LU are
     super-linear)."""
     from diffsound_amd import meshgen
     from oracle import fem, modal
     from oracle import oscillator as oosc
 
     # 16 threads = the host share of one GPU on this pool; measured on the MI355X host: 1 thread 3.9 s, 4-64 threads
-    # 2.9 s, all 256 hardware threads 18.2 s (oversubscribed: every small op forks a 256-thread team)
+    # 2.9 s, all 256 hardware threads 18.2 s on the 750-tet sample (oversubscribed: every small op forks a big team)
     nthreads = min(os.cpu_count() or 1, 16)
     torch.set_num_threads(nthreads)
     v, t = meshgen.kuhn_box(sample_cells)
-    t0 = time.time()
+    stages = {}
+    clock = [time.time()]
+
+    def lap(name):
+        now = time.time()
+        stages[name] = round(now - clock[0], 3)
+        clock[0] = now
+
+    t0 = clock[0]
     v, t = fem.to_high_order(torch.from_numpy(v), torch.from_numpy(t).long(), order)
     d = fem.OracleDeform(v, t, order)
+    lap("mesh_lifting_and_shape_function_derivatives")
     E = torch.tensor(MAT[1], requires_grad=True)
     nu = torch.tensor(MAT[2], requires_grad=True)
-    lam, mu = fem.lame(float(E), float(nu))
+    lam, mu = fem.lame(MAT[1], MAT[2])
     M3, _ = fem.assemble_mass(v, t, order, MAT[0])
+    lap("mass_assembly")
     K = fem.assemble_stiffness_faithful(d, lam, mu)
+    lap("stiffness_assembly")
     ev, U, _, _ = modal.eigsh_shift_invert(K, M3, modes)
+    lap("arpack_shift_invert")
     f = modal.undamped_freqs_material(d, M3, ev, U, E, nu)
+    lap("get_undamped_freqs")
     force = torch.zeros((1, 150))
     force[0, 0] = 1
     sig, _ = oosc.bank(f.float(), force, 8000, 32000, MAT[3], MAT[4])
     loss = (sig ** 2).mean()
+    lap("oscillator_and_loss")
     loss.backward()
+    lap("backward")
     dt = time.time() - t0
     ntets = t.shape[0]
-    scaled = dt * full_tets / ntets
+    cpu_model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                cpu_model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
     return {
-        "value": 1.0 / scaled,
-        "unit": "passes/s",
+        "value": 1.0 / dt,
+        "unit": f"passes/s at {ntets} tets (NOT the benchmark mesh)",
         "cores": nthreads,
+        "cpu_model": cpu_model,
+        "host_hardware_threads": os.cpu_count(),
         "kind": "port",
-        "sample": (f"one full fwd+bwd pass of the CPU oracle on a {sample_cells}^3-cell Kuhn box ({ntets} tets, "
-                   f"ord-{order}, {modes} modes) took {dt:.1f} s; extrapolated linearly in tets to {full_tets} tets"),
+        "sample": (f"ONE full fwd+bwd pass of the CPU oracle on a {sample_cells}^3-cell Kuhn box ({ntets} tets, "
+                   f"ord-{order}, n={3 * v.shape[0]}, {modes} modes), measured: {dt:.1f} s"),
         "sample_seconds": dt,
+        "stage_seconds": stages,
+        "extrapolated_to_benchmark_mesh": {
+            "value": 1.0 / (dt * full_tets / ntets), "unit": "passes/s",
+            "how": f"linear in tets to {full_tets} tets (optimistic for the CPU: assembly and the LU are super-linear)"},
     }
 
 
 def main():
     a = parse()
+    relaunch_as_ranks(a)  # N > 1: becomes N ranks under torch.distributed.run (never a silent single rank)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != a.gpus and world > 1:
-        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    assert world == a.gpus
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (there is no CPU path)")
     torch.cuda.set_device(local_rank)
@@ -143,6 +203,9 @@ def main():
     tgt, res0, audio0 = pipe.run_pass(MAT[1], MAT[2], backward=False)
     pipe.set_target(audio0)
 
+    tol = cfg.tol or 2e-6
+    worst = [0.0]
+
     def step(warm):
         loss_sum = 0.0  # (every pass runs its own numeric assembly: ModalPipeline.run_pass)
         its = []
@@ -151,6 +214,13 @@ def main():
         for h, (r, res, _) in zip(mine, outs):
             if a.warm_start:
                 warm[h] = res.block_vectors
+            # convergence gate: an unconverged pass is not a pass
+            if not (r.iterations < cfg.maxit and r.max_rerr < tol and np.isfinite(r.loss)
+                    and np.isfinite(r.grad_E) and np.isfinite(r.grad_nu)):
+                raise SystemExit(f"bench.py: hypothesis {h} (E={Es[h]:.4g}, nu={nus[h]:.4g}) did not converge: "
+                                 f"{r.iterations} iterations, backward error {r.max_rerr:.3g} (tol {tol:.1g}), "
+                                 f"loss {r.loss}, grad ({r.grad_E}, {r.grad_nu})")
+            worst[0] = max(worst[0], r.max_rerr)
             loss_sum += r.loss
             its.append(r.iterations)
         total = all_reduce_loss(loss_sum, dev)
@@ -225,6 +295,23 @@ def main():
         torch.cuda.synchronize()
         solo_ms = e0.elapsed_time(e1) / 30
         fine_bytes = ops0.cheb_term_bytes(a.block)
+        solo = fine_bytes / (solo_ms * 1e-3) / 1e9
+        del Wk, Wp, R0
+        # STREAM triad a = b + s c on the same device, right here: 3 arrays of 1 GiB (4x the Infinity Cache)
+        from diffsound_amd import _hip
+        ne = 1 << 28
+        ta, tb, tc = (torch.empty(ne, device=dev) for _ in range(3))
+        tb.fill_(1.0), tc.fill_(2.0)
+        L = _hip.lib()
+        for _ in range(3):
+            _hip.check(L.ds_stream_triad(ta.data_ptr(), tb.data_ptr(), tc.data_ptr(), ne, 0.5, _hip.stream_ptr()), "ds_stream_triad")
+        e0.record()
+        for _ in range(20):
+            _hip.check(L.ds_stream_triad(ta.data_ptr(), tb.data_ptr(), tc.data_ptr(), ne, 0.5, _hip.stream_ptr()), "ds_stream_triad")
+        e1.record()
+        torch.cuda.synchronize()
+        stream_gbs = 3.0 * ne * 4 / (e0.elapsed_time(e1) / 20 * 1e-3) / 1e9
+        del ta, tb, tc
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "spmm_pmc_bytes_per_launch.json")
         if os.path.exists(pmc):
@@ -232,21 +319,23 @@ def main():
                 traffic = json.load(open(pmc)).get(f"cells{a.cells}_cols{a.block}")
             except Exception:
                 traffic = None
-        roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "kernel": (f"spmm_union_kernel<{a.block // 4},1,*>: W' = W + c1(W - W_prev) + c2 T(R0 - K W) on a "
-                           f"{a.block}-column block (fine and corner-node level launches)"),
-                "algorithmic_bytes_per_launch": float(nbytes.mean()), "avg_launch_ms": float(ms.mean()),
-                "launches_timed": int(len(ms)), "levels": levels,
-                "note": (f"{nlanes} hypothesis lanes launch concurrently on separate HIP streams, so a launch shares the "
-                         "device with the other lanes' kernels and its event-timed duration is stretched accordingly; "
-                         "the launches of the first lane are the ones timed (the other lanes issue the same launches "
-                         "through the native V-cycle driver); "
-                         "'solo' is the same kernel, fine level, alone on the device right after the timed region; "
-                         "'traffic' is the PMC figure of a fine-level launch"),
-                "solo": {"avg_launch_ms": solo_ms, "algorithmic_bytes_per_launch": fine_bytes,
-                         "achieved": fine_bytes / (solo_ms * 1e-3) / 1e9,
-                         "frac": fine_bytes / (solo_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}}
+        roof = {"bound": "hbm", "achieved": solo, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": solo / HBM_PEAK_GBS, "traffic": traffic,
+                "stream_triad": stream_gbs, "frac_of_stream": solo / stream_gbs,
+                "kernel": (f"spmm_union_kernel<{a.block // 4},1>: W' = W + c1(W - W_prev) + c2 T(R0 - K W) on a "
+                           f"{a.block}-column block, fine level"),
+                "algorithmic_bytes_per_launch": fine_bytes, "avg_launch_ms": solo_ms,
+                "how": ("'achieved' = algorithmic bytes of ONE fine-level fused-term launch / its HIP-event time with the "
+                        "kernel alone on the device, on the compact blocks the V-cycle runs it on, right after the timed "
+                        "region (30 back-to-back launches); 'stream_triad' = ds_stream_triad on 3 x 1 GiB arrays, same "
+                        "device, same run; 'traffic' = PMC bytes of one such launch (profiles/)"),
+                "in_situ": {"achieved": achieved, "frac": achieved / HBM_PEAK_GBS,
+                            "algorithmic_bytes_per_launch": float(nbytes.mean()), "avg_launch_ms": float(ms.mean()),
+                            "launches_timed": int(len(ms)), "levels": levels,
+                            "note": (f"HIP events around every fused-term launch of the FIRST hypothesis lane inside the timed "
+                                     f"region, fine and corner-node level; {nlanes} lanes launch concurrently on separate "
+                                     "streams, so a launch shares the device with the other lanes' kernels and its "
+                                     "duration is stretched accordingly")}}
 
     if getattr(pipe.ops, "coarse", None) is not None and a.precond != "chebyshev":
         precond_desc = (f"two-level V-cycle: Chebyshev({a.smooth_degree}, ratio {a.smooth_ratio:g}) block-Jacobi smoother + "
@@ -278,6 +367,8 @@ def main():
                 "eigensolver": (f"LOBPCG(ortho) block {a.block}, {precond_desc}, "
                                 f"cold start{' (warm)' if a.warm_start else ''}, mean iterations {np.mean(iters):.1f}"),
                 "symbolic_pattern_seconds_not_timed": t_sym,
+                "convergence_gate": (f"every timed pass converged: backward error of all {a.modes} pairs < {tol:.1g} "
+                                     f"(worst {worst[0]:.3g}), iterations < {cfg.maxit}, finite loss and gradients"),
             },
             "roofline": roof,
         }

@@ -50,6 +50,7 @@ _SIGNATURES = {
     "ds_mix": (_I, [_P, _I64, _I, _P, _I, _P, _I64, _I64, _F, _F, _P]),
     "ds_osc_bank_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _D, _P, _P]),
     "ds_osc_bank_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _D, _P, _P, _P, _P, _P]),
+    "ds_stream_triad": (_I, [_P, _P, _P, _I64, _F, _P]),
 }
 
 class LevelDesc(ctypes.Structure):

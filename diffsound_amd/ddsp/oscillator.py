@@ -41,7 +41,9 @@ class WeightedSum(nn.Module):
 
     def __init__(self, dims: list, vlist: list):
         super().__init__()
-        self.register_buffer("values_list", torch.tensor([float(v) for v in vlist], dtype=torch.float32))
+        # (a plain attribute in the reference: not part of the state_dict, so checkpoints load strictly both ways)
+        self.register_buffer("values_list", torch.tensor([float(v) for v in vlist], dtype=torch.float32),
+                             persistent=False)
         self.params = nn.Parameter(torch.zeros(*dims, len(self.values_list)))
         self.params.data.uniform_(-4, 4)
 

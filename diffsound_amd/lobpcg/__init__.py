@@ -23,16 +23,31 @@ from .modal_solver import ModalSolver, SolverConfig, SolverState
 
 
 class _CallableOps:
-    """Wraps ops so that ``apply_K`` calls a user callable A(X) -> AX (reference _linalg_utils.py:34-35)."""
+    """Wraps ops so that every product with A calls a user callable A(X) -> AX (reference _linalg_utils.py:34-35).
+    The base ops are built on the pencil (B, B) for the pattern and the mass products only: nothing of A is known
+    but its action, so the block-Jacobi blocks are the identity (no preconditioner, as in the reference when iK is
+    None) and the fp64 polish forms X^T (A X) from the callable's own product."""
 
     def __init__(self, base, fn, sign):
         self._base, self._fn, self._sign = base, fn, sign
+        eye = torch.eye(3, dtype=torch.float32, device=base.device).reshape(1, 9)
+        base.dinv = eye.repeat(base.nv, 1).contiguous()
 
     def __getattr__(self, name):
         return getattr(self._base, name)
 
     def apply_K(self, X, out):
         out.copy_(self._fn(X.contiguous()) * self._sign)
+
+    def polish_products(self, X):
+        b = self._base
+        Xc = X.contiguous()
+        AX = (self._fn(Xc) * self._sign).to(torch.float64).contiguous()
+        GA = b.gram(Xc, AX, exact=True)
+        _, (mkind, mvals) = b.polish_terms()
+        MX = b._scratch("polish", Xc.shape, torch.float64)
+        b._spmm(mkind, mvals, Xc, MX)
+        return [GA], [1.0], b.gram(Xc, MX)
 
 
 def _solve(A, B, k, X, E, n, iK, niter, tol, largest, method, tracker, ortho_iparams, ortho_fparams,

@@ -56,6 +56,7 @@ class PassResult:
     freqs: torch.Tensor
     iterations: int
     eigenvalues: torch.Tensor
+    max_rerr: float = float("nan")  # largest backward error ||K u - lambda M u|| / (||u|| (||K|| + lambda ||M||)) of the wanted pairs
 
 
 class ModalPipeline:
@@ -92,10 +93,11 @@ class ModalPipeline:
         holder = self if _lane is None else _lane
         if assemble:
             holder.system.assemble()
+        lam_f, mu_f = float(lam.detach()), float(mu.detach())
         if holder.ops is None:
-            holder.ops = HipModalOps(holder.system, float(lam), float(mu))
+            holder.ops = HipModalOps(holder.system, lam_f, mu_f)
         else:
-            holder.ops.set_material(float(lam), float(mu))
+            holder.ops.set_material(lam_f, mu_f)
         res = ModalSolver(holder.ops, self.cfg).solve(self.modes, X0=warm)
         ev = res.eigenvalues
         dev = ev.device
@@ -110,7 +112,8 @@ class ModalPipeline:
         if backward:
             loss.backward()
             gE, gnu = float(model.E.grad), float(model.nu.grad)
-        return PassResult(float(loss), gE, gnu, freqs.detach(), res.iterations, ev), res, audio.detach()
+        rerr = float(res.rerr.max()) if res.rerr is not None else float("nan")
+        return PassResult(float(loss), gE, gnu, freqs.detach(), res.iterations, ev, rerr), res, audio.detach()
 
 
 class _Lane:

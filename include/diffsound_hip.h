@@ -259,6 +259,12 @@ int ds_osc_bank_bwd(const float* gy, const double* d, const double* w, const flo
                     const float* force, int A, int m, int F, int S, double sr, float* gs,
                     double* gd, double* gw, float* gamp, ds_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * STREAM triad  a = b + s c  (n f32 elements, n % 4 == 0, 16-byte aligned): the measured HBM bandwidth
+ * (3 n 4 bytes per call) that bench.py quotes the SpMM against.  Not part of the modal path.
+ * ---------------------------------------------------------------------------------------------- */
+int ds_stream_triad(float* a, const float* b, const float* c, int64_t n, float s, ds_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
