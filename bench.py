@@ -55,11 +55,37 @@ def parse():
     ap.add_argument("--rr-refresh", type=int, default=-1,
                     help="recompute K [X P W] and the whole Gram matrix every this many iterations (-1 = solver default)")
     ap.add_argument("--warm-start", action="store_true", help="amortised variant: reuse the previous block")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl = RCCL over xGMI (the product); gloo = rehearsal of the N > 1 path without RCCL")
+    ap.add_argument("--share-devices", action="store_true",
+                    help="rehearsal on a box with fewer GPUs than ranks: rank r uses device r %% device_count "
+                         "(needs --dist-backend gloo: RCCL refuses two ranks on one device)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-cells", type=int, default=8,
                     help="the CPU oracle runs ONE full pass on a Kuhn box of this many cells per edge (8 -> 3072 tets, the "
                          "smallest ord-2 size of BASELINE.md section 3; 12 takes several minutes)")
     return ap.parse_args()
+
+
+def solver_config(a=None, **over):
+    """The eigensolver settings of the benchmark (``a``: parsed arguments; None = the defaults) - also what the
+    parity tests of tests/test_parity_gpu.py run, so the numbers timed here are the numbers checked there."""
+    from diffsound_amd.lobpcg.modal_solver import SolverConfig
+
+    if a is None:
+        saved, sys.argv = sys.argv, sys.argv[:1]
+        try:
+            a = parse()
+        finally:
+            sys.argv = saved
+    for k, v in over.items():
+        setattr(a, k, v)
+    cfg = SolverConfig(block=a.block, cheb_degree=a.cheb_degree, cheb_ratio=a.cheb_ratio,
+                       lmax_cap=float({1: 4, 2: 10}[a.order]), precond=a.precond, smooth_degree=a.smooth_degree,
+                       smooth_ratio=a.smooth_ratio, coarse_degree=a.coarse_degree, coarse_ratio=a.coarse_ratio)
+    if a.rr_refresh >= 0:
+        cfg.rr_refresh = a.rr_refresh
+    return cfg
 
 
 def relaunch_as_ranks(a):
@@ -75,7 +101,9 @@ def relaunch_as_ranks(a):
     if a.gpus <= 1:
         return
     ndev = torch.cuda.device_count()
-    if ndev < a.gpus:
+    if a.share_devices and a.dist_backend != "gloo":
+        raise SystemExit("bench.py: --share-devices needs --dist-backend gloo")
+    if ndev < a.gpus and not (a.share_devices and ndev >= 1):
         raise SystemExit(f"bench.py: --gpus {a.gpus} but only {ndev} HIP device(s) are visible")
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
@@ -168,13 +196,15 @@ def main():
     assert world == a.gpus
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (there is no CPU path)")
+    if a.share_devices:
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
 
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group(a.dist_backend, rank=rank, world_size=world)
 
     from diffsound_amd import meshgen
     from diffsound_amd.diffelastic.mesh import TetMesh
@@ -184,11 +214,7 @@ def main():
     # ---- synthetic inputs, resident in HBM before timing -------------------------------------
     v, t = meshgen.kuhn_box(a.cells)
     mesh = TetMesh(torch.from_numpy(v).to(dev), torch.from_numpy(t).long().to(dev)).to_high_order(a.order)
-    cfg = SolverConfig(block=a.block, cheb_degree=a.cheb_degree, cheb_ratio=a.cheb_ratio,
-                       lmax_cap=float({1: 4, 2: 10}[a.order]), precond=a.precond, smooth_degree=a.smooth_degree,
-                       smooth_ratio=a.smooth_ratio, coarse_degree=a.coarse_degree, coarse_ratio=a.coarse_ratio)
-    if a.rr_refresh >= 0:
-        cfg.rr_refresh = a.rr_refresh
+    cfg = solver_config(a)
     t_sym = time.time()
     pipe = ModalPipeline(mesh.vertices, mesh.tets, a.order, a.modes, MAT, solver_config=cfg)
     torch.cuda.synchronize()
@@ -259,7 +285,7 @@ def main():
     if world > 1:
         dist.barrier()
     dt = time.time() - t0
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev if a.dist_backend == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax[0])
@@ -371,6 +397,8 @@ def main():
                                      f"(worst {worst[0]:.3g}), iterations < {cfg.maxit}, finite loss and gradients"),
             },
             "roofline": roof,
+            "loss_sum_last_step": total,
+            "collective": (f"{a.dist_backend} all-reduce of the scalar loss over {world} ranks" if world > 1 else "none (1 rank)"),
         }
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.cpu_sample_cells, a.order, a.modes, sysd.T)

@@ -187,7 +187,10 @@ def all_reduce_loss(loss_sum, device):
     """Sum of per-rank loss sums.  The data path has no other collective."""
     import torch.distributed as dist
 
+    on = dist.is_available() and dist.is_initialized()
+    if on and dist.get_backend() != "nccl":
+        device = "cpu"  # gloo rehearsal of the N > 1 path
     t = torch.tensor([loss_sum], dtype=torch.float64, device=device)
-    if dist.is_available() and dist.is_initialized():
+    if on:
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return float(t[0])

@@ -319,3 +319,46 @@ def test_gt_oscillator_and_forward_curve(dev):
     refc = refc / np.abs(refc).max(axis=1, keepdims=True)
     assert np.linalg.norm(out.cpu().numpy() - refc) / np.linalg.norm(refc) < 1e-3
     assert float(out.abs().max()) == pytest.approx(1.0, abs=1e-6)
+
+
+def test_lobpcg_callable_A_iK_and_standard_problem(golden, dev):
+    """The remaining argument forms of the reference API (_lobpcg.py:123-140, _linalg_utils.py:27-39): a CALLABLE A
+    must give the same pairs as the sparse A it wraps; iK as a dense tensor and as a callable; lobpcg(B=None) is the
+    standard problem A x = lambda x."""
+    from src.lobpcg import lobpcg, lobpcg_func
+
+    g = golden("g6_lobpcg_ref.npz")
+    Kd, Md = g["K"].astype(np.float64), g["M"].astype(np.float64)
+    w = sla.eigh(Kd, Md, eigvals_only=True)
+    scale = w[6:14].max()
+    K = torch.from_numpy(g["K"]).to(dev).to_sparse()
+    M = torch.from_numpy(g["M"]).to(dev).to_sparse()
+    E0, X0 = lobpcg_func(K, M, 14, largest=False, niter=300)
+    calls = []
+
+    def A(X):
+        calls.append(X.shape[1])
+        return torch.sparse.mm(K, X)
+
+    E1, X1, rerr = lobpcg_func(A, M, 14, largest=False, niter=600, return_rerr=True)
+    assert calls and E1.shape == (14,) and X1.shape == X0.shape and rerr.shape == (14,)
+    assert np.abs(E1.cpu().numpy()[6:] - w[6:14]).max() / scale < 1e-4         # not "about 1 for every pair"
+    assert np.abs(E1.cpu().numpy() - E0.cpu().numpy()).max() / scale < 1e-4
+    Xd = X1.double().cpu().numpy()
+    assert np.abs(Xd.T @ Md @ Xd - np.eye(14)).max() < 1e-3
+    assert np.abs(Xd.T @ Kd @ Xd - np.diag(E1.double().cpu().numpy())).max() / scale < 1e-3
+    # largest end through the callable as well (reference default largest=True)
+    E2, _ = lobpcg_func(A, M, 4, niter=600)
+    assert np.abs(E2.cpu().numpy() - w[::-1][:4]).max() / w.max() < 1e-3
+    # iK: a dense approximate inverse (shifted, the pencil is singular) as tensor and as callable
+    iKd = torch.from_numpy(np.linalg.inv(Kd + 1e-3 * scale * Md)).float().to(dev)
+    E3, _ = lobpcg_func(K, M, 14, iK=iKd, largest=False, niter=300)
+    E4, _ = lobpcg_func(K, M, 14, iK=lambda R: iKd @ R, largest=False, niter=300)
+    for E in (E3, E4):
+        assert np.abs(E.cpu().numpy()[6:] - w[6:14]).max() / scale < 1e-4
+    # standard problem: lobpcg(A) with B=None, lowest end of M (SPD, well conditioned)
+    ws = np.linalg.eigvalsh(Md)
+    E5, X5 = lobpcg(M, k=6, largest=False, niter=600)
+    assert np.abs(E5.cpu().numpy() - ws[:6]).max() / ws[:6].max() < 1e-3
+    X5d = X5.double().cpu().numpy()
+    assert np.abs(X5d.T @ X5d - np.eye(6)).max() < 1e-3

@@ -1,0 +1,61 @@
+"""The N > 1 path of bench.py on real devices: `python bench.py --gpus 2` must start two ranks by itself, shard the
+hypotheses round-robin, all-reduce the scalar loss and report n_gpus = 2 with the same loss sum as one rank running
+all hypotheses.  With >= 2 visible devices the collective is RCCL (backend "nccl"); on a one-GPU box the same
+path is rehearsed with two gloo ranks sharing the device.   pytest -m gpu."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SMALL = ["--steps", "1", "--warmup", "0", "--cells", "6", "--modes", "16", "--block", "24", "--no-cpu-baseline"]
+
+
+def _bench(*args):
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None), env.pop("RANK", None), env.pop("LOCAL_RANK", None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True, text=True,
+                         timeout=600, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(line) == 1, out.stdout[-2000:]  # rank 0 prints ONE JSON line
+    return json.loads(line[0])
+
+
+@pytest.fixture(scope="module")
+def ndev():
+    if not torch.cuda.is_available():
+        pytest.skip("no HIP device")
+    return torch.cuda.device_count()
+
+
+@pytest.fixture(scope="module")
+def one_rank(ndev):
+    return _bench("--gpus", "1", "--hyp-per-gpu", "4", "--lanes", "2", *SMALL)
+
+
+def test_two_ranks_sharing_one_device_gloo(ndev, one_rank):
+    two = _bench("--gpus", "2", "--hyp-per-gpu", "2", "--lanes", "2", "--dist-backend", "gloo", "--share-devices", *SMALL)
+    assert two["n_gpus"] == 2 and "gloo" in two["collective"]
+    assert abs(two["loss_sum_last_step"] / one_rank["loss_sum_last_step"] - 1) < 1e-6
+
+
+def test_two_ranks_rccl(ndev, one_rank):
+    if ndev < 2:
+        pytest.skip("RCCL needs one device per rank; this box has one")
+    two = _bench("--gpus", "2", "--hyp-per-gpu", "2", "--lanes", "2", *SMALL)
+    assert two["n_gpus"] == 2 and "nccl" in two["collective"]
+    assert abs(two["loss_sum_last_step"] / one_rank["loss_sum_last_step"] - 1) < 1e-6
+
+
+def test_more_gpus_than_devices_is_an_error(ndev):
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(ndev + 1), *SMALL],
+                         capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert out.returncode != 0 and "visible" in out.stderr
+    assert not [ln for ln in out.stdout.splitlines() if ln.startswith("{")]

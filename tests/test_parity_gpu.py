@@ -1,0 +1,118 @@
+"""Parity of the whole pass (assembly -> eigensolve -> read-out -> oscillator -> loss -> backward) with the BENCHMARK's
+solver settings (bench.solver_config) on the configurations the benchmark runs:
+  * 8^3 ord-2 Kuhn box, 32 modes: eigenvalues, audio and d loss / d(E, nu) against the CPU oracle;
+  * configs[2] itself (26^3 ord-2, 64 modes): one full fwd+bwd pass must converge, and d loss / dE must agree with
+    a central finite difference of the loss in E (two more cold-start passes);
+  * configs[0]'s plate (40 x 40 x 1 cells, ord-1, 32 modes) against the oracle.
+Tolerances are BASELINE.md section 3's: eigenvalues 1e-4 each, audio rel-L2 1e-3, gradients 2e-3.   pytest -m gpu."""
+import numpy as np
+import pytest
+import torch
+
+import bench
+from oracle import fem, modal
+from oracle import oscillator as oosc
+
+pytestmark = pytest.mark.gpu
+MAT = (2700.0, 5e10, 0.25, 6.0, 1e-7)
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no HIP device")
+    return torch.device("cuda:0")
+
+
+def _oracle_pass(v, t, order, modes, E, nu, target=None):
+    """Oracle pass: ARPACK eigenvalues, audio, loss and d loss / d(E, nu) - the oscillator and the loss through
+    autograd, the eigenvalue perturbation through the closed form that tests/test_oracle_golden.py pins against
+    the reference's autograd gradients."""
+    vo, to = fem.to_high_order(torch.from_numpy(v), torch.from_numpy(t).long(), order)
+    d = fem.OracleDeform(vo, to, order)
+    lam, mu = fem.lame(E, nu)
+    Kl = fem.assemble_stiffness(d, 1.0, 0.0)
+    Km = fem.assemble_stiffness(d, 0.0, 1.0)
+    M3, _ = fem.assemble_mass(vo, to, order, MAT[0])
+    ev, U, _, _ = modal.eigsh_shift_invert((lam * Kl + mu * Km).tocsr(), M3, modes)
+    f = torch.from_numpy(np.sqrt(ev) / 2 / np.pi).float().reshape(-1, 1).requires_grad_(True)
+    force = torch.zeros((1, 150))
+    force[0, 0] = 1
+    sig, _ = oosc.bank(f, force, 8000, 32000, MAT[3], MAT[4])
+    loss = (sig ** 2).mean() if target is None else ((sig - target) ** 2).mean()
+    loss.backward()
+    dfE, dfnu = modal.closed_form_freq_grads(Kl, Km, f.detach().numpy().reshape(-1), U, E, nu)
+    gf = f.grad.numpy().reshape(-1).astype(np.float64)
+    return ev, sig.detach(), float(loss.detach()), float((gf * dfE).sum()), float((gf * dfnu).sum())
+
+
+def test_ord2_pass_with_bench_settings_matches_oracle(dev):
+    from diffsound_amd import meshgen
+    from diffsound_amd.diffelastic.mesh import TetMesh
+    from diffsound_amd.pipeline import ModalPipeline
+
+    modes = 32
+    v, t = meshgen.kuhn_box(8)  # 3072 tets -> 4913 ord-2 nodes
+    mesh = TetMesh(torch.from_numpy(v).to(dev), torch.from_numpy(t).long().to(dev)).to_high_order(2)
+    cfg = bench.solver_config(block=40, order=2)
+    pipe = ModalPipeline(mesh.vertices, mesh.tets, 2, modes, MAT, solver_config=cfg)
+    # target = the table material rendered by the oracle; hypothesis = another material
+    _, tgt, _, _, _ = _oracle_pass(v, t, 2, modes, MAT[1], MAT[2])
+    pipe.set_target(tgt.to(dev))
+    E, nu = 6.3e10, 0.31
+    r, res, audio = pipe.run_pass(E, nu, backward=True)
+    ev, sig, loss, gE, gnu = _oracle_pass(v, t, 2, modes, E, nu, target=tgt)
+    assert r.iterations < cfg.maxit and r.max_rerr < 2e-6
+    assert np.abs(res.eigenvalues.cpu().numpy() / ev - 1).max() < 1e-4          # per eigenvalue
+    assert float((audio.cpu() - sig).norm() / sig.norm()) < 1e-3
+    assert abs(r.loss / loss - 1) < 2e-3
+    assert abs(r.grad_E / gE - 1) < 2e-3, (r.grad_E, gE)
+    assert abs(r.grad_nu / gnu - 1) < 2e-3, (r.grad_nu, gnu)
+
+
+def test_c3_full_pass_with_bench_settings_converges_and_matches_finite_difference(dev):
+    """configs[2] with the benchmark's own settings: fwd+bwd, every pair converged, finite gradients, and
+    d loss / dE against (loss(E(1+h)) - loss(E(1-h))) / (2 E h).  h = 5e-5: the lowest modes ring for ~0.2 s, so the
+    phase moves by ~0.03 rad over the step (truncation ~2e-4), while the eigenvalues are good to ~1e-8 (noise ~2e-4)."""
+    from diffsound_amd import meshgen
+    from diffsound_amd.diffelastic.mesh import TetMesh
+    from diffsound_amd.pipeline import ModalPipeline
+
+    v, t = meshgen.kuhn_box(26)
+    mesh = TetMesh(torch.from_numpy(v).to(dev), torch.from_numpy(t).long().to(dev)).to_high_order(2)
+    cfg = bench.solver_config()
+    pipe = ModalPipeline(mesh.vertices, mesh.tets, 2, 64, MAT, solver_config=cfg)
+    _, _, audio0 = pipe.run_pass(MAT[1], MAT[2], backward=False)
+    pipe.set_target(audio0)
+    E, nu, h = 6.3e10, 0.31, 5e-5
+    r, res, _ = pipe.run_pass(E, nu, backward=True)
+    assert r.iterations < 40 and r.max_rerr < 2e-6
+    assert int((res.rerr < 2e-6).sum()) == 64                                     # nconv >= k
+    assert np.isfinite(r.loss) and np.isfinite(r.grad_E) and np.isfinite(r.grad_nu) and r.loss > 0
+    lp = pipe.run_pass(E * (1 + h), nu, backward=False)[0].loss
+    lm = pipe.run_pass(E * (1 - h), nu, backward=False)[0].loss
+    fd = (lp - lm) / (2 * E * h)
+    assert abs(r.grad_E / fd - 1) < 2e-3, (r.grad_E, fd)
+    hn = 2e-5
+    lp = pipe.run_pass(E, nu + hn, backward=False)[0].loss
+    lm = pipe.run_pass(E, nu - hn, backward=False)[0].loss
+    fdn = (lp - lm) / (2 * hn)
+    assert abs(r.grad_nu / fdn - 1) < 5e-3, (r.grad_nu, fdn)
+
+
+def test_config0_plate_ord1_matches_oracle(dev):
+    """BASELINE.json configs[0] geometry: 40 x 40 x 1-cell plate, ord-1, 32 modes."""
+    from diffsound_amd import meshgen
+    from diffsound_amd.diffelastic.mesh import TetMesh
+    from diffsound_amd.pipeline import ModalPipeline
+
+    modes = 32
+    v, t = meshgen.plate()
+    assert t.shape[0] == 9600
+    mesh = TetMesh(torch.from_numpy(v).to(dev), torch.from_numpy(t).long().to(dev)).to_high_order(1)
+    pipe = ModalPipeline(mesh.vertices, mesh.tets, 1, modes, MAT)
+    r, res, audio = pipe.run_pass(MAT[1], MAT[2], backward=True)
+    ev, sig, loss, gE, gnu = _oracle_pass(v, t, 1, modes, MAT[1], MAT[2])
+    assert np.abs(res.eigenvalues.cpu().numpy() / ev - 1).max() < 1e-4
+    assert float((audio.cpu() - sig).norm() / sig.norm()) < 1e-3
+    assert abs(r.grad_E / gE - 1) < 2e-3 and abs(r.grad_nu / gnu - 1) < 2e-3
