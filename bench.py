@@ -54,6 +54,15 @@ def parse():
     ap.add_argument("--coarse-ratio", type=float, default=550.0)
     ap.add_argument("--rr-refresh", type=int, default=-1,
                     help="recompute K [X P W] and the whole Gram matrix every this many iterations (-1 = solver default)")
+    ap.add_argument("--tol", type=float, default=1e-5,
+                    help="backward-error tolerance of the eigensolve, ||K u - lambda M u|| / (||u|| (||K|| + lambda ||M||)) "
+                         "per wanted pair: 1e-5 is the tolerance the metric states for fp32 iterates (SURVEY.md 8(d)); "
+                         "0 = the library default 2e-6")
+    ap.add_argument("--nested-tol", type=float, default=1e-2,
+                    help="> 0: nested iteration - the random start is first iterated on the corner-node level to this "
+                         "backward error and prolongated (SolverConfig.nested_tol); 0 = start the fine level from the "
+                         "random block directly")
+    ap.add_argument("--nested-maxit", type=int, default=8)
     ap.add_argument("--warm-start", action="store_true", help="amortised variant: reuse the previous block")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (the product); gloo = rehearsal of the N > 1 path without RCCL")
@@ -85,6 +94,9 @@ def solver_config(a=None, **over):
                        smooth_ratio=a.smooth_ratio, coarse_degree=a.coarse_degree, coarse_ratio=a.coarse_ratio)
     if a.rr_refresh >= 0:
         cfg.rr_refresh = a.rr_refresh
+    cfg.tol = a.tol
+    cfg.nested_tol, cfg.nested_maxit = a.nested_tol, a.nested_maxit
+    cfg.nested_cheb_degree, cfg.nested_cheb_ratio = a.coarse_degree, a.coarse_ratio
     return cfg
 
 
@@ -231,6 +243,7 @@ def main():
 
     tol = cfg.tol or 2e-6
     worst = [0.0]
+    cits = []
 
     def step(warm):
         loss_sum = 0.0  # (every pass runs its own numeric assembly: ModalPipeline.run_pass)
@@ -249,6 +262,7 @@ def main():
             worst[0] = max(worst[0], r.max_rerr)
             loss_sum += r.loss
             its.append(r.iterations)
+            cits.append(r.coarse_iterations)
         total = all_reduce_loss(loss_sum, dev)
         return total, its
 
@@ -391,7 +405,10 @@ def main():
                                 "hypotheses in flight per GPU (one HIP stream + host thread each)"),
                 "precision": "fp32 block vectors and SpMM, fp64 Gram accumulation / Rayleigh-Ritz / read-out",
                 "eigensolver": (f"LOBPCG(ortho) block {a.block}, {precond_desc}, "
-                                f"cold start{' (warm)' if a.warm_start else ''}, mean iterations {np.mean(iters):.1f}"),
+                                f"cold start{' (warm)' if a.warm_start else ''}, mean iterations {np.mean(iters):.1f}"
+                                + (f" after a nested start (mean {np.mean(cits):.1f} corner-node level iterations to "
+                                   f"{a.nested_tol:g})" if a.nested_tol > 0 else "")
+                                + f", backward-error tolerance {tol:g}"),
                 "symbolic_pattern_seconds_not_timed": t_sym,
                 "convergence_gate": (f"every timed pass converged: backward error of all {a.modes} pairs < {tol:.1g} "
                                      f"(worst {worst[0]:.3g}), iterations < {cfg.maxit}, finite loss and gradients"),

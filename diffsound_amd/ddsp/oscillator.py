@@ -65,6 +65,38 @@ class DirectValue(nn.Module):
         return modifed_sigmoid(self.value)
 
 
+class FilteredNoise(nn.Module):
+    """Time-varying filtered white noise (DDSP style): per 64-sample frame a learnable magnitude response
+    (65 bins) is turned into a Hann-windowed linear-phase FIR, applied to a fresh white-noise frame by FFT
+    convolution, and the frames are overlap-added.  Interface of reference src/ddsp/filtered_noise.py:7-67
+    (``coefficient_bank`` parameter, ``forward() -> (noise_num, sample_num)``); plain torch.fft plumbing, the
+    noise branch is outside the hot path."""
+
+    def __init__(self, noise_num, sample_num, filter_coeff_length=65, frame_length=64, attenuate_gain=1.0,
+                 device="cuda"):
+        super().__init__()
+        self.noise_num, self.sample_num = noise_num, sample_num
+        self.filter_coeff_length, self.frame_length, self.attenuate_gain = filter_coeff_length, frame_length, attenuate_gain
+        self.coefficient_bank = nn.Parameter(torch.zeros(noise_num, sample_num // frame_length + 1, filter_coeff_length))
+        self.coefficient_bank.data.uniform_(-1, 1)
+
+    def forward(self):
+        mag = modifed_sigmoid(self.coefficient_bank)
+        B, nf, L = mag.shape
+        taps = 2 * L - 1
+        dev = mag.device
+        ir = torch.fft.irfft(torch.complex(mag, torch.zeros_like(mag)), n=taps, dim=-1)  # zero-phase
+        ir = torch.roll(ir, L - 1, dims=-1) * torch.hann_window(taps, dtype=torch.float32, device=dev)
+        nfft = taps + self.frame_length - 1
+        noise = torch.rand(B, nf, self.frame_length, device=dev) * 2 - 1
+        frames = torch.fft.irfft(torch.fft.rfft(noise, n=nfft) * torch.fft.rfft(ir, n=nfft), n=nfft)
+        frames = frames * self.attenuate_gain
+        total = (nf - 1) * self.frame_length + nfft
+        out = F.fold(frames.transpose(1, 2), output_size=(1, total), kernel_size=(1, nfft),
+                     stride=(1, self.frame_length)).reshape(B, total)
+        return out[:, : self.sample_num]
+
+
 class _OscBank(torch.autograd.Function):
     """y[a,t] = sum_j force[a,j] sum_m amp[a,m] exp(-d_m tau) sin(w_m tau) at tau = (t-j+1)/sr."""
 
@@ -177,23 +209,63 @@ class DampedOscillator(_BankBase):
         self.beta_list = torch.exp(torch.linspace(np.log(mat.beta / 10), np.log(mat.beta * 10), bin_num))
         self.beta = WeightedSum([1, mode_num, 1], list(self.beta_list))
         self.amp = DirectValue([audio_num, mode_num, 1])
+        # unused by forward(), kept so that the reference's checkpoints load strictly (oscillator.py:78: "just for load")
+        self.noise = FilteredNoise(audio_num, 8000)
 
     def forward(self, freq_linear, non_linear_rate=0.0, noise_rate=0.0):
         return self._render(freq_linear, self.alpha(), self.beta(), self.amp())
 
-    def forward_curve(self, freq_linear, damping_curve):
-        """Damping from a host callback per mode, peak-normalised output (reference oscillator.py:143-176)."""
-        fr = freq_linear.detach().cpu().numpy().reshape(-1)
-        damp = torch.tensor([float(damping_curve(fi)) for fi in fr], dtype=torch.float64)
+    def _curve_render(self, freq_linear, damping_curve):
         dev = _device_of(self._force)
         if self._force.device != dev:
             self._force = self._force.to(dev)
-        w0sq = (freq_linear.reshape(self.mode_num).to(dev).double() * (2 * np.pi)) ** 2
-        d = damp.to(dev)
+        f = freq_linear.reshape(self.mode_num).to(dev).double()
+        d = curve_on_device(damping_curve, f.detach())  # the reference evaluates the curve on detached frequencies
+        w0sq = (f * (2 * np.pi)) ** 2
         w = torch.sqrt(w0sq - d ** 2)
         self.damped_freq = (w / (2 * np.pi)).float().reshape(1, self.mode_num, 1)
-        sig = oscillator_bank(d, w, None, self._force, self.sample_num, self.sr)
+        return oscillator_bank(d, w, None, self._force, self.sample_num, self.sr)
+
+    def early(self, freq_linear, damping_curve):
+        """Damping per mode from ``damping_curve``, unit amplitudes, no normalisation (reference oscillator.py:85-109)."""
+        return self._curve_render(freq_linear, damping_curve)
+
+    def forward_curve(self, freq_linear, damping_curve):
+        """As ``early`` with the output peak-normalised per clip (reference oscillator.py:143-176)."""
+        sig = self._curve_render(freq_linear, damping_curve)
         return sig / torch.max(torch.abs(sig), dim=1, keepdim=True)[0]
+
+
+def curve_on_device(curve, f):
+    """damping_curve(f_i) for every mode WITHOUT the reference's per-mode host callback (oscillator.py:152-154,
+    one ``interp1d`` call and two host-to-device copies per mode): a piecewise-linear table - an object with knot
+    arrays ``x`` / ``y`` such as the ``scipy.interpolate.interp1d(x, y, fill_value="extrapolate")`` of
+    experiments/material_real_train.py:151, or an ``(x, y)`` pair - is uploaded once and interpolated (linearly
+    extrapolated beyond the end knots) on the device; any other callable is evaluated ONCE on the whole frequency
+    vector (element by element only if it rejects arrays).  f: (m,) fp64 device tensor -> (m,) fp64 on f.device."""
+    table = None
+    if isinstance(curve, (tuple, list)) and len(curve) == 2:
+        table = curve
+    elif hasattr(curve, "x") and hasattr(curve, "y") and getattr(curve, "_kind", "linear") in ("linear", 1):
+        table = (curve.x, curve.y)
+    if table is not None:
+        x = torch.as_tensor(np.asarray(table[0], dtype=np.float64), device=f.device)
+        y = torch.as_tensor(np.asarray(table[1], dtype=np.float64), device=f.device)
+        if x.numel() == 1:
+            return y.expand_as(f).clone()
+        o = torch.argsort(x)
+        x, y = x[o], y[o]
+        i = torch.searchsorted(x, f.contiguous()).clamp_(1, x.numel() - 1)
+        x0, x1, y0, y1 = x[i - 1], x[i], y[i - 1], y[i]
+        return y0 + (y1 - y0) * (f - x0) / (x1 - x0)
+    fr = f.detach().cpu().numpy()
+    try:
+        vals = np.asarray(curve(fr), dtype=np.float64).reshape(-1)
+        if vals.shape != fr.shape:
+            raise ValueError
+    except Exception:
+        vals = np.array([float(curve(fi)) for fi in fr], dtype=np.float64)
+    return torch.from_numpy(vals).to(f.device)
 
 
 def init_damps(osc):
@@ -204,38 +276,6 @@ def init_damps(osc):
         loss = (osc.alpha() - osc.mat.alpha) ** 2 / osc.mat.alpha ** 2 + (osc.beta() - osc.mat.beta) ** 2 / osc.mat.beta ** 2
         loss.mean().backward()
         optimizer.step()
-
-
-class FilteredNoise(nn.Module):
-    """Time-varying filtered white noise (DDSP style): per 64-sample frame a learnable magnitude response
-    (65 bins) is turned into a Hann-windowed linear-phase FIR, applied to a fresh white-noise frame by FFT
-    convolution, and the frames are overlap-added.  Interface of reference src/ddsp/filtered_noise.py:7-67
-    (``coefficient_bank`` parameter, ``forward() -> (noise_num, sample_num)``); plain torch.fft plumbing, the
-    noise branch is outside the hot path."""
-
-    def __init__(self, noise_num, sample_num, filter_coeff_length=65, frame_length=64, attenuate_gain=1.0,
-                 device="cuda"):
-        super().__init__()
-        self.noise_num, self.sample_num = noise_num, sample_num
-        self.filter_coeff_length, self.frame_length, self.attenuate_gain = filter_coeff_length, frame_length, attenuate_gain
-        self.coefficient_bank = nn.Parameter(torch.zeros(noise_num, sample_num // frame_length + 1, filter_coeff_length))
-        self.coefficient_bank.data.uniform_(-1, 1)
-
-    def forward(self):
-        mag = modifed_sigmoid(self.coefficient_bank)
-        B, nf, L = mag.shape
-        taps = 2 * L - 1
-        dev = mag.device
-        ir = torch.fft.irfft(torch.complex(mag, torch.zeros_like(mag)), n=taps, dim=-1)  # zero-phase
-        ir = torch.roll(ir, L - 1, dims=-1) * torch.hann_window(taps, dtype=torch.float32, device=dev)
-        nfft = taps + self.frame_length - 1
-        noise = torch.rand(B, nf, self.frame_length, device=dev) * 2 - 1
-        frames = torch.fft.irfft(torch.fft.rfft(noise, n=nfft) * torch.fft.rfft(ir, n=nfft), n=nfft)
-        frames = frames * self.attenuate_gain
-        total = (nf - 1) * self.frame_length + nfft
-        out = F.fold(frames.transpose(1, 2), output_size=(1, total), kernel_size=(1, nfft),
-                     stride=(1, self.frame_length)).reshape(B, total)
-        return out[:, : self.sample_num]
 
 
 class GTDampedOscillator(_BankBase):

@@ -56,6 +56,7 @@ class PassResult:
     freqs: torch.Tensor
     iterations: int
     eigenvalues: torch.Tensor
+    coarse_iterations: int = 0
     max_rerr: float = float("nan")  # largest backward error ||K u - lambda M u|| / (||u|| (||K|| + lambda ||M||)) of the wanted pairs
 
 
@@ -113,7 +114,8 @@ class ModalPipeline:
             loss.backward()
             gE, gnu = float(model.E.grad), float(model.nu.grad)
         rerr = float(res.rerr.max()) if res.rerr is not None else float("nan")
-        return PassResult(float(loss), gE, gnu, freqs.detach(), res.iterations, ev, rerr), res, audio.detach()
+        return (PassResult(float(loss.detach()), gE, gnu, freqs.detach(), res.iterations, ev, res.coarse_iterations, rerr),
+                res, audio.detach())
 
 
 class _Lane:

@@ -1,0 +1,31 @@
+"""Experiment: eigensolve tolerance vs iterations and accuracy on the C3 mesh (bench settings)."""
+import sys, time
+sys.path.insert(0, ".")
+import numpy as np, torch
+import bench
+from diffsound_amd import meshgen
+from diffsound_amd.diffelastic.mesh import TetMesh
+from diffsound_amd.pipeline import ModalPipeline
+dev = torch.device("cuda:0")
+MAT = (2700.0, 5e10, 0.25, 6.0, 1e-7)
+v, t = meshgen.kuhn_box(26)
+mesh = TetMesh(torch.from_numpy(v).to(dev), torch.from_numpy(t).long().to(dev)).to_high_order(2)
+ref = None
+for tol in (5e-7, 2e-6, 5e-6, 1e-5, 2e-5):
+    cfg = bench.solver_config(tol=tol)
+    pipe = ModalPipeline(mesh.vertices, mesh.tets, 2, 64, MAT, solver_config=cfg)
+    _, _, a0 = pipe.run_pass(MAT[1], MAT[2], backward=False)
+    if ref is None:
+        tgt = a0
+    pipe.set_target(tgt)
+    rows = []
+    for E, nu in ((6.3e10, 0.31), (2.2e10, 0.15), (9e10, 0.38)):
+        torch.cuda.synchronize(); t0 = time.time()
+        r, res, audio = pipe.run_pass(E, nu, backward=True)
+        torch.cuda.synchronize(); dt = time.time() - t0
+        rows.append((r, res.eigenvalues.cpu().numpy(), audio.cpu(), dt))
+    if ref is None:
+        ref = rows
+    for (r, ev, au, dt), (r0, ev0, au0, _) in zip(rows, ref):
+        print(f"tol {tol:g}: it {r.iterations} {dt*1e3:.0f} ms rerr {r.max_rerr:.1e} | eig rel diff {np.abs(ev/ev0-1).max():.1e} "
+              f"audio relL2 {float((au-au0).norm()/au0.norm()):.1e} loss {abs(r.loss/r0.loss-1):.1e} gE {abs(r.grad_E/r0.grad_E-1):.1e} gnu {abs(r.grad_nu/r0.grad_nu-1):.1e}")
