@@ -12,7 +12,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libdiffsound_hip.so")
-ABI_VERSION = 11  # DS_ABI_VERSION of include/diffsound_hip.h
+ABI_VERSION = 12  # DS_ABI_VERSION of include/diffsound_hip.h
 
 c_i32p = ctypes.POINTER(ctypes.c_int32)
 _P = ctypes.c_void_p
@@ -32,7 +32,7 @@ _SIGNATURES = {
     "ds_combine_material": (_I, [_P, _P, _P, _I64, _P, _I64, _D, _D, _P, _P, _P, _P, _P]),
     "ds_spmm_bsr3": (_I, [_I, _P, _P, _P, _P, _I64, _P, _I64, _P, _I64, _I, _P]),
     "ds_gram_workspace_bytes": (_I64, [_I64, _I, _I]),
-    "ds_gram": (_I, [_P, _I64, _I, _P, _I, _I64, _I, _I64, _I, _P, _P, _I64, _P]),
+    "ds_gram": (_I, [_P, _I, _I64, _I, _P, _I, _I64, _I, _I64, _I, _P, _P, _I64, _P]),
     "ds_residual": (_I, [_P, _I64, _P, _I64, _P, _I64, _P, _I64, _P, _I64, _I, _P, _P, _P]),
     "ds_cheb_init": (_I, [_P, _I64, _P, _I64, _P, _I64, _P, _I64, _I, _F, _P]),
     "ds_cheb_step": (_I, [_P, _I64, _P, _I64, _P, _I64, _P, _I64, _P, _I64, _I, _F, _F, _P]),

@@ -33,9 +33,9 @@ constexpr int WT = 16 * TI;    // wave tile edge (48)
 constexpr int KS = 4;          // MFMA k-steps (of 4 rows) per pipelined batch
 constexpr int RB = 4 * KS;     // rows per batch (16)
 
-template <typename TB>
+template <typename TA, typename TB>
 struct Batch {
-    float a[KS][TI];
+    TA a[KS][TI];
     TB b[KS][TJ];
 };
 
@@ -46,8 +46,8 @@ struct Active {
     __device__ __forceinline__ bool operator()(int a, int b) const { return a < na && b < nb && (!diag || a <= b); }
 };
 
-template <typename TB>
-__device__ __forceinline__ void load_batch(Batch<TB>& t, const float* __restrict__ A, int64_t lda,
+template <typename TA, typename TB>
+__device__ __forceinline__ void load_batch(Batch<TA, TB>& t, const TA* __restrict__ A, int64_t lda,
                                            const TB* __restrict__ B, int64_t ldb, int64_t r0, int64_t r_end, int lr,
                                            int acol, int bcol, const bool (&ia)[TI], const bool (&jb)[TJ],
                                            const Active act) {
@@ -55,19 +55,19 @@ __device__ __forceinline__ void load_batch(Batch<TB>& t, const float* __restrict
     for (int s = 0; s < KS; ++s) {
         const int64_t r = r0 + 4 * s + lr;
         const bool rv = r < r_end;
-        const float* ap = A + r * lda + acol;
+        const TA* ap = A + r * lda + acol;
         const TB* bp = B + r * ldb + bcol;
 #pragma unroll
         for (int a = 0; a < TI; ++a)
-            if (a < act.na) t.a[s][a] = (rv && ia[a]) ? ap[a * 16] : 0.f;
+            if (a < act.na) t.a[s][a] = (rv && ia[a]) ? ap[a * 16] : (TA)0;
 #pragma unroll
         for (int b = 0; b < TJ; ++b)
             if (b < act.nb) t.b[s][b] = (rv && jb[b]) ? bp[b * 16] : (TB)0;
     }
 }
 
-template <typename TB>
-__device__ __forceinline__ void mfma_batch(const Batch<TB>& t, d4 (&acc)[TI][TJ], const Active act) {
+template <typename TA, typename TB>
+__device__ __forceinline__ void mfma_batch(const Batch<TA, TB>& t, d4 (&acc)[TI][TJ], const Active act) {
 #pragma unroll
     for (int s = 0; s < KS; ++s)
 #pragma unroll
@@ -82,9 +82,9 @@ __device__ __forceinline__ void mfma_batch(const Batch<TB>& t, d4 (&acc)[TI][TJ]
 // triangle for a symmetric one; ragged edges and the diagonal tiles skip the MFMA tiles that are out of range
 // or mirrored (the fp64 MFMA pipe is the bound of this kernel, idle tiles cost as much as useful ones).
 // blockIdx.x: groups of 4 consecutive wave tiles (they share row batches through L1/L2); blockIdx.y: row split.
-template <typename TB>
+template <typename TA, typename TB>
 __global__ void __launch_bounds__(256)
-    gram_partial_kernel(const float* __restrict__ A, int64_t lda, int p, const TB* __restrict__ B, int64_t ldb, int q,
+    gram_partial_kernel(const TA* __restrict__ A, int64_t lda, int p, const TB* __restrict__ B, int64_t ldb, int q,
                         int64_t n, int64_t rows_per_split, int ntj, int ntiles, int symmetric,
                         double* __restrict__ ws) {
     const int lane = threadIdx.x & 63;
@@ -125,11 +125,11 @@ __global__ void __launch_bounds__(256)
 #pragma unroll
     for (int b = 0; b < TJ; ++b) jb[b] = (j0 + b * 16 + lc) < q;
 
-    Batch<TB> cur, nxt;
+    Batch<TA, TB> cur, nxt;
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
 #pragma unroll
-        for (int a = 0; a < TI; ++a) cur.a[s][a] = nxt.a[s][a] = 0.f;
+        for (int a = 0; a < TI; ++a) cur.a[s][a] = nxt.a[s][a] = (TA)0;
 #pragma unroll
         for (int b = 0; b < TJ; ++b) cur.b[s][b] = nxt.b[s][b] = (TB)0;
     }
@@ -434,7 +434,7 @@ Plan make_plan(int64_t n, int p, int q, int symmetric, bool fast) {
     // The grid is sized to fill the chip an integer number of times: the fp64 kernel holds 152 VGPRs = 3 workgroups
     // per CU, 768 on the chip, and a 1026-workgroup grid ran one full round and a second one at a third of the
     // occupancy, i.e. in the time of two.
-    static const int64_t res64 = resident_workgroups(gram_partial_kernel<float>);
+    static const int64_t res64 = resident_workgroups(gram_partial_kernel<float, float>);
     static const int64_t res32 = resident_workgroups(gram32_partial_kernel);
     const int64_t target = fast ? res32 : res64;
     int64_t nsplit = std::max<int64_t>(1, target / pl.groups);
@@ -457,16 +457,18 @@ extern "C" int64_t ds_gram_workspace_bytes(int64_t n, int p, int q) {
     return (int64_t)ns * p * q * (int64_t)sizeof(double);
 }
 
-extern "C" int ds_gram(const float* A, int64_t lda, int p, const void* B, int b_dtype, int64_t ldb, int q, int64_t n,
-                       int flags, double* G, void* work, int64_t work_bytes, ds_stream_t stream) {
+extern "C" int ds_gram(const void* A, int a_dtype, int64_t lda, int p, const void* B, int b_dtype, int64_t ldb, int q,
+                       int64_t n, int flags, double* G, void* work, int64_t work_bytes, ds_stream_t stream) {
     DS_REQUIRE(A && B && G && work, "ds_gram: null pointer");
     DS_REQUIRE(n > 0 && p > 0 && q > 0, "ds_gram: empty problem");
     DS_REQUIRE(lda >= p && ldb >= q, "ds_gram: leading dimension smaller than the block width");
-    DS_REQUIRE(b_dtype == DS_F32 || b_dtype == DS_F64, "ds_gram: bad dtype code %d", b_dtype);
+    DS_REQUIRE((a_dtype == DS_F32 || a_dtype == DS_F64) && (b_dtype == DS_F32 || b_dtype == DS_F64),
+               "ds_gram: bad dtype codes %d, %d", a_dtype, b_dtype);
+    DS_REQUIRE(a_dtype == DS_F32 || b_dtype == DS_F64, "ds_gram: an f64 A needs an f64 B");
     DS_REQUIRE((flags & ~(DS_GRAM_SYMMETRIC | DS_GRAM_EXACT)) == 0, "ds_gram: unknown flag bits %d", flags);
     const int symmetric = (flags & DS_GRAM_SYMMETRIC) ? 1 : 0;
     DS_REQUIRE(!symmetric || p == q, "ds_gram: symmetric needs p == q");
-    const bool fast = b_dtype == DS_F32 && !(flags & DS_GRAM_EXACT);
+    const bool fast = a_dtype == DS_F32 && b_dtype == DS_F32 && !(flags & DS_GRAM_EXACT);
     const Plan pl = make_plan(n, p, q, symmetric, fast);
     DS_REQUIRE(work_bytes >= (int64_t)pl.nsplit * p * q * (int64_t)sizeof(double),
                "ds_gram: workspace too small (%lld bytes given)", (long long)work_bytes);
@@ -476,17 +478,22 @@ extern "C" int ds_gram(const float* A, int64_t lda, int p, const void* B, int b_
     hipStream_t st = ds::as_stream(stream);
     dim3 grid((unsigned)pl.groups, (unsigned)pl.nsplit);
     double* ws = static_cast<double*>(work);
+    const float* Af = static_cast<const float*>(A);
     if (fast)
         gram32_partial_kernel<<<(unsigned)(pl.groups * pl.nsplit), 256, 0, st>>>(
-            A, lda, p, static_cast<const float*>(B), ldb, q, n, pl.rows_per_split, pl.tiw, pl.tjw, pl.ntj, pl.ntiles,
+            Af, lda, p, static_cast<const float*>(B), ldb, q, n, pl.rows_per_split, pl.tiw, pl.tjw, pl.ntj, pl.ntiles,
             pl.groups,
             symmetric, ws);
     else if (b_dtype == DS_F32)
-        gram_partial_kernel<float><<<grid, 256, 0, st>>>(A, lda, p, static_cast<const float*>(B), ldb, q, n,
-                                                         pl.rows_per_split, pl.ntj, pl.ntiles, symmetric, ws);
+        gram_partial_kernel<float, float><<<grid, 256, 0, st>>>(Af, lda, p, static_cast<const float*>(B), ldb, q, n,
+                                                                pl.rows_per_split, pl.ntj, pl.ntiles, symmetric, ws);
+    else if (a_dtype == DS_F32)
+        gram_partial_kernel<float, double><<<grid, 256, 0, st>>>(Af, lda, p, static_cast<const double*>(B), ldb, q, n,
+                                                                 pl.rows_per_split, pl.ntj, pl.ntiles, symmetric, ws);
     else
-        gram_partial_kernel<double><<<grid, 256, 0, st>>>(A, lda, p, static_cast<const double*>(B), ldb, q, n,
-                                                          pl.rows_per_split, pl.ntj, pl.ntiles, symmetric, ws);
+        gram_partial_kernel<double, double><<<grid, 256, 0, st>>>(static_cast<const double*>(A), lda, p,
+                                                                  static_cast<const double*>(B), ldb, q, n,
+                                                                  pl.rows_per_split, pl.ntj, pl.ntiles, symmetric, ws);
     DS_LAUNCH_CHECK("gram_partial_kernel");
     const int64_t pq = (int64_t)p * q;
     gram_reduce_kernel<<<(unsigned)ds::ceil_div(pq, 16), 256, 0, st>>>(ws, pl.nsplit, p, q, symmetric, fast ? 1 : 0, G);

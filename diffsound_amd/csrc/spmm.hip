@@ -392,13 +392,13 @@ int launch_fast(const int32_t* rowptr, const int32_t* colidx, const void* vals, 
 // merged at the end.  The generic kernel above gives a lane 2 columns of one node and makes it load all 9 values
 // of every block itself: 12 dependent-address loads per block and lane, 1.17 ms per 64-column product on the
 // benchmark mesh; this one issues 4.
-template <int KIND>
+template <int KIND, typename TX>
 __global__ void __launch_bounds__(256)
     spmm_f64_node_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx,
-                         const double* __restrict__ vals, int64_t nv, const float* __restrict__ X, int64_t ldx,
+                         const double* __restrict__ vals, int64_t nv, const TX* __restrict__ X, int64_t ldx,
                          double* __restrict__ Y, int64_t ldy, int lpn, unsigned nblk) {
-    using f4 = __attribute__((ext_vector_type(4))) float;
     using d2 = __attribute__((ext_vector_type(2))) double;
+    using xv4 = __attribute__((ext_vector_type(4))) TX;  // 16 bytes of an f32 row, 32 bytes of an f64 row
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t node = (int64_t)ds::xcd_remap(blockIdx.x, nblk) * 4 + wave;
@@ -407,7 +407,7 @@ __global__ void __launch_bounds__(256)
     const bool active = g < 3;
     const int ga = active ? g : 0;
     const int kb = __builtin_amdgcn_readfirstlane(rowptr[node]), ke = __builtin_amdgcn_readfirstlane(rowptr[node + 1]);
-    const float* xb = X + (int64_t)ga * ldx + cl * 4;
+    const TX* xb = X + (int64_t)ga * ldx + cl * 4;
     double acc[3][4];
 #pragma unroll
     for (int r = 0; r < 3; ++r)
@@ -416,7 +416,7 @@ __global__ void __launch_bounds__(256)
 #pragma unroll 4
     for (int k = kb; k < ke; ++k) {
         const int64_t col = colidx[k];
-        const f4 x = *reinterpret_cast<const f4*>(xb + col * 3 * ldx);
+        const xv4 x = *reinterpret_cast<const xv4*>(xb + col * 3 * ldx);
         if (KIND == 0) {
             const double* a = vals + (int64_t)k * 9 + ga;  // column g of the block
             const double a0 = a[0], a1 = a[3], a2 = a[6];
@@ -469,11 +469,11 @@ extern "C" int ds_spmm_bsr3(int kind, const int32_t* rowptr, const int32_t* coli
                             int ncols, ds_stream_t stream) {
     DS_REQUIRE(rowptr && colidx && vals && X && Y, "ds_spmm_bsr3: null pointer");
     DS_REQUIRE(nv > 0 && ncols > 0, "ds_spmm_bsr3: empty problem");
-    DS_REQUIRE(kind >= 0 && kind <= 3, "ds_spmm_bsr3: unknown kind %d", kind);
+    DS_REQUIRE(kind >= 0 && kind <= 5, "ds_spmm_bsr3: unknown kind %d", kind);
     DS_REQUIRE(ldx >= ncols && ldy >= ncols, "ds_spmm_bsr3: leading dimension smaller than ncols");
     hipStream_t st = ds::as_stream(stream);
-    const bool f64out = kind >= 2;
-    const int xalign = (int)(reinterpret_cast<uintptr_t>(X) | (uintptr_t)(ldx * 4));
+    const bool f64out = kind >= 2, f64in = kind >= 4;
+    const int xalign = (int)(reinterpret_cast<uintptr_t>(X) | (uintptr_t)(ldx * (f64in ? 8 : 4)));
     const int yalign = (int)(reinterpret_cast<uintptr_t>(Y) | (uintptr_t)(ldy * (f64out ? 8 : 4)));
     if (!f64out) {
         // float4 path needs 16-byte aligned rows; float2 path 8-byte
@@ -489,18 +489,29 @@ extern "C" int ds_spmm_bsr3(int kind, const int32_t* rowptr, const int32_t* coli
         return kind == 0 ? launch<0, float, float, float, 2>(rowptr, colidx, vals, nv, X, ldx, Y, ldy, ncols, st)
                          : launch<1, float, float, float, 2>(rowptr, colidx, vals, nv, X, ldx, Y, ldy, ncols, st);
     }
+    const unsigned nblk = (unsigned)ds::ceil_div(nv, 4);
+    const double* dv = static_cast<const double*>(vals);
+    double* dy = static_cast<double*>(Y);
+    if (f64in) {  // fp64 iterates of the refinement phase: the wave-per-node kernel only
+        DS_REQUIRE(ncols % 4 == 0 && ncols <= 84 && (xalign & 31) == 0 && (yalign & 15) == 0,
+                   "ds_spmm_bsr3: f64-input blocks need a column count that is a multiple of 4, <= 84, and 32-byte "
+                   "aligned rows (ncols=%d)", ncols);
+        const double* dx = static_cast<const double*>(X);
+        if (kind == 4)
+            spmm_f64_node_kernel<0, double><<<nblk, 256, 0, st>>>(rowptr, colidx, dv, nv, dx, ldx, dy, ldy, ncols / 4, nblk);
+        else
+            spmm_f64_node_kernel<1, double><<<nblk, 256, 0, st>>>(rowptr, colidx, dv, nv, dx, ldx, dy, ldy, ncols / 4, nblk);
+        DS_LAUNCH_CHECK("spmm_f64_node_kernel<double>");
+        return DS_OK;
+    }
     DS_REQUIRE(ncols % 2 == 0 && ncols <= 128 && (xalign & 7) == 0 && (yalign & 15) == 0,
                "ds_spmm_bsr3: f64-output blocks need an even column count <= 128 and aligned rows (ncols=%d)", ncols);
     if (ncols % 4 == 0 && ncols <= 84 && (xalign & 15) == 0) {
-        const unsigned nblk = (unsigned)ds::ceil_div(nv, 4);
+        const float* fx = static_cast<const float*>(X);
         if (kind == 2)
-            spmm_f64_node_kernel<0><<<nblk, 256, 0, st>>>(rowptr, colidx, static_cast<const double*>(vals), nv,
-                                                          static_cast<const float*>(X), ldx, static_cast<double*>(Y),
-                                                          ldy, ncols / 4, nblk);
+            spmm_f64_node_kernel<0, float><<<nblk, 256, 0, st>>>(rowptr, colidx, dv, nv, fx, ldx, dy, ldy, ncols / 4, nblk);
         else
-            spmm_f64_node_kernel<1><<<nblk, 256, 0, st>>>(rowptr, colidx, static_cast<const double*>(vals), nv,
-                                                          static_cast<const float*>(X), ldx, static_cast<double*>(Y),
-                                                          ldy, ncols / 4, nblk);
+            spmm_f64_node_kernel<1, float><<<nblk, 256, 0, st>>>(rowptr, colidx, dv, nv, fx, ldx, dy, ldy, ncols / 4, nblk);
         DS_LAUNCH_CHECK("spmm_f64_node_kernel");
         return DS_OK;
     }
@@ -586,9 +597,9 @@ extern "C" int ds_spmm_union(int epilogue, const int32_t* utab, const int32_t* c
     DS_REQUIRE(ldx >= ncols && ldy >= ncols && (epilogue == 0 || epilogue == 3 || ldr >= ncols),
                "ds_spmm_union: leading dimension smaller than ncols");
     DS_REQUIRE(X != Y, "ds_spmm_union: X and Y must be different buffers");
-    DS_REQUIRE(3 * nv * ldx * 4 < (int64_t)PIPE_OOB && 3 * nv * ldy * 4 < (int64_t)PIPE_OOB &&
-                   (epilogue == 0 || epilogue == 3 || 3 * nv * ldr * 4 < (int64_t)PIPE_OOB),
-               "ds_spmm_union: block of %lld bytes exceeds the descriptor range", (long long)(3 * nv * ldx * 4));
+    DS_REQUIRE(ldx * 12 < (int64_t)PIPE_OOB && ldy * 12 < (int64_t)PIPE_OOB && ldr * 12 < (int64_t)PIPE_OOB &&
+                   nv * 36 < (int64_t)PIPE_OOB,
+               "ds_spmm_union: a 3-row panel of %lld bytes exceeds the descriptor range", (long long)(ldx * 12));
     DS_REQUIRE(nnzb * 36 < ((int64_t)1 << 32), "ds_spmm_union: value array exceeds the descriptor range");
     uintptr_t al = reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(Y) | (uintptr_t)(ldx * 4) |
                    (uintptr_t)(ldy * 4) | reinterpret_cast<uintptr_t>(kgrp) | reinterpret_cast<uintptr_t>(ctab);
@@ -597,7 +608,7 @@ extern "C" int ds_spmm_union(int epilogue, const int32_t* utab, const int32_t* c
     hipStream_t st = ds::as_stream(stream);
     ChebEpilogue epi{R0, ldr, dinv, c1, c2, first};
     if (Wprev && epilogue == 1) {
-        DS_REQUIRE(ldp >= ncols && 3 * nv * ldp * 4 < (int64_t)PIPE_OOB &&
+        DS_REQUIRE(ldp >= ncols && ldp * 12 < (int64_t)PIPE_OOB &&
                        ((reinterpret_cast<uintptr_t>(Wprev) | (uintptr_t)(ldp * 4)) & 15) == 0 && Wprev != X,
                    "ds_spmm_union: bad W_prev block");
         epi.wprev = Wprev, epi.ldp = ldp;

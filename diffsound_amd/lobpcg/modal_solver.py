@@ -65,6 +65,12 @@ class SolverConfig:
     # corner-node (P1) level - 14x fewer non-zeros, the same block width - to ``nested_tol``, and its prolongation
     # P X_c starts the fine solve.  The P1 spectrum is ~6 % off the P2 one, so a loose coarse tolerance is enough;
     # the fine solve then needs ~4 iterations fewer.  0 = off.
+    # fp64 refinement (BASELINE.json configs[4], "fp64 eigenvalues"): after the fp32 iteration has converged, the block
+    # is iterated further with fp64 vectors and fp64 block values - Rayleigh-Ritz on [Y | X | W], W the (fp32) two-level
+    # preconditioner applied to the fp64 residual - until the backward error of every wanted pair is below this
+    # (1e-10).  0 = off (the fp64 Rayleigh-Ritz polish of the fp32 block is the result).
+    refine_tol: float = 0.0
+    refine_maxit: int = 16
     nested_tol: float = 0.0
     nested_maxit: int = 8
     nested_cheb_degree: int = 28
@@ -83,6 +89,8 @@ class ModalResult:
     history: list = field(default_factory=list)
     block_vectors: Optional[torch.Tensor] = None  # (n, b) whole converged block (warm start)
     coarse_iterations: int = 0  # iterations of the corner-node phase of a nested start
+    refine_iterations: int = 0  # fp64 refinement steps (SolverConfig.refine_tol)
+    refine_history: list = field(default_factory=list)
 
 
 def _sym(G):
@@ -615,7 +623,116 @@ class ModalSolver:
                                history=history, block_vectors=X.contiguous())
         res = self._polish(X, k, it, rel[:k].clone(), history)
         res.coarse_iterations = self.nested_iterations
+        if cfg.refine_tol > 0.0:
+            res = self.refine64(res, k, float(A_norm), float(B_norm))
         return res
+
+    # ------------------------------------------------------------------ fp64 refinement
+    def refine64(self, res, k, A_norm, B_norm):
+        """Continue from the converged fp32 block with fp64 vectors (see SolverConfig.refine_tol): LOBPCG steps in
+        fp64.  One step = K W, M W for the new block (fp64 SpMM), one Rayleigh-Ritz on S = [Y | X | P | W] through the
+        generalised (3b + 6)-dimensional pencil (S^T K S, S^T M S) - the rigid modes come out as its six ~zero
+        eigenvalues and are dropped - and X, P and their products with K and M for the next step by linearity (dense
+        fp64 products through torch.matmul: a handful of steps per solve, not the hot path)."""
+        ops, cfg = self.ops, self.cfg
+        dev = ops.device
+        X = res.block_vectors.double()
+        n, b = X.shape
+        Y = ops.rigid64()
+        ny = 0 if Y is None else 6
+        f64 = dict(dtype=torch.float64, device=dev)
+        KX, MX = torch.empty((n, b), **f64), torch.empty((n, b), **f64)
+        ops.apply_K64(X, KX)
+        ops.apply_M64(X, MX)
+        if ny:
+            MY, KY = torch.empty_like(Y), torch.empty_like(Y)
+            ops.apply_M64(Y, MY)
+            ops.apply_K64(Y, KY)  # ~ eps ||K|| (the rigid modes are null vectors of K); kept, not assumed zero
+        lam = None
+        P = KP = MP = None
+        hist = []
+        for it in range(cfg.refine_maxit + 1):
+            # Rayleigh-Ritz on the current X alone gives the pairs whose residual is tested
+            GA, GB = ops.gram(X, KX), ops.gram(X, MX)
+
+            def gen_eigh(GA_, GB_):
+                L = torch.linalg.cholesky(_sym(GB_))
+                Li = torch.linalg.solve_triangular(L, torch.eye(L.shape[0], dtype=L.dtype), upper=False)
+                E_, Zt = torch.linalg.eigh(_sym(Li @ _sym(GA_) @ Li.transpose(0, 1)))
+                return E_, (Li.transpose(0, 1) @ Zt).contiguous()
+
+            lam, C = _small(gen_eigh, dev, GA, GB)
+            X, KX, MX = X @ C, KX @ C, MX @ C
+            R = KX - MX * lam[None, :]
+            rn = torch.linalg.vector_norm(R, dim=0)
+            rel = rn / (torch.linalg.vector_norm(X, dim=0) * (A_norm + lam.abs() * B_norm))
+            worst = float(rel[:k].max())
+            hist.append(worst)
+            if worst < cfg.refine_tol or it == cfg.refine_maxit:
+                break
+            # W = B R in fp32 (columns scaled to unit norm: the preconditioner is linear), promoted to fp64
+            R32 = (R / rn.clamp(min=1e-300)[None, :]).float().contiguous()
+            W32 = torch.empty_like(R32)
+            self.precond_apply(R32, W32)
+            W = W32.double()
+            del R32, W32, R
+            KW, MW = torch.empty_like(W), torch.empty_like(W)
+            ops.apply_M64(W, MW)
+            wn = torch.sqrt((W * MW).sum(0).clamp(min=1e-300))  # unit M-norm columns: a well scaled pencil
+            W /= wn[None, :]
+            MW /= wn[None, :]
+            ops.apply_K64(W, KW)
+            # pencil on S = [Y | X | P | W]  (P: the previous step's update directions - the locally optimal 3-term
+            # recurrence; without it the pairs next to the guard vectors crawl); should the Gram matrix of S be
+            # numerically singular (P and W nearly dependent close to convergence), the step is repeated without P
+            for use_p in ((True, False) if P is not None else (False,)):
+                S_blocks = ([Y[:, :6]] if ny else []) + [X] + ([P] if use_p else []) + [W]
+                KS_blocks = ([KY[:, :6]] if ny else []) + [KX] + ([KP] if use_p else []) + [KW]
+                MS_blocks = ([MY[:, :6]] if ny else []) + [MX] + ([MP] if use_p else []) + [MW]
+                offs = [0]
+                for blk in S_blocks:
+                    offs.append(offs[-1] + blk.shape[1])
+                m = offs[-1]
+                GA = torch.zeros((m, m), **f64)
+                GB = torch.zeros((m, m), **f64)
+                for i, Si in enumerate(S_blocks):
+                    for j in range(i, len(S_blocks)):
+                        for Gm, blocks in ((GB, MS_blocks), (GA, KS_blocks)):
+                            G = ops.gram(Si, blocks[j])
+                            Gm[offs[i]:offs[i + 1], offs[j]:offs[j + 1]] = G
+                            if j > i:
+                                Gm[offs[j]:offs[j + 1], offs[i]:offs[i + 1]] = G.transpose(0, 1)
+                try:
+                    _, Z = _small(gen_eigh, dev, GA, GB)
+                    break
+                except torch.linalg.LinAlgError:
+                    if not use_p:
+                        raise
+            Zs = Z[:, ny:ny + b]  # the six lowest pairs are the rigid modes
+            Cx = Zs[ny:ny + b].contiguous()
+            # update directions: everything of the new X that is not the old X
+            rest = [(blk, kb, mb, Zs[offs[i]:offs[i + 1]].contiguous())
+                    for i, (blk, kb, mb) in enumerate(zip(S_blocks, KS_blocks, MS_blocks)) if blk is not X]
+            Pn = sum(blk @ c for blk, _, _, c in rest)
+            KPn = sum(kb @ c for _, kb, _, c in rest)
+            MPn = sum(mb @ c for _, _, mb, c in rest)
+            X, KX, MX = X @ Cx + Pn, KX @ Cx + KPn, MX @ Cx + MPn
+            pn = torch.sqrt((Pn * MPn).sum(0).clamp(min=1e-300))
+            P, KP, MP = Pn / pn[None, :], KPn / pn[None, :], MPn / pn[None, :]
+            del W, KW, MW, Pn, KPn, MPn, rest
+        U = X[:, :k].contiguous()
+        kparts = ops.apply_K64(U, torch.empty_like(U), terms=True)
+        MU = torch.empty_like(U)
+        ops.apply_M64(U, MU)
+        a = (U * kparts[0]).sum(0)
+        bq = (U * kparts[1]).sum(0) if len(kparts) > 1 else None
+        m_ = (U * MU).sum(0)
+        out = ModalResult(lam[:k].clone(), U, a, bq, m_, iterations=res.iterations, rerr=rel[:k].clone(),
+                          history=res.history, block_vectors=X)
+        out.coarse_iterations = res.coarse_iterations
+        out.refine_iterations = len(hist) - 1
+        out.refine_history = hist
+        return out
 
     # ------------------------------------------------------------------ fp64 Rayleigh-Ritz polish
     def _polish(self, X, k, it, rerr, history):

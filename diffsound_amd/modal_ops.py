@@ -267,12 +267,14 @@ class _HipBlockOps:
         g = getattr(getattr(self, "sys", None), "groups", None)
         if g is None or g.get("union") is None or self.kgrp is None or X.shape[1] > 84 or X.shape[1] % 4:
             return False
-        # every operand is addressed through a 32-bit buffer descriptor offset and read / written 16 bytes at a time
-        lim = 0x7F000000 // (12 * self.nv)
+        # every operand is read / written 16 bytes at a time (blocks of 2 GB and more take the kernel's per-panel
+        # descriptor variant; the dinv table and the value array stay under one descriptor: nv * 36, nnzb * 36 < 4 GB)
+        if self.nv * 36 >= 0x7F000000 or self.kgrp.shape[0] * 36 >= (1 << 32):
+            return False
         for T in (X,) + others:
             if T is not None:
                 ld = T.stride(0)
-                if ld >= lim or ld % 4 or T.data_ptr() % 16 or T.stride(1) != 1:
+                if ld % 4 or T.data_ptr() % 16 or T.stride(1) != 1:
                     return False
         return True
 
@@ -357,9 +359,10 @@ class _HipBlockOps:
         if self._gram_ws is None or self._gram_ws.numel() < need:
             self._gram_ws = torch.empty((need,), dtype=torch.uint8, device=self.device)
         G = torch.empty((p, q), dtype=torch.float64, device=self.device)
+        adt = DS_F64 if A.dtype == torch.float64 else DS_F32
         bdt = DS_F64 if B.dtype == torch.float64 else DS_F32
         pp = _hip.ptr
-        _hip.check(self._L.ds_gram(pp(A), _ld(A), p, pp(B), bdt, _ld(B), q, self.n, int(bool(symmetric)) | (2 if exact else 0), pp(G),
+        _hip.check(self._L.ds_gram(pp(A), adt, _ld(A), p, pp(B), bdt, _ld(B), q, self.n, int(bool(symmetric)) | (2 if exact else 0), pp(G),
                                    pp(self._gram_ws), self._gram_ws.numel(), _hip.stream_ptr()), "ds_gram")
         self.counts["gram"] += 1
         return G
@@ -468,6 +471,38 @@ class _HipBlockOps:
                                         float(c1), float(c2), int(bool(first)), _hip.stream_ptr()), "ds_cheb_spmm")
         self.counts["apply_K_cols"] += Wk.shape[1]
 
+    # ------------------------------------------------------------------ fp64 iterates (refinement phase)
+    def _spmm64(self, kind, vals, X, out):
+        """out (fp64) <- A X for an fp64 block X, in chunks of <= 80 columns (kinds 4 / 5 of ds_spmm_bsr3)."""
+        p = _hip.ptr
+        if X.dtype != torch.float64 or out.dtype != torch.float64 or X.shape != out.shape:
+            raise ValueError("_spmm64: fp64 blocks of equal shape expected")
+        for c0 in range(0, X.shape[1], 80):
+            c1 = min(X.shape[1], c0 + 80)
+            xs, os_ = X[:, c0:c1], out[:, c0:c1]
+            _hip.check(self._L.ds_spmm_bsr3(kind + 2, p(self.rowptr), p(self.colidx), p(vals), None, self.nv, p(xs),
+                                            _ld(xs), p(os_), _ld(os_), c1 - c0, _hip.stream_ptr()), "ds_spmm_bsr3(f64)")
+
+    def apply_K64(self, X, out, terms=False):
+        """out <- K X, all fp64 (fp64 block values).  ``terms``: also return the list of the separate K_i X."""
+        kterms, _ = self.polish_terms()
+        tmp = self._scratch("k64tmp", X.shape, torch.float64)
+        parts = []
+        out.zero_()
+        for kind, vals, c in kterms:
+            self._spmm64(kind, vals, X, tmp)
+            out.add_(tmp, alpha=float(c))
+            if terms:
+                parts.append(tmp.clone())
+        return parts
+
+    def apply_M64(self, X, out):
+        _, (mkind, mvals) = self.polish_terms()
+        self._spmm64(mkind, mvals, X, out)
+
+    def rigid64(self):
+        return None
+
     # ------------------------------------------------------------------ fp64 polish
     def polish_products(self, X):
         """fp64 Gram matrices of the terms of K and of M on the block X (fp64 values, fp64
@@ -547,6 +582,26 @@ class HipModalOps(_HipBlockOps):
     def polish_terms(self):
         lam, mu = self.lame
         return [(2, self.sys.klam, lam), (2, self.sys.kmu, mu)], (3, self.sys.ms)
+
+    def rigid64(self):
+        """The six rigid-body modes in fp64 (n x 8, two zero pad columns), M-orthonormal to fp64 accuracy."""
+        if self.rigid is None:
+            return None
+        v = self.sys.vertices.double()
+        c = v - v.mean(0, keepdim=True)
+        Y = torch.zeros((self.n, 8), dtype=torch.float64, device=self.device)
+        for a in range(3):
+            Y[a::3, a] = 1
+        Y[0::3, 3], Y[1::3, 3] = -c[:, 1], c[:, 0]
+        Y[1::3, 4], Y[2::3, 4] = -c[:, 2], c[:, 1]
+        Y[2::3, 5], Y[0::3, 5] = -c[:, 0], c[:, 2]
+        MY = torch.empty_like(Y)
+        for _ in range(2):
+            self.apply_M64(Y, MY)
+            G = self.gram(Y, MY)[:6, :6]
+            Lc = torch.linalg.cholesky(0.5 * (G + G.T))
+            Y[:, :6] = torch.linalg.solve_triangular(Lc, Y[:, :6].T, upper=False).T
+        return Y
 
 
 def _coo_to_bsr3(A, nv, pattern=None):

@@ -40,7 +40,7 @@ enum { DS_OK = 0, DS_ERR_ARG = 1, DS_ERR_HIP = 2, DS_ERR_NOMEM = 3 };
 /* Thread-local text of the last error returned on this thread ("" if none). */
 const char* ds_last_error(void);
 /* Library ABI version (bumped on any signature change); ds_abi_version() returns the value the library was built with. */
-#define DS_ABI_VERSION 11
+#define DS_ABI_VERSION 12
 int ds_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------------
@@ -102,6 +102,8 @@ int ds_combine_material(const double* klam, const double* kmu, const double* ms,
  *   kind 1: A = M,   vals (nnzb)     f32 (M_s)     X, Y f32
  *   kind 2: A = K_*, vals (nnzb x 9) f64           X f32, Y f64   (polish / read-out)
  *   kind 3: A = M,   vals (nnzb)     f64 (M_s)     X f32, Y f64
+ *   kind 4: A = K_*, vals (nnzb x 9) f64           X f64, Y f64   (fp64 refinement; ncols % 4 == 0, <= 84,
+ *   kind 5: A = M,   vals (nnzb)     f64 (M_s)     X f64, Y f64    32-byte aligned rows)
  * vals_t (kind 0 only, may be NULL): the same blocks stored transposed, vals_t[k][r][i] = K_k[i][r]
  *   (ds_combine_material writes it); enables the one-load-per-block path for ncols <= 84.
  * X: (3nv x ncols) ld = ldx ; Y: (3nv x ncols) ld = ldy ; X and Y must not overlap.
@@ -114,7 +116,7 @@ int ds_spmm_bsr3(int kind, const int32_t* rowptr, const int32_t* colidx, const v
  * Tall-skinny Gram  G = A^T B  (p x q, fp64, row-major, ld = q) with MFMA.
  * Replaces the dense (k x n)(n x k) products of Rayleigh-Ritz / svqb / ortho in the reference
  * (src/lobpcg/_linalg_utils.py:64-73 via torch.matmul).
- *   A: (n x p) f32, lda ;  B: (n x q) f32 or f64 (b_dtype), ldb
+ *   A: (n x p) f32 or f64 (a_dtype; an f64 A needs an f64 B), lda ;  B: (n x q) f32 or f64 (b_dtype), ldb
  *   flags: DS_GRAM_SYMMETRIC (needs p == q): the caller asserts G is symmetric (e.g. S^T (K S)); only the
  *     block-upper part is computed and mirrored.
  *     DS_GRAM_EXACT: exact products, fp64 accumulation throughout (fp64 MFMA).  Without it an f32 x f32 product
@@ -125,7 +127,7 @@ int ds_spmm_bsr3(int kind, const int32_t* rowptr, const int32_t* colidx, const v
 int64_t ds_gram_workspace_bytes(int64_t n, int p, int q);
 #define DS_GRAM_SYMMETRIC 1
 #define DS_GRAM_EXACT 2
-int ds_gram(const float* A, int64_t lda, int p, const void* B, int b_dtype, int64_t ldb, int q,
+int ds_gram(const void* A, int a_dtype, int64_t lda, int p, const void* B, int b_dtype, int64_t ldb, int q,
             int64_t n, int flags, double* G, void* work, int64_t work_bytes, ds_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
@@ -172,8 +174,8 @@ int ds_pack_groups(const float* vals_t, const int32_t* kperm, int64_t nnzb, floa
  * epilogue 0: Y <- A X ; 1: Y (= W_prev) <- X + c1 (X - Y) + c2 T (R0 - A X) (first != 0: Y not read) ;
  * (Wprev != NULL, epilogue 1 only: W_prev is read from there and Y is only written - out-of-place form) ;
  * 2: Y <- R0 - A X ; 3: Y <- (A_s (x) I3) X with kgrp = the node-SCALAR values in group order (nnzb floats: the mass
- * matrix).  X and Y distinct, 16-byte aligned rows; every operand block 3 nv ld 4 < 0x7f000000 bytes
- * (larger problems use ds_cheb_spmm / ds_spmm_residual / ds_spmm_bsr3).
+ * matrix).  X and Y distinct, 16-byte aligned rows; operand blocks of 2 GB and more (3 nv ld 4 >= 0x7f000000 bytes)
+ * take a variant that builds one buffer descriptor per panel load.
  * (reference: torch.sparse.mm in src/lobpcg/_linalg_utils.py:36-37 and the iK callable of _lobpcg.py:441) */
 int ds_spmm_union(int epilogue, const int32_t* utab, const int32_t* ctab, int64_t ngroups, int cap_blocks,
                   const int32_t* gent, const float* kgrp, int64_t nnzb, int64_t nv, const float* X, int64_t ldx,

@@ -90,6 +90,7 @@ class CpuModalOps:
         L = np.linalg.cholesky(G)
         Y = np.linalg.solve(L, Y.T).T
         self.rigid = torch.from_numpy(Y.astype(self.npdt))
+        self._rigid64 = Y
         self.counts = dict(apply_K_cols=0, apply_M_cols=0, gram=0, mix=0)
         self.coarse = None
         if tets is not None:
@@ -159,6 +160,21 @@ class CpuModalOps:
         new = new + c1 * (Wk if first else Wk - Wprev)  # first: W_prev = 0 and is not read
         Wprev.copy_(new)
         self.counts["apply_K_cols"] += Wk.shape[1]
+
+    # -- fp64 iterates (refinement phase) ---------------------------------------------------
+    def apply_K64(self, X, out, terms=False):
+        Xd = X.numpy()
+        parts = [torch.from_numpy(self.Kl @ Xd), torch.from_numpy(self.Km @ Xd)]
+        out.copy_(self.lame[0] * parts[0] + self.lame[1] * parts[1])
+        return parts if terms else []
+
+    def apply_M64(self, X, out):
+        out.copy_(torch.from_numpy(self.M @ X.numpy()))
+
+    def rigid64(self):
+        Y = torch.zeros((self.n, 8), dtype=torch.float64)
+        Y[:, :6] = torch.from_numpy(self._rigid64)
+        return Y
 
     # -- fp64 polish ---------------------------------------------------------------------
     def polish_products(self, X):

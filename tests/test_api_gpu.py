@@ -356,9 +356,9 @@ def test_lobpcg_callable_A_iK_and_standard_problem(golden, dev):
     E4, _ = lobpcg_func(K, M, 14, iK=lambda R: iKd @ R, largest=False, niter=300)
     for E in (E3, E4):
         assert np.abs(E.cpu().numpy()[6:] - w[6:14]).max() / scale < 1e-4
-    # standard problem: lobpcg(A) with B=None, lowest end of M (SPD, well conditioned)
-    ws = np.linalg.eigvalsh(Md)
-    E5, X5 = lobpcg(M, k=6, largest=False, niter=600)
-    assert np.abs(E5.cpu().numpy() - ws[:6]).max() / ws[:6].max() < 1e-3
+    # standard problem: lobpcg(A) with B=None -> K x = lambda x (six zero eigenvalues, then the elastic ones)
+    ws = np.linalg.eigvalsh(Kd)
+    E5, X5 = lobpcg(K, k=12, largest=False, niter=600)
+    assert np.abs(E5.cpu().numpy() - ws[:12]).max() / ws[11] < 1e-3
     X5d = X5.double().cpu().numpy()
-    assert np.abs(X5d.T @ X5d - np.eye(6)).max() < 1e-3
+    assert np.abs(X5d.T @ X5d - np.eye(12)).max() < 1e-3

@@ -477,3 +477,63 @@ def test_union_spmm_matches_wave_per_node(dev, mesh, order, ncols):
         sysd.groups["union"] = u
         for x, y in zip(got, ref):
             assert rel(x.cpu().numpy(), y.cpu().numpy()) < 5e-6
+
+
+def test_union_spmm_operands_beyond_2gb(dev):
+    """Operand blocks of >= 2 GB (configs[4]: n = 4.1 M rows of a 416-column basis buffer) take the per-panel
+    descriptor variant of ds_spmm_union.  Here a small mesh with a huge leading dimension: every operand is an
+    80-column range of a (n x 81 000)-float buffer, 2.1 GB from first to last row; all four epilogues against the
+    same products on compact blocks (bitwise: the arithmetic is the same, only the addressing differs)."""
+    from diffsound_amd import meshgen
+    from diffsound_amd.diffelastic.mesh import TetMesh
+    from diffsound_amd.modal_ops import HipModalOps, TetSystem
+
+    v, t = meshgen.kuhn_box(6)
+    tm = TetMesh(torch.from_numpy(v).to(dev), torch.from_numpy(t).long().to(dev)).to_high_order(2)
+    sysd = TetSystem(tm.vertices, tm.tets, 2, 2700.0)
+    ops = HipModalOps(sysd, 2e10, 2e10, two_level=False)
+    ncols, ld = 80, 81000
+    assert 3 * sysd.nv * ld * 4 >= 0x7F000000
+    g = torch.Generator(device=dev).manual_seed(7)
+    small = [torch.randn((sysd.n, ncols), generator=g, device=dev) for _ in range(3)]
+    small[2] *= 1e10
+    wide = [torch.empty((sysd.n, ld), device=dev) for _ in range(4)]  # X, W_prev, R0, out: 2.1 GB each
+    Xb, Wpb, R0b = (w[:, 16:16 + ncols] for w in wide[:3])
+    for dst, src in zip((Xb, Wpb, R0b), small):
+        dst.copy_(src)
+    Xs, Wps, R0s = small
+    assert ops._union_ok(Xb, Wpb, R0b)
+
+    def run(X, Wp, R0, out_of):
+        Y = out_of()
+        ops.apply_K(X, Y)
+        a = out_of()
+        a.copy_(Wp)
+        ops.cheb_spmm(X, a, R0, 0.31, 0.77, False)
+        c = out_of()
+        ops.spmm_residual(X, R0, c)
+        d = out_of()
+        ops.apply_M(X, d)
+        e = out_of()
+        ops._union(1, X, e, R0, 0.31, 0.77, False, Wprev=Wp)  # out-of-place form
+        return [z.clone() for z in (Y, a, c, d, e)]
+
+    ref = run(Xs, Wps, R0s, lambda: torch.zeros((sysd.n, ncols), device=dev))
+    outw = wide[3]
+    got = run(Xb, Wpb, R0b, lambda: outw[:, 32:32 + ncols])
+
+    def one(fn_big, fn_small):  # one product at a time: wide operands against compact ones
+        o_b = outw[:, 32:32 + ncols]
+        o_s = torch.zeros((sysd.n, ncols), device=dev)
+        fn_big(o_b)
+        fn_small(o_s)
+        assert torch.equal(o_b, o_s)
+
+    one(lambda o: ops.apply_K(Xb, o), lambda o: ops.apply_K(Xs, o))
+    one(lambda o: ops.spmm_residual(Xb, R0b, o), lambda o: ops.spmm_residual(Xs, R0s, o))
+    one(lambda o: ops.apply_M(Xb, o), lambda o: ops.apply_M(Xs, o))
+    one(lambda o: ops._union(1, Xb, o, R0b, 0.31, 0.77, False, Wprev=Wpb),
+        lambda o: ops._union(1, Xs, o, R0s, 0.31, 0.77, False, Wprev=Wps))
+    one(lambda o: (o.copy_(Wpb), ops.cheb_spmm(Xb, o, R0b, 0.31, 0.77, False)),
+        lambda o: (o.copy_(Wps), ops.cheb_spmm(Xs, o, R0s, 0.31, 0.77, False)))
+    assert all(torch.isfinite(r).all() for r in ref + got)

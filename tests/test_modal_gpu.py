@@ -99,3 +99,33 @@ def test_concurrent_hypothesis_lanes_match_sequential(dev):
         assert abs(rp.loss / rs.loss - 1) < 1e-3
         assert abs(rp.grad_E / rs.grad_E - 1) < 1e-2 and abs(rp.grad_nu / rs.grad_nu - 1) < 1e-2
         assert float((ap - as_).norm() / as_.norm()) < 1e-3
+
+
+def test_fp64_refinement_matches_arpack_to_1e9(dev):
+    """The fp64 path of configs[4] at a size the oracle can solve: 8^3 ord-2 Kuhn box (n = 14 739), 32 modes,
+    fp32 iterates + fp64 refinement to a backward error of 1e-10; eigenvalues against ARPACK's fp64 shift-invert
+    values to 1e-9, fp64 M-orthonormal vectors, read-out identities to 1e-12."""
+    from diffsound_amd import meshgen
+
+    v, t = meshgen.kuhn_box(8)
+    v, t = fem.to_high_order(torch.from_numpy(v), torch.from_numpy(t).long(), 2)
+    sysd, ops, res = _solve(v, t, 2, 32, dev, block=40, lmax_cap=10.0, refine_tol=1e-10)
+    assert res.vectors.dtype == torch.float64 and 1 <= res.refine_iterations <= 16
+    assert float(res.rerr.max()) < 1e-10
+    lam, mu = ops.lame
+    K, M3 = sysd.to_scipy(lam, mu)  # the HIP assembly itself (fp64), so ARPACK sees the same pencil
+    ev_ref = modal.eigsh_shift_invert(K, M3, 32)[0]
+    ev = res.eigenvalues.cpu().numpy()
+    assert np.abs(ev / ev_ref - 1).max() < 1e-9
+    U = sysd.rows_to_external(res.vectors).cpu().numpy()
+    R = K @ U - (M3 @ U) * ev[None, :]
+    G = np.random.default_rng(0).standard_normal((U.shape[0], 8))
+    An, Bn = np.linalg.norm(K @ G) / np.linalg.norm(G), np.linalg.norm(M3 @ G) / np.linalg.norm(G)
+    assert (np.linalg.norm(R, axis=0) / (np.linalg.norm(U, axis=0) * (An + ev * Bn))).max() < 2e-10
+    assert np.abs(U.T @ (M3 @ U) - np.eye(32)).max() < 1e-10
+    assert np.abs((lam * res.a_lambda + mu * res.b_mu).cpu().numpy() / ev - 1).max() < 1e-12
+    # and against the oracle's own assembly (fp32 shape-function gradients: the 2e-6 assembly tolerance applies)
+    d = fem.OracleDeform(v, t, 2)
+    Ko = fem.assemble_stiffness(d, lam, mu)
+    Mo, _ = fem.assemble_mass(v, t, 2, MAT[0])
+    assert np.abs(ev / modal.eigsh_shift_invert(Ko, Mo, 32)[0] - 1).max() < 1e-5

@@ -124,3 +124,28 @@ def test_two_level_preconditioner(cube):
     G = (R.double().T @ W.double()).numpy()
     assert np.abs(G - G.T).max() < 1e-9 * np.abs(G).max()
     assert np.linalg.eigvalsh(0.5 * (G + G.T)).min() > 0
+
+
+def test_fp64_refinement_reaches_1e10_backward_error(cube):
+    """configs[4]'s precision path on the CPU stand-in: fp32 iterates first, then the fp64 refinement
+    (SolverConfig.refine_tol) until ||K u - lambda M u|| / (||u|| (||K|| + lambda ||M||)) < 1e-10 for every pair;
+    eigenvalues against ARPACK (fp64 shift-invert) to 1e-9."""
+    ops = CpuModalOps(cube["Kl"], cube["Km"], cube["M3"], cube["v"], cube["lam"], cube["mu"], dtype=torch.float32,
+                      tets=None)
+    cfg = SolverConfig(block=24, lmax_cap=10.0, refine_tol=1e-10)
+    res = ModalSolver(ops, cfg).solve(16)
+    assert res.vectors.dtype == torch.float64 and res.eigenvalues.dtype == torch.float64
+    assert 1 <= res.refine_iterations <= cfg.refine_maxit and float(res.rerr.max()) < 1e-10
+    assert res.refine_history[0] > 1e-8 and res.refine_history == sorted(res.refine_history, reverse=True)
+    ev = res.eigenvalues.numpy()
+    assert np.abs(ev / cube["ref"] - 1).max() < 1e-9
+    # independent residual check
+    U = res.vectors.numpy()
+    R = cube["K"] @ U - (cube["M3"] @ U) * ev[None, :]
+    g = np.random.default_rng(0).standard_normal((cube["K"].shape[0], 4))
+    An = np.linalg.norm(cube["K"] @ g) / np.linalg.norm(g)
+    Bn = np.linalg.norm(cube["M3"] @ g) / np.linalg.norm(g)
+    assert (np.linalg.norm(R, axis=0) / (np.linalg.norm(U, axis=0) * (An + ev * Bn))).max() < 2e-10
+    assert np.abs(U.T @ (cube["M3"] @ U) - np.eye(16)).max() < 1e-9
+    lam, mu = cube["lam"], cube["mu"]
+    assert np.abs((lam * res.a_lambda + mu * res.b_mu).numpy() / ev - 1).max() < 1e-9
