@@ -1,94 +1,128 @@
-"""Multi-scale spectral loss - the consumer of the rendered audio in every material experiment
-(mirror of reference src/ddsp/mss_loss.py:50-62, 69-122, 125-147).
+"""Multi-scale spectral loss head on HIP kernels.
 
-``MSSLoss(n_ffts, sample_rate, alpha, overlap, eps, type)`` with ``type`` in {"l1_loss", "rmse_loss"}: power
-spectrograms (Hann window of n_fft samples, hop = n_fft (1 - overlap), centred frames with reflect padding -
-what ``torchaudio.transforms.Spectrogram(n_fft, hop_length)`` computes, reference :79-80) at every scale,
-compared on linear and log2 magnitudes.  The spectrograms are ``torch.stft`` calls (rocFFT on the HIP device),
-i.e. device plumbing, not a hand-written kernel: at the reference's sizes (8000 samples, n_fft <= 2048) the
-whole loss is a few tens of microseconds.  The reference's default ``type="geomloss"`` delegates to the
-third-party Sinkhorn solver ``geomloss==0.2.6`` (requirements.txt:46) and is deliberately not provided.
+Interface of reference src/ddsp/mss_loss.py (``SSSLoss`` :70-122, ``MSSLoss`` :125-147: constructor arguments,
+``forward(x_pred, x_true, freq=None, scale=1.0)``, ``log_spec``); the arithmetic is three kernels of
+libdiffsound_hip.so (csrc/stft.hip) behind one ``torch.autograd.Function`` per scale, so the rendered audio is consumed
+where the oscillator bank left it in HBM: ``ds_stft_power`` (Hann-windowed, reflect-centred STFT power - what
+``torchaudio.transforms.Spectrogram(n_fft, hop_length)`` computes, reference :79-80), ``ds_spec_loss`` (the weighted
+L1 on linear and log2 power, reference :50-62, 98-103, or the log RMSE, :118-122, with d loss / d P) and
+``ds_stft_power_bwd`` (d loss / d audio).  Gradients reach ``x_pred`` only (the target is data).
+
+``type`` must be given as 'l1_loss' or 'rmse_loss'.  The reference's default 'geomloss' delegates to the third-party
+Sinkhorn solver ``geomloss==0.2.6`` (requirements.txt:46) and is not provided: asking for it - or omitting ``type`` -
+raises instead of silently computing another loss.
+PARITY UNPINNED against the reference module itself (it needs torchaudio / torchvision / geomloss, absent from the
+build image, and ships no vectors): checked against oracle/mss_loss.py and against torch.stft.
 """
 import numpy as np
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
+
+from .. import _hip
+
+_KIND = {"l1_loss": 0, "rmse_loss": 1}
 
 
-def clip_spec(x, scale):
-    """Keep the lowest ``scale`` fraction of the frequency bins (reference :15-17)."""
-    freq_length = x.shape[-2]
-    return x[..., :int(freq_length * scale), :]  # (batch, freq, time)
+def _as_clips(x):
+    _hip.require_gpu(x)
+    if x.dim() == 1:
+        x = x.unsqueeze(0)
+    if x.dim() != 2:
+        raise ValueError("spectral loss: audio must be (batch, samples)")
+    return x
 
 
-def weighted_l1_loss(x_pred, x_true):
-    """L1 distance with time weights rising linearly from 0 (first frame) - normalised to mean 1 - and the DC
-    bin removed (reference :50-62)."""
-    time_length = x_pred.shape[-1]
-    weight = 1 - torch.linspace(1.0, 0.9, time_length).to(x_pred.device)
-    weight = weight / weight.sum() * time_length
-    weight = weight.unsqueeze(0).unsqueeze(1)
-    return F.l1_loss(x_pred[:, 1:, :] * weight, x_true[:, 1:, :] * weight)
+def stft_power(x, n_fft, hop, keep_parts=False):
+    """(B, S) f32 HIP tensor -> power spectrogram (B, n_fft // 2 + 1, 1 + S // hop) [, re, im]."""
+    x = _as_clips(x).detach().float().contiguous()
+    B, S = x.shape
+    F_, T = n_fft // 2 + 1, 1 + S // hop
+    P = torch.empty((B, F_, T), dtype=torch.float32, device=x.device)
+    re = torch.empty_like(P) if keep_parts else None
+    im = torch.empty_like(P) if keep_parts else None
+    p = _hip.ptr
+    _hip.check(_hip.lib().ds_stft_power(p(x), B, S, n_fft, hop, p(P), p(re), p(im), _hip.stream_ptr()), "ds_stft_power")
+    return (P, re, im) if keep_parts else P
 
 
-class Spectrogram(nn.Module):
-    """Power spectrogram |STFT|^2 with torchaudio's defaults for (n_fft, hop_length): periodic Hann window of
-    n_fft samples, centred frames, reflect padding, one-sided, not normalised."""
+class _SpecLoss(torch.autograd.Function):
+    """One scale: loss(x_pred, x_true) -> scalar; backward to x_pred."""
 
-    def __init__(self, n_fft, hop_length):
-        super().__init__()
-        self.n_fft, self.hop_length = n_fft, hop_length
-        self.register_buffer("window", torch.hann_window(n_fft), persistent=False)
+    @staticmethod
+    def forward(ctx, x_pred, x_true, n_fft, hop, kind, alpha, eps, scale):
+        xp = _as_clips(x_pred)
+        B, S = xp.shape
+        need_grad = x_pred.requires_grad
+        Pp, re, im = stft_power(xp, n_fft, hop, keep_parts=True) if need_grad else (stft_power(xp, n_fft, hop), None, None)
+        Pt = stft_power(x_true, n_fft, hop)
+        if Pt.shape != Pp.shape:
+            raise ValueError("spectral loss: prediction and target must have the same shape")
+        F_, T = Pp.shape[1], Pp.shape[2]
+        fclip = int(F_ * scale)
+        sums = torch.empty((B, F_, 2), dtype=torch.float64, device=Pp.device)
+        gP = torch.empty_like(Pp) if need_grad else None
+        p = _hip.ptr
+        _hip.check(_hip.lib().ds_spec_loss(kind, p(Pp), p(Pt), B, F_, T, float(alpha), float(eps), fclip, p(sums), p(gP),
+                                           _hip.stream_ptr()), "ds_spec_loss")
+        tot = sums.sum((0, 1))
+        if kind == 0:
+            loss = (alpha * tot[0] + tot[1]) / (B * (F_ - 1) * T)
+            post = None
+        else:
+            loss = torch.sqrt(tot[0] / (B * fclip * T))
+            post = loss  # d sqrt(m) = d m / (2 sqrt(m)); the kernel wrote d (m) / 2
+        ctx.save_for_backward(gP, re, im, post if post is not None else torch.empty(0, device=Pp.device))
+        ctx.meta = (B, S, n_fft, hop, T, x_pred.dim(), post is not None)
+        return loss.float()
 
-    def forward(self, x):
-        spec = torch.stft(x, self.n_fft, hop_length=self.hop_length, win_length=self.n_fft,
-                          window=self.window.to(device=x.device, dtype=x.dtype), center=True, pad_mode="reflect",
-                          normalized=False, onesided=True, return_complex=True)
-        return spec.real ** 2 + spec.imag ** 2  # (batch, n_fft // 2 + 1, frames)
+    @staticmethod
+    def backward(ctx, g):
+        gP, re, im, post = ctx.saved_tensors
+        B, S, n_fft, hop, T, xdim, has_post = ctx.meta
+        if gP is None:
+            return (None,) * 8
+        gscale = g.double() / post if has_post else g.double()
+        gframes = torch.empty((B, T, n_fft), dtype=torch.float32, device=gP.device)
+        gx = torch.empty((B, S), dtype=torch.float32, device=gP.device)
+        p = _hip.ptr
+        _hip.check(_hip.lib().ds_stft_power_bwd(p(gP), p(re), p(im), B, S, n_fft, hop, float(gscale), p(gframes), p(gx),
+                                                _hip.stream_ptr()), "ds_stft_power_bwd")
+        return (gx if xdim == 2 else gx[0]), None, None, None, None, None, None, None
 
 
 class SSSLoss(nn.Module):
-    """Single-scale spectral loss (reference :69-122)."""
+    """Single-scale spectral loss (reference :70-122)."""
 
-    def __init__(self, n_fft, sample_rate, alpha=1.0, overlap=0.75, eps=1e-7, type="l1_loss"):
+    def __init__(self, n_fft, sample_rate, alpha=1.0, overlap=0.75, eps=1e-7, type=None):
         super().__init__()
-        if type not in ("l1_loss", "rmse_loss"):
+        if type not in _KIND:
             raise NotImplementedError(
-                f"SSSLoss type {type!r}: only 'l1_loss' and 'rmse_loss' are provided (the reference's 'geomloss' "
-                "variant needs the third-party Sinkhorn solver of geomloss)")
-        self.n_fft = n_fft
-        self.alpha = alpha
-        self.eps = eps
-        self.hop_length = int(n_fft * (1 - overlap))  # 25% of the length
-        self.spec = Spectrogram(n_fft, self.hop_length)
+                f"SSSLoss: type={type!r} - only 'l1_loss' and 'rmse_loss' are built (the reference's default 'geomloss' "
+                "is a third-party Sinkhorn solver); pass type explicitly")
+        self.n_fft, self.alpha, self.eps = n_fft, alpha, eps
+        self.hop_length = int(n_fft * (1 - overlap))
         self.loss_type = type
         self.sample_rate = sample_rate
+
+    def spec(self, x):
+        return stft_power(x, self.n_fft, self.hop_length)
 
     def log_func(self, x):
         return (x + self.eps).log2() - np.log2(self.eps)
 
     def log_spec(self, x, scale=1.0):
-        return self.log_func(clip_spec(self.spec(x), scale))
+        S = self.spec(x)
+        return self.log_func(S[..., :int(S.shape[-2] * scale), :])
 
     def forward(self, x_pred, x_true, freq=None, scale=1.0):
-        if self.loss_type == "l1_loss":
-            linear_true = self.spec(x_true)
-            linear_pred = self.spec(x_pred)
-            log_true = (linear_true + self.eps).log2()
-            log_pred = (linear_pred + self.eps).log2()
-            return self.alpha * weighted_l1_loss(log_pred, log_true) + weighted_l1_loss(linear_pred, linear_true)
-        log_true = self.log_spec(x_true, scale)
-        log_pred = self.log_spec(x_pred, scale)
-        return torch.sqrt(F.mse_loss(log_pred, log_true))
+        return _SpecLoss.apply(x_pred, x_true, self.n_fft, self.hop_length, _KIND[self.loss_type], self.alpha, self.eps,
+                               scale)
 
 
 class MSSLoss(nn.Module):
-    """Multi-scale spectral loss: sum of the single-scale losses (reference :125-147).
+    """Multi-scale spectral loss: sum of ``SSSLoss`` over ``n_ffts`` (reference :125-147)."""
 
-    mssloss = MSSLoss([2048, 1024, 512, 256], sample_rate, type="l1_loss"); mssloss(y_pred, y_gt)
-    with y_pred, y_gt of shape (batch, samples)."""
-
-    def __init__(self, n_ffts, sample_rate, alpha=1.0, overlap=0.75, eps=1e-7, type="l1_loss"):
+    def __init__(self, n_ffts, sample_rate, alpha=1.0, overlap=0.75, eps=1e-7, type=None):
         super().__init__()
         self.n_ffts = n_ffts
         self.losses = nn.ModuleList([SSSLoss(n_fft, sample_rate, alpha, overlap, eps, type) for n_fft in n_ffts])

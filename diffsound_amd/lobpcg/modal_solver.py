@@ -70,7 +70,7 @@ class SolverConfig:
     # preconditioner applied to the fp64 residual - until the backward error of every wanted pair is below this
     # (1e-10).  0 = off (the fp64 Rayleigh-Ritz polish of the fp32 block is the result).
     refine_tol: float = 0.0
-    refine_maxit: int = 16
+    refine_maxit: int = 40
     nested_tol: float = 0.0
     nested_maxit: int = 8
     nested_cheb_degree: int = 28

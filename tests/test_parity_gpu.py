@@ -62,7 +62,7 @@ def test_ord2_pass_with_bench_settings_matches_oracle(dev):
     E, nu = 6.3e10, 0.31
     r, res, audio = pipe.run_pass(E, nu, backward=True)
     ev, sig, loss, gE, gnu = _oracle_pass(v, t, 2, modes, E, nu, target=tgt)
-    assert r.iterations < cfg.maxit and r.max_rerr < 2e-6
+    assert r.iterations < cfg.maxit and r.max_rerr < cfg.tol <= 1e-5
     assert np.abs(res.eigenvalues.cpu().numpy() / ev - 1).max() < 1e-4          # per eigenvalue
     assert float((audio.cpu() - sig).norm() / sig.norm()) < 1e-3
     assert abs(r.loss / loss - 1) < 2e-3
@@ -73,7 +73,8 @@ def test_ord2_pass_with_bench_settings_matches_oracle(dev):
 def test_c3_full_pass_with_bench_settings_converges_and_matches_finite_difference(dev):
     """configs[2] with the benchmark's own settings: fwd+bwd, every pair converged, finite gradients, and
     d loss / dE against (loss(E(1+h)) - loss(E(1-h))) / (2 E h).  h = 5e-5: the lowest modes ring for ~0.2 s, so the
-    phase moves by ~0.03 rad over the step (truncation ~2e-4), while the eigenvalues are good to ~1e-8 (noise ~2e-4)."""
+    phase moves by ~0.03 rad over the step (truncation ~2e-4), while tightly converged eigenvalues are good to ~1e-8
+    (noise ~2e-4)."""
     from diffsound_amd import meshgen
     from diffsound_amd.diffelastic.mesh import TetMesh
     from diffsound_amd.pipeline import ModalPipeline
@@ -86,9 +87,12 @@ def test_c3_full_pass_with_bench_settings_converges_and_matches_finite_differenc
     pipe.set_target(audio0)
     E, nu, h = 6.3e10, 0.31, 5e-5
     r, res, _ = pipe.run_pass(E, nu, backward=True)
-    assert r.iterations < 40 and r.max_rerr < 2e-6
-    assert int((res.rerr < 2e-6).sum()) == 64                                     # nconv >= k
+    assert r.iterations < 40 and r.max_rerr < cfg.tol <= 1e-5
+    assert int((res.rerr < cfg.tol).sum()) == 64                                  # nconv >= k
     assert np.isfinite(r.loss) and np.isfinite(r.grad_E) and np.isfinite(r.grad_nu) and r.loss > 0
+    # the difference quotient needs losses that are smooth in (E, nu) to ~1e-7: its four passes run with a tight
+    # eigensolve tolerance; the gradient under test comes from the pass with the benchmark's settings above
+    pipe.cfg = bench.solver_config(tol=5e-7, nested_tol=0.0)
     lp = pipe.run_pass(E * (1 + h), nu, backward=False)[0].loss
     lm = pipe.run_pass(E * (1 - h), nu, backward=False)[0].loss
     fd = (lp - lm) / (2 * E * h)
