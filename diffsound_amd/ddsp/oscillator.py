@@ -80,7 +80,8 @@ class FilteredNoise(nn.Module):
         self.coefficient_bank = nn.Parameter(torch.zeros(noise_num, sample_num // frame_length + 1, filter_coeff_length))
         self.coefficient_bank.data.uniform_(-1, 1)
 
-    def forward(self):
+    def forward(self, noise=None):
+        """noise: optional (noise_num, frames, frame_length) tensor in [-1, 1) replacing the internal draw (tests)."""
         mag = modifed_sigmoid(self.coefficient_bank)
         B, nf, L = mag.shape
         taps = 2 * L - 1
@@ -88,7 +89,8 @@ class FilteredNoise(nn.Module):
         ir = torch.fft.irfft(torch.complex(mag, torch.zeros_like(mag)), n=taps, dim=-1)  # zero-phase
         ir = torch.roll(ir, L - 1, dims=-1) * torch.hann_window(taps, dtype=torch.float32, device=dev)
         nfft = taps + self.frame_length - 1
-        noise = torch.rand(B, nf, self.frame_length, device=dev) * 2 - 1
+        if noise is None:
+            noise = torch.rand(B, nf, self.frame_length, device=dev) * 2 - 1
         frames = torch.fft.irfft(torch.fft.rfft(noise, n=nfft) * torch.fft.rfft(ir, n=nfft), n=nfft)
         frames = frames * self.attenuate_gain
         total = (nf - 1) * self.frame_length + nfft
@@ -133,6 +135,50 @@ class _OscBank(torch.autograd.Function):
         _hip.check(_hip.lib().ds_osc_bank_bwd(p(gy), p(d), p(w), p(amp), p(force), A, m, nF, ctx.S, ctx.sr, p(gs),
                                               p(gd), p(gw), p(gamp), _hip.stream_ptr()), "ds_osc_bank_bwd")
         return gd, gw, gamp, None, None, None
+
+
+class _OscBankTV(torch.autograd.Function):
+    """Time-varying bank: y = FIR(sum_m amp exp(-cumsum(dmp / sr)) sin(2 pi cumsum(frq / sr))), dmp / frq (A, m, S)."""
+
+    @staticmethod
+    def forward(ctx, dmp, frq, amp, force, S, sr):
+        _hip.require_gpu(dmp, frq, force, amp)
+        dmp = dmp.detach().float().contiguous()
+        frq = frq.detach().float().contiguous()
+        force = force.detach().float().contiguous()
+        ampc = None if amp is None else amp.detach().float().contiguous()
+        A, m, S_ = dmp.shape
+        if S_ != S or frq.shape != dmp.shape or force.shape[0] != A:
+            raise ValueError("time-varying bank: dmp and frq must be (audio_num, mode_num, sample_num)")
+        L = _hip.lib()
+        work = torch.empty(L.ds_osc_tv_workspace_floats(A, m, S), dtype=torch.float32, device=dmp.device)
+        y = torch.empty((A, S), dtype=torch.float32, device=dmp.device)
+        p = _hip.ptr
+        _hip.check(L.ds_osc_tv_fwd(p(dmp), p(frq), p(ampc), p(force), A, m, force.shape[1], S, float(sr), p(work), p(y),
+                                   _hip.stream_ptr()), "ds_osc_tv_fwd")
+        ctx.save_for_backward(dmp, frq, force, ampc if ampc is not None else torch.empty(0, device=dmp.device))
+        ctx.has_amp = ampc is not None
+        ctx.sr = float(sr)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        dmp, frq, force, ampc = ctx.saved_tensors
+        amp = ampc if ctx.has_amp else None
+        A, m, S = dmp.shape
+        gy = gy.float().contiguous()
+        gs = torch.empty_like(gy)
+        gd, gf = torch.empty_like(dmp), torch.empty_like(frq)
+        gamp = torch.empty((A, m), dtype=torch.float32, device=gy.device) if amp is not None else None
+        p = _hip.ptr
+        _hip.check(_hip.lib().ds_osc_tv_bwd(p(gy), p(dmp), p(frq), p(amp), p(force), A, m, force.shape[1], S, ctx.sr,
+                                            p(gs), p(gd), p(gf), p(gamp), _hip.stream_ptr()), "ds_osc_tv_bwd")
+        return gd, gf, gamp, None, None, None
+
+
+def oscillator_bank_tv(dmp, frq, amp, force, sample_num, sr):
+    """Functional entry of the time-varying bank: dmp [1/s], frq [Hz] (A, m, S) HIP tensors (autograd ok)."""
+    return _OscBankTV.apply(dmp, frq, amp, force, int(sample_num), float(sr))
 
 
 def oscillator_bank(d, w, amp, force, sample_num, sr):
@@ -281,14 +327,16 @@ def init_damps(osc):
 class GTDampedOscillator(_BankBase):
     """Free-running bank with learnable frequencies (softplus-weighted over ``f_range``), dampings and
     amplitudes, used to pre-fit recorded audio (reference oscillator.py:178-243,
-    experiments/material_real_train.py:113-134).  The time-varying ``freq_nonlinear`` branch of the
-    reference (an (A, m, S, len(f_range)) parameter that its own callers always run with
-    ``non_linear_rate = 0``) is not materialised; a non-zero rate raises."""
+    experiments/material_real_train.py:113-134).  ``freq_nonlinear`` is the reference's per-sample frequency
+    offset, an (A, m, S, len(f_range)) parameter (:186-187, kept so that checkpoints and optimisers see the same
+    parameter set); with ``non_linear_rate = 0`` - what the reference's callers pass - it is not touched and the
+    closed-form bank renders the clip, otherwise the time-varying kernel (ds_osc_tv_fwd / ds_osc_tv_bwd) does."""
 
     def __init__(self, forces, audio_num, mode_num, sample_num, sr, f_range: list, mat: Material):
         super().__init__()
         self._setup(forces, audio_num, mode_num, sample_num, sr, mat)
         self.freq_linear = WeightedSum([1, mode_num, 1], f_range)
+        self.freq_nonlinear = WeightedSum([audio_num, mode_num, sample_num], f_range)
         bin_num = 64
         self.alpha_list = torch.exp(torch.linspace(np.log(mat.alpha / 10), np.log(mat.alpha * 100), bin_num))
         self.alpha = WeightedSum([1, mode_num, 1], list(self.alpha_list))
@@ -303,12 +351,25 @@ class GTDampedOscillator(_BankBase):
 
     def forward(self, non_linear_rate=0.0, noise_rate=0.0):
         if non_linear_rate != 0.0:
-            raise NotImplementedError("GTDampedOscillator: the time-varying frequency branch is not built "
-                                      "(the reference's callers use non_linear_rate = 0)")
-        sig = self._render(self.freq_linear(), self.alpha(), self.beta(), self.amp())
-        fd = self.damped_freq[0, :, 0].double()
-        d = self.damping().reshape(-1).double().to(fd.device)
-        self.undamped_freq = (torch.sqrt((2 * np.pi * fd) ** 2 + d ** 2) / (2 * np.pi)).float().reshape(1, -1, 1)
+            sig = self._render_time_varying(non_linear_rate)
+        else:
+            sig = self._render(self.freq_linear(), self.alpha(), self.beta(), self.amp())
+            fd = self.damped_freq[0, :, 0].double()
+            d = self.damping().reshape(-1).double().to(fd.device)
+            self.undamped_freq = (torch.sqrt((2 * np.pi * fd) ** 2 + d ** 2) / (2 * np.pi)).float().reshape(1, -1, 1)
         if noise_rate != 0.0:
             sig = sig + self.noise() * noise_rate
         return sig
+
+    def _render_time_varying(self, rate):
+        """reference :219-242 with the (A, m, S) cumsum / exp / sin / mode-sum / conv1d chain as one kernel pair."""
+        dev = _device_of(self._force)
+        if self._force.device != dev:
+            self._force = self._force.to(dev)
+        undamped = (self.freq_linear() + rate * self.freq_nonlinear()).to(dev)  # (A, m, S)
+        lbd = (undamped * 2 * np.pi) ** 2
+        damp = 0.5 * (self.alpha().to(dev) + self.beta().to(dev) * lbd)
+        freq = (lbd - damp ** 2) ** 0.5 / (2 * np.pi)
+        self.undamped_freq = ((2 * np.pi * freq) ** 2 + damp ** 2) ** 0.5 / (2 * np.pi)
+        amp = self.amp().reshape(self.audio_num, self.mode_num).to(dev)
+        return oscillator_bank_tv(damp, freq, amp, self._force, self.sample_num, self.sr)

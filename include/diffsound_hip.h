@@ -40,7 +40,7 @@ enum { DS_OK = 0, DS_ERR_ARG = 1, DS_ERR_HIP = 2, DS_ERR_NOMEM = 3 };
 /* Thread-local text of the last error returned on this thread ("" if none). */
 const char* ds_last_error(void);
 /* Library ABI version (bumped on any signature change); ds_abi_version() returns the value the library was built with. */
-#define DS_ABI_VERSION 13
+#define DS_ABI_VERSION 14
 int ds_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------------
@@ -260,6 +260,19 @@ int ds_osc_bank_fwd(const double* d, const double* w, const float* amp, const fl
 int ds_osc_bank_bwd(const float* gy, const double* d, const double* w, const float* amp,
                     const float* force, int A, int m, int F, int S, double sr, float* gs,
                     double* gd, double* gw, float* gamp, ds_stream_t stream);
+
+/* Time-varying bank (reference GTDampedOscillator.forward with non_linear_rate != 0, oscillator.py:217-243):
+ *   s[a,t] = sum_m amp[a,m] exp(-D[a,m,t]) sin(2 pi P[a,m,t]),  D = cumsum_t(dmp / sr),  P = cumsum_t(frq / sr)
+ *   y = causal FIR of s with force, as above.
+ * dmp, frq: (A x m x S) f32 per-sample damping rate [1/s] and damped frequency [Hz]; running sums in fp64.
+ * work: scratch of ds_osc_tv_workspace_floats(A, m, S) floats.  Backward: g_dmp, g_frq (A x m x S) f32, gamp (A x m)
+ * f32 or NULL; gs scratch (A x S) f32.  Deterministic. */
+int64_t ds_osc_tv_workspace_floats(int A, int m, int S);
+int ds_osc_tv_fwd(const float* dmp, const float* frq, const float* amp, const float* force, int A, int m, int F,
+                  int S, double sr, float* work, float* y, ds_stream_t stream);
+int ds_osc_tv_bwd(const float* gy, const float* dmp, const float* frq, const float* amp, const float* force, int A,
+                  int m, int F, int S, double sr, float* gs, float* g_dmp, float* g_frq, float* gamp,
+                  ds_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Multi-scale spectral loss head (reference src/ddsp/mss_loss.py:50-62, 70-122: SSSLoss types 'l1_loss' and

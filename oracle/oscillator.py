@@ -68,3 +68,42 @@ def bank_closed_form_f64(freq, forces, sample_num, sr, alpha, beta, amp=None):
     for a in range(A):
         out[a] = np.convolve(s[a], forces[a])[:sample_num]
     return out
+
+
+def bank_time_varying(freq_linear, freq_nonlinear, rate, alpha, beta, amp, forces, sample_num, sr):
+    """GTDampedOscillator.forward with a per-sample frequency offset (oscillator.py:217-243), the reference's own
+    chain of torch ops: undamped = f_lin + rate f_nl (A, m, S); damp = (alpha + beta (2 pi f)^2) / 2;
+    freq = sqrt((2 pi f)^2 - damp^2) / 2 pi; cumsums over time; amp exp(-D) sin(2 pi P); mode sum; grouped conv1d.
+    Returns (signal (A, S), undamped_freq read-out (A, m, S))."""
+    A = forces.shape[0]
+    undamped = freq_linear + rate * freq_nonlinear
+    lbd = (undamped * 2 * np.pi) ** 2
+    damp = 0.5 * (alpha + beta * lbd)
+    freq = (lbd - damp ** 2) ** 0.5 / (2 * np.pi)
+    und = ((2 * np.pi * freq) ** 2 + damp ** 2) ** 0.5 / (2 * np.pi)
+    D = torch.cumsum(damp / sr, dim=2)
+    P = torch.cumsum(freq / sr, dim=2)
+    signal = (amp * torch.exp(-D) * torch.sin(2 * np.pi * P)).sum(1).unsqueeze(0)
+    w = torch.flip(forces.reshape(A, 1, -1), [-1]).to(signal.dtype)
+    signal = F.conv1d(signal, w, groups=A, padding=forces.shape[-1] - 1).squeeze(0)
+    return signal[:, :sample_num], und
+
+
+def filtered_noise(coefficient_bank, noise, sample_num, frame_length=64, attenuate_gain=1.0):
+    """FilteredNoise.forward (src/ddsp/filtered_noise.py:20-67) in NumPy with the white noise GIVEN:
+    coefficient_bank (B, frames, L) logits, noise (B, frames, frame_length) in [-1, 1)."""
+    x = 2 * (1 / (1 + np.exp(-np.asarray(coefficient_bank, dtype=np.float64)))) ** 2.3 + 1e-6  # modifed_sigmoid, utils.py:6-9
+    B, nf, L = x.shape
+    taps = 2 * L - 1
+    ir = np.fft.irfft(x, n=taps, axis=-1)                       # zero-phase impulse responses (:32-35)
+    ir = np.roll(ir, L - 1, axis=-1)                            # causal linear phase (:39-40)
+    k = np.arange(taps)
+    ir = ir * (0.5 - 0.5 * np.cos(2 * np.pi * k / taps))        # torch.hann_window default: periodic (:24-25, 41-42)
+    nfft = taps + frame_length - 1
+    H = np.fft.rfft(ir, n=nfft, axis=-1)                        # zero-padded by frame_length - 1 (:43-46)
+    N = np.fft.rfft(np.asarray(noise, dtype=np.float64), n=nfft, axis=-1)  # zero-padded by 2 L - 2 (:51-53)
+    frames = np.fft.irfft(N * H, n=nfft, axis=-1) * attenuate_gain  # (:56-58)
+    out = np.zeros((B, (nf - 1) * frame_length + nfft))
+    for i in range(nf):                                         # overlap-add, stride frame_length (:61-65)
+        out[:, i * frame_length:i * frame_length + nfft] += frames[:, i]
+    return out[:, :sample_num]

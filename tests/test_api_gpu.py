@@ -307,8 +307,35 @@ def test_gt_oscillator_and_forward_curve(dev):
     assert rel(osc.undamped_freq.detach().reshape(-1).cpu().numpy(), f.reshape(-1).numpy()) < 1e-5
     noisy = osc(noise_rate=1e-3)
     assert noisy.shape == (A, S) and float((noisy - osc()).detach().abs().max()) > 0
-    with pytest.raises(NotImplementedError):
-        osc(non_linear_rate=0.1)
+    # time-varying branch (reference :219-242): per-sample frequency offsets, the (A, m, S) chain as one kernel pair
+    osc.zero_grad()
+    tv = osc(non_linear_rate=0.05)
+    with torch.no_grad():
+        ref_tv, und = oosc.bank_time_varying(osc.freq_linear().cpu().double(), osc.freq_nonlinear().cpu().double(), 0.05,
+                                             osc.alpha().cpu().double(), osc.beta().cpu().double(),
+                                             osc.amp().cpu().double(), forces.cpu().double(), S, sr)
+    assert tv.shape == (A, S) and float((tv.detach().cpu().double() - ref_tv).norm() / ref_tv.norm()) < 1e-4
+    assert osc.undamped_freq.shape == (A, m, S)
+    assert rel(osc.undamped_freq.detach().cpu().numpy(), und.numpy()) < 1e-5
+    gy = torch.randn((A, S), generator=torch.Generator().manual_seed(5)).to(dev)
+    (tv * gy).sum().backward()
+    got = {k: getattr(osc, k).params.grad.detach().cpu().double().clone() for k in ("freq_linear", "freq_nonlinear", "alpha", "beta")}
+    got["amp"] = osc.amp.value.grad.detach().cpu().double().clone()
+    # the same gradient through torch autograd on the oracle chain (fp64, CPU)
+    import copy
+    ref_osc = copy.deepcopy(osc).cpu().double()
+    ref_osc.zero_grad()
+    sig64, _ = oosc.bank_time_varying(ref_osc.freq_linear(), ref_osc.freq_nonlinear(), 0.05, ref_osc.alpha(),
+                                      ref_osc.beta(), ref_osc.amp(), forces.cpu().double(), S, sr)
+    (sig64 * gy.cpu().double()).sum().backward()
+    want = {k: getattr(ref_osc, k).params.grad for k in ("freq_linear", "freq_nonlinear", "alpha", "beta")}
+    want["amp"] = ref_osc.amp.value.grad
+    for k in want:
+        assert float((got[k] - want[k]).norm() / want[k].norm()) < 2e-3, k
+    assert torch.equal(osc(non_linear_rate=0.05), osc(non_linear_rate=0.05))  # deterministic
+    # checkpoints: the parameter set of the reference classes (oscillator.py:186-204, 67-78)
+    assert sorted(osc.state_dict()) == ["alpha.params", "amp.value", "beta.params", "freq_linear.params",
+                                        "freq_nonlinear.params", "noise.coefficient_bank"]
     # forward_curve: damping from a host callback per mode, peak-normalised
     dosc = DampedOscillator(forces, A, m, S, sr, f_range, Material(mat)).cuda()
     curve = lambda fr: 3.0 + 2e-7 * (2 * np.pi * fr) ** 2
@@ -319,6 +346,43 @@ def test_gt_oscillator_and_forward_curve(dev):
     refc = refc / np.abs(refc).max(axis=1, keepdims=True)
     assert np.linalg.norm(out.cpu().numpy() - refc) / np.linalg.norm(refc) < 1e-3
     assert float(out.abs().max()) == pytest.approx(1.0, abs=1e-6)
+    assert sorted(dosc.state_dict()) == ["alpha.params", "amp.value", "beta.params", "noise.coefficient_bank"]
+    # early(): the same render without the normalisation (reference :85-109)
+    raw = dosc.early(fl, curve)
+    assert torch.allclose(raw / raw.abs().max(dim=1, keepdim=True)[0], out, atol=1e-6)
+    # the damping curve of the real-audio experiment is an interp1d table (material_real_train.py:151): it is
+    # interpolated on the device, same numbers as the per-mode host callback of the reference
+    from scipy import interpolate
+
+    xs = np.array([270.0, 770.0, 1270.0, 5020.0, 9020.0])
+    ys = np.array([3.0, 5.5, 4.0, 40.0, 90.0])
+    table = interpolate.interp1d(xs, ys, fill_value="extrapolate")
+    out_t = dosc.forward_curve(fl, table)
+    out_c = dosc.forward_curve(fl, lambda fr: float(table(fr)))
+    assert torch.allclose(out_t, out_c, atol=2e-6)
+    fl_g = fl.clone().requires_grad_(True)
+    dosc.forward_curve(fl_g, table).pow(2).mean().backward()  # gradient reaches the frequencies (curve on detached f)
+    assert torch.isfinite(fl_g.grad).all() and float(fl_g.grad.abs().max()) > 0
+
+
+def test_filtered_noise_matches_oracle(dev):
+    """FilteredNoise (reference src/ddsp/filtered_noise.py:7-67) with the white noise injected, against the NumPy
+    restatement of the reference's steps."""
+    from oracle import oscillator as oosc
+    from src.ddsp.oscillator import FilteredNoise
+
+    torch.manual_seed(11)
+    fnz = FilteredNoise(3, 8000).to(dev)
+    nf = 8000 // 64 + 1
+    assert fnz.coefficient_bank.shape == (3, nf, 65)
+    noise = torch.rand((3, nf, 64), generator=torch.Generator().manual_seed(2)) * 2 - 1
+    out = fnz(noise.to(dev))
+    ref = oosc.filtered_noise(fnz.coefficient_bank.detach().cpu().numpy(), noise.numpy(), 8000)
+    assert out.shape == (3, 8000)
+    assert np.linalg.norm(out.detach().cpu().numpy() - ref) / np.linalg.norm(ref) < 1e-5
+    assert fnz().shape == (3, 8000) and float((fnz() - fnz()).abs().max()) > 0  # fresh noise per call
+    out.pow(2).mean().backward()
+    assert torch.isfinite(fnz.coefficient_bank.grad).all()
 
 
 def test_lobpcg_callable_A_iK_and_standard_problem(golden, dev):
