@@ -322,14 +322,14 @@ def test_gt_oscillator_and_forward_curve(dev):
     got = {k: getattr(osc, k).params.grad.detach().cpu().double().clone() for k in ("freq_linear", "freq_nonlinear", "alpha", "beta")}
     got["amp"] = osc.amp.value.grad.detach().cpu().double().clone()
     # the same gradient through torch autograd on the oracle chain (fp64, CPU)
-    import copy
-    ref_osc = copy.deepcopy(osc).cpu().double()
-    ref_osc.zero_grad()
-    sig64, _ = oosc.bank_time_varying(ref_osc.freq_linear(), ref_osc.freq_nonlinear(), 0.05, ref_osc.alpha(),
-                                      ref_osc.beta(), ref_osc.amp(), forces.cpu().double(), S, sr)
+    names = ("freq_linear", "freq_nonlinear", "alpha", "beta")
+    leaf = {k: getattr(osc, k).params.detach().cpu().double().requires_grad_(True) for k in names}
+    leaf["amp"] = osc.amp.value.detach().cpu().double().requires_grad_(True)
+    ws = {k: oosc.weighted_sum(getattr(osc, k).values_list.cpu().double(), leaf[k]) for k in names}
+    sig64, _ = oosc.bank_time_varying(ws["freq_linear"], ws["freq_nonlinear"], 0.05, ws["alpha"], ws["beta"],
+                                      oosc.modified_sigmoid(leaf["amp"]), forces.cpu().double(), S, sr)
     (sig64 * gy.cpu().double()).sum().backward()
-    want = {k: getattr(ref_osc, k).params.grad for k in ("freq_linear", "freq_nonlinear", "alpha", "beta")}
-    want["amp"] = ref_osc.amp.value.grad
+    want = {k: v.grad for k, v in leaf.items()}
     for k in want:
         assert float((got[k] - want[k]).norm() / want[k].norm()) < 2e-3, k
     assert torch.equal(osc(non_linear_rate=0.05), osc(non_linear_rate=0.05))  # deterministic
