@@ -409,7 +409,9 @@ def main():
                                 + (f" after a nested start (mean {np.mean(cits):.1f} corner-node level iterations to "
                                    f"{a.nested_tol:g})" if a.nested_tol > 0 else "")
                                 + f", backward-error tolerance {tol:g}"),
-                "symbolic_pattern_seconds_not_timed": t_sym,
+                "symbolic_seconds_not_timed": t_sym,
+                "symbolic_phase": ("pattern + contribution lists + neighbour-union tables on the device (ds_dpattern_build), "
+                                   "plus the corner-node level, operators and first assembly; once per topology"),
                 "convergence_gate": (f"every timed pass converged: backward error of all {a.modes} pairs < {tol:.1g} "
                                      f"(worst {worst[0]:.3g}), iterations < {cfg.maxit}, finite loss and gradients"),
             },

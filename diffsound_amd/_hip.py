@@ -12,7 +12,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libdiffsound_hip.so")
-ABI_VERSION = 14  # DS_ABI_VERSION of include/diffsound_hip.h
+ABI_VERSION = 15  # DS_ABI_VERSION of include/diffsound_hip.h
 
 c_i32p = ctypes.POINTER(ctypes.c_int32)
 _P = ctypes.c_void_p
@@ -28,6 +28,11 @@ _SIGNATURES = {
     "ds_pattern_sizes": (_I, [_P, ctypes.POINTER(_I64), ctypes.POINTER(_I64), ctypes.POINTER(_I64)]),
     "ds_pattern_export": (_I, [_P, _P, _P, _P, _P, _P]),
     "ds_pattern_free": (None, [_P]),
+    "ds_dpattern_build": (_I, [_P, _I64, _I, _I64, _I, _P, ctypes.POINTER(_P)]),
+    "ds_dpattern_sizes": (_I, [_P, ctypes.POINTER(_I64), ctypes.POINTER(_I64), ctypes.POINTER(_I64), ctypes.POINTER(_I64),
+                               ctypes.POINTER(_I)]),
+    "ds_dpattern_export": (_I, [_P] * 12),
+    "ds_dpattern_free": (None, [_P]),
     "ds_assemble_kml": (_I, [_P, _P, _I64, _I, _I64, _P, _P, _I64, _P, _P, _P, _P, _P, _P, _P]),
     "ds_combine_material": (_I, [_P, _P, _P, _I64, _P, _I64, _D, _D, _P, _P, _P, _P, _P]),
     "ds_spmm_bsr3": (_I, [_I, _P, _P, _P, _P, _I64, _P, _I64, _P, _I64, _I, _P]),
@@ -154,6 +159,38 @@ class Pattern:
                                           ptr(self.cptr), ptr(self.clist)), "ds_pattern_export")
         finally:
             lib().ds_pattern_free(handle)
+
+
+class DevicePattern:
+    """Symbolic phase on the device (ds_dpattern_build): every table as an int32 tensor on ``tets``' device.
+    ``ctab`` / ``utab`` are None when a group exceeds ``cap`` (the caller then cuts the chunks with ``union_chunks``)."""
+
+    def __init__(self, tets_i32, nv, cap):
+        t = tets_i32
+        if not t.is_cuda or t.dtype != torch.int32 or not t.is_contiguous() or t.dim() != 2:
+            raise ValueError("DevicePattern: tets must be a contiguous (T, N) int32 HIP tensor")
+        handle = ctypes.c_void_p()
+        check(lib().ds_dpattern_build(ptr(t), t.shape[0], t.shape[1], nv, cap, stream_ptr(), ctypes.byref(handle)),
+              "ds_dpattern_build")
+        try:
+            a, b, c, d, s = _I64(), _I64(), _I64(), _I64(), _I()
+            check(lib().ds_dpattern_sizes(handle, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c), ctypes.byref(d),
+                                          ctypes.byref(s)), "ds_dpattern_sizes")
+            self.nv, self.nnzb, self.ncontrib, self.ne, self.ngroups = nv, a.value, b.value, c.value, d.value
+            self.single = bool(s.value)
+            mk = lambda n: torch.empty(n, dtype=torch.int32, device=t.device)
+            self.rowptr, self.colidx, self.diagidx = mk(nv + 1), mk(self.nnzb), mk(nv)
+            self.cptr, self.clist = mk(self.nnzb + 1), mk(self.ncontrib)
+            self.gptr, self.gent, self.goff, self.kperm = mk(self.ngroups + 1), mk(self.ne), mk(self.ne + 1), mk(self.nnzb)
+            self.ctab = torch.empty((self.ngroups, 4), dtype=torch.int32, device=t.device)
+            check(lib().ds_dpattern_export(handle, ptr(self.rowptr), ptr(self.colidx), ptr(self.diagidx), ptr(self.cptr),
+                                           ptr(self.clist), ptr(self.gptr), ptr(self.gent), ptr(self.goff),
+                                           ptr(self.kperm), ptr(self.ctab), stream_ptr()), "ds_dpattern_export")
+            torch.cuda.current_stream(t.device).synchronize()  # the handle's arrays are freed below
+        finally:
+            lib().ds_dpattern_free(handle)
+        if not self.single:
+            self.ctab = None
 
 
 class Groups:

@@ -69,33 +69,34 @@ class TetSystem:
         self.n = 3 * self.nv
         self.T = self.tets.shape[0]
         self.density = float(density)
-        pat = _hip.Pattern(self.tets.cpu(), self.nv)
-        self.nnzb = pat.nnzb
+        # symbolic phase on the device (ds_dpattern_build): pattern, per-slot contribution lists (the numeric phase
+        # then needs neither COO, sort nor atomics) and the tables of the neighbour-union SpMM (ds_spmm_union, the
+        # kernel of every product on blocks of <= 84 columns): one wavefront per 4 consecutive nodes walks the union
+        # of their neighbours (with the Morton numbering 0.58 x as many panel loads as one wavefront per node).  Every
+        # group is cut into chunks of whole entries that fit the kernel's LDS images (cap entries / blocks; almost
+        # always ONE chunk): ctab rows (e0, e1, b0, b1), utab rows (first chunk, end chunk) per group.
         dev = self.device
-        self.rowptr = pat.rowptr.to(dev)
-        self.colidx = pat.colidx.to(dev)
-        self.diagidx = pat.diagidx.to(dev)
-        self.cptr = pat.cptr.to(dev)
-        self.clist = pat.clist.to(dev)
+        pat = _hip.DevicePattern(self.tets, self.nv, UNION_CAP)
+        self.nnzb = pat.nnzb
+        self.rowptr, self.colidx, self.diagidx, self.cptr, self.clist = pat.rowptr, pat.colidx, pat.diagidx, pat.cptr, pat.clist
         self.dtab = torch.from_numpy(fem_tables.stiffness_table(self.order)).to(dev)
         self.mtab = torch.from_numpy(fem_tables.mass_table(self.order, self.density)).to(dev)
         self.klam = torch.empty((self.nnzb, 9), dtype=torch.float64, device=dev)
         self.kmu = torch.empty((self.nnzb, 9), dtype=torch.float64, device=dev)
         self.ms = torch.empty((self.nnzb,), dtype=torch.float64, device=dev)
         self._tetgeo = torch.empty((self.T, 13), dtype=torch.float64, device=dev)
-        # Node groups of the neighbour-union SpMM (ds_spmm_union, the kernel of every product on blocks of <= 84
-        # columns): one wavefront per 4 consecutive nodes walks the union of their neighbours (with the Morton
-        # numbering 0.58 x as many panel loads as one wavefront per node).  Every group is cut into chunks of whole
-        # entries that fit the kernel's LDS images (cap entries / blocks; almost always ONE chunk): ctab rows
-        # (e0, e1, b0, b1), utab rows (first chunk, end chunk) per group.
         self.groups = None
         if self.nv >= 8:
-            gr = _hip.Groups(pat.rowptr, pat.colidx, self.nv)
-            ut, ct = _hip.union_chunks(gr.gptr, gr.goff, UNION_CAP)
+            if pat.single:
+                ng = pat.ngroups
+                utab = torch.arange(ng + 1, dtype=torch.int32, device=dev)
+                ut, ct = torch.stack([utab[:-1], utab[1:]], 1).contiguous(), pat.ctab
+            else:  # a group that exceeds the LDS image: cut its chunks with the host rule (rare)
+                ut, ct = _hip.union_chunks(pat.gptr.cpu(), pat.goff.cpu(), UNION_CAP)
+                ut, ct = (None, None) if ct is None else (ut.to(dev), ct.to(dev))
             if ct is not None:
-                kperm = gr.kperm.to(dev)
-                self.groups = dict(ne=gr.ne, gent=gr.gent.to(dev), kperm=kperm, kperm64=kperm.long(),
-                                   union=dict(utab=ut.to(dev), ctab=ct.to(dev), capb=UNION_CAP, ngroups=ut.shape[0],
+                self.groups = dict(ne=pat.ne, gent=pat.gent, kperm=pat.kperm, kperm64=pat.kperm.long(),
+                                   union=dict(utab=ut, ctab=ct, capb=UNION_CAP, ngroups=ut.shape[0],
                                               single=bool(ct.shape[0] == ut.shape[0])))  # every group one chunk
         self._coarse = None
         self.assemble()

@@ -537,3 +537,43 @@ def test_union_spmm_operands_beyond_2gb(dev):
     one(lambda o: (o.copy_(Wpb), ops.cheb_spmm(Xb, o, R0b, 0.31, 0.77, False)),
         lambda o: (o.copy_(Wps), ops.cheb_spmm(Xs, o, R0s, 0.31, 0.77, False)))
     assert all(torch.isfinite(r).all() for r in ref + got)
+
+
+@pytest.mark.parametrize("mesh,order", [("2", 1), ("3", 2), ("bowl", 1), ("bowl", 2), ("6", 2), ("3+unused", 1)])
+def test_device_symbolic_phase_matches_host(dev, mesh, order):
+    """ds_dpattern_build (pattern, contribution lists, neighbour-union tables, chunk table - rocPRIM sorts + small
+    kernels on the device) against the host routines ds_pattern_build / ds_groups_build / union_chunks: every array
+    identical; and against the reference-generated goldens through test_pattern_and_assembly (nnz of the bowl)."""
+    from diffsound_amd import _hip, meshgen
+    from diffsound_amd.diffelastic.mesh import TetMesh
+    from diffsound_amd.modal_ops import UNION_CAP
+
+    if mesh == "bowl":
+        m = np.load("tests/golden/g0_bowl_mesh.npz")
+        v, t = m["verts"], m["tets"]
+    elif mesh == "3+unused":
+        v, t = meshgen.kuhn_box(3)
+        v = np.concatenate([v, np.array([[9.0, 9.0, 9.0 + 0.01 * i] for i in range(9)], dtype=v.dtype)], 0)
+    else:
+        v, t = meshgen.kuhn_box(int(mesh))
+    tm = TetMesh(torch.from_numpy(v).to(dev), torch.from_numpy(t).long().to(dev)).to_high_order(order)
+    nv = tm.vertices.shape[0]
+    tets = tm.tets.to(torch.int32).contiguous()
+    d = _hip.DevicePattern(tets, nv, UNION_CAP)
+    h = _hip.Pattern(tets.cpu(), nv)
+    assert (d.nnzb, d.ncontrib) == (h.nnzb, h.ncontrib)
+    for name in ("rowptr", "colidx", "diagidx", "cptr", "clist"):
+        assert torch.equal(getattr(d, name).cpu(), getattr(h, name)), name
+    g = _hip.Groups(h.rowptr, h.colidx, nv)
+    assert (d.ngroups, d.ne) == (g.ngroups, g.ne)
+    for name in ("gptr", "gent", "goff", "kperm"):
+        assert torch.equal(getattr(d, name).cpu(), getattr(g, name)), name
+    ut, ct = _hip.union_chunks(g.gptr, g.goff, UNION_CAP)
+    assert d.single == (ct.shape[0] == ut.shape[0])
+    if d.single:
+        assert torch.equal(d.ctab.cpu(), ct)
+    if mesh == "bowl":  # the reference's coalesced K has exactly these many scalar non-zeros (SURVEY.md 8)
+        assert d.nnzb * 9 == {1: 294381, 2: 3674016}[order]
+    # a group larger than the cap is reported, not mis-tabulated
+    small = _hip.DevicePattern(tets, nv, 8)
+    assert (not small.single) and small.ctab is None
