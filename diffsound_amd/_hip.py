@@ -12,7 +12,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libdiffsound_hip.so")
-ABI_VERSION = 15  # DS_ABI_VERSION of include/diffsound_hip.h
+ABI_VERSION = 16  # DS_ABI_VERSION of include/diffsound_hip.h
 
 c_i32p = ctypes.POINTER(ctypes.c_int32)
 _P = ctypes.c_void_p
@@ -79,7 +79,55 @@ class TwoLevelDesc(ctypes.Structure):
                 ("ldc", _I64), ("ncols", ctypes.c_int32), ("Wc", _P), ("ldwc", _I64)]
 
 
+class LapackTable(ctypes.Structure):
+    """ds_lapack_t: Fortran-convention dsyevd / dgemm entry points."""
+    _fields_ = [("dsyevd", _P), ("dgemm", _P)]
+
+
+class LobpcgDesc(ctypes.Structure):
+    """ds_lobpcg_t of include/diffsound_hip.h."""
+    _i32 = ctypes.c_int32
+    _fields_ = [("n", _I64), ("nv", _I64), ("b", _i32), ("k", _i32), ("ny", _i32), ("maxit", _i32), ("lock", _i32),
+                ("ortho_passes", _i32), ("rr_refresh", _i32), ("gram_exact", _i32), ("tol", _D), ("ortho_tol", _D),
+                ("A_norm", _D), ("B_norm", _D), ("S", _P), ("S2", _P), ("KS", _P), ("KS2", _P), ("R", _P), ("MX", _P),
+                ("MW", _P), ("lds", _I64), ("ldks", _I64), ("ldr", _I64), ("level", LevelDesc), ("mgrp", _P),
+                ("rowptr", _P), ("colidx", _P), ("k32", _P), ("k32t", _P), ("twolevel", ctypes.POINTER(TwoLevelDesc)),
+                ("pa", _P), ("pb", _P), ("ldp", _I64), ("gbuf", _P), ("cbuf", _P), ("nrm", _P), ("lam_dev", _P),
+                ("gram_work", _P), ("gram_work_bytes", _I64), ("lam", ctypes.POINTER(_D)), ("rerr", ctypes.POINTER(_D)),
+                ("history", ctypes.POINTER(_D)), ("history_cap", _i32), ("iterations", _i32), ("result_in_s2", _i32)]
+
+
+_lapack = None
+
+
+def lapack_table():
+    """ds_lapack_t filled with SciPy's LAPACK / BLAS entry points (scipy.linalg.cython_lapack / cython_blas export them
+    as PyCapsules).  The <= 3b x 3b problems are fastest on one thread and are solved by several lanes at once, so the
+    BLAS behind them is limited to one thread (threadpoolctl) the first time the table is built."""
+    global _lapack
+    if _lapack is None:
+        import scipy.linalg.cython_blas as cb
+        import scipy.linalg.cython_lapack as cl
+
+        get = ctypes.pythonapi.PyCapsule_GetPointer
+        name = ctypes.pythonapi.PyCapsule_GetName
+        get.restype, get.argtypes = ctypes.c_void_p, [ctypes.py_object, ctypes.c_char_p]
+        name.restype, name.argtypes = ctypes.c_char_p, [ctypes.py_object]
+        addr = lambda cap: get(cap, name(cap))
+        t = LapackTable(addr(cl.__pyx_capi__["dsyevd"]), addr(cb.__pyx_capi__["dgemm"]))
+        try:
+            from threadpoolctl import threadpool_limits
+
+            t._limits = threadpool_limits(limits=1, user_api="blas")
+        except Exception:  # threadpoolctl missing: the BLAS keeps its own thread count
+            t._limits = None
+        _lapack = t
+    return _lapack
+
+
 _SIGNATURES["ds_twolevel_apply"] = (_I, [ctypes.POINTER(TwoLevelDesc), _P])
+_SIGNATURES["ds_chebyshev_apply"] = (_I, [ctypes.POINTER(LevelDesc), _P, _I64, _P, _I64, _P, _P, _I64, _I, _P])
+_SIGNATURES["ds_lobpcg_iterate"] = (_I, [ctypes.POINTER(LobpcgDesc), ctypes.POINTER(LapackTable), _P])
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 _lib = None
 

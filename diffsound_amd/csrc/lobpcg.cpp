@@ -1,0 +1,499 @@
+// Native driver of the block eigensolver's iteration - the loop of ModalSolver.solve (lobpcg/modal_solver.py) as ONE
+// call per eigensolve: residual test, hard locking, preconditioner (ds_twolevel_apply or the one-level Chebyshev
+// polynomial), single-sweep projected Cholesky-QR, Rayleigh-Ritz by recurrence, the [X' P'] = [X P W] [Z1 Zp] updates.
+// It issues the same kernels (ds_spmm_union, ds_gram, ds_mix, ds_residual, ...) on the caller's stream and does the
+// <= 3b x 3b dense steps on the calling host thread (LAPACK dsyevd / BLAS dgemm supplied by the embedding application
+// through ds_lapack_t - the Python binding passes SciPy's), so a hypothesis lane spends its whole solve outside the
+// interpreter: no interpreter lock between its launches, none between the lanes.
+//
+// Reference: the iteration of src/lobpcg/_lobpcg.py:344-376, 433-477 (LOBPCG.run / _update_ortho), whose per-iteration
+// host synchronisations (float(torch.norm(..)) :655,663; the Python loop over a device tensor :323-328) are the two
+// small device-to-host copies of this loop (residual norms, Gram blocks).  Semantics are those of the Python loop it
+// replaces, statement for statement; tests/test_modal_gpu.py runs both and compares.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <vector>
+
+#include "ds_common.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------------------------
+// small dense algebra, row-major double
+struct Mat {
+    int r = 0, c = 0;
+    std::vector<double> a;
+    Mat() = default;
+    Mat(int r_, int c_) : r(r_), c(c_), a((size_t)r_ * c_, 0.0) {}
+    double& operator()(int i, int j) { return a[(size_t)i * c + j]; }
+    double operator()(int i, int j) const { return a[(size_t)i * c + j]; }
+};
+
+void symmetrize(Mat& G) {
+    for (int i = 0; i < G.r; ++i)
+        for (int j = i + 1; j < G.c; ++j) {
+            const double v = 0.5 * (G(i, j) + G(j, i));
+            G(i, j) = G(j, i) = v;
+        }
+}
+
+bool all_finite(const Mat& G) {
+    for (double v : G.a)
+        if (!std::isfinite(v)) return false;
+    return true;
+}
+
+// C = op(A) op(B), row-major, through column-major dgemm: C^T = op(B)^T op(A)^T
+Mat gemm(const ds_lapack_t& la, const Mat& A, bool ta, const Mat& B, bool tb) {
+    const int m = ta ? A.c : A.r, k = ta ? A.r : A.c, n = tb ? B.r : B.c;
+    Mat C(m, n);
+    if (m == 0 || n == 0 || k == 0) return C;
+    char opb = tb ? 'T' : 'N', opa = ta ? 'T' : 'N';
+    int mm = n, nn = m, kk = k, ldb = B.c, lda = A.c, ldc = n;
+    double one = 1.0, zero = 0.0;
+    la.dgemm(&opb, &opa, &mm, &nn, &kk, &one, const_cast<double*>(B.a.data()), &ldb, const_cast<double*>(A.a.data()), &lda,
+             &zero, C.a.data(), &ldc);
+    return C;
+}
+
+// lower Cholesky factor of a symmetric matrix (row-major L, L L^T = A); false on breakdown
+bool cholesky(const Mat& A, Mat& L) {
+    const int n = A.r;
+    L = Mat(n, n);
+    for (int j = 0; j < n; ++j) {
+        double d = A(j, j);
+        for (int k = 0; k < j; ++k) d -= L(j, k) * L(j, k);
+        if (!(d > 0.0) || !std::isfinite(d)) return false;
+        const double ljj = std::sqrt(d);
+        L(j, j) = ljj;
+        for (int i = j + 1; i < n; ++i) {
+            double s = A(i, j);
+            for (int k = 0; k < j; ++k) s -= L(i, k) * L(j, k);
+            L(i, j) = s / ljj;
+        }
+    }
+    return all_finite(L);
+}
+
+Mat lower_inverse(const Mat& L) {
+    const int n = L.r;
+    Mat X(n, n);
+    for (int j = 0; j < n; ++j) {
+        X(j, j) = 1.0 / L(j, j);
+        for (int i = j + 1; i < n; ++i) {
+            double s = 0.0;
+            for (int k = j; k < i; ++k) s -= L(i, k) * X(k, j);
+            X(i, j) = s / L(i, i);
+        }
+    }
+    return X;
+}
+
+// eigenvalues ascending, Z columns = eigenvectors (row-major Z); returns false when LAPACK reports failure
+bool eigh(const ds_lapack_t& la, const Mat& Gsym, std::vector<double>& w, Mat& Z) {
+    const int n = Gsym.r;
+    std::vector<double> A = Gsym.a;  // symmetric: row-major == column-major
+    w.assign(n, 0.0);
+    char jobz = 'V', uplo = 'L';
+    int nn = n, lda = n, info = 0, lwork = -1, liwork = -1, iq = 0;
+    double wq = 0.0;
+    la.dsyevd(&jobz, &uplo, &nn, A.data(), &lda, w.data(), &wq, &lwork, &iq, &liwork, &info);
+    if (info != 0) return false;
+    lwork = (int)wq;
+    liwork = iq;
+    std::vector<double> work((size_t)std::max(1, lwork));
+    std::vector<int> iwork((size_t)std::max(1, liwork));
+    la.dsyevd(&jobz, &uplo, &nn, A.data(), &lda, w.data(), work.data(), &lwork, iwork.data(), &liwork, &info);
+    if (info != 0) return false;
+    Z = Mat(n, n);  // column-major eigenvector j = A[j * n + i]  ->  Z(i, j)
+    for (int j = 0; j < n; ++j)
+        for (int i = 0; i < n; ++i) Z(i, j) = A[(size_t)j * n + i];
+    return true;
+}
+
+// T with (W T)^T M (W T) = I given G = W^T M W, clamped-eigenvalue form (ModalSolver._svqb_transform)
+bool svqb_transform(const ds_lapack_t& la, const Mat& G, Mat& T) {
+    const int n = G.r;
+    std::vector<double> d(n);
+    for (int i = 0; i < n; ++i) d[i] = 1.0 / std::sqrt(std::max(G(i, i), 1e-300));
+    Mat Gs = G;
+    symmetrize(Gs);
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) Gs(i, j) *= d[i] * d[j];
+    std::vector<double> E;
+    Mat Z;
+    if (!eigh(la, Gs, E, Z)) return false;
+    double emax = 0.0;
+    for (double e : E) emax = std::max(emax, std::fabs(e));
+    T = Mat(n, n);
+    for (int j = 0; j < n; ++j) {
+        const double e = std::max(E[j], 1e-12 * emax);
+        const double s = 1.0 / std::sqrt(e);
+        for (int i = 0; i < n; ++i) T(i, j) = d[i] * Z(i, j) * s;
+    }
+    return true;
+}
+
+// (T, amp) of ModalSolver._orthonormalizer_q; rem: optional squared M-norms removed by the preceding projection
+bool orthonormalizer_q(const ds_lapack_t& la, const Mat& Gin, const std::vector<double>* rem, Mat& T, double& amp) {
+    Mat G = Gin;
+    symmetrize(G);
+    const int n = G.r;
+    std::vector<double> diag(n), d(n);
+    for (int i = 0; i < n; ++i) {
+        diag[i] = std::max(G(i, i), 1e-300);
+        d[i] = 1.0 / std::sqrt(diag[i]);
+    }
+    Mat Gs = G;
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) Gs(i, j) *= d[i] * d[j];
+    Mat L;
+    if (!cholesky(Gs, L)) {
+        amp = std::numeric_limits<double>::infinity();
+        return svqb_transform(la, G, T);
+    }
+    double lmin = std::numeric_limits<double>::infinity();
+    for (int i = 0; i < n; ++i) lmin = std::min(lmin, L(i, i));
+    amp = 1.0 / std::max(lmin, 1e-300);
+    if (rem)
+        for (int i = 0; i < n; ++i) amp = std::max(amp, std::sqrt((*rem)[i] / diag[i]));
+    const Mat Li = lower_inverse(L);
+    T = Mat(n, n);
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) T(i, j) = d[i] * Li(j, i);
+    return true;
+}
+
+// orthonormal basis (Euclidean) of the columns of Tm: scaled Cholesky-QR twice (ModalSolver._orthonormal_columns)
+bool orthonormal_columns(const ds_lapack_t& la, const Mat& Tm, Mat& Q) {
+    Q = Tm;
+    for (int pass = 0; pass < 2; ++pass) {
+        Mat G = gemm(la, Q, true, Q, false);
+        const int n = G.r;
+        std::vector<double> d(n);
+        for (int i = 0; i < n; ++i) d[i] = 1.0 / std::sqrt(std::max(G(i, i), 1e-300));
+        symmetrize(G);
+        for (int i = 0; i < n; ++i)
+            for (int j = 0; j < n; ++j) G(i, j) *= d[i] * d[j];
+        Mat L;
+        if (!cholesky(G, L)) return false;  // (the Python loop falls back to Householder QR: the caller does, too)
+        const Mat Li = lower_inverse(L);
+        Mat X(n, n);
+        for (int i = 0; i < n; ++i)
+            for (int j = 0; j < n; ++j) X(i, j) = d[i] * Li(j, i);
+        Q = gemm(la, Q, false, X, false);
+    }
+    return true;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int COEF_SLOTS = 8;
+
+struct PinnedRing {  // per host thread, grown on demand, kept for the life of the thread
+    float* host = nullptr;
+    size_t slot_floats = 0;
+    int reserve(size_t floats_per_slot) {
+        if (floats_per_slot <= slot_floats) return DS_OK;
+        if (host) (void)hipHostFree(host);
+        host = nullptr, slot_floats = 0;
+        int rc = ds::check_hip(hipHostMalloc(reinterpret_cast<void**>(&host), floats_per_slot * COEF_SLOTS * sizeof(float), 0),
+                               "hipHostMalloc(coefficient staging)");
+        if (rc == DS_OK) slot_floats = floats_per_slot;
+        return rc;
+    }
+};
+thread_local PinnedRing g_ring;
+
+struct Ctx {
+    ds_lobpcg_t* p;
+    hipStream_t st;
+    ds_stream_t stream;
+    const ds_lapack_t& la;
+    float *S, *S2, *KS, *KS2;
+
+    int hip(hipError_t e, const char* what) { return ds::check_hip(e, what); }
+
+    int gram(const float* A, int64_t lda, int pc, const float* B, int64_t ldb, int qc, bool sym, Mat& out) {
+        const int flags = (sym ? DS_GRAM_SYMMETRIC : 0) | (p->gram_exact ? DS_GRAM_EXACT : 0);
+        int rc = ds_gram(A, DS_F32, lda, pc, B, DS_F32, ldb, qc, p->n, flags, p->gbuf, p->gram_work, p->gram_work_bytes,
+                         stream);
+        if (rc != DS_OK) return rc;
+        out = Mat(pc, qc);
+        rc = hip(hipMemcpyAsync(out.a.data(), p->gbuf, sizeof(double) * (size_t)pc * qc, hipMemcpyDeviceToHost, st),
+                 "ds_lobpcg_iterate: Gram block to host");
+        if (rc != DS_OK) return rc;
+        return hip(hipStreamSynchronize(st), "ds_lobpcg_iterate: stream synchronise");
+    }
+
+    // coefficient matrices travel through a ring of pinned host slots and matching device slots: an asynchronous copy
+    // may read its source after the call returns, and a slot is reused only after >= 8 further updates - every
+    // iteration synchronises the stream (Gram blocks) at least twice in between
+    int mix(const float* A, int64_t lda, int pc, const Mat& C, float* Out, int64_t ldo, float alpha = 1.f, float beta = 0.f) {
+        const size_t cnt = (size_t)C.r * C.c;
+        float* h = ring->host + (size_t)slot * ring->slot_floats;
+        float* dv = p->cbuf + (size_t)slot * ring->slot_floats;
+        slot = (slot + 1) % COEF_SLOTS;
+        for (size_t i = 0; i < cnt; ++i) h[i] = (float)C.a[i];
+        int rc = hip(hipMemcpyAsync(dv, h, sizeof(float) * cnt, hipMemcpyHostToDevice, st),
+                     "ds_lobpcg_iterate: coefficients to device");
+        if (rc != DS_OK) return rc;
+        return ds_mix(A, lda, pc, dv, C.c, Out, ldo, p->n, alpha, beta, stream);
+    }
+
+    int apply_K(const float* X, int64_t ldx, float* Y, int64_t ldy, int ncols) {
+        const ds_level_t& L = p->level;
+        if (ncols <= 84 && ncols % 4 == 0)
+            return ds_spmm_union(0, L.utab, L.ctab, L.ngroups, L.cap_blocks, L.gent, L.kgrp, L.nnzb, L.nv, X, ldx, Y, ldy,
+                                 nullptr, 0, nullptr, ncols, 0.f, 0.f, 0, nullptr, 0, stream);
+        for (int c0 = 0; c0 < ncols; c0 += 256) {  // wide blocks (the periodic full refresh): wave-per-node kernels
+            const int c1 = std::min(ncols, c0 + 256);
+            int rc = ds_spmm_bsr3(0, p->rowptr, p->colidx, p->k32, p->k32t, p->nv, X + c0, ldx, Y + c0, ldy, c1 - c0, stream);
+            if (rc != DS_OK) return rc;
+        }
+        return DS_OK;
+    }
+
+    int apply_M(const float* X, int64_t ldx, float* Y, int64_t ldy, int ncols) {
+        const ds_level_t& L = p->level;
+        return ds_spmm_union(3, L.utab, L.ctab, L.ngroups, L.cap_blocks, L.gent, p->mgrp, L.nnzb, L.nv, X, ldx, Y, ldy,
+                             nullptr, 0, nullptr, ncols, 0.f, 0.f, 0, nullptr, 0, stream);
+    }
+
+    int copy_cols(float* dst, int64_t ldd, const float* src, int64_t lds_, int ncols) {
+        if (ncols <= 0) return DS_OK;
+        return hip(hipMemcpy2DAsync(dst, (size_t)ldd * 4, src, (size_t)lds_ * 4, (size_t)ncols * 4, (size_t)p->n,
+                                    hipMemcpyDeviceToDevice, st),
+                   "ds_lobpcg_iterate: column copy");
+    }
+
+    // W <- B R  (two-level V-cycle, or the one-level Chebyshev polynomial W = p(T K) T R)
+    int precond(float* R, int na, float* W, int64_t ldw) {
+        if (p->twolevel) {
+            ds_twolevel_t d = *p->twolevel;
+            d.R = R, d.ldr = p->ldr, d.W = W, d.ldw = ldw, d.ncols = na;
+            return ds_twolevel_apply(&d, stream);
+        }
+        return ds_chebyshev_apply(&p->level, R, p->ldr, W, ldw, p->pa, p->pb, p->ldp, na, stream);
+    }
+
+    PinnedRing* ring = &g_ring;
+    int slot = 0;
+
+    // W (n x na, column range [w0, w0 + na) of S) M-orthogonal to V = S[:, :w0] and M-orthonormal
+    int orthonormalize(int w0, int na) {
+        const double eps = 6e-8;
+        float* W = S + w0;
+        const int64_t ld = p->lds;
+        for (int ip = 0; ip < p->ortho_passes; ++ip) {
+            int rc = apply_M(W, ld, p->MW, p->ldr, na);
+            if (rc != DS_OK) return rc;
+            bool done = false;
+            double amp = 0.0;
+            if (w0 > 0 && ip == 0) {
+                Mat G;
+                if ((rc = gram(S, ld, w0 + na, p->MW, p->ldr, na, false, G)) != DS_OK) return rc;
+                Mat C(w0, na), G0(na, na);
+                for (int i = 0; i < w0; ++i)
+                    for (int j = 0; j < na; ++j) C(i, j) = G(i, j);
+                for (int i = 0; i < na; ++i)
+                    for (int j = 0; j < na; ++j) G0(i, j) = G(w0 + i, j);
+                symmetrize(G0);
+                Mat CtC = gemm(la, C, true, C, false);
+                Mat Gp(na, na);
+                bool ok = true;
+                for (int i = 0; i < na; ++i)
+                    for (int j = 0; j < na; ++j) Gp(i, j) = G0(i, j) - CtC(i, j);
+                for (int i = 0; i < na; ++i)
+                    if (Gp(i, i) <= 1e-9 * std::fabs(G0(i, i))) ok = false;
+                Mat L;
+                if (ok && all_finite(Gp) && cholesky(Gp, L)) {
+                    std::vector<double> rem(na);
+                    for (int i = 0; i < na; ++i) rem[i] = CtC(i, i);
+                    Mat T;
+                    if (!orthonormalizer_q(la, Gp, &rem, T, amp)) {
+                        ds::set_error("ds_lobpcg_iterate: dsyevd failed in the orthonormalisation");
+                        return DS_ERR_ARG;
+                    }
+                    const Mat CT = gemm(la, C, false, T, false);
+                    Mat coef(w0 + na, na);
+                    for (int i = 0; i < w0; ++i)
+                        for (int j = 0; j < na; ++j) coef(i, j) = -CT(i, j);
+                    for (int i = 0; i < na; ++i)
+                        for (int j = 0; j < na; ++j) coef(w0 + i, j) = T(i, j);
+                    if ((rc = mix(S, ld, w0 + na, coef, W, ld)) != DS_OK) return rc;  // in place (W trails V in S)
+                    done = true;
+                }
+            }
+            if (!done) {
+                std::vector<double> rem;
+                if (w0 > 0) {
+                    Mat C;
+                    if ((rc = gram(S, ld, w0, p->MW, p->ldr, na, false, C)) != DS_OK) return rc;
+                    if ((rc = mix(S, ld, w0, C, W, ld, -1.f, 1.f)) != DS_OK) return rc;
+                    rem.assign(na, 0.0);
+                    for (int i = 0; i < w0; ++i)
+                        for (int j = 0; j < na; ++j) rem[j] += C(i, j) * C(i, j);
+                    if ((rc = apply_M(W, ld, p->MW, p->ldr, na)) != DS_OK) return rc;
+                }
+                Mat G;
+                if ((rc = gram(W, ld, na, p->MW, p->ldr, na, true, G)) != DS_OK) return rc;
+                Mat T;
+                if (!orthonormalizer_q(la, G, w0 > 0 ? &rem : nullptr, T, amp)) {
+                    ds::set_error("ds_lobpcg_iterate: dsyevd failed in the orthonormalisation");
+                    return DS_ERR_ARG;
+                }
+                if ((rc = mix(W, ld, na, T, W, ld)) != DS_OK) return rc;  // in place: na <= 84 columns
+            }
+            if (p->ortho_tol > 0.0 && eps * amp < p->ortho_tol) break;
+        }
+        return DS_OK;
+    }
+};
+
+}  // namespace
+
+extern "C" int ds_lobpcg_iterate(ds_lobpcg_t* p, const ds_lapack_t* lapack, ds_stream_t stream) {
+    DS_REQUIRE(p && lapack && lapack->dsyevd && lapack->dgemm, "ds_lobpcg_iterate: null descriptor or LAPACK table");
+    DS_REQUIRE(p->S && p->S2 && p->KS && p->KS2 && p->R && p->MX && p->MW && p->lam && p->rerr && p->gbuf && p->cbuf &&
+                   p->nrm && p->lam_dev && p->gram_work && p->mgrp,
+               "ds_lobpcg_iterate: null buffer");
+    DS_REQUIRE(p->b > 0 && p->b <= 84 && p->b % 4 == 0 && p->k > 0 && p->k <= p->b && (p->ny == 0 || p->ny % 4 == 0),
+               "ds_lobpcg_iterate: block width must be a multiple of 4 <= 84 (got %d)", p->b);
+    DS_REQUIRE(p->n == 3 * p->nv && p->n >= 3 * p->b + p->ny, "ds_lobpcg_iterate: bad problem size");
+    DS_REQUIRE(p->twolevel || (p->pa && p->pb), "ds_lobpcg_iterate: no preconditioner scratch");
+    Ctx c{p, ds::as_stream(stream), stream, *lapack, p->S, p->S2, p->KS, p->KS2};
+    const int b = p->b, k = p->k, ny = p->ny;
+    {   // cbuf holds COEF_SLOTS slots of (ny + 3 b) x 2 b floats
+        const int rcr = g_ring.reserve((size_t)(ny + 3 * b) * 2 * b);
+        if (rcr != DS_OK) return rcr;
+    }
+    const int64_t n = p->n, lds = p->lds, ldks = p->ldks, ldr = p->ldr;
+    int rc;
+    std::vector<double> lam(p->lam, p->lam + b), rel(b, std::numeric_limits<double>::infinity());
+    Mat Gxp(b, b);
+    for (int i = 0; i < b; ++i) Gxp(i, i) = lam[i];
+    int ncl = 0, npc = 0, k0 = 0, since_refresh = 0, it = 0;
+    double worst = std::numeric_limits<double>::infinity();
+    for (it = 0; it <= p->maxit; ++it) {
+        int na = b - ncl;
+        float* X = c.S + ny;
+        float* Xa = X + ncl;
+        if ((rc = c.apply_M(Xa, lds, p->MX, ldr, na)) != DS_OK) return rc;
+        if ((rc = c.hip(hipMemcpyAsync(p->lam_dev, lam.data() + ncl, sizeof(double) * na, hipMemcpyHostToDevice, c.st),
+                        "ds_lobpcg_iterate: Ritz values to device")) != DS_OK)
+            return rc;
+        if ((rc = ds_residual(c.KS + k0, ldks, p->R, ldr, p->MX, ldr, Xa, lds, p->lam_dev, n, na, p->nrm, p->nrm + 1024,
+                              stream)) != DS_OK)
+            return rc;
+        std::vector<double> nrm(2048);
+        if ((rc = c.hip(hipMemcpyAsync(nrm.data(), p->nrm, sizeof(double) * 2048, hipMemcpyDeviceToHost, c.st),
+                        "ds_lobpcg_iterate: residual norms to host")) != DS_OK)
+            return rc;
+        if ((rc = c.hip(hipStreamSynchronize(c.st), "ds_lobpcg_iterate: stream synchronise")) != DS_OK) return rc;
+        for (int j = 0; j < na; ++j)
+            rel[ncl + j] = std::sqrt(nrm[j] / nrm[1024 + j]) / (p->A_norm + std::fabs(lam[ncl + j]) * p->B_norm);
+        int nconv = 0;
+        while (nconv < k && rel[nconv] < p->tol) ++nconv;  // leading converged pairs only (reference _lobpcg.py:321-328)
+        worst = 0.0;
+        for (int j = 0; j < k; ++j) worst = std::max(worst, rel[j]);
+        if (p->history && it < p->history_cap) p->history[it] = worst;
+        if (nconv >= k || it == p->maxit) break;
+        // hard locking: converged leading columns leave the Ritz problem, the residual block and the preconditioner
+        const int new_ncl = p->lock ? (nconv / 4) * 4 : 0;
+        if (new_ncl > ncl) {
+            const int shift = new_ncl - ncl;
+            if ((rc = c.copy_cols(p->MW, ldr, p->R + shift, ldr, na - shift)) != DS_OK) return rc;
+            if ((rc = c.copy_cols(p->R, ldr, p->MW, ldr, na - shift)) != DS_OK) return rc;
+            Mat G2(Gxp.r - shift, Gxp.c - shift);
+            for (int i = 0; i < G2.r; ++i)
+                for (int j = 0; j < G2.c; ++j) G2(i, j) = Gxp(i + shift, j + shift);
+            Gxp = G2;
+            k0 += shift;
+            ncl = new_ncl;
+            na = b - ncl;
+        }
+        const int w0 = ny + b + npc;
+        float* W = c.S + w0;
+        if ((rc = c.precond(p->R, na, W, lds)) != DS_OK) return rc;
+        if ((rc = c.orthonormalize(w0, na)) != DS_OK) return rc;
+        const int sz = na + npc + na, nxp = na + npc;
+        float* Sa = c.S + ny + ncl;
+        float* KSa = c.KS + k0;
+        const bool full = p->rr_refresh <= 0 || since_refresh >= p->rr_refresh;
+        Mat G(sz, sz);
+        if (full) {
+            if ((rc = c.apply_K(Sa, lds, KSa, ldks, sz)) != DS_OK) return rc;
+            if ((rc = c.gram(Sa, lds, sz, KSa, ldks, sz, true, G)) != DS_OK) return rc;
+            since_refresh = 0;
+        } else {
+            if ((rc = c.apply_K(W, lds, KSa + nxp, ldks, na)) != DS_OK) return rc;
+            Mat GA;
+            if ((rc = c.gram(Sa, lds, sz, KSa + nxp, ldks, na, false, GA)) != DS_OK) return rc;
+            for (int i = 0; i < nxp; ++i)
+                for (int j = 0; j < nxp; ++j) G(i, j) = Gxp(i, j);
+            for (int i = 0; i < sz; ++i)
+                for (int j = 0; j < na; ++j) G(i, nxp + j) = GA(i, j);
+            for (int i = 0; i < na; ++i)
+                for (int j = 0; j < nxp; ++j) G(nxp + i, j) = GA(j, i);
+            ++since_refresh;
+        }
+        symmetrize(G);
+        // Rayleigh-Ritz: lowest na pairs, and P = the part of the old active X that left the new Ritz block
+        std::vector<double> E;
+        Mat Z;
+        if (!eigh(*lapack, G, E, Z)) {
+            ds::set_error("ds_lobpcg_iterate: dsyevd failed in the Rayleigh-Ritz step");
+            return DS_ERR_ARG;
+        }
+        Mat Z1(sz, na);
+        for (int i = 0; i < sz; ++i)
+            for (int j = 0; j < na; ++j) Z1(i, j) = Z(i, j);
+        Mat Z1top(na, na);
+        for (int i = 0; i < na; ++i)
+            for (int j = 0; j < na; ++j) Z1top(i, j) = Z1(i, j);
+        Mat Tm = gemm(*lapack, Z1, false, Z1top, true);  // Z1 Z1[:na]^T
+        for (double& v : Tm.a) v = -v;
+        for (int i = 0; i < na; ++i) Tm(i, i) += 1.0;
+        Mat Zp;
+        if (!orthonormal_columns(*lapack, Tm, Zp)) {  // rank-deficient P block: clamped-eigenvalue basis instead
+            Mat GT = gemm(*lapack, Tm, true, Tm, false), Tq;
+            if (!svqb_transform(*lapack, GT, Tq)) {
+                ds::set_error("ds_lobpcg_iterate: dsyevd failed on the P block");
+                return DS_ERR_ARG;
+            }
+            Zp = gemm(*lapack, Tm, false, Tq, false);
+        }
+        Mat ZZ(sz, 2 * na);
+        for (int i = 0; i < sz; ++i)
+            for (int j = 0; j < na; ++j) {
+                ZZ(i, j) = Z1(i, j);
+                ZZ(i, na + j) = Zp(i, j);
+            }
+        Gxp = gemm(*lapack, ZZ, true, gemm(*lapack, G, false, ZZ, false), false);
+        symmetrize(Gxp);
+        for (int j = 0; j < na; ++j) lam[ncl + j] = E[j];
+        if (ncl && (rc = c.copy_cols(c.S2 + ny, lds, c.S + ny, lds, ncl)) != DS_OK) return rc;
+        if (2 * na <= 160) {
+            if ((rc = c.mix(Sa, lds, sz, ZZ, c.S2 + ny + ncl, lds)) != DS_OK) return rc;
+            if ((rc = c.mix(KSa, ldks, sz, ZZ, c.KS2, ldks)) != DS_OK) return rc;
+        } else {
+            if ((rc = c.mix(Sa, lds, sz, Z1, c.S2 + ny + ncl, lds)) != DS_OK) return rc;
+            if ((rc = c.mix(Sa, lds, sz, Zp, c.S2 + ny + b, lds)) != DS_OK) return rc;
+            if ((rc = c.mix(KSa, ldks, sz, Z1, c.KS2, ldks)) != DS_OK) return rc;
+            if ((rc = c.mix(KSa, ldks, sz, Zp, c.KS2 + na, ldks)) != DS_OK) return rc;
+        }
+        std::swap(c.S, c.S2);
+        std::swap(c.KS, c.KS2);
+        k0 = 0;
+        npc = na;
+    }
+    p->iterations = it;
+    p->result_in_s2 = (c.S == p->S) ? 0 : 1;
+    std::memcpy(p->lam, lam.data(), sizeof(double) * b);
+    std::memcpy(p->rerr, rel.data(), sizeof(double) * b);
+    return DS_OK;
+}

@@ -54,6 +54,13 @@ int chebyshev(const ds_level_t& L, const float* R, int64_t ldr, float* Wout, int
 
 }  // namespace
 
+extern "C" int ds_chebyshev_apply(const ds_level_t* level, const float* R, int64_t ldr, float* W, int64_t ldw, float* a,
+                                  float* b, int64_t lds, int ncols, ds_stream_t stream) {
+    DS_REQUIRE(level && R && W && a && b, "ds_chebyshev_apply: null pointer");
+    DS_REQUIRE(level->degree >= 1 && level->lmax > level->lmin && level->lmin > 0, "ds_chebyshev_apply: bad polynomial");
+    return chebyshev(*level, R, ldr, W, ldw, a, b, lds, ncols, false, stream);
+}
+
 extern "C" int ds_twolevel_apply(const ds_twolevel_t* p, ds_stream_t stream) {
     DS_REQUIRE(p, "ds_twolevel_apply: null descriptor");
     DS_REQUIRE(p->R && p->W && p->Wc && p->D && p->AD && p->Rr && p->Rc && p->Ec && p->Dc && p->ADc,

@@ -61,6 +61,7 @@ class SolverConfig:
     # the Gram matrix (a third of the SpMM columns, half of the Gram flops).  Every ``rr_refresh``-th
     # iteration recomputes K [X P W] and the whole Gram matrix from the vectors (0 = every iteration).
     rr_refresh: int = 8
+    native: bool = True  # run the iteration through ds_lobpcg_iterate when possible (False: the Python loop below)
     # Nested iteration (ops with a ``coarse`` level, cold starts only): the random start block is first iterated on the
     # corner-node (P1) level - 14x fewer non-zeros, the same block width - to ``nested_tol``, and its prolongation
     # P X_c starts the fine solve.  The P1 spectrum is ~6 % off the P2 one, so a loose coarse tolerance is enough;
@@ -363,13 +364,17 @@ class SolverState:
 
 
 class ModalSolver:
-    def __init__(self, ops, cfg: Optional[SolverConfig] = None, precond=None):
+    def __init__(self, ops, cfg: Optional[SolverConfig] = None, precond=None, precond_object=None):
         """precond: optional callable (R, W) -> None writing the preconditioned residual into W
-        (the ``iK`` argument of the reference API); default Chebyshev block-Jacobi."""
+        (the ``iK`` argument of the reference API); default Chebyshev block-Jacobi.  precond_object: an already built
+        ChebyshevBlockJacobi / TwoLevelChebyshev on these ops (its power iteration is then not repeated)."""
         self.ops = ops
         self.cfg = cfg or SolverConfig()
         self.ortho_log = []
-        if precond is not None:
+        if precond_object is not None:
+            self.precond = precond_object
+            self.precond_apply = precond_object.apply
+        elif precond is not None:
             self.precond_apply = precond
             self.precond = None
         else:
@@ -454,7 +459,7 @@ class ModalSolver:
         if pre is not None and (pre.degree != ccfg.cheb_degree
                                 or abs(pre.lmax / pre.lmin - ccfg.cheb_ratio) > 1e-6 * ccfg.cheb_ratio):
             pre = None  # the V-cycle's corner-level polynomial is reused when it is the one asked for
-        cs = ModalSolver(co, ccfg, precond=None if pre is None else pre.apply)
+        cs = ModalSolver(co, ccfg, precond_object=pre)
         rc = cs.solve(k, polish=False)
         self.nested_iterations = rc.iterations
         X0 = torch.zeros((ops.n, b), dtype=ops.dtype, device=ops.device)
@@ -528,7 +533,23 @@ class ModalSolver:
         Gxp = torch.diag(lam.detach().to(torch.float64).cpu()) if dev.type == "cuda" else torch.diag(lam.to(torch.float64))
         since_refresh = 0
         rel = torch.full((b,), float("inf"), dtype=torch.float64, device=dev)
-        for it in range(cfg.maxit + 1):
+        # The iteration as ONE native call (ds_lobpcg_iterate) when the ops offer it and nothing needs the interpreter
+        # between iterations (no tracker callback, the built-in preconditioners): same kernels, same dense steps, but
+        # a hypothesis lane then runs its whole solve without the interpreter lock.
+        native = None
+        if (cfg.native and tracker is None and self.precond is not None and dt == torch.float32
+                and hasattr(ops, "native_lobpcg")):
+            native = ops.native_lobpcg(self.precond, cfg, k, b, ny, S, S2, KS, KS2, R, MX, MW, lam, float(A_norm),
+                                       float(B_norm), tol)
+        if native is not None:
+            it, in_s2, lam, rel, history = native
+            if in_s2:
+                S, S2 = S2, S
+                KS, KS2 = KS2, KS
+            state.ivars.update(istep=it, converged_count=int((rel[:k] < tol).sum()), iterations_left=cfg.maxit - it)
+            state.tvars["rerr"] = rel[:k]
+            state.E, state.X = lam, S[:, ny:ny + b]
+        for it in (range(cfg.maxit + 1) if native is None else ()):
             na = b - ncl
             X = S[:, ny:ny + b]
             Xa = X[:, ncl:]
@@ -617,6 +638,8 @@ class ModalSolver:
             k0 = 0
             npc = na
 
+        if native is not None:
+            it = native[0]
         X = S[:, ny:ny + b]
         if not polish:  # (the corner-level phase of a nested start: the rotated fp32 block is all that is wanted)
             return ModalResult(lam[:k].clone(), X[:, :k], None, None, None, iterations=it, rerr=rel[:k].clone(),

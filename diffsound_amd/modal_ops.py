@@ -324,6 +324,85 @@ class _HipBlockOps:
 
     _tl_desc = None
 
+    # ------------------------------------------------------------------ native iteration driver
+    def native_lobpcg(self, precond, cfg, k, b, ny, S, S2, KS, KS2, R, MX, MW, lam, A_norm, B_norm, tol):
+        """Run the eigensolver's iteration through ds_lobpcg_iterate (csrc/lobpcg.cpp).  Returns None when this
+        configuration has to stay on the Python loop (block wider than the union kernels take, a mass matrix that is
+        not node-scalar, a preconditioner the driver does not know), else
+        (iterations, result_in_s2, lam (b,) fp64 device, rerr (b,) fp64 device, history [(it, worst backward error)])."""
+        from .lobpcg.modal_solver import ChebyshevBlockJacobi, TwoLevelChebyshev
+
+        g = getattr(getattr(self, "sys", None), "groups", None)
+        if (g is None or g.get("union") is None or self.kgrp is None or self.mgrp is None or self.m_kind != 1
+                or b > 84 or b % 4 or ny % 4 or not self._union_ok(R, MX, MW, S[:, ny:ny + b], KS[:, :b])):
+            return None
+        dev = self.device
+        d = _hip.LobpcgDesc()
+        keep = []  # tensors the descriptor points into
+        if isinstance(precond, TwoLevelChebyshev):
+            co = self.coarse
+            if co is None or precond.ops is not self:
+                return None
+            tl = _hip.TwoLevelDesc()
+            t = self._xfer
+            tl.rptr, tl.rcol, tl.rw = t["rptr"].data_ptr(), t["rcol"].data_ptr(), t["rw"].data_ptr()
+            tl.pptr, tl.pcol, tl.pw = t["pptr"].data_ptr(), t["pcol"].data_ptr(), t["pw"].data_ptr()
+            sm, cs = precond.smooth, precond.coarse
+            if (self.level_desc(tl.fine, sm.degree, sm.lmax, sm.lmin) is None
+                    or co.level_desc(tl.coarse, cs.degree, cs.lmax, cs.lmin) is None):
+                return None
+            scr = self._scratch("native_tl_fine", (4, self.n, b), torch.float32)
+            scc = co._scratch("native_tl_coarse", (4, co.n, b), torch.float32)
+            tl.Wc, tl.D, tl.AD, tl.Rr = (scr[i].data_ptr() for i in range(4))
+            tl.ldwc = tl.ldd = tl.lda = tl.ldrr = b
+            tl.Rc, tl.Ec, tl.Dc, tl.ADc = (scc[i].data_ptr() for i in range(4))
+            tl.ldc = b
+            tl.R = tl.W = 1  # (set per application by the driver; non-null for its argument check)
+            d.twolevel = ctypes.pointer(tl)
+            keep += [tl, scr, scc]
+            self.level_desc(d.level, sm.degree, sm.lmax, sm.lmin)
+        elif isinstance(precond, ChebyshevBlockJacobi):
+            if precond.ops is not self or self.level_desc(d.level, precond.degree, precond.lmax, precond.lmin) is None:
+                return None
+            scr = self._scratch("native_cheb", (2, self.n, b), torch.float32)
+            d.pa, d.pb, d.ldp = scr[0].data_ptr(), scr[1].data_ptr(), b
+            keep.append(scr)
+        else:
+            return None
+        d.n, d.nv, d.b, d.k, d.ny = self.n, self.nv, b, k, ny
+        d.maxit, d.lock, d.ortho_passes, d.rr_refresh = cfg.maxit, int(cfg.lock), cfg.ortho_passes, cfg.rr_refresh
+        d.gram_exact = int(bool(self.gram_exact))
+        d.tol, d.ortho_tol, d.A_norm, d.B_norm = float(tol), float(cfg.ortho_tol), A_norm, B_norm
+        d.S, d.S2, d.KS, d.KS2 = S.data_ptr(), S2.data_ptr(), KS.data_ptr(), KS2.data_ptr()
+        d.R, d.MX, d.MW = R.data_ptr(), MX.data_ptr(), MW.data_ptr()
+        d.lds, d.ldks, d.ldr = S.stride(0), KS.stride(0), R.stride(0)
+        if not (S2.stride(0) == d.lds and KS2.stride(0) == d.ldks and MX.stride(0) == d.ldr and MW.stride(0) == d.ldr):
+            return None
+        d.mgrp = self.mgrp.data_ptr()
+        d.rowptr, d.colidx, d.k32, d.k32t = (self.rowptr.data_ptr(), self.colidx.data_ptr(), self.k32.data_ptr(),
+                                             self.k32t.data_ptr())
+        m = ny + 3 * b
+        gbuf = self._scratch("native_g", (m * 3 * b,), torch.float64)
+        cbuf = self._scratch("native_c", (8 * m * 2 * b,), torch.float32)
+        lam_dev = self._scratch("native_lam", (b,), torch.float64)
+        need = self._L.ds_gram_workspace_bytes(self.n, m, 3 * b)
+        if self._gram_ws is None or self._gram_ws.numel() < need:
+            self._gram_ws = torch.empty((need,), dtype=torch.uint8, device=dev)
+        d.gbuf, d.cbuf, d.nrm, d.lam_dev = gbuf.data_ptr(), cbuf.data_ptr(), self._nrm.data_ptr(), lam_dev.data_ptr()
+        d.gram_work, d.gram_work_bytes = self._gram_ws.data_ptr(), self._gram_ws.numel()
+        lam_h = (ctypes.c_double * b)(*lam.detach().double().cpu().tolist())
+        rerr_h = (ctypes.c_double * b)()
+        hist_h = (ctypes.c_double * (cfg.maxit + 1))()
+        d.lam, d.rerr, d.history, d.history_cap = lam_h, rerr_h, hist_h, cfg.maxit + 1
+        _hip.check(self._L.ds_lobpcg_iterate(ctypes.byref(d), ctypes.byref(_hip.lapack_table()), _hip.stream_ptr()),
+                   "ds_lobpcg_iterate")
+        it = int(d.iterations)
+        lam_t = torch.tensor(list(lam_h), dtype=torch.float64, device=dev)
+        rel_t = torch.tensor(list(rerr_h), dtype=torch.float64, device=dev)
+        history = [(i, hist_h[i]) for i in range(min(it + 1, cfg.maxit + 1))]
+        del keep
+        return it, bool(d.result_in_s2), lam_t, rel_t, history
+
     def _union(self, epilogue, X, Y, R0=None, c1=0.0, c2=0.0, first=False, Wprev=None):
         pp = _hip.ptr
         g = self.sys.groups

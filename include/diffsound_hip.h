@@ -40,7 +40,7 @@ enum { DS_OK = 0, DS_ERR_ARG = 1, DS_ERR_HIP = 2, DS_ERR_NOMEM = 3 };
 /* Thread-local text of the last error returned on this thread ("" if none). */
 const char* ds_last_error(void);
 /* Library ABI version (bumped on any signature change); ds_abi_version() returns the value the library was built with. */
-#define DS_ABI_VERSION 15
+#define DS_ABI_VERSION 16
 int ds_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------------
@@ -246,6 +246,59 @@ typedef struct {
     int64_t ldwc;    /* = ldd = lda */
 } ds_twolevel_t;
 int ds_twolevel_apply(const ds_twolevel_t* p, ds_stream_t stream);
+/* One-level form: W <- p(T K) T R with the level's degree / [lmin, lmax] (Chebyshev block-Jacobi polynomial, every term
+ * one fused ds_spmm_union launch); a, b: compact scratch blocks (rows x ncols, leading dimension lds). */
+int ds_chebyshev_apply(const ds_level_t* level, const float* R, int64_t ldr, float* W, int64_t ldw, float* a, float* b,
+                       int64_t lds, int ncols, ds_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * The eigensolver's iteration as ONE native call (csrc/lobpcg.cpp): the loop of the reference's LOBPCG.run /
+ * _update_ortho (src/lobpcg/_lobpcg.py:344-376, 433-477) in the re-designed form of lobpcg/modal_solver.py - residual
+ * test, hard locking, preconditioner, single-sweep projected Cholesky-QR, Rayleigh-Ritz by recurrence, basis update -
+ * issued on `stream`; the <= 3b x 3b dense steps run on the calling thread with the LAPACK / BLAS routines of
+ * ds_lapack_t (Fortran calling convention, e.g. SciPy's cython_lapack / cython_blas function pointers).  Synchronises
+ * the stream a few times per iteration (residual norms, Gram blocks).
+ * On entry: S = [Y (ny rigid columns, 0 or a multiple of 4) | X (b Ritz vectors, M-orthonormal) | - | -], KS[:, :b] = K X,
+ * lam = the b Ritz values, S2[:, :ny] = Y.  On exit: the basis buffer holding X (S2 if result_in_s2), lam, rerr (per
+ * column: ||K x - lam M x|| / (||x|| (A_norm + |lam| B_norm))), iterations.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+    void (*dsyevd)(char* jobz, char* uplo, int* n, double* a, int* lda, double* w, double* work, int* lwork, int* iwork,
+                   int* liwork, int* info);
+    void (*dgemm)(char* ta, char* tb, int* m, int* n, int* k, double* alpha, double* a, int* lda, double* b, int* ldb,
+                  double* beta, double* c, int* ldc);
+} ds_lapack_t;
+typedef struct {
+    int64_t n, nv;            /* n = 3 nv rows */
+    int32_t b, k, ny;         /* block width (multiple of 4, <= 84), wanted pairs, rigid columns */
+    int32_t maxit, lock, ortho_passes, rr_refresh, gram_exact;
+    double tol, ortho_tol, A_norm, B_norm;
+    float *S, *S2;            /* (n x (ny + 3 b)), leading dimension lds */
+    float *KS, *KS2;          /* (n x 3 b), leading dimension ldks */
+    float *R, *MX, *MW;       /* (n x b), leading dimension ldr */
+    int64_t lds, ldks, ldr;
+    ds_level_t level;         /* K of this level: neighbour-union tables + block-Jacobi blocks; degree / lmin / lmax of
+                                 the one-level polynomial when twolevel == NULL */
+    const float* mgrp;        /* node-scalar mass values in group order (ds_spmm_union epilogue 3) */
+    const int32_t *rowptr, *colidx;   /* BSR pattern and values for the wide products of the periodic full refresh */
+    const float *k32, *k32t;
+    const ds_twolevel_t* twolevel;    /* two-level preconditioner (scratch blocks with >= b columns), or NULL */
+    float *pa, *pb;           /* one-level preconditioner scratch (n x b), leading dimension ldp */
+    int64_t ldp;
+    double* gbuf;             /* device, (ny + 3 b) x 3 b doubles: Gram results */
+    float* cbuf;              /* device, 8 x (ny + 3 b) x 2 b floats: update coefficients (a ring of 8 slots) */
+    double* nrm;              /* device, 2 x 1024 doubles */
+    double* lam_dev;          /* device, b doubles */
+    void* gram_work;
+    int64_t gram_work_bytes;
+    double* lam;              /* host, b: in / out */
+    double* rerr;             /* host, b: out */
+    double* history;          /* host, history_cap entries or NULL: max backward error of the wanted pairs per iteration */
+    int32_t history_cap;
+    int32_t iterations;       /* out */
+    int32_t result_in_s2;     /* out */
+} ds_lobpcg_t;
+int ds_lobpcg_iterate(ds_lobpcg_t* p, const ds_lapack_t* lapack, ds_stream_t stream);
 
 /* Out <- alpha * A C + beta * Out,  A (n x p) f32, C (p x q) f32 row-major device, Out (n x q) f32.
  * Out may overlap A (e.g. be a column range of it) when q <= 160: every row tile is read completely before it is

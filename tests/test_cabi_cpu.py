@@ -25,7 +25,7 @@ def test_header_symbols_exported():
     _hip = _lib()
     header = open(os.path.join(ROOT, "include", "diffsound_hip.h")).read()
     declared = set(re.findall(r"\b(ds_[a-z0-9_]+)\s*\(", header))
-    declared -= {"ds_pattern_t", "ds_stream_t"}
+    declared = {d for d in declared if not d.endswith("_t")}  # type names followed by a parenthesis in comments
     assert declared, "no declarations parsed"
     lib = _hip.lib()
     for name in sorted(declared):

@@ -129,3 +129,35 @@ def test_fp64_refinement_matches_arpack_to_1e9(dev):
     Ko = fem.assemble_stiffness(d, lam, mu)
     Mo, _ = fem.assemble_mass(v, t, 2, MAT[0])
     assert np.abs(ev / modal.eigsh_shift_invert(Ko, Mo, 32)[0] - 1).max() < 1e-5
+
+
+@pytest.mark.parametrize("mesh,order,k,block,nested", [(6, 2, 32, 40, 0.0), (6, 2, 32, 40, 1e-2), (8, 1, 16, 24, 0.0)])
+def test_native_iteration_driver_matches_python_loop(dev, mesh, order, k, block, nested):
+    """ds_lobpcg_iterate (the iteration as one native call, LAPACK from SciPy) against the Python loop it replaces:
+    same kernels and dense steps, so the same iteration count and eigenvalues to the rounding of the two LAPACKs;
+    two-level preconditioner (ord-2), nested start, one-level polynomial (ord-1)."""
+    from diffsound_amd import meshgen
+    from diffsound_amd.lobpcg.modal_solver import ModalSolver, SolverConfig
+    from diffsound_amd.modal_ops import HipModalOps, TetSystem
+
+    v, t = meshgen.kuhn_box(mesh)
+    v, t = fem.to_high_order(torch.from_numpy(v), torch.from_numpy(t).long(), order)
+    sysd = TetSystem(v.to(dev), t.to(dev), order, MAT[0])
+    lam, mu = fem.lame(MAT[1], MAT[2])
+    ops = HipModalOps(sysd, lam, mu)
+    out = {}
+    for native in (True, False):
+        cfg = SolverConfig(block=block, lmax_cap=float({1: 4, 2: 10}[order]), tol=1e-5, nested_tol=nested, native=native)
+        calls = []
+        orig = ops.native_lobpcg
+        ops.native_lobpcg = lambda *a, _o=orig, **kw: (calls.append(1), _o(*a, **kw))[1]
+        try:
+            out[native] = ModalSolver(ops, cfg).solve(k)
+        finally:
+            del ops.native_lobpcg
+        assert bool(calls) == native  # the driver really ran (and only when asked)
+    a, b_ = out[True], out[False]
+    assert abs(a.iterations - b_.iterations) <= 1 and a.coarse_iterations == b_.coarse_iterations
+    assert float(a.rerr.max()) < 1e-5 and float(b_.rerr.max()) < 1e-5
+    assert float((a.eigenvalues / b_.eigenvalues - 1).abs().max()) < 1e-6
+    assert len(a.history) == a.iterations + 1 and a.history[-1][1] < 1e-5
