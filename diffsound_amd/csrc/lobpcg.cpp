@@ -234,8 +234,9 @@ struct Ctx {
     // iteration synchronises the stream (Gram blocks) at least twice in between
     int mix(const float* A, int64_t lda, int pc, const Mat& C, float* Out, int64_t ldo, float alpha = 1.f, float beta = 0.f) {
         const size_t cnt = (size_t)C.r * C.c;
-        float* h = ring->host + (size_t)slot * ring->slot_floats;
-        float* dv = p->cbuf + (size_t)slot * ring->slot_floats;
+        const size_t stride = (size_t)(p->ny + 3 * p->b) * 2 * p->b;  // slot size of THIS solve (the ring may be larger)
+        float* h = ring->host + (size_t)slot * stride;
+        float* dv = p->cbuf + (size_t)slot * stride;
         slot = (slot + 1) % COEF_SLOTS;
         for (size_t i = 0; i < cnt; ++i) h[i] = (float)C.a[i];
         int rc = hip(hipMemcpyAsync(dv, h, sizeof(float) * cnt, hipMemcpyHostToDevice, st),

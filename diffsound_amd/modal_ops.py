@@ -234,6 +234,7 @@ class _HipBlockOps:
         self.device = device
         self._L = _hip.lib()
         self._gram_ws = None
+        self._native_ws = {}
         self.gram_exact = False
         self._tmp = {}
         self._nrm = torch.empty((2, 1024), dtype=torch.float64, device=device)
@@ -385,7 +386,12 @@ class _HipBlockOps:
         gbuf = self._scratch("native_g", (m * 3 * b,), torch.float64)
         cbuf = self._scratch("native_c", (8 * m * 2 * b,), torch.float32)
         lam_dev = self._scratch("native_lam", (b,), torch.float64)
-        need = self._L.ds_gram_workspace_bytes(self.n, m, 3 * b)
+        key = (self.n, b, ny)
+        need = self._native_ws.get(key)
+        if need is None:  # the split count depends on the shape: take the largest need over every shape the driver forms
+            need = max(self._L.ds_gram_workspace_bytes(self.n, p_, q_)
+                       for p_ in range(4, m + 1, 4) for q_ in sorted(set(range(4, b + 1, 4)) | {p_}) if q_ <= 3 * b)
+            self._native_ws[key] = need
         if self._gram_ws is None or self._gram_ws.numel() < need:
             self._gram_ws = torch.empty((need,), dtype=torch.uint8, device=dev)
         d.gbuf, d.cbuf, d.nrm, d.lam_dev = gbuf.data_ptr(), cbuf.data_ptr(), self._nrm.data_ptr(), lam_dev.data_ptr()

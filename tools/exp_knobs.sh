@@ -6,17 +6,6 @@ run() {
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
 e=d['config']['eigensolver']
-print(round(d['value'],2), 'passes/s;', e[e.find('mean iterations'):])"
+print(round(d['value'],2), 'passes/s;', e[e.find('mean iterations'):][:60])"
 }
-run
-run --smooth-degree 1
-run --smooth-degree 3
-run --block 72
-run --block 88
-run --coarse-degree 20 --coarse-ratio 300
-run --coarse-degree 36 --coarse-ratio 800
-run --nested-tol 3e-3
-run --nested-tol 3e-2
-run --lanes 3
-run --lanes 6
-run --hyp-per-gpu 16 --lanes 4
+for a in "$@"; do run $a; done
