@@ -196,6 +196,17 @@ constexpr int COEF_SLOTS = 8;
 struct PinnedRing {  // per host thread, grown on demand, kept for the life of the thread
     float* host = nullptr;
     size_t slot_floats = 0;
+    double* back = nullptr;  // device-to-host staging (Gram blocks, residual norms): a pageable destination would
+    size_t back_doubles = 0; // send the "asynchronous" copy through the runtime's shared staging path
+    int reserve_back(size_t doubles) {
+        if (doubles <= back_doubles) return DS_OK;
+        if (back) (void)hipHostFree(back);
+        back = nullptr, back_doubles = 0;
+        int rc = ds::check_hip(hipHostMalloc(reinterpret_cast<void**>(&back), doubles * sizeof(double), 0),
+                               "hipHostMalloc(result staging)");
+        if (rc == DS_OK) back_doubles = doubles;
+        return rc;
+    }
     int reserve(size_t floats_per_slot) {
         if (floats_per_slot <= slot_floats) return DS_OK;
         if (host) (void)hipHostFree(host);
@@ -223,10 +234,13 @@ struct Ctx {
                          stream);
         if (rc != DS_OK) return rc;
         out = Mat(pc, qc);
-        rc = hip(hipMemcpyAsync(out.a.data(), p->gbuf, sizeof(double) * (size_t)pc * qc, hipMemcpyDeviceToHost, st),
+        double* stage = ring->back + 2048 + 128;
+        rc = hip(hipMemcpyAsync(stage, p->gbuf, sizeof(double) * (size_t)pc * qc, hipMemcpyDeviceToHost, st),
                  "ds_lobpcg_iterate: Gram block to host");
         if (rc != DS_OK) return rc;
-        return hip(hipStreamSynchronize(st), "ds_lobpcg_iterate: stream synchronise");
+        rc = hip(hipStreamSynchronize(st), "ds_lobpcg_iterate: stream synchronise");
+        if (rc == DS_OK) std::memcpy(out.a.data(), stage, sizeof(double) * (size_t)pc * qc);
+        return rc;
     }
 
     // coefficient matrices travel through a ring of pinned host slots and matching device slots: an asynchronous copy
@@ -369,7 +383,9 @@ extern "C" int ds_lobpcg_iterate(ds_lobpcg_t* p, const ds_lapack_t* lapack, ds_s
     Ctx c{p, ds::as_stream(stream), stream, *lapack, p->S, p->S2, p->KS, p->KS2};
     const int b = p->b, k = p->k, ny = p->ny;
     {   // cbuf holds COEF_SLOTS slots of (ny + 3 b) x 2 b floats
-        const int rcr = g_ring.reserve((size_t)(ny + 3 * b) * 2 * b);
+        int rcr = g_ring.reserve((size_t)(ny + 3 * b) * 2 * b);
+        if (rcr != DS_OK) return rcr;
+        rcr = g_ring.reserve_back(2048 + 128 + (size_t)(ny + 3 * b) * 3 * b);  // norms | Ritz values | Gram block
         if (rcr != DS_OK) return rcr;
     }
     const int64_t n = p->n, lds = p->lds, ldks = p->ldks, ldr = p->ldr;
@@ -384,14 +400,16 @@ extern "C" int ds_lobpcg_iterate(ds_lobpcg_t* p, const ds_lapack_t* lapack, ds_s
         float* X = c.S + ny;
         float* Xa = X + ncl;
         if ((rc = c.apply_M(Xa, lds, p->MX, ldr, na)) != DS_OK) return rc;
-        if ((rc = c.hip(hipMemcpyAsync(p->lam_dev, lam.data() + ncl, sizeof(double) * na, hipMemcpyHostToDevice, c.st),
+        double* lam_pin = g_ring.back + 2048;  // (the previous iteration's copy completed before its last synchronise)
+        std::memcpy(lam_pin, lam.data() + ncl, sizeof(double) * na);
+        if ((rc = c.hip(hipMemcpyAsync(p->lam_dev, lam_pin, sizeof(double) * na, hipMemcpyHostToDevice, c.st),
                         "ds_lobpcg_iterate: Ritz values to device")) != DS_OK)
             return rc;
         if ((rc = ds_residual(c.KS + k0, ldks, p->R, ldr, p->MX, ldr, Xa, lds, p->lam_dev, n, na, p->nrm, p->nrm + 1024,
                               stream)) != DS_OK)
             return rc;
-        std::vector<double> nrm(2048);
-        if ((rc = c.hip(hipMemcpyAsync(nrm.data(), p->nrm, sizeof(double) * 2048, hipMemcpyDeviceToHost, c.st),
+        double* nrm = g_ring.back;
+        if ((rc = c.hip(hipMemcpyAsync(nrm, p->nrm, sizeof(double) * 2048, hipMemcpyDeviceToHost, c.st),
                         "ds_lobpcg_iterate: residual norms to host")) != DS_OK)
             return rc;
         if ((rc = c.hip(hipStreamSynchronize(c.st), "ds_lobpcg_iterate: stream synchronise")) != DS_OK) return rc;
