@@ -275,18 +275,14 @@ def main():
         # --warmup 0: the lanes' streams, operators and value arrays are set-up, not part of a step
         pipe.run_batch([(MAT[1], MAT[2])] * min(a.lanes, len(mine)), lanes=a.lanes, backward=False)
 
-    # ---- instrument the dominant kernel: every launch of the fused Chebyshev-term SpMM on a full b-column block,
-    #      fine and corner-node level alike (they are ONE kernel, rocprofv3 reports them under one name), with HIP
-    #      events on the launching stream; narrower blocks (after locking) run another instantiation
-    #      The FIRST lane is instrumented: it issues the terms one by one from the solver loop; the other lanes run the
-    #      whole V-cycle through the native driver (ds_twolevel_apply), which leaves no place for per-launch events.
-    events = []
+    # ---- instrument the dominant kernel: every launch of the fused Chebyshev-term SpMM (fine and corner-node level
+    #      alike: they are ONE kernel) on the FIRST hypothesis lane's stream is bracketed by HIP events inside the
+    #      library (ds_profile_stream) - the launches come from the native drivers, not from Python
+    from diffsound_amd import _hip
     lane_ops = [ln.ops for ln in pipe._lanes if ln.ops is not None] or [pipe.ops]
-    for o in lane_ops[:1]:
-        for lvl in (o, getattr(o, "coarse", None)):
-            if lvl is not None:
-                lvl.spmm_event_cols = a.block
-                lvl.cheb_events = events
+    prof_stream = pipe._lanes[0].stream.cuda_stream if pipe._lanes else torch.cuda.current_stream(dev).cuda_stream
+    PROF_CAP = 20000
+    _hip.check(_hip.lib().ds_profile_stream(prof_stream, PROF_CAP), "ds_profile_stream")
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -304,22 +300,30 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax[0])
 
-    for o in lane_ops:
-        for lvl in (o, getattr(o, "coarse", None)):
-            if lvl is not None:
-                lvl.cheb_events = None
+    import ctypes
+    pms = (ctypes.c_float * PROF_CAP)()
+    pnv, pnz = (ctypes.c_int64 * PROF_CAP)(), (ctypes.c_int64 * PROF_CAP)()
+    pnc, pfi = (ctypes.c_int32 * PROF_CAP)(), (ctypes.c_int32 * PROF_CAP)()
+    nrec = int(_hip.lib().ds_profile_collect(pms, pnv, pnz, pnc, pfi, PROF_CAP))
     sysd = pipe.system
     roof = None
-    if events:
-        ms = np.array([s_.elapsed_time(e_) for s_, e_, _ in events])
-        nbytes = np.array([b_ for _, _, b_ in events], dtype=np.float64)
+    if nrec:
+        ms_all = np.array(pms[:nrec], dtype=np.float64)
+        nv_a, nz_a = np.array(pnv[:nrec], dtype=np.float64), np.array(pnz[:nrec], dtype=np.float64)
+        nc_a, fi_a = np.array(pnc[:nrec], dtype=np.float64), np.array(pfi[:nrec], dtype=np.float64)
+        # algorithmic bytes of a fused term (HipModalOps.cheb_term_bytes): values + ids, row pointers, block-Jacobi blocks,
+        # W_k gathered, R0 and W_{k-1} read (not when `first`), W_{k+1} written
+        by_all = nz_a * 40 + (nv_a + 1) * 4 + nv_a * 36 + (4 - fi_a) * 3 * nv_a * nc_a * 4
+        full = nc_a == a.block  # full-width blocks (after locking the narrower ones run another instantiation)
+        ms, nbytes = ms_all[full], by_all[full]
         achieved = float(nbytes.sum() / (ms.sum() * 1e-3) / 1e9)
         nlanes = min(a.lanes, a.hyp_per_gpu)
-        fine = nbytes > 0.5 * nbytes.max()  # fine-level launches (the corner-node level moves ~13x fewer bytes)
+        fine = nv_a[full] == sysd.nv
         levels = {name: {"launches": int(m.sum()), "avg_launch_ms": float(ms[m].mean()),
                          "algorithmic_bytes_per_launch": float(nbytes[m].mean()),
                          "achieved": float(nbytes[m].sum() / (ms[m].sum() * 1e-3) / 1e9)}
                   for name, m in (("fine", fine), ("corner_node", ~fine)) if m.any()}
+        all_widths = {"launches": int(nrec), "achieved": float(by_all.sum() / (ms_all.sum() * 1e-3) / 1e9)}
         # the same kernel alone on the device (fine level, 80 columns): what one launch achieves when it does not
         # share the chip with the other hypothesis lanes' kernels
         ops0 = lane_ops[0]
@@ -338,7 +342,6 @@ def main():
         solo = fine_bytes / (solo_ms * 1e-3) / 1e9
         del Wk, Wp, R0
         # STREAM triad a = b + s c on the same device, right here: 3 arrays of 1 GiB (4x the Infinity Cache)
-        from diffsound_amd import _hip
         ne = 1 << 28
         ta, tb, tc = (torch.empty(ne, device=dev) for _ in range(3))
         tb.fill_(1.0), tc.fill_(2.0)
@@ -371,11 +374,11 @@ def main():
                         "device, same run; 'traffic' = PMC bytes of one such launch (profiles/)"),
                 "in_situ": {"achieved": achieved, "frac": achieved / HBM_PEAK_GBS,
                             "algorithmic_bytes_per_launch": float(nbytes.mean()), "avg_launch_ms": float(ms.mean()),
-                            "launches_timed": int(len(ms)), "levels": levels,
-                            "note": (f"HIP events around every fused-term launch of the FIRST hypothesis lane inside the timed "
-                                     f"region, fine and corner-node level; {nlanes} lanes launch concurrently on separate "
-                                     "streams, so a launch shares the device with the other lanes' kernels and its "
-                                     "duration is stretched accordingly")}}
+                            "launches_timed": int(len(ms)), "levels": levels, "all_block_widths": all_widths,
+                            "note": (f"HIP events (ds_profile_stream) around every fused-term launch on the FIRST hypothesis "
+                                     f"lane's stream inside the timed region, {a.block}-column blocks, fine and corner-node "
+                                     f"level; {nlanes} lanes launch concurrently on separate streams, so a launch shares "
+                                     "the device with the other lanes' kernels and its duration is stretched accordingly")}}
 
     if getattr(pipe.ops, "coarse", None) is not None and a.precond != "chebyshev":
         precond_desc = (f"two-level V-cycle: Chebyshev({a.smooth_degree}, ratio {a.smooth_ratio:g}) block-Jacobi smoother + "

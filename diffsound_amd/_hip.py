@@ -12,7 +12,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libdiffsound_hip.so")
-ABI_VERSION = 16  # DS_ABI_VERSION of include/diffsound_hip.h
+ABI_VERSION = 17  # DS_ABI_VERSION of include/diffsound_hip.h
 
 c_i32p = ctypes.POINTER(ctypes.c_int32)
 _P = ctypes.c_void_p
@@ -59,6 +59,8 @@ _SIGNATURES = {
     "ds_osc_tv_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _D, _P, _P, _P]),
     "ds_osc_tv_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _D, _P, _P, _P, _P, _P]),
     "ds_stream_triad": (_I, [_P, _P, _P, _I64, _F, _P]),
+    "ds_profile_stream": (_I, [_P, _I64]),
+    "ds_profile_collect": (_I64, [_P, _P, _P, _P, _P, _I64]),
     "ds_stft_power": (_I, [_P, _I, _I, _I, _I, _P, _P, _P, _P]),
     "ds_spec_loss": (_I, [_I, _P, _P, _I, _I, _I, _F, _F, _I, _P, _P, _P]),
     "ds_stft_power_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _F, _P, _P, _P]),

@@ -12,7 +12,10 @@
 // address (hardware broadcast).  Accumulation in registers, one store per output element.
 // Algorithmic bytes per launch: nnzb*(vals + 4) + (nv+1)*4 + 2*3nv*ncols*sizeof(T).
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
+#include <mutex>
+#include <vector>
 
 #include "ds_common.h"
 
@@ -582,6 +585,53 @@ extern "C" int ds_spmm_residual(const int32_t* rowptr, const int32_t* colidx, co
 }
 
 
+// ------------------------------------------------------------------------------------------------
+// Launch timing hook (bench.py's live roofline figure): while a stream is registered with ds_profile_stream, every
+// fused Chebyshev-term launch (epilogue 1) on it is bracketed by HIP events; ds_profile_collect returns the durations
+// with the shape of each launch.  One registered stream at a time; a relaxed flag keeps the cost off every other launch.
+namespace {
+struct TermRecord {
+    hipEvent_t e0, e1;
+    int64_t nv, nnzb;
+    int ncols, first;
+};
+std::atomic<void*> g_prof_stream{nullptr};
+std::mutex g_prof_mutex;
+std::vector<TermRecord> g_prof_records;
+size_t g_prof_cap = 0;
+}  // namespace
+
+extern "C" int ds_profile_stream(ds_stream_t stream, int64_t capacity) {
+    std::lock_guard<std::mutex> lock(g_prof_mutex);
+    for (auto& r : g_prof_records) {
+        (void)hipEventDestroy(r.e0);
+        (void)hipEventDestroy(r.e1);
+    }
+    g_prof_records.clear();
+    g_prof_cap = capacity > 0 ? (size_t)capacity : 0;
+    g_prof_stream.store(capacity > 0 ? stream : nullptr);
+    return DS_OK;
+}
+
+extern "C" int64_t ds_profile_collect(float* ms, int64_t* nv, int64_t* nnzb, int32_t* ncols, int32_t* first, int64_t cap) {
+    std::lock_guard<std::mutex> lock(g_prof_mutex);
+    g_prof_stream.store(nullptr);
+    int64_t n = 0;
+    for (auto& r : g_prof_records) {
+        if (n < cap && hipEventSynchronize(r.e1) == hipSuccess) {
+            float t = 0.f;
+            if (hipEventElapsedTime(&t, r.e0, r.e1) == hipSuccess) {
+                ms[n] = t, nv[n] = r.nv, nnzb[n] = r.nnzb, ncols[n] = r.ncols, first[n] = r.first;
+                ++n;
+            }
+        }
+        (void)hipEventDestroy(r.e0);
+        (void)hipEventDestroy(r.e1);
+    }
+    g_prof_records.clear();
+    return n;
+}
+
 extern "C" int ds_spmm_union(int epilogue, const int32_t* utab, const int32_t* ctab, int64_t ngroups, int cap_blocks,
                              const int32_t* gent,
                              const float* kgrp, int64_t nnzb, int64_t nv, const float* X, int64_t ldx, float* Y,
@@ -614,6 +664,22 @@ extern "C" int ds_spmm_union(int epilogue, const int32_t* utab, const int32_t* c
         epi.wprev = Wprev, epi.ldp = ldp;
     }
     const int lpn = ncols / 4;
+    if (epilogue == 1 && g_prof_stream.load(std::memory_order_relaxed) == stream && stream != nullptr) {
+        std::lock_guard<std::mutex> lock(g_prof_mutex);
+        if (g_prof_records.size() < g_prof_cap) {
+            TermRecord r{nullptr, nullptr, nv, nnzb, ncols, first};
+            if (hipEventCreate(&r.e0) == hipSuccess && hipEventCreate(&r.e1) == hipSuccess) {
+                (void)hipEventRecord(r.e0, st);
+                const int rc = lpn == 20 ? launch_union<20, 1>(utab, ctab, ngroups, cap_blocks, gent, kgrp, nnzb, nv, X, ldx, Y,
+                                                               ldy, lpn, st, epi)
+                                         : launch_union<0, 1>(utab, ctab, ngroups, cap_blocks, gent, kgrp, nnzb, nv, X, ldx, Y,
+                                                              ldy, lpn, st, epi);
+                (void)hipEventRecord(r.e1, st);
+                g_prof_records.push_back(r);
+                return rc;
+            }
+        }
+    }
 #define DS_U(L, E) return launch_union<L, E>(utab, ctab, ngroups, cap_blocks, gent, kgrp, nnzb, nv, X, ldx, Y, ldy, lpn, st, epi)
     if (lpn == 20) {
         if (epilogue == 1) DS_U(20, 1);

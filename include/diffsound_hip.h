@@ -40,7 +40,7 @@ enum { DS_OK = 0, DS_ERR_ARG = 1, DS_ERR_HIP = 2, DS_ERR_NOMEM = 3 };
 /* Thread-local text of the last error returned on this thread ("" if none). */
 const char* ds_last_error(void);
 /* Library ABI version (bumped on any signature change); ds_abi_version() returns the value the library was built with. */
-#define DS_ABI_VERSION 16
+#define DS_ABI_VERSION 17
 int ds_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------------
@@ -366,6 +366,14 @@ int ds_spec_loss(int kind, const float* Pp, const float* Pt, int B, int F, int T
                  double* sums, float* gP, ds_stream_t stream);
 int ds_stft_power_bwd(const float* gP, const float* re, const float* im, int B, int S, int n_fft, int hop,
                       float gscale, float* gframes, float* gx, ds_stream_t stream);
+
+/* Launch timing hook for the benchmark's live roofline figure: while `stream` is registered (capacity > 0; 0 or a
+ * NULL stream un-registers), every fused Chebyshev-term launch (ds_spmm_union epilogue 1) issued on it - from Python or
+ * from the native drivers - is bracketed by HIP events.  ds_profile_collect un-registers, waits for the events and
+ * returns the number of records copied: duration [ms], nv, nnzb, ncols and the `first` flag of each launch (the
+ * algorithmic bytes follow from those).  One stream at a time. */
+int ds_profile_stream(ds_stream_t stream, int64_t capacity);
+int64_t ds_profile_collect(float* ms, int64_t* nv, int64_t* nnzb, int32_t* ncols, int32_t* first, int64_t cap);
 
 /* ------------------------------------------------------------------------------------------------
  * STREAM triad  a = b + s c  (n f32 elements, n % 4 == 0, 16-byte aligned): the measured HBM bandwidth
