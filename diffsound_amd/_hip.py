@@ -12,7 +12,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libdiffsound_hip.so")
-ABI_VERSION = 17  # DS_ABI_VERSION of include/diffsound_hip.h
+ABI_VERSION = 18  # DS_ABI_VERSION of include/diffsound_hip.h
 
 c_i32p = ctypes.POINTER(ctypes.c_int32)
 _P = ctypes.c_void_p
@@ -78,7 +78,8 @@ class TwoLevelDesc(ctypes.Structure):
     _fields_ = [("fine", LevelDesc), ("coarse", LevelDesc), ("rptr", _P), ("rcol", _P), ("rw", _P), ("pptr", _P),
                 ("pcol", _P), ("pw", _P), ("R", _P), ("ldr", _I64), ("W", _P), ("ldw", _I64), ("D", _P), ("ldd", _I64),
                 ("AD", _P), ("lda", _I64), ("Rr", _P), ("ldrr", _I64), ("Rc", _P), ("Ec", _P), ("Dc", _P), ("ADc", _P),
-                ("ldc", _I64), ("ncols", ctypes.c_int32), ("Wc", _P), ("ldwc", _I64)]
+                ("ldc", _I64), ("ncols", ctypes.c_int32), ("Wc", _P), ("ldwc", _I64), ("storage", ctypes.c_int32),
+                ("R16", _P), ("ldr16", _I64)]
 
 
 class LapackTable(ctypes.Structure):
@@ -94,7 +95,7 @@ class LobpcgDesc(ctypes.Structure):
                 ("A_norm", _D), ("B_norm", _D), ("S", _P), ("S2", _P), ("KS", _P), ("KS2", _P), ("R", _P), ("MX", _P),
                 ("MW", _P), ("lds", _I64), ("ldks", _I64), ("ldr", _I64), ("level", LevelDesc), ("mgrp", _P),
                 ("rowptr", _P), ("colidx", _P), ("k32", _P), ("k32t", _P), ("twolevel", ctypes.POINTER(TwoLevelDesc)),
-                ("pa", _P), ("pb", _P), ("ldp", _I64), ("gbuf", _P), ("cbuf", _P), ("nrm", _P), ("lam_dev", _P),
+                ("pa", _P), ("pb", _P), ("ldp", _I64), ("pr16", _P), ("gbuf", _P), ("cbuf", _P), ("nrm", _P), ("lam_dev", _P),
                 ("gram_work", _P), ("gram_work_bytes", _I64), ("lam", ctypes.POINTER(_D)), ("rerr", ctypes.POINTER(_D)),
                 ("history", ctypes.POINTER(_D)), ("history_cap", _i32), ("iterations", _i32), ("result_in_s2", _i32)]
 
@@ -129,6 +130,11 @@ def lapack_table():
 
 _SIGNATURES["ds_twolevel_apply"] = (_I, [ctypes.POINTER(TwoLevelDesc), _P])
 _SIGNATURES["ds_chebyshev_apply"] = (_I, [ctypes.POINTER(LevelDesc), _P, _I64, _P, _I64, _P, _P, _I64, _I, _P])
+_SIGNATURES["ds_chebyshev_apply16"] = (_I, [ctypes.POINTER(LevelDesc), _P, _I64, _P, _I64, _P, _P, _P, _I64, _I, _P])
+_SIGNATURES["ds_spmm_union16"] = (_I, [_I, _P, _P, _I64, _I, _P, _P, _I64, _I64, _P, _I64, _P, _I64, _I, _P, _I64, _P, _I, _F,
+                                      _F, _I, _P, _I64, _P])
+_SIGNATURES["ds_cheb_init16"] = (_I, [_P, _I, _I64, _P, _I64, _P, _I64, _P, _I64, _I, _F, _P])
+_SIGNATURES["ds_scalar_csr_spmm16"] = (_I, [_P, _P, _P, _I64, _P, _I64, _P, _I64, _I, _F, _P])
 _SIGNATURES["ds_lobpcg_iterate"] = (_I, [ctypes.POINTER(LobpcgDesc), ctypes.POINTER(LapackTable), _P])
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 _lib = None

@@ -292,6 +292,7 @@ struct Ctx {
             d.R = R, d.ldr = p->ldr, d.W = W, d.ldw = ldw, d.ncols = na;
             return ds_twolevel_apply(&d, stream);
         }
+        if (p->pr16) return ds_chebyshev_apply16(&p->level, R, p->ldr, W, ldw, p->pa, p->pb, p->pr16, p->ldp, na, stream);
         return ds_chebyshev_apply(&p->level, R, p->ldr, W, ldw, p->pa, p->pb, p->ldp, na, stream);
     }
 

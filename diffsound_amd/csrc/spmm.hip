@@ -15,6 +15,7 @@
 #include <atomic>
 #include <cstdlib>
 #include <mutex>
+#include <type_traits>
 #include <vector>
 
 #include "ds_common.h"
@@ -694,3 +695,49 @@ extern "C" int ds_spmm_union(int epilogue, const int32_t* utab, const int32_t* c
 #undef DS_U
 }
 
+
+// bf16-block form of the two preconditioner epilogues (the V-cycle's iterates are stored in bf16, arithmetic in fp32):
+// X, R0, W_prev bf16; Y bf16, or fp32 when y_f32 (the last term of a cycle, written into the solver's basis buffer).
+extern "C" int ds_spmm_union16(int epilogue, const int32_t* utab, const int32_t* ctab, int64_t ngroups, int cap_blocks,
+                               const int32_t* gent, const float* kgrp, int64_t nnzb, int64_t nv, const void* X,
+                               int64_t ldx, void* Y, int64_t ldy, int y_f32, const void* R0, int64_t ldr,
+                               const float* dinv, int ncols, float c1, float c2, int first, const void* Wprev,
+                               int64_t ldp, ds_stream_t stream) {
+    DS_REQUIRE(ctab && gent && kgrp && X && Y && R0, "ds_spmm_union16: null pointer");
+    DS_REQUIRE(epilogue == 1 || epilogue == 2, "ds_spmm_union16: epilogue must be 1 (Chebyshev term) or 2 (residual)");
+    DS_REQUIRE(epilogue != 1 || dinv, "ds_spmm_union16: the Chebyshev epilogue needs dinv");
+    DS_REQUIRE(nv > 0 && ngroups == (nv + 3) / 4 && nnzb > 0 && ncols > 0 && ncols % 4 == 0 && ncols <= 84,
+               "ds_spmm_union16: ncols must be a multiple of 4 <= 84 and ngroups = ceil(nv / 4)");
+    DS_REQUIRE(cap_blocks > 0 && cap_blocks <= UN_CAPB, "ds_spmm_union16: a chunk of %d blocks exceeds the LDS image", cap_blocks);
+    DS_REQUIRE(ldx >= ncols && ldy >= ncols && ldr >= ncols, "ds_spmm_union16: leading dimension smaller than ncols");
+    DS_REQUIRE(X != Y, "ds_spmm_union16: X and Y must be different buffers");
+    DS_REQUIRE(3 * nv * std::max(std::max(ldx, ldr), std::max(ldy, ldp)) * 4 < (int64_t)PIPE_OOB && nv * 36 < (int64_t)PIPE_OOB,
+               "ds_spmm_union16: operand block exceeds the descriptor range");
+    DS_REQUIRE(nnzb * 36 < ((int64_t)1 << 32), "ds_spmm_union16: value array exceeds the descriptor range");
+    uintptr_t al = reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(R0) | (uintptr_t)(ldx * 2) | (uintptr_t)(ldr * 2);
+    al |= reinterpret_cast<uintptr_t>(Y) | (uintptr_t)(ldy * (y_f32 ? 4 : 2));
+    DS_REQUIRE((al & 7) == 0 && (!y_f32 || ((reinterpret_cast<uintptr_t>(Y) | (uintptr_t)(ldy * 4)) & 15) == 0) &&
+                   ((reinterpret_cast<uintptr_t>(kgrp) | reinterpret_cast<uintptr_t>(ctab)) & 15) == 0,
+               "ds_spmm_union16: bf16 rows must be 8-byte aligned (fp32 output rows, kgrp and ctab 16-byte)");
+    hipStream_t st = ds::as_stream(stream);
+    ChebEpilogue epi{static_cast<const float*>(R0), ldr, dinv, c1, c2, first};
+    if (Wprev && epilogue == 1) {
+        DS_REQUIRE(ldp >= ncols && ((reinterpret_cast<uintptr_t>(Wprev) | (uintptr_t)(ldp * 2)) & 7) == 0 && Wprev != X,
+                   "ds_spmm_union16: bad W_prev block");
+        epi.wprev = static_cast<const float*>(Wprev), epi.ldp = ldp;
+    }
+    DS_REQUIRE(!y_f32 || epilogue == 1, "ds_spmm_union16: an fp32 result is the Chebyshev term's only");
+    const float* Xf = static_cast<const float*>(X);
+    float* Yf = static_cast<float*>(Y);
+    const int lpn = ncols / 4;
+#define DS_U16(L, E, O) return launch_union<L, E, true, O>(utab, ctab, ngroups, cap_blocks, gent, kgrp, nnzb, nv, Xf, ldx, Yf, ldy, lpn, st, epi)
+    if (lpn == 20) {
+        if (epilogue == 2) DS_U16(20, 2, false);
+        if (y_f32) DS_U16(20, 1, true);
+        DS_U16(20, 1, false);
+    }
+    if (epilogue == 2) DS_U16(0, 2, false);
+    if (y_f32) DS_U16(0, 1, true);
+    DS_U16(0, 1, false);
+#undef DS_U16
+}

@@ -52,7 +52,74 @@ int chebyshev(const ds_level_t& L, const float* R, int64_t ldr, float* Wout, int
     return DS_OK;
 }
 
+// The same recurrence on bf16 blocks (ds_spmm_union16): R16 is the bf16 right-hand side every term reads; the iterates
+// ping-pong between the bf16 scratch blocks A and B; the LAST term writes Wout - bf16, or fp32 when out32 (the result
+// that goes back to the solver).  Not from a guess: W_1 = T Rinit / theta, Rinit fp32 (rinit_f32: the solver's residual
+// block, whose bf16 copy is written to R16 on the way) or bf16 (then Rinit == R16).
+int chebyshev16(const ds_level_t& L, const void* Rinit, int rinit_f32, int64_t ldri, void* R16, int64_t ldr, void* Wout,
+                int64_t ldw, int out32, void* A, void* B, int64_t lds, int ncols, bool from_guess, ds_stream_t stream) {
+    const double theta = 0.5 * (L.lmax + L.lmin), delta = 0.5 * (L.lmax - L.lmin);
+    const double sigma1 = theta / delta;
+    double rho = 1.0 / sigma1;
+    const int terms = from_guess ? L.degree : L.degree - 1;
+    if (terms == 0 && out32) {
+        ds::set_error("chebyshev16: a degree-1 polynomial has no fused term to convert its result");
+        return DS_ERR_ARG;
+    }
+    void *cur = A, *oth = B;
+    if (!from_guess) {
+        int rc = ds_cheb_init16(Rinit, rinit_f32, ldri, terms == 0 ? Wout : cur, terms == 0 ? ldw : lds,
+                                rinit_f32 ? R16 : nullptr, ldr, L.dinv, L.nv, ncols, (float)(1.0 / theta), stream);
+        if (rc != DS_OK) return rc;
+    }
+    for (int k = 0; k < terms; ++k) {
+        float c1, c2;
+        if (from_guess && k == 0) {
+            c1 = 0.f, c2 = (float)(1.0 / theta);
+        } else {
+            const double rho_new = 1.0 / (2.0 * sigma1 - rho);
+            c1 = (float)(rho_new * rho), c2 = (float)(2.0 * rho_new / delta);
+            rho = rho_new;
+        }
+        const bool last = k == terms - 1;
+        int rc = ds_spmm_union16(1, L.utab, L.ctab, L.ngroups, L.cap_blocks, L.gent, L.kgrp, L.nnzb, L.nv, cur, lds,
+                                 last ? Wout : oth, last ? ldw : lds, last ? out32 : 0, R16, ldr, L.dinv, ncols, c1, c2,
+                                 k == 0 ? 1 : 0, last ? oth : nullptr, last ? lds : 0, stream);
+        if (rc != DS_OK) return rc;
+        void* t = cur;
+        cur = oth, oth = t;
+    }
+    return DS_OK;
+}
+
+int twolevel16(const ds_twolevel_t* p, ds_stream_t stream) {
+    const int c = p->ncols;
+    // W1 = S R (bf16 iterates in Wc / D / AD; R16 = bf16 copy of R, written by the first step)
+    int rc = chebyshev16(p->fine, p->R, 1, p->ldr, p->R16, p->ldr16, p->Wc, p->ldwc, 0, p->D, p->AD, p->ldd, c, false, stream);
+    if (rc != DS_OK) return rc;
+    rc = ds_spmm_union16(2, p->fine.utab, p->fine.ctab, p->fine.ngroups, p->fine.cap_blocks, p->fine.gent, p->fine.kgrp,
+                         p->fine.nnzb, p->fine.nv, p->Wc, p->ldwc, p->Rr, p->ldrr, 0, p->R16, p->ldr16, nullptr, c, 0.f, 0.f,
+                         0, nullptr, 0, stream);
+    if (rc != DS_OK) return rc;
+    rc = ds_scalar_csr_spmm16(p->rptr, p->rcol, p->rw, p->coarse.nv, p->Rr, p->ldrr, p->Rc, p->ldc, c, 0.f, stream);
+    if (rc != DS_OK) return rc;
+    rc = chebyshev16(p->coarse, p->Rc, 0, p->ldc, p->Rc, p->ldc, p->Ec, p->ldc, 0, p->Dc, p->ADc, p->ldc, c, false, stream);
+    if (rc != DS_OK) return rc;
+    rc = ds_scalar_csr_spmm16(p->pptr, p->pcol, p->pw, p->fine.nv, p->Ec, p->ldc, p->Wc, p->ldwc, c, 1.f, stream);
+    if (rc != DS_OK) return rc;
+    // W = W2 + S (R - K W2): from the guess W2 (in Wc); the last term writes the fp32 result into W
+    return chebyshev16(p->fine, nullptr, 0, 0, p->R16, p->ldr16, p->W, p->ldw, 1, p->Wc, p->D, p->ldd, c, true, stream);
+}
+
 }  // namespace
+
+extern "C" int ds_chebyshev_apply16(const ds_level_t* level, const float* R, int64_t ldr, float* W, int64_t ldw, void* a,
+                                    void* b, void* r16, int64_t lds, int ncols, ds_stream_t stream) {
+    DS_REQUIRE(level && R && W && a && b && r16, "ds_chebyshev_apply16: null pointer");
+    DS_REQUIRE(level->degree >= 2 && level->lmax > level->lmin && level->lmin > 0,
+               "ds_chebyshev_apply16: needs a polynomial of degree >= 2");
+    return chebyshev16(*level, R, 1, ldr, r16, lds, W, ldw, 1, a, b, lds, ncols, false, stream);
+}
 
 extern "C" int ds_chebyshev_apply(const ds_level_t* level, const float* R, int64_t ldr, float* W, int64_t ldw, float* a,
                                   float* b, int64_t lds, int ncols, ds_stream_t stream) {
@@ -71,6 +138,11 @@ extern "C" int ds_twolevel_apply(const ds_twolevel_t* p, ds_stream_t stream) {
     DS_REQUIRE(p->fine.degree >= 1 && p->coarse.degree >= 1 && p->fine.lmax > p->fine.lmin && p->fine.lmin > 0.0 &&
                    p->coarse.lmax > p->coarse.lmin && p->coarse.lmin > 0.0,
                "ds_twolevel_apply: bad polynomial degrees / spectral intervals");
+    if (p->storage == 1) {
+        DS_REQUIRE(p->R16 && p->ldr16 >= p->ncols && p->fine.degree >= 1, "ds_twolevel_apply: bf16 storage needs the R16 block");
+        return twolevel16(p, stream);
+    }
+    DS_REQUIRE(p->storage == 0, "ds_twolevel_apply: storage must be 0 (fp32) or 1 (bf16)");
     const int c = p->ncols;
     // fine-level iterates live in the compact blocks Wc / D / AD; W is written once, by the last term of the cycle
     int rc = chebyshev(p->fine, p->R, p->ldr, p->Wc, p->ldwc, p->D, p->AD, p->ldd, c, false, stream);  // W1 = S R

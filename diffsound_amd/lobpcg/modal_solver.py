@@ -61,6 +61,10 @@ class SolverConfig:
     # the Gram matrix (a third of the SpMM columns, half of the Gram flops).  Every ``rr_refresh``-th
     # iteration recomputes K [X P W] and the whole Gram matrix from the vectors (0 = every iteration).
     rr_refresh: int = 8
+    # storage of the preconditioner's internal blocks (V-cycle iterates, residuals, corner-level vectors): "bf16" halves
+    # the bytes of every fused term - the cycle is bound by them - and leaves the outer iteration counts unchanged
+    # (fp32 arithmetic in registers; the cycle's input R and output W stay fp32); "fp32" keeps everything in fp32
+    precond_storage: str = "bf16"
     native: bool = True  # run the iteration through ds_lobpcg_iterate when possible (False: the Python loop below)
     # Nested iteration (ops with a ``coarse`` level, cold starts only): the random start block is first iterated on the
     # corner-node (P1) level - 14x fewer non-zeros, the same block width - to ``nested_tol``, and its prolongation
@@ -314,6 +318,8 @@ class TwoLevelChebyshev:
 
     def __init__(self, ops, cfg):
         self.ops = ops
+        self.storage = cfg.precond_storage
+        self._buf16 = None
         args = (cfg.power_iters, cfg.seed, cfg.lmax_safety)
         self.smooth = ChebyshevBlockJacobi(ops, cfg.smooth_degree, cfg.smooth_ratio, *args, cap=cfg.lmax_cap)
         self.coarse = ChebyshevBlockJacobi(ops.coarse, cfg.coarse_degree, cfg.coarse_ratio, *args,
@@ -333,6 +339,15 @@ class TwoLevelChebyshev:
                 self._buf = (mk(R.shape[0]), mk(nc), mk(nc), mk(R.shape[0]))
             Rr, Rc, Ec, Wc = self._buf
             native = getattr(ops, "twolevel_apply", None)
+            if native is not None and self.use_native and self.storage == "bf16" and R.is_cuda:
+                if self._buf16 is None or self._buf16[0].shape[2] != w:
+                    mk = lambda cnt, rows: torch.empty((cnt, rows, w), dtype=torch.bfloat16, device=R.device)
+                    self._buf16 = (mk(5, R.shape[0]), mk(4, nc))
+                f16, c16 = self._buf16
+                if native((self.smooth.degree, self.smooth.lmax, self.smooth.lmin),
+                          (self.coarse.degree, self.coarse.lmax, self.coarse.lmin), Rs, Ws, f16[1], f16[2], f16[3], c16[0],
+                          c16[1], c16[2], c16[3], f16[0], R16=f16[4]):
+                    continue
             if native is not None and self.use_native:
                 D, AD = self.smooth._buffers(Rs)
                 Dc, ADc = self.coarse._buffers(Rc)

@@ -291,14 +291,21 @@ class _HipBlockOps:
         d.degree, d.lmax, d.lmin = int(degree), float(lmax), float(lmin)
         return d
 
-    def twolevel_apply(self, smooth, coarse, R, W, D, AD, Rr, Rc, Ec, Dc, ADc, Wc):
+    def twolevel_apply(self, smooth, coarse, R, W, D, AD, Rr, Rc, Ec, Dc, ADc, Wc, R16=None):
         """The whole two-level V-cycle W = B R through the native driver (ds_twolevel_apply): one call instead of
         ~45 launches issued one by one.  ``smooth`` / ``coarse``: (degree, lmax, lmin) of the two Chebyshev operators.
+        R16 given: every scratch block (D ... Wc, R16) is bf16 and the cycle runs on bf16 iterates (R, W stay fp32).
         Returns False (nothing done) when a level or a block does not qualify for the neighbour-union kernels."""
         co = self.coarse
-        if co is None or self.cheb_events is not None or co.cheb_events is not None:
-            return False  # (the bench times the fused terms launch by launch: that lane keeps the Python path)
-        if not (self._union_ok(R, W, D, AD, Rr, Wc) and co._union_ok(Rc, Ec, Dc, ADc)):
+        if co is None:
+            return False
+        if R16 is not None:
+            blocks = (D, AD, Rr, Wc, R16, Rc, Ec, Dc, ADc)
+            ok = all(t.dtype == torch.bfloat16 and t.stride(1) == 1 and t.stride(0) % 4 == 0 and t.data_ptr() % 8 == 0
+                     for t in blocks) and self._union_ok(R, W) and self.kgrp is not None and co.kgrp is not None
+            if not ok:
+                return False
+        elif not (self._union_ok(R, W, D, AD, Rr, Wc) and co._union_ok(Rc, Ec, Dc, ADc)):
             return False
         d = self._tl_desc
         if d is None:
@@ -317,6 +324,8 @@ class _HipBlockOps:
         d.Rc, d.Ec, d.Dc, d.ADc, d.ldc = Rc.data_ptr(), Ec.data_ptr(), Dc.data_ptr(), ADc.data_ptr(), Rc.stride(0)
         d.ncols = R.shape[1]
         d.Wc, d.ldwc = Wc.data_ptr(), Wc.stride(0)
+        d.storage = 0 if R16 is None else 1
+        d.R16, d.ldr16 = (None, 0) if R16 is None else (R16.data_ptr(), R16.stride(0))
         _hip.check(self._L.ds_twolevel_apply(ctypes.byref(d), _hip.stream_ptr()), "ds_twolevel_apply")
         c = R.shape[1]
         self.counts["apply_K_cols"] += c * (max(smooth[0] - 1, 0) + 1 + smooth[0])
@@ -352,12 +361,16 @@ class _HipBlockOps:
             if (self.level_desc(tl.fine, sm.degree, sm.lmax, sm.lmin) is None
                     or co.level_desc(tl.coarse, cs.degree, cs.lmax, cs.lmin) is None):
                 return None
-            scr = self._scratch("native_tl_fine", (4, self.n, b), torch.float32)
-            scc = co._scratch("native_tl_coarse", (4, co.n, b), torch.float32)
+            bf = cfg.precond_storage == "bf16"
+            sdt = torch.bfloat16 if bf else torch.float32
+            scr = self._scratch("native_tl_fine", (5, self.n, b), sdt)
+            scc = co._scratch("native_tl_coarse", (4, co.n, b), sdt)
             tl.Wc, tl.D, tl.AD, tl.Rr = (scr[i].data_ptr() for i in range(4))
             tl.ldwc = tl.ldd = tl.lda = tl.ldrr = b
             tl.Rc, tl.Ec, tl.Dc, tl.ADc = (scc[i].data_ptr() for i in range(4))
             tl.ldc = b
+            tl.storage = 1 if bf else 0
+            tl.R16, tl.ldr16 = (scr[4].data_ptr(), b) if bf else (None, 0)
             tl.R = tl.W = 1  # (set per application by the driver; non-null for its argument check)
             d.twolevel = ctypes.pointer(tl)
             keep += [tl, scr, scc]
@@ -365,8 +378,10 @@ class _HipBlockOps:
         elif isinstance(precond, ChebyshevBlockJacobi):
             if precond.ops is not self or self.level_desc(d.level, precond.degree, precond.lmax, precond.lmin) is None:
                 return None
-            scr = self._scratch("native_cheb", (2, self.n, b), torch.float32)
+            bf = cfg.precond_storage == "bf16" and precond.degree >= 2
+            scr = self._scratch("native_cheb", (3, self.n, b), torch.bfloat16 if bf else torch.float32)
             d.pa, d.pb, d.ldp = scr[0].data_ptr(), scr[1].data_ptr(), b
+            d.pr16 = scr[2].data_ptr() if bf else None
             keep.append(scr)
         else:
             return None

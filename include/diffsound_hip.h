@@ -40,7 +40,7 @@ enum { DS_OK = 0, DS_ERR_ARG = 1, DS_ERR_HIP = 2, DS_ERR_NOMEM = 3 };
 /* Thread-local text of the last error returned on this thread ("" if none). */
 const char* ds_last_error(void);
 /* Library ABI version (bumped on any signature change); ds_abi_version() returns the value the library was built with. */
-#define DS_ABI_VERSION 17
+#define DS_ABI_VERSION 18
 int ds_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------------
@@ -244,12 +244,31 @@ typedef struct {
     int32_t ncols;
     float* Wc;       /* fine scratch: the cycle's iterate (compact), W itself is written once at the end */
     int64_t ldwc;    /* = ldd = lda */
+    int32_t storage; /* 0: every scratch block fp32 ; 1: every scratch block bf16 (same fields, 2-byte elements; R and W
+                        stay fp32): the preconditioner's iterates need no more mantissa, and its terms are bound by
+                        the bytes of their vector streams */
+    void* R16;       /* storage 1: fine bf16 scratch for the copy of R (rows x ncols, leading dimension ldr16) */
+    int64_t ldr16;
 } ds_twolevel_t;
 int ds_twolevel_apply(const ds_twolevel_t* p, ds_stream_t stream);
 /* One-level form: W <- p(T K) T R with the level's degree / [lmin, lmax] (Chebyshev block-Jacobi polynomial, every term
  * one fused ds_spmm_union launch); a, b: compact scratch blocks (rows x ncols, leading dimension lds). */
 int ds_chebyshev_apply(const ds_level_t* level, const float* R, int64_t ldr, float* W, int64_t ldw, float* a, float* b,
                        int64_t lds, int ncols, ds_stream_t stream);
+/* ... with bf16 scratch blocks a, b, r16 (rows x ncols bf16, leading dimension lds); degree >= 2. */
+int ds_chebyshev_apply16(const ds_level_t* level, const float* R, int64_t ldr, float* W, int64_t ldw, void* a, void* b,
+                         void* r16, int64_t lds, int ncols, ds_stream_t stream);
+/* bf16-block forms used by the bf16 V-cycle: the fused terms (X, R0, W_prev bf16; Y bf16, or fp32 when y_f32), the
+ * first Chebyshev iterate W1 = c T R (R fp32 - then Rcopy, if not NULL, receives its bf16 copy - or bf16) and the level
+ * transfer.  Leading dimensions in elements; bf16 rows 8-byte aligned. */
+int ds_spmm_union16(int epilogue, const int32_t* utab, const int32_t* ctab, int64_t ngroups, int cap_blocks,
+                    const int32_t* gent, const float* kgrp, int64_t nnzb, int64_t nv, const void* X, int64_t ldx,
+                    void* Y, int64_t ldy, int y_f32, const void* R0, int64_t ldr, const float* dinv, int ncols,
+                    float c1, float c2, int first, const void* Wprev, int64_t ldp, ds_stream_t stream);
+int ds_cheb_init16(const void* R, int r_f32, int64_t ldr, void* W, int64_t ldw, void* Rcopy, int64_t ldc,
+                   const float* dinv, int64_t nv, int ncols, float c, ds_stream_t stream);
+int ds_scalar_csr_spmm16(const int32_t* rowptr, const int32_t* colidx, const float* w, int64_t nrows, const void* X,
+                         int64_t ldx, void* Y, int64_t ldy, int ncols, float beta, ds_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * The eigensolver's iteration as ONE native call (csrc/lobpcg.cpp): the loop of the reference's LOBPCG.run /
@@ -285,6 +304,7 @@ typedef struct {
     const ds_twolevel_t* twolevel;    /* two-level preconditioner (scratch blocks with >= b columns), or NULL */
     float *pa, *pb;           /* one-level preconditioner scratch (n x b), leading dimension ldp */
     int64_t ldp;
+    void* pr16;               /* not NULL: pa, pb, pr16 are bf16 blocks and the polynomial runs on bf16 iterates */
     double* gbuf;             /* device, (ny + 3 b) x 3 b doubles: Gram results */
     float* cbuf;              /* device, 8 x (ny + 3 b) x 2 b floats: update coefficients (a ring of 8 slots) */
     double* nrm;              /* device, 2 x 1024 doubles */

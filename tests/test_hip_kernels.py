@@ -286,7 +286,7 @@ def test_two_level_cycle_matches_oracle(case, dev):
     h, c = case["hops"], case["cops"]
     if case["order"] != 2:
         pytest.skip("no coarse level on an ord-1 mesh")
-    cfg = SolverConfig(lmax_cap=10.0, smooth_degree=3, coarse_degree=12, coarse_ratio=50.0)
+    cfg = SolverConfig(lmax_cap=10.0, smooth_degree=3, coarse_degree=12, coarse_ratio=50.0, precond_storage="fp32")
     ph, pc = TwoLevelChebyshev(h, cfg), TwoLevelChebyshev(c, cfg)
     assert abs(ph.smooth.lmax / pc.smooth.lmax - 1) < 0.05 and abs(ph.coarse.lmax / pc.coarse.lmax - 1) < 0.05
     for a, b in ((ph.smooth, pc.smooth), (ph.coarse, pc.coarse)):  # same polynomial on both sides
@@ -315,6 +315,89 @@ def test_two_level_cycle_matches_oracle(case, dev):
     assert torch.equal(Wn, Wh)
     assert (k2[0] - k1[0], k2[1] - k1[1]) == (k1[0] - k0[0], k1[1] - k0[1])  # same product counts either way
     assert calls[0] > 0
+    # bf16 storage of the cycle's internal blocks (the default): the same operator up to the rounding of the stored
+    # iterates (8-bit mantissas, fp32 arithmetic), deterministic, fp32 in and out
+    p16 = TwoLevelChebyshev(h, SolverConfig(lmax_cap=10.0, smooth_degree=3, coarse_degree=12, coarse_ratio=50.0))
+    assert p16.storage == "bf16"
+    for a, b in ((p16.smooth, pc.smooth), (p16.coarse, pc.coarse)):
+        a.lmax, a.lmin = b.lmax, b.lmin
+    W16 = torch.full((h.n, 96), float("nan"), device=dev)
+    p16.apply(R.to(dev), W16)
+    assert W16.dtype == torch.float32 and bool(torch.isfinite(W16).all())
+    assert rel(W16.cpu().numpy(), Wc.numpy()) < 3e-2
+    cols = np.linalg.norm(W16.cpu().numpy() - Wc.numpy(), axis=0) / np.linalg.norm(Wc.numpy(), axis=0)
+    assert cols.max() < 5e-2  # every column, not only on average
+    W16b = torch.empty((h.n, 96), device=dev)
+    p16.apply(R.to(dev), W16b)
+    assert torch.equal(W16, W16b)
+
+
+@pytest.mark.parametrize("ncols", [80, 40, 84])
+def test_bf16_union_terms_match_fp32_terms(dev, ncols):
+    """ds_spmm_union16 (bf16 X / R0 / W_prev, fp32 arithmetic) against ds_spmm_union on the bf16-rounded operands:
+    the Chebyshev term with bf16 and with fp32 output, the residual; plus the bf16 first iterate (ds_cheb_init16) and
+    the bf16 level transfer against their fp32 counterparts."""
+    from diffsound_amd import _hip, meshgen
+    from diffsound_amd.diffelastic.mesh import TetMesh
+    from diffsound_amd.modal_ops import HipModalOps, TetSystem
+
+    v, t = meshgen.kuhn_box(6)
+    tm = TetMesh(torch.from_numpy(v).to(dev), torch.from_numpy(t).long().to(dev)).to_high_order(2)
+    sysd = TetSystem(tm.vertices, tm.tets, 2, 2700.0)
+    ops = HipModalOps(sysd, 2e10, 2e10)
+    g = torch.Generator(device=dev).manual_seed(ncols)
+    mk = lambda scale=1.0: (torch.randn((sysd.n, ncols), generator=g, device=dev) * scale).bfloat16()
+    X, Wp, R0 = mk(), mk(), mk(1e10)
+    Xf, Wpf, R0f = X.float(), Wp.float(), R0.float()
+    L, p, u, gr = _hip.lib(), _hip.ptr, sysd.groups["union"], sysd.groups
+    ut = None if u["single"] else p(u["utab"])
+
+    def term16(epi, out, y32, first, wprev=None):
+        _hip.check(L.ds_spmm_union16(epi, ut, p(u["ctab"]), u["ngroups"], u["capb"], p(gr["gent"]), p(ops.kgrp), ops.kgrp.shape[0],
+                                     sysd.nv, p(X), ncols, p(out), out.stride(0), int(y32), p(R0), ncols, p(ops.dinv), ncols, 0.31,
+                                     0.77, int(first), p(wprev), 0 if wprev is None else ncols, _hip.stream_ptr()), "ds_spmm_union16")
+
+    for first in (False, True):
+        ref = Wpf.clone()
+        ops._union(1, Xf, ref, R0f, 0.31, 0.77, first)
+        o32 = torch.full((sysd.n, ncols + 8), float("nan"), device=dev)
+        term16(1, o32[:, 4:4 + ncols], True, first, wprev=Wp)          # out of place, fp32 result in a column range
+        assert torch.equal(o32[:, 4:4 + ncols], ref) and bool(torch.isnan(o32[:, :4]).all())
+        o16 = Wp.clone()
+        term16(1, o16, False, first)                                   # in place on the bf16 W_prev
+        assert torch.equal(o16, ref.bfloat16())
+    refr = torch.empty_like(Xf)
+    ops._union(2, Xf, refr, R0f)
+    r16 = torch.empty_like(X)
+    term16(2, r16, False, False)
+    assert torch.equal(r16, refr.bfloat16())
+    # first iterate W1 = c T R from an fp32 block (with its bf16 copy) and from a bf16 block
+    Rf = torch.randn((sysd.n, ncols), generator=g, device=dev) * 1e9
+    Dref, Wref = torch.empty_like(Rf), torch.empty_like(Rf)
+    ops.cheb_init(Rf, Dref, Wref, 0.37)
+    W1, Rc = torch.empty_like(X), torch.empty_like(X)
+    _hip.check(L.ds_cheb_init16(p(Rf), 1, ncols, p(W1), ncols, p(Rc), ncols, p(ops.dinv), sysd.nv, ncols, 0.37, _hip.stream_ptr()),
+               "ds_cheb_init16")
+    assert torch.equal(W1, Wref.bfloat16()) and torch.equal(Rc, Rf.bfloat16())
+    ops.cheb_init(Rc.float(), Dref, Wref, 0.37)
+    W2 = torch.empty_like(X)
+    _hip.check(L.ds_cheb_init16(p(Rc), 0, ncols, p(W2), ncols, None, 0, p(ops.dinv), sysd.nv, ncols, 0.37, _hip.stream_ptr()),
+               "ds_cheb_init16")
+    assert torch.equal(W2, Wref.bfloat16())
+    # level transfer on bf16 panels
+    co, tr = ops.coarse, ops._xfer
+    Rcf = torch.empty((co.n, ncols), device=dev)
+    ops.restrict(Xf, Rcf)
+    Rc16 = torch.empty((co.n, ncols), dtype=torch.bfloat16, device=dev)
+    _hip.check(L.ds_scalar_csr_spmm16(p(tr["rptr"]), p(tr["rcol"]), p(tr["rw"]), co.nv, p(X), ncols, p(Rc16), ncols, ncols, 0.0,
+                                      _hip.stream_ptr()), "ds_scalar_csr_spmm16")
+    assert torch.equal(Rc16, Rcf.bfloat16())
+    Wf = Wpf.clone()
+    ops.prolong_add(Rc16.float(), Wf)
+    W16 = Wp.clone()
+    _hip.check(L.ds_scalar_csr_spmm16(p(tr["pptr"]), p(tr["pcol"]), p(tr["pw"]), sysd.nv, p(Rc16), ncols, p(W16), ncols, ncols, 1.0,
+                                      _hip.stream_ptr()), "ds_scalar_csr_spmm16")
+    assert torch.equal(W16, Wf.bfloat16())
 
 
 def test_polish_products(case, dev):
