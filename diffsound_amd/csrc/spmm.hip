@@ -711,8 +711,10 @@ extern "C" int ds_spmm_union16(int epilogue, const int32_t* utab, const int32_t*
     DS_REQUIRE(cap_blocks > 0 && cap_blocks <= UN_CAPB, "ds_spmm_union16: a chunk of %d blocks exceeds the LDS image", cap_blocks);
     DS_REQUIRE(ldx >= ncols && ldy >= ncols && ldr >= ncols, "ds_spmm_union16: leading dimension smaller than ncols");
     DS_REQUIRE(X != Y, "ds_spmm_union16: X and Y must be different buffers");
-    DS_REQUIRE(3 * nv * std::max(std::max(ldx, ldr), std::max(ldy, ldp)) * 4 < (int64_t)PIPE_OOB && nv * 36 < (int64_t)PIPE_OOB,
-               "ds_spmm_union16: operand block exceeds the descriptor range");
+    // (the bf16 inputs go through buffer descriptors; the result is stored through plain 64-bit addresses)
+    DS_REQUIRE(3 * nv * std::max(std::max(ldx, ldr), ldp) * 2 < (int64_t)PIPE_OOB && nv * 36 < (int64_t)PIPE_OOB,
+               "ds_spmm_union16: a bf16 operand block of %lld bytes exceeds the descriptor range",
+               (long long)(3 * nv * std::max(std::max(ldx, ldr), ldp) * 2));
     DS_REQUIRE(nnzb * 36 < ((int64_t)1 << 32), "ds_spmm_union16: value array exceeds the descriptor range");
     uintptr_t al = reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(R0) | (uintptr_t)(ldx * 2) | (uintptr_t)(ldr * 2);
     al |= reinterpret_cast<uintptr_t>(Y) | (uintptr_t)(ldy * (y_f32 ? 4 : 2));
