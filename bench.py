@@ -310,10 +310,12 @@ def main():
     if nrec:
         ms_all = np.array(pms[:nrec], dtype=np.float64)
         nv_a, nz_a = np.array(pnv[:nrec], dtype=np.float64), np.array(pnz[:nrec], dtype=np.float64)
-        nc_a, fi_a = np.array(pnc[:nrec], dtype=np.float64), np.array(pfi[:nrec], dtype=np.float64)
+        nc_a = np.array(pnc[:nrec], dtype=np.float64)
+        fl_a = np.array(pfi[:nrec], dtype=np.int64)
+        fi_a, eb_a = (fl_a & 1).astype(np.float64), (fl_a >> 8).astype(np.float64)  # `first` flag, bytes per vector element
         # algorithmic bytes of a fused term (HipModalOps.cheb_term_bytes): values + ids, row pointers, block-Jacobi blocks,
         # W_k gathered, R0 and W_{k-1} read (not when `first`), W_{k+1} written
-        by_all = nz_a * 40 + (nv_a + 1) * 4 + nv_a * 36 + (4 - fi_a) * 3 * nv_a * nc_a * 4
+        by_all = nz_a * 40 + (nv_a + 1) * 4 + nv_a * 36 + (4 - fi_a) * 3 * nv_a * nc_a * eb_a
         full = nc_a == a.block  # full-width blocks (after locking the narrower ones run another instantiation)
         ms, nbytes = ms_all[full], by_all[full]
         achieved = float(nbytes.sum() / (ms.sum() * 1e-3) / 1e9)
@@ -327,18 +329,21 @@ def main():
         # the same kernel alone on the device (fine level, 80 columns): what one launch achieves when it does not
         # share the chip with the other hypothesis lanes' kernels
         ops0 = lane_ops[0]
-        Wk = torch.randn((sysd.n, a.block), device=dev)
-        Wp, R0 = torch.randn_like(Wk), torch.randn_like(Wk)
+        bf = cfg.precond_storage == "bf16"
+        vdt = torch.bfloat16 if bf else torch.float32
+        Wk = torch.randn((sysd.n, a.block), device=dev).to(vdt)
+        Wp, R0 = torch.randn((sysd.n, a.block), device=dev).to(vdt), torch.randn((sysd.n, a.block), device=dev).to(vdt)
+        term = (lambda: ops0.cheb_spmm16(Wk, Wp, R0, 0.3, 0.7, False)) if bf else (lambda: ops0._cheb_spmm_launch(Wk, Wp, R0, 0.3, 0.7, False))
         for _ in range(3):
-            ops0._cheb_spmm_launch(Wk, Wp, R0, 0.3, 0.7, False)
+            term()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(30):
-            ops0._cheb_spmm_launch(Wk, Wp, R0, 0.3, 0.7, False)
+            term()
         e1.record()
         torch.cuda.synchronize()
         solo_ms = e0.elapsed_time(e1) / 30
-        fine_bytes = ops0.cheb_term_bytes(a.block)
+        fine_bytes = ops0.cheb_term_bytes(a.block, elem_bytes=2 if bf else 4)
         solo = fine_bytes / (solo_ms * 1e-3) / 1e9
         del Wk, Wp, R0
         # STREAM triad a = b + s c on the same device, right here: 3 arrays of 1 GiB (4x the Infinity Cache)
@@ -359,14 +364,15 @@ def main():
         pmc = os.path.join(ROOT, "profiles", "spmm_pmc_bytes_per_launch.json")
         if os.path.exists(pmc):
             try:
-                traffic = json.load(open(pmc)).get(f"cells{a.cells}_cols{a.block}")
+                traffic = json.load(open(pmc)).get(f"cells{a.cells}_cols{a.block}_{'bf16' if bf else 'fp32'}")
             except Exception:
                 traffic = None
         roof = {"bound": "hbm", "achieved": solo, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": solo / HBM_PEAK_GBS, "traffic": traffic,
                 "stream_triad": stream_gbs, "frac_of_stream": solo / stream_gbs,
-                "kernel": (f"spmm_union_kernel<{a.block // 4},1>: W' = W + c1(W - W_prev) + c2 T(R0 - K W) on a "
-                           f"{a.block}-column block, fine level"),
+                "kernel": (f"spmm_union_kernel<{a.block // 4},1,...,{'bf16' if bf else 'fp32'} blocks>: W' = W + c1(W - W_prev) + "
+                           f"c2 T(R0 - K W) on a {a.block}-column block, fine level (fp32 K blocks, "
+                           f"{'bf16' if bf else 'fp32'} iterates, fp32 arithmetic)"),
                 "algorithmic_bytes_per_launch": fine_bytes, "avg_launch_ms": solo_ms,
                 "how": ("'achieved' = algorithmic bytes of ONE fine-level fused-term launch / its HIP-event time with the "
                         "kernel alone on the device, on the compact blocks the V-cycle runs it on, right after the timed "
@@ -406,7 +412,8 @@ def main():
                 "hypotheses_per_gpu_per_step": a.hyp_per_gpu,
                 "parallelism": (f"dp{world} over material hypotheses, scalar loss all-reduce; {min(a.lanes, a.hyp_per_gpu)} "
                                 "hypotheses in flight per GPU (one HIP stream + host thread each)"),
-                "precision": "fp32 block vectors and SpMM, fp64 Gram accumulation / Rayleigh-Ritz / read-out",
+                "precision": ("fp32 block vectors and SpMM, fp64 Gram accumulation / Rayleigh-Ritz / read-out; the preconditioner's "
+                              f"internal blocks in {cfg.precond_storage}"),
                 "eigensolver": (f"LOBPCG(ortho) block {a.block}, {precond_desc}, "
                                 f"cold start{' (warm)' if a.warm_start else ''}, mean iterations {np.mean(iters):.1f}"
                                 + (f" after a nested start (mean {np.mean(cits):.1f} corner-node level iterations to "

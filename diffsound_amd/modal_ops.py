@@ -525,11 +525,21 @@ class _HipBlockOps:
             e1.record()
             self.cheb_events.append((e0, e1, self.cheb_term_bytes(Wk.shape[1], first)))
 
-    def cheb_term_bytes(self, ncols, first=False):
+    def cheb_term_bytes(self, ncols, first=False, elem_bytes=4):
         """Algorithmic bytes of one fused Chebyshev-term launch: K values + ids, row pointers, block-Jacobi blocks,
-        W_k (gathered), R0 and W_{k-1} read (W_{k-1} = 0 is not read when ``first``), W_{k+1} written."""
+        W_k (gathered), R0 and W_{k-1} read (W_{k-1} = 0 is not read when ``first``), W_{k+1} written
+        (``elem_bytes`` = 2 for the bf16 blocks of the production preconditioner)."""
         nnzb = self.colidx.shape[0]
-        return nnzb * (36 + 4) + (self.nv + 1) * 4 + self.nv * 36 + (3 if first else 4) * self.n * ncols * 4
+        return nnzb * (36 + 4) + (self.nv + 1) * 4 + self.nv * 36 + (3 if first else 4) * self.n * ncols * elem_bytes
+
+    def cheb_spmm16(self, Wk, Wprev, R0, c1, c2, first):
+        """The fused term on bf16 blocks (ds_spmm_union16), in place on W_prev: what the bf16 V-cycle launches."""
+        pp = _hip.ptr
+        g, u = self.sys.groups, self.sys.groups["union"]
+        _hip.check(self._L.ds_spmm_union16(1, None if u.get("single") else pp(u["utab"]), pp(u["ctab"]), u["ngroups"], u["capb"],
+                                           pp(g["gent"]), pp(self.kgrp), self.kgrp.shape[0], self.nv, pp(Wk), _ld(Wk), pp(Wprev),
+                                           _ld(Wprev), 0, pp(R0), _ld(R0), pp(self.dinv), Wk.shape[1], float(c1), float(c2),
+                                           int(bool(first)), None, 0, _hip.stream_ptr()), "ds_spmm_union16")
 
     # ------------------------------------------------------------------ two-level preconditioner pieces
     coarse = None  # ops of the corner-node level (HipModalOps on an ord-2 mesh sets it)
@@ -673,7 +683,7 @@ class HipModalOps(_HipBlockOps):
         MY = torch.empty((self.n, 8), dtype=torch.float64, device=self.device)
         for _ in range(2):  # second pass removes the fp32 rounding of the first
             self._spmm(3, self.sys.ms, Y32, MY)
-            G = (Y32.double()[:, :6].T @ MY[:, :6])
+            G = self.gram(Y32, MY)[:6, :6]  # (a 6 x n by n x 6 fp64 product takes rocBLAS 24 ms at the benchmark size)
             Lc = torch.linalg.cholesky(0.5 * (G + G.T))
             Y6 = torch.linalg.solve_triangular(Lc, Y32.double()[:, :6].T, upper=False).T
             Y32 = torch.zeros_like(Y32)

@@ -390,8 +390,9 @@ int ds_stft_power_bwd(const float* gP, const float* re, const float* im, int B, 
 /* Launch timing hook for the benchmark's live roofline figure: while `stream` is registered (capacity > 0; 0 or a
  * NULL stream un-registers), every fused Chebyshev-term launch (ds_spmm_union epilogue 1) issued on it - from Python or
  * from the native drivers - is bracketed by HIP events.  ds_profile_collect un-registers, waits for the events and
- * returns the number of records copied: duration [ms], nv, nnzb, ncols and the `first` flag of each launch (the
- * algorithmic bytes follow from those).  One stream at a time. */
+ * returns the number of records copied: duration [ms], nv, nnzb, ncols and `first` | element bytes of the vector
+ * blocks << 8 (4: fp32 term, 2: bf16 term of ds_spmm_union16) of each launch - the algorithmic bytes follow from those.
+ * One stream at a time. */
 int ds_profile_stream(ds_stream_t stream, int64_t capacity);
 int64_t ds_profile_collect(float* ms, int64_t* nv, int64_t* nnzb, int32_t* ncols, int32_t* first, int64_t cap);
 

@@ -11,7 +11,10 @@ mesh = TetMesh(torch.from_numpy(v).to(dev), torch.from_numpy(t).long().to(dev)).
 sysd = TetSystem(mesh.vertices, mesh.tets, 2, 2700.0)
 ops = HipModalOps(sysd, 2e10, 2e10, two_level=False)
 X = torch.randn(sysd.n, 80, device=dev); W = torch.randn(sysd.n, 80, device=dev); R0 = torch.randn(sysd.n, 80, device=dev)
+bf = len(sys.argv) > 2 and sys.argv[2] == "bf16"
+if bf:
+    X, W, R0 = X.bfloat16(), W.bfloat16(), R0.bfloat16()
 for _ in range(int(sys.argv[1]) if len(sys.argv) > 1 else 4):
-    ops.cheb_spmm(X, W, R0, 0.3, 0.7, False)
+    (ops.cheb_spmm16 if bf else ops.cheb_spmm)(X, W, R0, 0.3, 0.7, False)
 torch.cuda.synchronize()
 print("done", flush=True)
