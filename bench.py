@@ -346,6 +346,18 @@ def main():
         fine_bytes = ops0.cheb_term_bytes(a.block, elem_bytes=2 if bf else 4)
         solo = fine_bytes / (solo_ms * 1e-3) / 1e9
         del Wk, Wp, R0
+        # the eigensolver's own stiffness product K W (fp32 blocks, the "LOBPCG SpMM" of the north star), alone as well
+        Xk, Yk = torch.randn((sysd.n, a.block), device=dev), torch.empty((sysd.n, a.block), device=dev)
+        for _ in range(3):
+            ops0.apply_K(Xk, Yk)
+        e0.record()
+        for _ in range(30):
+            ops0.apply_K(Xk, Yk)
+        e1.record()
+        torch.cuda.synchronize()
+        kw_ms = e0.elapsed_time(e1) / 30
+        kw_bytes = sysd.nnzb * 40 + (sysd.nv + 1) * 4 + 2 * sysd.n * a.block * 4
+        del Xk, Yk
         # STREAM triad a = b + s c on the same device, right here: 3 arrays of 1 GiB (4x the Infinity Cache)
         ne = 1 << 28
         ta, tb, tc = (torch.empty(ne, device=dev) for _ in range(3))
@@ -378,6 +390,10 @@ def main():
                         "kernel alone on the device, on the compact blocks the V-cycle runs it on, right after the timed "
                         "region (30 back-to-back launches); 'stream_triad' = ds_stream_triad on 3 x 1 GiB arrays, same "
                         "device, same run; 'traffic' = PMC bytes of one such launch (profiles/)"),
+                "lobpcg_spmm": {"kernel": f"spmm_union_kernel<{a.block // 4},0>: Y = K X on a {a.block}-column fp32 block (K W of the iteration)",
+                                "algorithmic_bytes_per_launch": kw_bytes, "avg_launch_ms": kw_ms,
+                                "achieved": kw_bytes / (kw_ms * 1e-3) / 1e9, "frac": kw_bytes / (kw_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                "frac_of_stream": kw_bytes / (kw_ms * 1e-3) / 1e9 / stream_gbs},
                 "in_situ": {"achieved": achieved, "frac": achieved / HBM_PEAK_GBS,
                             "algorithmic_bytes_per_launch": float(nbytes.mean()), "avg_launch_ms": float(ms.mean()),
                             "launches_timed": int(len(ms)), "levels": levels, "all_block_widths": all_widths,

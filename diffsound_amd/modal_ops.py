@@ -239,10 +239,6 @@ class _HipBlockOps:
         self._tmp = {}
         self._nrm = torch.empty((2, 1024), dtype=torch.float64, device=device)
         self.counts = dict(apply_K_cols=0, apply_M_cols=0, gram=0, mix=0)
-        # optional profiling hook (bench.py): HIP events around every K-SpMM of ``spmm_event_cols`` columns
-        self.spmm_events = None
-        self.cheb_events = None
-        self.spmm_event_cols = 0
 
     # ------------------------------------------------------------------ sparse products
     def _spmm(self, kind, vals, X, out):
@@ -254,16 +250,9 @@ class _HipBlockOps:
         for c0 in range(0, ncols, maxc):
             c1 = min(ncols, c0 + maxc)
             xs, os_ = X[:, c0:c1], out[:, c0:c1]
-            timed = self.spmm_events is not None and kind == 0 and (c1 - c0) == self.spmm_event_cols
-            if timed:
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
             vt = self.k32t if (kind == 0 and vals is self.k32) else None
             _hip.check(self._L.ds_spmm_bsr3(kind, p(self.rowptr), p(self.colidx), p(vals), p(vt), self.nv, p(xs),
                                             _ld(xs), p(os_), _ld(os_), c1 - c0, _hip.stream_ptr()), "ds_spmm_bsr3")
-            if timed:
-                e1.record()
-                self.spmm_events.append((e0, e1))
 
     def _union_ok(self, X, *others):
         g = getattr(getattr(self, "sys", None), "groups", None)
@@ -516,14 +505,7 @@ class _HipBlockOps:
 
     def cheb_spmm(self, Wk, Wprev, R0, c1, c2, first):
         """Wprev <- Wk + c1 (Wk - Wprev) + c2 T (R0 - K Wk): one fused launch per polynomial term."""
-        timed = self.cheb_events is not None and Wk.shape[1] == self.spmm_event_cols
-        if timed:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
         self._cheb_spmm_launch(Wk, Wprev, R0, c1, c2, first)
-        if timed:
-            e1.record()
-            self.cheb_events.append((e0, e1, self.cheb_term_bytes(Wk.shape[1], first)))
 
     def cheb_term_bytes(self, ncols, first=False, elem_bytes=4):
         """Algorithmic bytes of one fused Chebyshev-term launch: K values + ids, row pointers, block-Jacobi blocks,
