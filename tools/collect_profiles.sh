@@ -15,9 +15,9 @@ mkdir -p $out
 python3 bench.py > $out/${tag}_bench_n1.json 2> $out/${tag}_bench_stderr.log
 echo "bench done"; tail -c 300 $out/${tag}_bench_n1.json; echo
 rm -rf /tmp/prof_b /tmp/prof_l1
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_b -o bench -- python3 bench.py --no-cpu-baseline > $out/${tag}_bench_prof.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_b -o bench -- python3 bench.py --no-cpu-baseline --steps 8 > $out/${tag}_bench_prof.log 2>&1
 python3 tools/summarize_prof.py /tmp/prof_b $out/${tag}_bench_kernel_stats.csv --top 45
-python3 tools/gpu_busy.py /tmp/prof_b 0.5 > $out/${tag}_gpu_busy.txt; cat $out/${tag}_gpu_busy.txt
+python3 tools/gpu_busy.py /tmp/prof_b 0.4 > $out/${tag}_gpu_busy.txt; cat $out/${tag}_gpu_busy.txt  # last 40 % of the run: timed steps only
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_l1 -o bench -- python3 bench.py --no-cpu-baseline --lanes 1 --hyp-per-gpu 2 --steps 4 --warmup 1 > $out/${tag}_bench_prof_l1.log 2>&1
 python3 tools/summarize_prof.py /tmp/prof_l1 $out/${tag}_bench_lanes1_kernel_stats.csv --top 45
 # PMC bytes of the fused term (two passes: the TCC counters do not fit one)

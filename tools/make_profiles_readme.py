@@ -52,7 +52,7 @@ GPU, cold-start eigensolve and numeric assembly in every pass.  Collected by `to
 * dominant kernel `{r["kernel"]}`: {r["algorithmic_bytes_per_launch"] / 1e6:.1f} MB algorithmic per launch, {r["avg_launch_ms"]:.3f} ms alone on the device
   → **{r["achieved"]:.0f} GB/s = {100 * r["frac"]:.1f} % of 8 TB/s, {100 * r["frac_of_stream"]:.1f} % of the STREAM triad measured in the same run ({r["stream_triad"]:.0f} GB/s)**;
   in situ (4 lanes sharing the chip): fine {r["in_situ"]["levels"]["fine"]["avg_launch_ms"]:.3f} ms, corner-node {r["in_situ"]["levels"]["corner_node"]["avg_launch_ms"]:.3f} ms per launch;
-* the eigensolver's K·W: {r.get("lobpcg_spmm", {}).get("achieved", float("nan")):.0f} GB/s = {100 * r.get("lobpcg_spmm", {}).get("frac_of_stream", float("nan")):.0f} % of STREAM (in `r02_bench_lanes1_kernel_stats.csv`: `spmm_union_kernel<20, 0, …>` 0.159 ms for 451.9 MB);
+* the eigensolver's K·W: {r.get("lobpcg_spmm", {}).get("achieved", float("nan")):.0f} GB/s = {100 * r.get("lobpcg_spmm", {}).get("frac_of_stream", float("nan")):.0f} % of STREAM ({r.get("lobpcg_spmm", {}).get("avg_launch_ms", float("nan")):.3f} ms for 451.9 MB, fine level, alone on the device; in `r02_bench_lanes1_kernel_stats.csv` the name `spmm_union_kernel<20, 0, …>` also covers the short corner-level launches of the nested start);
 * CPU baseline: {cb["sample"]} on {cb["cores"]} threads of {cb["cpu_model"]} ({cb["host_hardware_threads"]} hardware threads on the host); stages {cb["stage_seconds"]}.
 
 ## One hypothesis at a time (`r02_bench_lanes1_kernel_stats.csv`; 11 passes incl. the target render and one warm-up step)
