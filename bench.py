@@ -52,6 +52,12 @@ def parse():
     ap.add_argument("--smooth-ratio", type=float, default=10.0)
     ap.add_argument("--coarse-degree", type=int, default=28)
     ap.add_argument("--coarse-ratio", type=float, default=550.0)
+    ap.add_argument("--power-iters", type=int, default=30,
+                    help="power iterations for lambda_max(T K) of the Chebyshev intervals (a quarter of them on every pass "
+                         "after the first); 0 = none, the rigorous bound (nodes per element: 10 / 4) is the interval's end")
+    ap.add_argument("--warm-power-iters", type=int, default=-1,
+                    help="power iterations on every pass after the first (the dominant block of the previous material's "
+                         "estimate is the start); -1 = library default")
     ap.add_argument("--rr-refresh", type=int, default=-1,
                     help="recompute K [X P W] and the whole Gram matrix every this many iterations (-1 = solver default)")
     ap.add_argument("--tol", type=float, default=1e-5,
@@ -95,6 +101,11 @@ def solver_config(a=None, **over):
     if a.rr_refresh >= 0:
         cfg.rr_refresh = a.rr_refresh
     cfg.tol = a.tol
+    cfg.power_iters = a.power_iters
+    if a.warm_power_iters > 0:
+        from diffsound_amd.lobpcg.modal_solver import ChebyshevBlockJacobi
+
+        ChebyshevBlockJacobi.warm_power_iters = a.warm_power_iters
     cfg.nested_tol, cfg.nested_maxit = a.nested_tol, a.nested_maxit
     cfg.nested_cheb_degree, cfg.nested_cheb_ratio = a.coarse_degree, a.coarse_ratio
     return cfg

@@ -213,13 +213,20 @@ class ChebyshevBlockJacobi:
     def __init__(self, ops, degree, ratio, power_iters=30, seed=0, safety=1.2, cap=0.0):
         self.ops = ops
         self.degree = max(1, int(degree))
+        if power_iters <= 0:  # no estimate: the rigorous bound lambda_max(T K) <= nodes per element is the interval's end
+            if cap <= 0.0:
+                raise ValueError("ChebyshevBlockJacobi: power_iters = 0 needs a rigorous bound (lmax_cap)")
+            self.lmax = float(cap)
+            self.lmin = self.lmax / float(ratio)
+            self._D = self._AD = None
+            return
         n, dev, dt = ops.n, ops.device, ops.dtype
         # The dominant vectors of T K barely move when the material changes, so an ops object that already went
         # through a power iteration hands its block over and a quarter of the steps re-converge the bound (the
         # eigensolve itself still starts cold; only this spectral bound of the preconditioner is warm).
         x = getattr(ops, "_power_block", None)
         if x is not None and x.shape == (n, 8) and x.dtype == dt:
-            power_iters = max(6, power_iters // 4)
+            power_iters = max(1, min(power_iters, ChebyshevBlockJacobi.warm_power_iters))
         else:
             g = torch.Generator(device=dev).manual_seed(seed + 17)  # device-side RNG: no 100 MB host round trip
             x = torch.randn((n, 8), generator=g, dtype=torch.float32, device=dev).to(dt)
@@ -246,6 +253,10 @@ class ChebyshevBlockJacobi:
         self._AD = None
 
     _CHUNK = 80  # columns per fused launch (the fused kernel takes <= 84)
+    # power iterations when the ops hand over the block of an earlier estimate (another material on the same mesh):
+    # lambda_max(T K) depends on the Poisson ratio only, and mildly (3.1 ... 3.6 over nu = 0.12 ... 0.38 on the
+    # benchmark mesh), the dominant vectors hardly at all
+    warm_power_iters = 3  # (7, 4, 2 and 1 give the same outer iteration counts on the benchmark; the 1.2 safety factor stays)
 
     def apply(self, R, W, from_guess=False):
         """W <- p(T K) T R (R may be destroyed).  ``from_guess``: W holds an initial guess W_0 and the same
