@@ -48,10 +48,10 @@ def parse():
     ap.add_argument("--block", type=int, default=80)
     ap.add_argument("--precond", default="auto", choices=["auto", "chebyshev", "twolevel"],
                     help="auto = two-level V-cycle on ord-2 meshes, one-level Chebyshev polynomial otherwise")
-    ap.add_argument("--smooth-degree", type=int, default=2)
+    ap.add_argument("--smooth-degree", type=int, default=3)
     ap.add_argument("--smooth-ratio", type=float, default=10.0)
-    ap.add_argument("--coarse-degree", type=int, default=28)
-    ap.add_argument("--coarse-ratio", type=float, default=550.0)
+    ap.add_argument("--coarse-degree", type=int, default=22)
+    ap.add_argument("--coarse-ratio", type=float, default=350.0)
     ap.add_argument("--power-iters", type=int, default=30,
                     help="power iterations for lambda_max(T K) of the Chebyshev intervals (a quarter of them on every pass "
                          "after the first); 0 = none, the rigorous bound (nodes per element: 10 / 4) is the interval's end")
