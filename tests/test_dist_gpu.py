@@ -38,6 +38,25 @@ def one_rank(ndev):
     return _bench("--gpus", "1", "--hyp-per-gpu", "4", "--lanes", "2", *SMALL)
 
 
+def test_bench_line_contract(one_rank):
+    """The ONE JSON line of bench.py: the keys the driver reads, the roofline object, the convergence gate."""
+    d = one_rank
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert key in d, key
+    assert d["metric"] == "fwd+bwd modal-analysis passes/sec, 100k-tet ord-2 mesh, 64 modes" and d["unit"] == "passes/s"
+    assert d["n_gpus"] == 1 and d["steps"] == 1 and d["warmup"] == 0 and d["higher_is_better"] is True
+    assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic" and d["dtype"] == "f32"
+    assert "workload" in d["config"] and "model" not in d["config"] and "convergence_gate" in d["config"]
+    assert d["value"] > 0 and abs(d["value"] - 4 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+    r = d["roofline"]
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic", "stream_triad", "frac_of_stream", "in_situ", "lobpcg_spmm"):
+        assert key in r, key
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and 0 < r["frac"] < 1
+    assert 3000 < r["stream_triad"] < 8000 and r["in_situ"]["launches_timed"] > 0
+
+
 def test_two_ranks_sharing_one_device_gloo(ndev, one_rank):
     two = _bench("--gpus", "2", "--hyp-per-gpu", "2", "--lanes", "2", "--dist-backend", "gloo", "--share-devices", *SMALL)
     assert two["n_gpus"] == 2 and "gloo" in two["collective"]

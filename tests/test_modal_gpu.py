@@ -131,11 +131,14 @@ def test_fp64_refinement_matches_arpack_to_1e9(dev):
     assert np.abs(ev / modal.eigsh_shift_invert(Ko, Mo, 32)[0] - 1).max() < 1e-5
 
 
-@pytest.mark.parametrize("mesh,order,k,block,nested", [(6, 2, 32, 40, 0.0), (6, 2, 32, 40, 1e-2), (8, 1, 16, 24, 0.0)])
-def test_native_iteration_driver_matches_python_loop(dev, mesh, order, k, block, nested):
+@pytest.mark.parametrize("mesh,order,k,block,nested,storage", [(6, 2, 32, 40, 0.0, "bf16"), (6, 2, 32, 40, 1e-2, "bf16"),
+                                                                (8, 1, 16, 24, 0.0, "bf16"), (6, 2, 32, 40, 1e-2, "fp32"),
+                                                                (6, 2, 72, 84, 0.0, "bf16"), (8, 1, 16, 24, 0.0, "fp32")])
+def test_native_iteration_driver_matches_python_loop(dev, mesh, order, k, block, nested, storage):
     """ds_lobpcg_iterate (the iteration as one native call, LAPACK from SciPy) against the Python loop it replaces:
     same kernels and dense steps, so the same iteration count and eigenvalues to the rounding of the two LAPACKs;
-    two-level preconditioner (ord-2), nested start, one-level polynomial (ord-1)."""
+    two-level preconditioner (ord-2), nested start, one-level polynomial (ord-1), bf16 and fp32 preconditioner blocks,
+    an 84-column block (the [X' P'] update then takes four launches instead of two)."""
     from diffsound_amd import meshgen
     from diffsound_amd.lobpcg.modal_solver import ModalSolver, SolverConfig
     from diffsound_amd.modal_ops import HipModalOps, TetSystem
@@ -147,7 +150,8 @@ def test_native_iteration_driver_matches_python_loop(dev, mesh, order, k, block,
     ops = HipModalOps(sysd, lam, mu)
     out = {}
     for native in (True, False):
-        cfg = SolverConfig(block=block, lmax_cap=float({1: 4, 2: 10}[order]), tol=1e-5, nested_tol=nested, native=native)
+        cfg = SolverConfig(block=block, lmax_cap=float({1: 4, 2: 10}[order]), tol=1e-5, nested_tol=nested, native=native,
+                           precond_storage=storage)
         calls = []
         orig = ops.native_lobpcg
         ops.native_lobpcg = lambda *a, _o=orig, **kw: (calls.append(1), _o(*a, **kw))[1]
