@@ -719,8 +719,17 @@ class ModalSolver:
             hist.append(worst)
             if worst < cfg.refine_tol or it == cfg.refine_maxit:
                 break
+            # soft locking: only the pairs that still miss the tolerance (with a margin) and the guard columns get a new
+            # search direction; the others stay in X and take part in every Rayleigh-Ritz step, nothing else
+            act = rel >= 0.3 * cfg.refine_tol
+            act[k:] = True
+            idx = torch.nonzero(act).reshape(-1)
+            if idx.numel() % 4:  # (the preconditioner's kernels take multiples of 4 columns)
+                rest_ = torch.nonzero(~act).reshape(-1)
+                pad = rest_[torch.argsort(rel[rest_], descending=True)[:4 - idx.numel() % 4]]
+                idx = torch.sort(torch.cat([idx, pad])).values
             # W = B R in fp32 (columns scaled to unit norm: the preconditioner is linear), promoted to fp64
-            R32 = (R / rn.clamp(min=1e-300)[None, :]).float().contiguous()
+            R32 = (R[:, idx] / rn[idx].clamp(min=1e-300)[None, :]).float().contiguous()
             W32 = torch.empty_like(R32)
             self.precond_apply(R32, W32)
             W = W32.double()
@@ -766,6 +775,7 @@ class ModalSolver:
             KPn = sum(kb @ c for _, kb, _, c in rest)
             MPn = sum(mb @ c for _, _, mb, c in rest)
             X, KX, MX = X @ Cx + Pn, KX @ Cx + KPn, MX @ Cx + MPn
+            Pn, KPn, MPn = Pn[:, idx], KPn[:, idx], MPn[:, idx]  # directions of the active pairs only
             pn = torch.sqrt((Pn * MPn).sum(0).clamp(min=1e-300))
             P, KP, MP = Pn / pn[None, :], KPn / pn[None, :], MPn / pn[None, :]
             del W, KW, MW, Pn, KPn, MPn, rest
