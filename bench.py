@@ -75,6 +75,9 @@ def parse():
     ap.add_argument("--share-devices", action="store_true",
                     help="rehearsal on a box with fewer GPUs than ranks: rank r uses device r %% device_count "
                          "(needs --dist-backend gloo: RCCL refuses two ranks on one device)")
+    ap.add_argument("--loss", default="mse", choices=["mse", "mss"],
+                    help="scalar loss head: mse = the headline metric's; mss = the reference experiments' multi-scale "
+                         "spectral loss (MSSLoss [1024..64], 'l1_loss', material_sync_train.py:124) on the STFT kernels")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-cells", type=int, default=8,
                     help="the CPU oracle runs ONE full pass on a Kuhn box of this many cells per edge (8 -> 3072 tets, the "
@@ -239,7 +242,12 @@ def main():
     mesh = TetMesh(torch.from_numpy(v).to(dev), torch.from_numpy(t).long().to(dev)).to_high_order(a.order)
     cfg = solver_config(a)
     t_sym = time.time()
-    pipe = ModalPipeline(mesh.vertices, mesh.tets, a.order, a.modes, MAT, solver_config=cfg)
+    loss_fn = None
+    if a.loss == "mss":
+        from diffsound_amd.ddsp.mss_loss import MSSLoss
+
+        loss_fn = MSSLoss([1024, 512, 256, 128, 64], 32000, type="l1_loss")
+    pipe = ModalPipeline(mesh.vertices, mesh.tets, a.order, a.modes, MAT, solver_config=cfg, loss_fn=loss_fn)
     torch.cuda.synchronize()
     t_sym = time.time() - t_sym
     nhyp = a.hyp_per_gpu * world
@@ -437,6 +445,7 @@ def main():
                 "workload": (f"Kuhn box {a.cells}^3 cells = {sysd.T} tets, ord-{a.order} ({sysd.nv} nodes, n={sysd.n}, "
                              f"nnz={sysd.nnzb * 9}), {a.modes} modes, fwd+bwd w.r.t. (E, nu), S=8000 @ 32 kHz"),
                 "hypotheses_per_gpu_per_step": a.hyp_per_gpu,
+                "loss": "MSE against a fixed target clip" if a.loss == "mse" else "MSSLoss [1024..64] l1_loss (STFT kernels)",
                 "parallelism": (f"dp{world} over material hypotheses, scalar loss all-reduce; {min(a.lanes, a.hyp_per_gpu)} "
                                 "hypotheses in flight per GPU (one HIP stream + host thread each)"),
                 "precision": ("fp32 block vectors and SpMM, fp64 Gram accumulation / Rayleigh-Ritz / read-out; the preconditioner's "

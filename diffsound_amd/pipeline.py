@@ -65,8 +65,11 @@ class ModalPipeline:
     oscillator, target audio."""
 
     def __init__(self, vertices, tets, order, modes, mat, sample_num=8000, sr=32000, force_frames=150,
-                 solver_config=None, target_freqs=None):
+                 solver_config=None, target_freqs=None, loss_fn=None):
         self.device = vertices.device
+        # scalar loss head (audio, target) -> 0-dim tensor; None = the MSE of the headline metric.  The reference's
+        # experiments put MSSLoss here (experiments/material_sync_train.py:124,159): pass that module.
+        self.loss_fn = loss_fn
         self.modes = modes
         self.mat = Material(mat)
         self.cfg = solver_config or SolverConfig()
@@ -107,6 +110,8 @@ class ModalPipeline:
         audio = holder.osc(freqs)
         if self.target is None:
             loss = (audio ** 2).mean()
+        elif self.loss_fn is not None:
+            loss = self.loss_fn(audio, self.target)
         else:
             loss = ((audio - self.target) ** 2).mean()
         gE = gnu = float("nan")

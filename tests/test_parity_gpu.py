@@ -120,3 +120,45 @@ def test_config0_plate_ord1_matches_oracle(dev):
     assert np.abs(res.eigenvalues.cpu().numpy() / ev - 1).max() < 1e-4
     assert float((audio.cpu() - sig).norm() / sig.norm()) < 1e-3
     assert abs(r.grad_E / gE - 1) < 2e-3 and abs(r.grad_nu / gnu - 1) < 2e-3
+
+
+def test_mesh_front_end_on_the_device(golden, dev):
+    """SURVEY.md section 8 row f3 with the tensors resident on the GPU (what DiffSoundObj hands over): ord-2
+    lifting against the reference's output (G2 fixture, bit-identical vertices / tets / transform), and the
+    largest-connected-component pass against scipy's csgraph labels; both stay on the device (no host copy of the
+    mesh)."""
+    import scipy.sparse as sp
+    import scipy.sparse.csgraph as csgraph
+
+    from diffsound_amd import meshgen
+    from diffsound_amd.diffelastic.mesh import TetMesh, largest_connected_component
+
+    g = golden("g2_cube2.npz")
+    m = TetMesh(torch.from_numpy(g["verts"]).to(dev), torch.from_numpy(g["tets"]).to(dev)).to_high_order(2)
+    assert m.vertices.device.type == "cuda" and m.tets.device.type == "cuda"
+    assert np.array_equal(m.vertices.cpu().numpy(), g["o2_vertices"]) and np.array_equal(m.tets.cpu().numpy(), g["o2_tets"])
+    assert np.array_equal(m.transform_matrix.cpu().numpy(), g["o2_transform"])
+    # the same lifting at C3's size: node / element counts of BASELINE.json configs[1], every tet positively oriented
+    v, t = meshgen.kuhn_box(26)
+    big = TetMesh(torch.from_numpy(v).to(dev), torch.from_numpy(t).long().to(dev)).to_high_order(2)
+    assert big.vertices.shape == (148877, 3) and big.tets.shape == (105456, 10)
+    host = TetMesh(torch.from_numpy(v), torch.from_numpy(t).long()).to_high_order(2)
+    assert torch.equal(big.tets.cpu(), host.tets) and torch.equal(big.vertices.cpu(), host.vertices)
+    # connected components: three bodies with scrambled numbering, the middle one is the largest
+    v1, t1 = meshgen.kuhn_box(5)
+    v2, t2 = meshgen.kuhn_box(3)
+    vv = np.concatenate([v2 + 10.0, v1, v2 - 10.0])
+    tt = np.concatenate([t2, t1 + len(v2), t2 + len(v2) + len(v1)])
+    perm = np.random.default_rng(0).permutation(len(vv))
+    inv = np.empty_like(perm)
+    inv[perm] = np.arange(len(vv))
+    vv, tt = vv[perm], inv[tt]
+    vo, to = largest_connected_component(torch.from_numpy(vv).to(dev), torch.from_numpy(tt).to(dev))
+    assert vo.device.type == "cuda" and to.device.type == "cuda"
+    rows = np.concatenate([tt[:, i] for i in range(4)])
+    cols = np.concatenate([tt[:, (i + 1) % 4] for i in range(4)])
+    A = sp.coo_matrix((np.ones(len(rows)), (rows, cols)), shape=(len(vv), len(vv))).tocsr()
+    labels = csgraph.connected_components(A, directed=False)[1]
+    keep = labels == np.argmax(np.bincount(labels))
+    assert np.array_equal(vo.cpu().numpy(), vv[keep])
+    assert to.shape[0] == len(t1) and np.allclose(vo.cpu().numpy()[to.cpu().numpy()], vv[tt[keep[tt].all(1)]])
