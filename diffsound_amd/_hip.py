@@ -12,7 +12,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libdiffsound_hip.so")
-ABI_VERSION = 18  # DS_ABI_VERSION of include/diffsound_hip.h
+ABI_VERSION = 19  # DS_ABI_VERSION of include/diffsound_hip.h
 
 c_i32p = ctypes.POINTER(ctypes.c_int32)
 _P = ctypes.c_void_p
@@ -30,9 +30,11 @@ _SIGNATURES = {
     "ds_pattern_free": (None, [_P]),
     "ds_dpattern_build": (_I, [_P, _I64, _I, _I64, _I, _P, ctypes.POINTER(_P)]),
     "ds_dpattern_sizes": (_I, [_P, ctypes.POINTER(_I64), ctypes.POINTER(_I64), ctypes.POINTER(_I64), ctypes.POINTER(_I64),
-                               ctypes.POINTER(_I)]),
-    "ds_dpattern_export": (_I, [_P] * 12),
+                               ctypes.POINTER(_I64)]),
+    "ds_dpattern_export": (_I, [_P] * 13),
     "ds_dpattern_free": (None, [_P]),
+    "ds_edge_table": (_I, [_P, _I64, _I64, _P, _P, _P, ctypes.POINTER(_I64), _P]),
+    "ds_unique_rows3": (_I, [_P, _I64, _P, _P, ctypes.POINTER(_I64), _P]),
     "ds_assemble_kml": (_I, [_P, _P, _I64, _I, _I64, _P, _P, _I64, _P, _P, _P, _P, _P, _P, _P]),
     "ds_combine_material": (_I, [_P, _P, _P, _I64, _P, _I64, _D, _D, _P, _P, _P, _P, _P]),
     "ds_spmm_bsr3": (_I, [_I, _P, _P, _P, _P, _I64, _P, _I64, _P, _I64, _I, _P]),
@@ -219,7 +221,7 @@ class Pattern:
 
 class DevicePattern:
     """Symbolic phase on the device (ds_dpattern_build): every table as an int32 tensor on ``tets``' device.
-    ``ctab`` / ``utab`` are None when a group exceeds ``cap`` (the caller then cuts the chunks with ``union_chunks``)."""
+    ``utab`` (ngroups, 2) = chunk range of each group, ``ctab`` (nchunks, 4) = (e0, e1, b0, b1) per chunk."""
 
     def __init__(self, tets_i32, nv, cap):
         t = tets_i32
@@ -229,24 +231,56 @@ class DevicePattern:
         check(lib().ds_dpattern_build(ptr(t), t.shape[0], t.shape[1], nv, cap, stream_ptr(), ctypes.byref(handle)),
               "ds_dpattern_build")
         try:
-            a, b, c, d, s = _I64(), _I64(), _I64(), _I64(), _I()
+            a, b, c, d, e = _I64(), _I64(), _I64(), _I64(), _I64()
             check(lib().ds_dpattern_sizes(handle, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c), ctypes.byref(d),
-                                          ctypes.byref(s)), "ds_dpattern_sizes")
-            self.nv, self.nnzb, self.ncontrib, self.ne, self.ngroups = nv, a.value, b.value, c.value, d.value
-            self.single = bool(s.value)
+                                          ctypes.byref(e)), "ds_dpattern_sizes")
+            self.nv, self.nnzb, self.ncontrib, self.ne, self.ngroups, self.nchunks = nv, a.value, b.value, c.value, d.value, e.value
+            self.single = self.nchunks == self.ngroups  # every group is one chunk
             mk = lambda n: torch.empty(n, dtype=torch.int32, device=t.device)
             self.rowptr, self.colidx, self.diagidx = mk(nv + 1), mk(self.nnzb), mk(nv)
             self.cptr, self.clist = mk(self.nnzb + 1), mk(self.ncontrib)
             self.gptr, self.gent, self.goff, self.kperm = mk(self.ngroups + 1), mk(self.ne), mk(self.ne + 1), mk(self.nnzb)
-            self.ctab = torch.empty((self.ngroups, 4), dtype=torch.int32, device=t.device)
+            self.utab = torch.empty((self.ngroups, 2), dtype=torch.int32, device=t.device)
+            self.ctab = torch.empty((self.nchunks, 4), dtype=torch.int32, device=t.device)
             check(lib().ds_dpattern_export(handle, ptr(self.rowptr), ptr(self.colidx), ptr(self.diagidx), ptr(self.cptr),
                                            ptr(self.clist), ptr(self.gptr), ptr(self.gent), ptr(self.goff),
-                                           ptr(self.kperm), ptr(self.ctab), stream_ptr()), "ds_dpattern_export")
+                                           ptr(self.kperm), ptr(self.utab), ptr(self.ctab), stream_ptr()), "ds_dpattern_export")
             torch.cuda.current_stream(t.device).synchronize()  # the handle's arrays are freed below
         finally:
             lib().ds_dpattern_free(handle)
-        if not self.single:
-            self.ctab = None
+
+
+def edge_table(tets4, nv):
+    """ds_edge_table: (T, 4) long HIP tensor -> (ea, eb, tet_edge): the distinct undirected edges (ea < eb, sorted)
+    and the (T, 6) edge ids of every element's local edges, all long tensors on the same device."""
+    t = tets4
+    if not t.is_cuda or t.dtype != torch.int64 or t.dim() != 2 or t.shape[1] != 4:
+        raise ValueError("edge_table: tets must be a (T, 4) int64 HIP tensor")
+    t = t.contiguous()
+    T = t.shape[0]
+    ea = torch.empty(6 * T, dtype=torch.int64, device=t.device)
+    eb = torch.empty(6 * T, dtype=torch.int64, device=t.device)
+    te = torch.empty((T, 6), dtype=torch.int64, device=t.device)
+    ne = _I64()
+    with torch.cuda.device(t.device):
+        check(lib().ds_edge_table(ptr(t), T, nv, ptr(ea), ptr(eb), ptr(te), ctypes.byref(ne), stream_ptr()), "ds_edge_table")
+    return ea[:ne.value], eb[:ne.value], te
+
+
+def unique_rows3(xyz):
+    """ds_unique_rows3: (n, 3) fp32 HIP tensor -> (inv (n,), first (n_unique,)) as torch.unique(dim=0,
+    return_inverse=True) numbers the rows; first[i] = lowest row index holding the i-th distinct coordinate."""
+    x = xyz
+    if not x.is_cuda or x.dtype != torch.float32 or x.dim() != 2 or x.shape[1] != 3:
+        raise ValueError("unique_rows3: need an (n, 3) float32 HIP tensor")
+    x = x.contiguous()
+    n = x.shape[0]
+    inv = torch.empty(n, dtype=torch.int64, device=x.device)
+    first = torch.empty(n, dtype=torch.int64, device=x.device)
+    nu = _I64()
+    with torch.cuda.device(x.device):
+        check(lib().ds_unique_rows3(ptr(x), n, ptr(inv), ptr(first), ctypes.byref(nu), stream_ptr()), "ds_unique_rows3")
+    return inv, first[:nu.value]
 
 
 class Groups:

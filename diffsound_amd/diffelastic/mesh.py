@@ -169,14 +169,23 @@ class TetMesh:
             return TetMesh(self.vertices, self.tets, order=1)
         T, nv = self.tets.shape[0], self.vertices.shape[0]
         dev = self.vertices.device
-        vf = self.vertices[self.tets]
-        mids = [(vf[:, a] + vf[:, b]) / 2 for a, b in _EDGES]
-        new_vertices = torch.cat([self.vertices] + mids, dim=0)
         new_tets = torch.zeros((T, 10), dtype=self.tets.dtype, device=dev)
         for slot, corner in zip((0, 2, 4, 9), range(4)):
             new_tets[:, slot] = self.tets[:, corner]
-        for e, slot in enumerate(_EDGE_SLOTS):
-            new_tets[:, slot] = torch.arange(nv + e * T, nv + (e + 1) * T, device=dev)
+        if self.vertices.is_cuda and self.tets.dtype == torch.int64 and T > 0:
+            # device path: one midpoint per distinct edge (ds_edge_table), not one per (element, edge)
+            from .. import _hip
+
+            ea, eb, tet_edge = _hip.edge_table(self.tets, nv)
+            mids = [(self.vertices[ea] + self.vertices[eb]) / 2]
+            for e, slot in enumerate(_EDGE_SLOTS):
+                new_tets[:, slot] = nv + tet_edge[:, e]
+        else:
+            vf = self.vertices[self.tets]
+            mids = [(vf[:, a] + vf[:, b]) / 2 for a, b in _EDGES]
+            for e, slot in enumerate(_EDGE_SLOTS):
+                new_tets[:, slot] = torch.arange(nv + e * T, nv + (e + 1) * T, device=dev)
+        new_vertices = torch.cat([self.vertices] + mids, dim=0)
         mesh = TetMesh(new_vertices, new_tets, order=2)
         mesh.remove_duplicate_vertices()
         return mesh
@@ -184,11 +193,16 @@ class TetMesh:
     def remove_duplicate_vertices(self):
         """Merge bit-identical coordinates; nodes end up in lexicographic (x,y,z) order and keep the
         coordinates (and autograd history) of the lowest original index (reference mesh.py:162-179)."""
-        _, inv = torch.unique(self.vertices.detach(), dim=0, return_inverse=True)
-        nu = int(inv.max()) + 1
-        first = torch.full((nu,), self.vertices.shape[0], dtype=torch.long, device=self.vertices.device)
-        first.scatter_reduce_(0, inv, torch.arange(self.vertices.shape[0], device=self.vertices.device),
-                              reduce="amin", include_self=True)
+        if self.vertices.is_cuda and self.vertices.dtype == torch.float32 and self.vertices.shape[0] > 0:
+            from .. import _hip
+
+            inv, first = _hip.unique_rows3(self.vertices.detach())  # radix sort on the coordinate bits, no float unique
+        else:
+            _, inv = torch.unique(self.vertices.detach(), dim=0, return_inverse=True)
+            nu = int(inv.max()) + 1
+            first = torch.full((nu,), self.vertices.shape[0], dtype=torch.long, device=self.vertices.device)
+            first.scatter_reduce_(0, inv, torch.arange(self.vertices.shape[0], device=self.vertices.device),
+                                  reduce="amin", include_self=True)
         self.tets = inv[self.tets]
         self.vertices = self.vertices[first]
         if hasattr(self, "_transform_matrix"):

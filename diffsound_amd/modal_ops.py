@@ -87,17 +87,9 @@ class TetSystem:
         self._tetgeo = torch.empty((self.T, 13), dtype=torch.float64, device=dev)
         self.groups = None
         if self.nv >= 8:
-            if pat.single:
-                ng = pat.ngroups
-                utab = torch.arange(ng + 1, dtype=torch.int32, device=dev)
-                ut, ct = torch.stack([utab[:-1], utab[1:]], 1).contiguous(), pat.ctab
-            else:  # a group that exceeds the LDS image: cut its chunks with the host rule (rare)
-                ut, ct = _hip.union_chunks(pat.gptr.cpu(), pat.goff.cpu(), UNION_CAP)
-                ut, ct = (None, None) if ct is None else (ut.to(dev), ct.to(dev))
-            if ct is not None:
-                self.groups = dict(ne=pat.ne, gent=pat.gent, kperm=pat.kperm, kperm64=pat.kperm.long(),
-                                   union=dict(utab=ut, ctab=ct, capb=UNION_CAP, ngroups=ut.shape[0],
-                                              single=bool(ct.shape[0] == ut.shape[0])))  # every group one chunk
+            self.groups = dict(ne=pat.ne, gent=pat.gent, kperm=pat.kperm, kperm64=pat.kperm.long(),
+                               union=dict(utab=pat.utab, ctab=pat.ctab, capb=UNION_CAP, ngroups=pat.ngroups,
+                                          single=pat.single))  # single: every group is one chunk
         self._coarse = None
         self.assemble()
 

@@ -40,7 +40,7 @@ enum { DS_OK = 0, DS_ERR_ARG = 1, DS_ERR_HIP = 2, DS_ERR_NOMEM = 3 };
 /* Thread-local text of the last error returned on this thread ("" if none). */
 const char* ds_last_error(void);
 /* Library ABI version (bumped on any signature change); ds_abi_version() returns the value the library was built with. */
-#define DS_ABI_VERSION 18
+#define DS_ABI_VERSION 19
 int ds_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------------
@@ -70,23 +70,36 @@ int ds_groups_export(const ds_groups_t* g, int32_t* gptr, int32_t* gent, int32_t
 void ds_groups_free(ds_groups_t* g);
 
 /* The same symbolic phase ON THE DEVICE (csrc/dpattern.hip): pattern, contribution lists, neighbour-union tables and
- * the chunk table (one chunk per group of 4 rows with at most cap_blocks entries / blocks) from device connectivity,
- * entry for entry what ds_pattern_build + ds_groups_build produce on the host.  The handle owns device arrays;
- * ds_dpattern_build synchronises `stream` (the table sizes come back to the host); ds_dpattern_export copies into
- * caller-allocated DEVICE arrays (any pointer may be NULL): rowptr[nv+1], colidx[nnzb], diagidx[nv], cptr[nnzb+1],
- * clist[ncontrib], gptr[ngroups+1], gent[ne], goff[ne+1], kperm[nnzb], ctab[ngroups x 4].  *single == 0: some group
- * exceeds cap_blocks and ctab is not usable as it stands (cut those groups with the host rule).
+ * the chunk tables (every group of 4 rows cut into chunks of whole entries with at most cap_blocks entries / blocks;
+ * almost always one chunk per group) from device connectivity, entry for entry what ds_pattern_build +
+ * ds_groups_build and the host cutting rule produce.  The handle owns device arrays; ds_dpattern_build synchronises
+ * `stream` (the table sizes come back to the host); ds_dpattern_export copies into caller-allocated DEVICE arrays (any
+ * pointer may be NULL): rowptr[nv+1], colidx[nnzb], diagidx[nv], cptr[nnzb+1], clist[ncontrib], gptr[ngroups+1],
+ * gent[ne], goff[ne+1], kperm[nnzb], utab[ngroups x 2] (chunk range of each group), ctab[nchunks x 4] (e0, e1, b0, b1).
  * (reference: COO triplets + coalesce() on every assembly, src/diffelastic/diff_model.py:214-220, 299-312, for a mesh
  * that the geometry experiments rebuild every iteration, src/dmtet/geometry/dmtet_thickness.py:251) */
 typedef struct ds_dpattern ds_dpattern_t;
 int ds_dpattern_build(const int32_t* tets, int64_t T, int N, int64_t nv, int cap_blocks, ds_stream_t stream,
                       ds_dpattern_t** out);
 int ds_dpattern_sizes(const ds_dpattern_t* p, int64_t* nnzb, int64_t* ncontrib, int64_t* ne, int64_t* ngroups,
-                      int* single);
+                      int64_t* nchunks);
 int ds_dpattern_export(const ds_dpattern_t* p, int32_t* rowptr, int32_t* colidx, int32_t* diagidx, int32_t* cptr,
-                       int32_t* clist, int32_t* gptr, int32_t* gent, int32_t* goff, int32_t* kperm, int32_t* ctab,
-                       ds_stream_t stream);
+                       int32_t* clist, int32_t* gptr, int32_t* gent, int32_t* goff, int32_t* kperm, int32_t* utab,
+                       int32_t* ctab, ds_stream_t stream);
 void ds_dpattern_free(ds_dpattern_t* p);
+
+/* Mesh front end ON THE DEVICE (csrc/dpattern.hip), replacing the float-`unique` of the reference's ord-2 lifting and
+ * duplicate merge (src/diffelastic/mesh.py:101-179), which the geometry experiments run on a new mesh every iteration
+ * (src/dmtet/geometry/dmtet_thickness.py:251-285).  Both synchronise `stream` (a count comes back to the host).
+ *  ds_edge_table  : tets (T x 4) int64 DEVICE (torch long) -> the distinct undirected edges, ea[i] < eb[i], sorted by
+ *                   (ea, eb) (arrays of capacity 6 T), and tet_edge (T x 6): the edge id of each local edge in the
+ *                   reference's order (0,1) (1,2) (0,2) (0,3) (1,3) (2,3); *n_edges on the HOST.
+ *  ds_unique_rows3: xyz (n x 3) fp32 DEVICE -> inv[n] (id of every row among the distinct rows in lexicographic
+ *                   (x, y, z) order; -0.0 == +0.0 as in torch.unique) and first[id] = lowest row index with that
+ *                   coordinate (capacity n); *n_unique on the HOST. */
+int ds_edge_table(const int64_t* tets, int64_t T, int64_t nv, int64_t* ea, int64_t* eb, int64_t* tet_edge,
+                  int64_t* n_edges, ds_stream_t stream);
+int ds_unique_rows3(const float* xyz, int64_t n, int64_t* inv, int64_t* first, int64_t* n_unique, ds_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Numeric assembly (DEVICE).  K_lambda, K_mu (geometry-only parts of K = lam*K_lambda + mu*K_mu,

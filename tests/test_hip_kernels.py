@@ -653,10 +653,66 @@ def test_device_symbolic_phase_matches_host(dev, mesh, order):
         assert torch.equal(getattr(d, name).cpu(), getattr(g, name)), name
     ut, ct = _hip.union_chunks(g.gptr, g.goff, UNION_CAP)
     assert d.single == (ct.shape[0] == ut.shape[0])
-    if d.single:
-        assert torch.equal(d.ctab.cpu(), ct)
+    assert torch.equal(d.utab.cpu(), ut) and torch.equal(d.ctab.cpu(), ct)
     if mesh == "bowl":  # the reference's coalesced K has exactly these many scalar non-zeros
         assert d.nnzb * 9 == {1: 294381, 2: 3674016}[order]
-    # a group larger than the cap is reported, not mis-tabulated
-    small = _hip.DevicePattern(tets, nv, 8)
-    assert (not small.single) and small.ctab is None
+    # groups larger than the cap are cut into several chunks, by the same greedy rule as on the host
+    for cap in (8, 20):
+        small = _hip.DevicePattern(tets, nv, cap)
+        ut, ct = _hip.union_chunks(g.gptr, g.goff, cap)
+        assert not small.single and small.nchunks == ct.shape[0]
+        assert torch.equal(small.utab.cpu(), ut) and torch.equal(small.ctab.cpu(), ct)
+        assert int((small.ctab[:, 1] - small.ctab[:, 0]).max()) <= cap and int((small.ctab[:, 3] - small.ctab[:, 2]).max()) <= cap
+
+
+def test_mesh_front_end_primitives(dev):
+    """ds_unique_rows3 against torch.unique(dim=0, return_inverse=True) on the host (duplicates, negative values,
+    -0.0 / +0.0, denormals) and ds_edge_table against a NumPy edge set; then the lifted bowl against the reference's
+    own output for it (G3 fixture: o2_vertices / o2_tets, bit-identical) and the torch path."""
+    from diffsound_amd import _hip, meshgen
+    from diffsound_amd.diffelastic.mesh import TetMesh
+
+    rng = np.random.default_rng(5)
+    base = rng.standard_normal((3000, 3)).astype(np.float32)
+    base[:50, 0] = 0.0
+    base[50:100, 0] = -0.0
+    base[100:120] = np.float32(1e-42)  # denormal rows
+    base[120:200, 1] = base[120:200, 0]
+    x = np.concatenate([base, base[rng.integers(0, 3000, size=5000)], -base[:500]])
+    x = x[rng.permutation(len(x))]
+    xt = torch.from_numpy(x)
+    uniq, inv_ref = torch.unique(xt, dim=0, return_inverse=True)
+    inv, first = _hip.unique_rows3(xt.to(dev))
+    assert first.shape[0] == uniq.shape[0]
+    assert torch.equal(inv.cpu(), inv_ref)
+    assert torch.equal(xt[first.cpu()].abs(), uniq.abs()) and torch.equal(xt[first.cpu()] == 0, uniq == 0)
+    # representative = lowest original index of the group
+    low = torch.full((uniq.shape[0],), len(x), dtype=torch.long).scatter_reduce_(0, inv_ref, torch.arange(len(x)), reduce="amin")
+    assert torch.equal(first.cpu(), low)
+    # edge table
+    v, t = meshgen.kuhn_box(5)
+    t = t.astype(np.int64)
+    ea, eb, te = _hip.edge_table(torch.from_numpy(t).to(dev), len(v))
+    pairs = np.array([(0, 1), (1, 2), (0, 2), (0, 3), (1, 3), (2, 3)])
+    e = np.sort(t[:, pairs], axis=2)  # (T, 6, 2)
+    uniq_e, inv_e = np.unique(e.reshape(-1, 2), axis=0, return_inverse=True)
+    assert np.array_equal(np.stack([ea.cpu().numpy(), eb.cpu().numpy()], 1), uniq_e)
+    assert np.array_equal(te.cpu().numpy(), inv_e.reshape(-1, 6))
+    with pytest.raises(RuntimeError, match="outside"):
+        _hip.edge_table(torch.from_numpy(t).to(dev), len(v) - 1)
+    # lifted bowl: device path (edge table + radix unique) == torch path on the host, bit for bit
+    m = np.load("tests/golden/g0_bowl_mesh.npz")
+    g = np.load("tests/golden/g3_bowl_o2.npz")
+    vt, tt = torch.from_numpy(m["verts"]), torch.from_numpy(m["tets"]).long()
+    d = TetMesh(vt.to(dev), tt.to(dev)).to_high_order(2)
+    h = TetMesh(vt, tt).to_high_order(2)
+    assert torch.equal(d.vertices.cpu(), h.vertices) and torch.equal(d.tets.cpu(), h.tets)
+    assert np.array_equal(d.vertices.cpu().numpy(), g["o2_vertices"]) and np.array_equal(d.tets.cpu().numpy(), g["o2_tets"])
+    # midpoints stay differentiable w.r.t. the corners, same gradient as the host path
+    vd = vt.to(dev).requires_grad_(True)
+    md = TetMesh(vd, tt.to(dev)).to_high_order(2)
+    w = torch.randn(md.vertices.shape, generator=torch.Generator().manual_seed(1))
+    (md.vertices * w.to(dev)).sum().backward()
+    vh = vt.clone().requires_grad_(True)
+    (TetMesh(vh, tt).to_high_order(2).vertices * w).sum().backward()
+    assert torch.allclose(vd.grad.cpu(), vh.grad, rtol=1e-5, atol=1e-6)
