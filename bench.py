@@ -75,6 +75,9 @@ def parse():
     ap.add_argument("--share-devices", action="store_true",
                     help="rehearsal on a box with fewer GPUs than ranks: rank r uses device r %% device_count "
                          "(needs --dist-backend gloo: RCCL refuses two ranks on one device)")
+    ap.add_argument("--mfma-groups", default="8,0",
+                    help="nodes per wavefront of the MFMA form of the preconditioner's bf16 terms on the fine and on the "
+                         "corner-node level (4 or 8; 0 = the VALU kernel on that level)")
     ap.add_argument("--loss", default="mse", choices=["mse", "mss"],
                     help="scalar loss head: mse = the headline metric's; mss = the reference experiments' multi-scale "
                          "spectral loss (MSSLoss [1024..64], 'l1_loss', material_sync_train.py:124) on the STFT kernels")
@@ -242,6 +245,9 @@ def main():
     mesh = TetMesh(torch.from_numpy(v).to(dev), torch.from_numpy(t).long().to(dev)).to_high_order(a.order)
     cfg = solver_config(a)
     t_sym = time.time()
+    from diffsound_amd.modal_ops import HipModalOps
+
+    HipModalOps.mfma_groups = tuple(int(x) for x in a.mfma_groups.split(","))
     loss_fn = None
     if a.loss == "mss":
         from diffsound_amd.ddsp.mss_loss import MSSLoss

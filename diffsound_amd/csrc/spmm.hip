@@ -369,6 +369,7 @@ int launch_wn(const int32_t* rowptr, const int32_t* colidx, const void* vals, co
 }
 
 #include "spmm_union.inc"
+#include "spmm_mfma.inc"
 
 template <int KIND>
 int launch_fast(const int32_t* rowptr, const int32_t* colidx, const void* vals, const void* vals_t, int64_t nv,
@@ -762,4 +763,84 @@ extern "C" int ds_spmm_union16(int epilogue, const int32_t* utab, const int32_t*
     if (y_f32) DS_U16(0, 1, true);
     DS_U16(0, 1, false);
 #undef DS_U16
+}
+
+// ------------------------------------------------------------------------------------------------
+// MFMA form of the bf16 preconditioner terms (spmm_mfma.inc)
+extern "C" int ds_pack_kc(const float* k32, const int32_t* kperm, int64_t nnzb, void* kc, ds_stream_t stream) {
+    DS_REQUIRE(k32 && kperm && kc && nnzb > 0, "ds_pack_kc: bad argument");
+    DS_REQUIRE((reinterpret_cast<uintptr_t>(kc) & 7) == 0, "ds_pack_kc: kc must be 8-byte aligned");
+    pack_kc_kernel<<<(unsigned)ds::ceil_div(nnzb * 3, 256), 256, 0, ds::as_stream(stream)>>>(k32, kperm, nnzb,
+                                                                                            static_cast<i2s*>(kc));
+    DS_LAUNCH_CHECK("pack_kc_kernel");
+    return DS_OK;
+}
+
+template <int G, int NT>
+static int launch_mfma(int epilogue, int y_f32, const int32_t* gptr, const int32_t* gcol, const int32_t* gmeta,
+                       const int32_t* gbase, const void* kc, int64_t nnzb, int64_t ngroups, int64_t nv, const float* X,
+                       int64_t ldx, float* Y, int64_t ldy, int lpn, hipStream_t st, const ChebEpilogue& epi) {
+    const char* kcp = static_cast<const char*>(kc);
+    if (epilogue == 2)
+        spmm_union_mfma_kernel<G, NT, 2, false><<<(unsigned)ngroups, 64, 0, st>>>(gptr, gcol, gmeta, gbase, kcp, nnzb, (unsigned)ngroups, nv, X, ldx, Y, ldy, lpn, epi);
+    else if (y_f32)
+        spmm_union_mfma_kernel<G, NT, 1, true><<<(unsigned)ngroups, 64, 0, st>>>(gptr, gcol, gmeta, gbase, kcp, nnzb, (unsigned)ngroups, nv, X, ldx, Y, ldy, lpn, epi);
+    else
+        spmm_union_mfma_kernel<G, NT, 1, false><<<(unsigned)ngroups, 64, 0, st>>>(gptr, gcol, gmeta, gbase, kcp, nnzb, (unsigned)ngroups, nv, X, ldx, Y, ldy, lpn, epi);
+    DS_LAUNCH_CHECK("spmm_union_mfma_kernel");
+    return DS_OK;
+}
+
+extern "C" int ds_spmm_union16m(int epilogue, int group_nodes, const int32_t* gptr, const int32_t* gcol,
+                                const int32_t* gmeta, const int32_t* gbase, const void* kc, int64_t nnzb,
+                                int64_t ngroups, int max_entries, int64_t nv, const void* X, int64_t ldx, void* Y,
+                                int64_t ldy, int y_f32, const void* R0, int64_t ldr, const float* dinv, int ncols,
+                                float c1, float c2, int first, const void* Wprev, int64_t ldp, ds_stream_t stream) {
+    DS_REQUIRE(gptr && gcol && gmeta && gbase && kc && X && Y && R0, "ds_spmm_union16m: null pointer");
+    DS_REQUIRE(epilogue == 1 || epilogue == 2, "ds_spmm_union16m: epilogue must be 1 (Chebyshev term) or 2 (residual)");
+    DS_REQUIRE(epilogue != 1 || dinv, "ds_spmm_union16m: the Chebyshev epilogue needs dinv");
+    DS_REQUIRE(group_nodes == 4 || group_nodes == 8, "ds_spmm_union16m: groups of 4 or 8 nodes");
+    DS_REQUIRE(nv > 0 && ngroups == (nv + group_nodes - 1) / group_nodes && ncols > 0 && ncols % 4 == 0 && ncols <= 84,
+               "ds_spmm_union16m: ncols must be a multiple of 4 <= 84 and ngroups = ceil(nv / group_nodes)");
+    DS_REQUIRE(max_entries > 0 && max_entries <= 256, "ds_spmm_union16m: a group with %d union entries exceeds 256", max_entries);
+    DS_REQUIRE(nnzb > 0 && nnzb * 24 < (int64_t)PIPE_OOB, "ds_spmm_union16m: the block array exceeds the descriptor range");
+    DS_REQUIRE(ldx >= ncols && ldy >= ncols && ldr >= ncols, "ds_spmm_union16m: leading dimension smaller than ncols");
+    DS_REQUIRE(X != Y, "ds_spmm_union16m: X and Y must be different buffers");
+    DS_REQUIRE(3 * nv * std::max(std::max(ldx, ldr), ldp) * 2 < (int64_t)PIPE_OOB && nv * 36 < (int64_t)PIPE_OOB,
+               "ds_spmm_union16m: a bf16 operand block exceeds the descriptor range");
+    uintptr_t al = reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(R0) | (uintptr_t)(ldx * 2) | (uintptr_t)(ldr * 2);
+    al |= reinterpret_cast<uintptr_t>(Y) | (uintptr_t)(ldy * (y_f32 ? 4 : 2)) | reinterpret_cast<uintptr_t>(kc);
+    DS_REQUIRE((al & 7) == 0 && (!y_f32 || ((reinterpret_cast<uintptr_t>(Y) | (uintptr_t)(ldy * 4)) & 15) == 0),
+               "ds_spmm_union16m: bf16 rows and kc must be 8-byte aligned (fp32 output rows 16-byte)");
+    DS_REQUIRE(!y_f32 || epilogue == 1, "ds_spmm_union16m: an fp32 result is the Chebyshev term's only");
+    hipStream_t st = ds::as_stream(stream);
+    ChebEpilogue epi{static_cast<const float*>(R0), ldr, dinv, c1, c2, first};
+    if (Wprev && epilogue == 1) {
+        DS_REQUIRE(ldp >= ncols && ((reinterpret_cast<uintptr_t>(Wprev) | (uintptr_t)(ldp * 2)) & 7) == 0 && Wprev != X,
+                   "ds_spmm_union16m: bad W_prev block");
+        epi.wprev = static_cast<const float*>(Wprev), epi.ldp = ldp;
+    }
+    const float* Xf = static_cast<const float*>(X);
+    float* Yf = static_cast<float*>(Y);
+    const int lpn = ncols / 4;
+    const int nt = (ncols + 15) / 16;
+#define DS_MF_GO(GG, N) return launch_mfma<GG, N>(epilogue, y_f32, gptr, gcol, gmeta, gbase, kc, nnzb, ngroups, nv, Xf, ldx, Yf, ldy, lpn, st, epi)
+    auto go = [&]() -> int {
+        if (group_nodes == 4) {
+            switch (nt) {
+                case 1: DS_MF_GO(4, 1); case 2: DS_MF_GO(4, 2); case 3: DS_MF_GO(4, 3);
+                case 4: DS_MF_GO(4, 4); case 5: DS_MF_GO(4, 5); default: DS_MF_GO(4, 6);
+            }
+        }
+        switch (nt) {
+            case 1: DS_MF_GO(8, 1); case 2: DS_MF_GO(8, 2); case 3: DS_MF_GO(8, 3);
+            case 4: DS_MF_GO(8, 4); case 5: DS_MF_GO(8, 5); default: DS_MF_GO(8, 6);
+        }
+    };
+#undef DS_MF_GO
+    if (epilogue == 1 && !y_f32) {
+        int rc = DS_OK;
+        if (profiled_launch(stream, st, nv, nnzb, ncols, first, 2, go, rc)) return rc;
+    }
+    return go();
 }

@@ -52,6 +52,18 @@ int chebyshev(const ds_level_t& L, const float* R, int64_t ldr, float* Wout, int
     return DS_OK;
 }
 
+// The level's bf16 term: the MFMA form when the level carries its tables, else the VALU kernel.
+int union16(const ds_level_t& L, int epilogue, const void* X, int64_t ldx, void* Y, int64_t ldy, int y_f32, const void* R0,
+            int64_t ldr, const float* dinv, int ncols, float c1, float c2, int first, const void* Wprev, int64_t ldp,
+            ds_stream_t stream) {
+    if (L.mf_group_nodes)
+        return ds_spmm_union16m(epilogue, L.mf_group_nodes, L.mf_gptr, L.mf_gcol, L.mf_gmeta, L.mf_gbase, L.mf_kc, L.nnzb,
+                                (L.nv + L.mf_group_nodes - 1) / L.mf_group_nodes, L.mf_max_entries, L.nv, X, ldx, Y, ldy, y_f32,
+                                R0, ldr, dinv, ncols, c1, c2, first, Wprev, ldp, stream);
+    return ds_spmm_union16(epilogue, L.utab, L.ctab, L.ngroups, L.cap_blocks, L.gent, L.kgrp, L.nnzb, L.nv, X, ldx, Y, ldy, y_f32,
+                           R0, ldr, dinv, ncols, c1, c2, first, Wprev, ldp, stream);
+}
+
 // The same recurrence on bf16 blocks (ds_spmm_union16): R16 is the bf16 right-hand side every term reads; the iterates
 // ping-pong between the bf16 scratch blocks A and B; the LAST term writes Wout - bf16, or fp32 when out32 (the result
 // that goes back to the solver).  Not from a guess: W_1 = T Rinit / theta, Rinit fp32 (rinit_f32: the solver's residual
@@ -82,9 +94,8 @@ int chebyshev16(const ds_level_t& L, const void* Rinit, int rinit_f32, int64_t l
             rho = rho_new;
         }
         const bool last = k == terms - 1;
-        int rc = ds_spmm_union16(1, L.utab, L.ctab, L.ngroups, L.cap_blocks, L.gent, L.kgrp, L.nnzb, L.nv, cur, lds,
-                                 last ? Wout : oth, last ? ldw : lds, last ? out32 : 0, R16, ldr, L.dinv, ncols, c1, c2,
-                                 k == 0 ? 1 : 0, last ? oth : nullptr, last ? lds : 0, stream);
+        int rc = union16(L, 1, cur, lds, last ? Wout : oth, last ? ldw : lds, last ? out32 : 0, R16, ldr, L.dinv, ncols, c1, c2,
+                         k == 0 ? 1 : 0, last ? oth : nullptr, last ? lds : 0, stream);
         if (rc != DS_OK) return rc;
         void* t = cur;
         cur = oth, oth = t;
@@ -97,9 +108,7 @@ int twolevel16(const ds_twolevel_t* p, ds_stream_t stream) {
     // W1 = S R (bf16 iterates in Wc / D / AD; R16 = bf16 copy of R, written by the first step)
     int rc = chebyshev16(p->fine, p->R, 1, p->ldr, p->R16, p->ldr16, p->Wc, p->ldwc, 0, p->D, p->AD, p->ldd, c, false, stream);
     if (rc != DS_OK) return rc;
-    rc = ds_spmm_union16(2, p->fine.utab, p->fine.ctab, p->fine.ngroups, p->fine.cap_blocks, p->fine.gent, p->fine.kgrp,
-                         p->fine.nnzb, p->fine.nv, p->Wc, p->ldwc, p->Rr, p->ldrr, 0, p->R16, p->ldr16, nullptr, c, 0.f, 0.f,
-                         0, nullptr, 0, stream);
+    rc = union16(p->fine, 2, p->Wc, p->ldwc, p->Rr, p->ldrr, 0, p->R16, p->ldr16, nullptr, c, 0.f, 0.f, 0, nullptr, 0, stream);
     if (rc != DS_OK) return rc;
     rc = ds_scalar_csr_spmm16(p->rptr, p->rcol, p->rw, p->coarse.nv, p->Rr, p->ldrr, p->Rc, p->ldc, c, 0.f, stream);
     if (rc != DS_OK) return rc;

@@ -93,6 +93,32 @@ class TetSystem:
         self._coarse = None
         self.assemble()
 
+    def mfma_tables(self, group_nodes=8):
+        """Topology tables of the MFMA form of the bf16 terms (ds_spmm_union16m) for groups of 4 or 8 consecutive nodes:
+        gptr / gcol = the sorted union of the column ids of each group's rows; gmeta per entry = presence mask of the
+        group's nodes | (first block of the entry inside the group) << 8; gbase = first block of each group; kperm = BSR
+        block of every position of the (group, entry, node) order.  Built once per topology with device sorts."""
+        cache = self.__dict__.setdefault("_mfma_tables", {})
+        if group_nodes not in cache:
+            G, nv, dev = int(group_nodes), self.nv, self.device
+            rows = torch.repeat_interleave(torch.arange(nv, device=dev), (self.rowptr[1:] - self.rowptr[:-1]).long())
+            key = ((rows // G) * nv + self.colidx.long()) * G + rows % G
+            key, order = torch.sort(key)
+            ekey, inv, counts = torch.unique_consecutive(key // G, return_inverse=True, return_counts=True)
+            ng = (nv + G - 1) // G
+            gptr = torch.searchsorted(ekey // nv, torch.arange(ng + 1, device=dev))
+            goff = torch.zeros(ekey.numel() + 1, dtype=torch.int64, device=dev)
+            goff[1:] = torch.cumsum(counts, 0)
+            mask = torch.zeros(ekey.numel(), dtype=torch.int64, device=dev)
+            mask.scatter_add_(0, inv, torch.ones_like(key) << (key % G))
+            gbase = goff[gptr[:-1].clamp(max=ekey.numel())]
+            within = goff[:-1] - torch.repeat_interleave(gbase, gptr[1:] - gptr[:-1])
+            ne_g = gptr[1:] - gptr[:-1]
+            cache[group_nodes] = dict(G=G, ngroups=ng, gptr=gptr.to(torch.int32), gcol=(ekey % nv).to(torch.int32).contiguous(),
+                                      gmeta=(mask | (within << 8)).to(torch.int32).contiguous(), gbase=gbase.to(torch.int32).contiguous(),
+                                      kperm=order.to(torch.int32).contiguous(), max_entries=int(ne_g.max()))
+        return cache[group_nodes]
+
     def with_own_values(self):
         """A view of this system that shares the mesh, pattern and tables but OWNS its assembled values
         (K_lambda, K_mu, M_s, per-tet geometry; 0.7 GB on the benchmark mesh): concurrent hypothesis lanes each
@@ -270,7 +296,17 @@ class _HipBlockOps:
         d.utab, d.ctab, d.ngroups, d.cap_blocks = (None if u.get("single") else u["utab"].data_ptr()), u["ctab"].data_ptr(), u["ngroups"], u["capb"]
         d.gent, d.kgrp, d.nnzb, d.nv, d.dinv = g["gent"].data_ptr(), self.kgrp.data_ptr(), self.kgrp.shape[0], self.nv, self.dinv.data_ptr()
         d.degree, d.lmax, d.lmin = int(degree), float(lmax), float(lmin)
+        mt = self._mfma
+        if mt is not None and self.kc is not None:  # the level's bf16 terms run on the matrix cores (ds_spmm_union16m)
+            d.mf_group_nodes, d.mf_max_entries = mt["G"], mt["max_entries"]
+            d.mf_gptr, d.mf_gcol, d.mf_gmeta, d.mf_gbase = (mt[k].data_ptr() for k in ("gptr", "gcol", "gmeta", "gbase"))
+            d.mf_kc = self.kc.data_ptr()
+        else:
+            d.mf_group_nodes = 0
         return d
+
+    _mfma = None  # tables of the MFMA form of the bf16 terms (TetSystem.mfma_tables), None: the VALU kernel
+    kc = None     # (nnzb, 3, 4) bf16: the 3x3 blocks in the order of those tables (ds_pack_kc)
 
     def twolevel_apply(self, smooth, coarse, R, W, D, AD, Rr, Rc, Ec, Dc, ADc, Wc, R16=None):
         """The whole two-level V-cycle W = B R through the native driver (ds_twolevel_apply): one call instead of
@@ -502,13 +538,27 @@ class _HipBlockOps:
     def cheb_term_bytes(self, ncols, first=False, elem_bytes=4):
         """Algorithmic bytes of one fused Chebyshev-term launch: K values + ids, row pointers, block-Jacobi blocks,
         W_k (gathered), R0 and W_{k-1} read (W_{k-1} = 0 is not read when ``first``), W_{k+1} written
-        (``elem_bytes`` = 2 for the bf16 blocks of the production preconditioner)."""
+        (``elem_bytes`` = 2 for the bf16 blocks of the production preconditioner).  The MFMA form of the bf16 term
+        reads the blocks as bf16 rows of 8 bytes (24 per block) and two words per union entry instead."""
         nnzb = self.colidx.shape[0]
-        return nnzb * (36 + 4) + (self.nv + 1) * 4 + self.nv * 36 + (3 if first else 4) * self.n * ncols * elem_bytes
+        vec = (3 if first else 4) * self.n * ncols * elem_bytes
+        mt = self._mfma
+        if elem_bytes == 2 and mt is not None and self.kc is not None:
+            return nnzb * 24 + mt["gcol"].numel() * 8 + mt["ngroups"] * 8 + self.nv * 36 + vec
+        return nnzb * (36 + 4) + (self.nv + 1) * 4 + self.nv * 36 + vec
 
     def cheb_spmm16(self, Wk, Wprev, R0, c1, c2, first):
-        """The fused term on bf16 blocks (ds_spmm_union16), in place on W_prev: what the bf16 V-cycle launches."""
+        """The fused term on bf16 blocks, in place on W_prev: what the bf16 V-cycle launches (ds_spmm_union16m when the
+        level carries the MFMA tables, else ds_spmm_union16)."""
         pp = _hip.ptr
+        mt = self._mfma
+        if mt is not None and self.kc is not None:
+            _hip.check(self._L.ds_spmm_union16m(1, mt["G"], pp(mt["gptr"]), pp(mt["gcol"]), pp(mt["gmeta"]), pp(mt["gbase"]),
+                                                pp(self.kc), self.kc.shape[0], mt["ngroups"], mt["max_entries"], self.nv, pp(Wk),
+                                                _ld(Wk), pp(Wprev), _ld(Wprev), 0, pp(R0), _ld(R0), pp(self.dinv), Wk.shape[1],
+                                                float(c1), float(c2), int(bool(first)), None, 0, _hip.stream_ptr()),
+                       "ds_spmm_union16m")
+            return
         g, u = self.sys.groups, self.sys.groups["union"]
         _hip.check(self._L.ds_spmm_union16(1, None if u.get("single") else pp(u["utab"]), pp(u["ctab"]), u["ngroups"], u["capb"],
                                            pp(g["gent"]), pp(self.kgrp), self.kgrp.shape[0], self.nv, pp(Wk), _ld(Wk), pp(Wprev),
@@ -606,9 +656,15 @@ class _HipBlockOps:
 class HipModalOps(_HipBlockOps):
     """One material hypothesis (lam, mu) on a TetSystem."""
 
-    def __init__(self, system: TetSystem, lam, mu, two_level=None, _level=0):
+    # nodes per wavefront of the MFMA form of the preconditioner's bf16 terms on (fine level, corner-node level); 0 keeps
+    # a level on the VALU kernel (ds_spmm_union16)
+    mfma_groups = (8, 0)
+
+    def __init__(self, system: TetSystem, lam, mu, two_level=None, _level=0, mfma_groups=None):
         """two_level: build the corner-node level for the two-level preconditioner (ord-2 meshes; default on)."""
         self.sys = system
+        if mfma_groups is not None:
+            self.mfma_groups = tuple(mfma_groups)
         self._init_common(system.rowptr, system.colidx, system.nv, system.device)
         dev = self.device
         self.k32 = torch.empty((system.nnzb, 9), dtype=torch.float32, device=dev)
@@ -621,7 +677,12 @@ class HipModalOps(_HipBlockOps):
             lvl = system.coarse_level()
             if lvl is not None:
                 self._xfer = lvl
-                self.coarse = HipModalOps(lvl["sys"], lam, mu, two_level=False, _level=1)
+                self.coarse = HipModalOps(lvl["sys"], lam, mu, two_level=False, _level=1, mfma_groups=self.mfma_groups)
+        G = self.mfma_groups[min(_level, 1)]
+        if G and system.groups is not None and system.nnzb * 24 < 0x7F000000:
+            mt = system.mfma_tables(G)
+            if mt["max_entries"] <= 256:
+                self._mfma = mt
         self.set_material(lam, mu)
         self.rigid = self._rigid_basis() if _level == 0 else None
 
@@ -641,6 +702,11 @@ class HipModalOps(_HipBlockOps):
                                               _hip.stream_ptr()), "ds_pack_groups")
             if self.m_kind == 1:
                 self.mgrp = self.ms32[s.groups["kperm64"]].contiguous()  # node-scalar mass values in group order
+            if self._mfma is not None:
+                if self.kc is None:
+                    self.kc = torch.empty((s.nnzb, 3, 4), dtype=torch.bfloat16, device=self.device)
+                _hip.check(self._L.ds_pack_kc(p(self.k32), p(self._mfma["kperm"]), s.nnzb, p(self.kc), _hip.stream_ptr()),
+                           "ds_pack_kc")
 
     def _rigid_basis(self):
         """Translations + rotations about the centroid, M-orthonormalised in fp64; stored (n, 8) fp32 with

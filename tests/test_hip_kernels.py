@@ -400,6 +400,69 @@ def test_bf16_union_terms_match_fp32_terms(dev, ncols):
     assert torch.equal(W16, Wf.bfloat16())
 
 
+@pytest.mark.parametrize("mesh,ncols,G", [(6, 80, 8), (6, 40, 8), (6, 84, 8), (6, 52, 4), (3, 80, 8), (10, 80, 8), (10, 80, 4),
+                                          (5, 16, 8)])
+def test_mfma_union_terms_match_valu_terms(dev, mesh, ncols, G):
+    """ds_spmm_union16m (block products on the matrix cores, 3x3 blocks rounded to bf16 and packed by ds_pack_kc, one
+    wave per 4 or 8 nodes) against ds_spmm_union16 fed the same bf16-rounded blocks: the two differ
+    by the order of the fp32 accumulation only.  Chebyshev term with fp32 and bf16 output, first term, out-of-place
+    W_prev, residual; meshes whose last group is incomplete and with several batches of entries per group."""
+    from diffsound_amd import _hip, meshgen
+    from diffsound_amd.diffelastic.mesh import TetMesh
+    from diffsound_amd.modal_ops import HipModalOps, TetSystem
+
+    v, t = meshgen.kuhn_box(mesh)
+    tm = TetMesh(torch.from_numpy(v).to(dev), torch.from_numpy(t).long().to(dev)).to_high_order(2)
+    sysd = TetSystem(tm.vertices, tm.tets, 2, 2700.0)
+    ops = HipModalOps(sysd, 2e10, 2e10)
+    g = torch.Generator(device=dev).manual_seed(ncols + mesh)
+    mk = lambda scale=1.0: (torch.randn((sysd.n, ncols), generator=g, device=dev) * scale).bfloat16()
+    X, Wp, R0 = mk(), mk(), mk(1e10)
+    L, p, u, gr = _hip.lib(), _hip.ptr, sysd.groups["union"], sysd.groups
+    ut = None if u["single"] else p(u["utab"])
+    k16 = ops.kgrp.bfloat16().float().contiguous()  # the VALU kernel on the rounded blocks = the reference
+    mt = sysd.mfma_tables(G)
+    assert mt["ngroups"] == (sysd.nv + G - 1) // G and int(mt["gptr"][-1]) == mt["gcol"].numel()
+    kc = torch.empty((sysd.nnzb, 3, 4), dtype=torch.bfloat16, device=dev)
+    _hip.check(L.ds_pack_kc(p(ops.k32), p(mt["kperm"]), sysd.nnzb, p(kc), _hip.stream_ptr()), "ds_pack_kc")
+    want = ops.k32.view(-1, 3, 3)[mt["kperm"].long()].bfloat16()
+    assert torch.equal(kc[:, :, :3], want) and float(kc[:, :, 3].abs().max()) == 0.0
+
+    def valu(epi, out, y32, first, wprev=None):
+        _hip.check(L.ds_spmm_union16(epi, ut, p(u["ctab"]), u["ngroups"], u["capb"], p(gr["gent"]), p(k16), k16.shape[0],
+                                     sysd.nv, p(X), ncols, p(out), out.stride(0), int(y32), p(R0), ncols, p(ops.dinv), ncols, 0.31,
+                                     0.77, int(first), p(wprev), 0 if wprev is None else ncols, _hip.stream_ptr()), "ds_spmm_union16")
+
+    def mfma(epi, out, y32, first, wprev=None):
+        _hip.check(L.ds_spmm_union16m(epi, G, p(mt["gptr"]), p(mt["gcol"]), p(mt["gmeta"]), p(mt["gbase"]), p(kc), sysd.nnzb,
+                                      mt["ngroups"], mt["max_entries"], sysd.nv, p(X), ncols, p(out), out.stride(0), int(y32), p(R0),
+                                      ncols, p(ops.dinv), ncols, 0.31, 0.77, int(first), p(wprev), 0 if wprev is None else ncols,
+                                      _hip.stream_ptr()), "ds_spmm_union16m")
+
+    def close(a, b, tol):
+        a, b = a.float(), b.float()
+        return float((a - b).abs().max() / b.abs().max()) < tol
+
+    for first in (False, True):
+        a32 = torch.full((sysd.n, ncols + 8), float("nan"), device=dev)
+        b32 = torch.full((sysd.n, ncols + 8), float("nan"), device=dev)
+        valu(1, a32[:, 4:4 + ncols], True, first, wprev=Wp)
+        mfma(1, b32[:, 4:4 + ncols], True, first, wprev=Wp)
+        assert bool(torch.isnan(b32[:, :4]).all()) and bool(torch.isnan(b32[:, 4 + ncols:]).all())
+        assert close(b32[:, 4:4 + ncols], a32[:, 4:4 + ncols], 2e-6)
+        a16, b16 = Wp.clone(), Wp.clone()
+        valu(1, a16, False, first)
+        mfma(1, b16, False, first)
+        assert close(b16, a16, 8e-3) and float((b16 != a16).float().mean()) < 0.02  # bf16 results: rare one-ulp flips
+    ar, br = torch.empty_like(X), torch.empty_like(X)
+    valu(2, ar, False, False)
+    mfma(2, br, False, False)
+    assert close(br, ar, 8e-3) and float((br != ar).float().mean()) < 0.02
+    br2 = torch.empty_like(X)
+    mfma(2, br2, False, False)
+    assert torch.equal(br, br2)  # deterministic
+
+
 def test_polish_products(case, dev):
     h, c = case["hops"], case["cops"]
     g = torch.Generator().manual_seed(9)
