@@ -779,21 +779,23 @@ extern "C" int ds_pack_kc(const float* k32, const int32_t* kperm, int64_t nnzb, 
 template <int G, int NT>
 static int launch_mfma(int epilogue, int y_f32, const int32_t* gptr, const int32_t* gcol, const int32_t* gmeta,
                        const int32_t* gbase, const void* kc, int64_t nnzb, int64_t ngroups, int64_t nv, const float* X,
-                       int64_t ldx, float* Y, int64_t ldy, int lpn, hipStream_t st, const ChebEpilogue& epi) {
+                       int64_t ldx, float* Y, int64_t ldy, int lpn, int acap, hipStream_t st, const ChebEpilogue& epi) {
     const char* kcp = static_cast<const char*>(kc);
+    const size_t lds = (size_t)mf_panel_bytes(lpn * 4, G) + (size_t)acap + 32;
     if (epilogue == 2)
-        spmm_union_mfma_kernel<G, NT, 2, false><<<(unsigned)ngroups, 64, 0, st>>>(gptr, gcol, gmeta, gbase, kcp, nnzb, (unsigned)ngroups, nv, X, ldx, Y, ldy, lpn, epi);
+        spmm_union_mfma_kernel<G, NT, 2, false><<<(unsigned)ngroups, 64, lds, st>>>(gptr, gcol, gmeta, gbase, kcp, nnzb, (unsigned)ngroups, nv, X, ldx, Y, ldy, lpn, acap, epi);
     else if (y_f32)
-        spmm_union_mfma_kernel<G, NT, 1, true><<<(unsigned)ngroups, 64, 0, st>>>(gptr, gcol, gmeta, gbase, kcp, nnzb, (unsigned)ngroups, nv, X, ldx, Y, ldy, lpn, epi);
+        spmm_union_mfma_kernel<G, NT, 1, true><<<(unsigned)ngroups, 64, lds, st>>>(gptr, gcol, gmeta, gbase, kcp, nnzb, (unsigned)ngroups, nv, X, ldx, Y, ldy, lpn, acap, epi);
     else
-        spmm_union_mfma_kernel<G, NT, 1, false><<<(unsigned)ngroups, 64, 0, st>>>(gptr, gcol, gmeta, gbase, kcp, nnzb, (unsigned)ngroups, nv, X, ldx, Y, ldy, lpn, epi);
+        spmm_union_mfma_kernel<G, NT, 1, false><<<(unsigned)ngroups, 64, lds, st>>>(gptr, gcol, gmeta, gbase, kcp, nnzb, (unsigned)ngroups, nv, X, ldx, Y, ldy, lpn, acap, epi);
     DS_LAUNCH_CHECK("spmm_union_mfma_kernel");
     return DS_OK;
 }
 
 extern "C" int ds_spmm_union16m(int epilogue, int group_nodes, const int32_t* gptr, const int32_t* gcol,
                                 const int32_t* gmeta, const int32_t* gbase, const void* kc, int64_t nnzb,
-                                int64_t ngroups, int max_entries, int64_t nv, const void* X, int64_t ldx, void* Y,
+                                int64_t ngroups, int max_entries, int max_batch_blocks, int64_t nv, const void* X,
+                                int64_t ldx, void* Y,
                                 int64_t ldy, int y_f32, const void* R0, int64_t ldr, const float* dinv, int ncols,
                                 float c1, float c2, int first, const void* Wprev, int64_t ldp, ds_stream_t stream) {
     DS_REQUIRE(gptr && gcol && gmeta && gbase && kc && X && Y && R0, "ds_spmm_union16m: null pointer");
@@ -803,6 +805,9 @@ extern "C" int ds_spmm_union16m(int epilogue, int group_nodes, const int32_t* gp
     DS_REQUIRE(nv > 0 && ngroups == (nv + group_nodes - 1) / group_nodes && ncols > 0 && ncols % 4 == 0 && ncols <= 84,
                "ds_spmm_union16m: ncols must be a multiple of 4 <= 84 and ngroups = ceil(nv / group_nodes)");
     DS_REQUIRE(max_entries > 0 && max_entries <= 256, "ds_spmm_union16m: a group with %d union entries exceeds 256", max_entries);
+    DS_REQUIRE(max_batch_blocks > 0 && max_batch_blocks <= 32 * group_nodes,
+               "ds_spmm_union16m: max_batch_blocks must be in (0, 32 x group_nodes]");
+    const int acap = ((max_batch_blocks * 24 + 1023) / 1024) * 1024;  // whole 1 KiB staging pieces
     DS_REQUIRE(nnzb > 0 && nnzb * 24 < (int64_t)PIPE_OOB, "ds_spmm_union16m: the block array exceeds the descriptor range");
     DS_REQUIRE(ldx >= ncols && ldy >= ncols && ldr >= ncols, "ds_spmm_union16m: leading dimension smaller than ncols");
     DS_REQUIRE(X != Y, "ds_spmm_union16m: X and Y must be different buffers");
@@ -824,7 +829,7 @@ extern "C" int ds_spmm_union16m(int epilogue, int group_nodes, const int32_t* gp
     float* Yf = static_cast<float*>(Y);
     const int lpn = ncols / 4;
     const int nt = (ncols + 15) / 16;
-#define DS_MF_GO(GG, N) return launch_mfma<GG, N>(epilogue, y_f32, gptr, gcol, gmeta, gbase, kc, nnzb, ngroups, nv, Xf, ldx, Yf, ldy, lpn, st, epi)
+#define DS_MF_GO(GG, N) return launch_mfma<GG, N>(epilogue, y_f32, gptr, gcol, gmeta, gbase, kc, nnzb, ngroups, nv, Xf, ldx, Yf, ldy, lpn, acap, st, epi)
     auto go = [&]() -> int {
         if (group_nodes == 4) {
             switch (nt) {

@@ -114,7 +114,11 @@ class TetSystem:
             gbase = goff[gptr[:-1].clamp(max=ekey.numel())]
             within = goff[:-1] - torch.repeat_interleave(gbase, gptr[1:] - gptr[:-1])
             ne_g = gptr[1:] - gptr[:-1]
-            cache[group_nodes] = dict(G=G, ngroups=ng, gptr=gptr.to(torch.int32), gcol=(ekey % nv).to(torch.int32).contiguous(),
+            # blocks per batch of 32 entries (counted from each group's first entry): sizes the kernel's LDS
+            eidx = torch.arange(ekey.numel(), device=dev)
+            batch = (ekey // nv) * 8 + (eidx - torch.repeat_interleave(gptr[:-1], ne_g)) // 32
+            per_batch = torch.zeros(ng * 8, dtype=torch.int64, device=dev).scatter_add_(0, batch, counts)
+            cache[group_nodes] = dict(G=G, max_batch_blocks=int(per_batch.max()), ngroups=ng, gptr=gptr.to(torch.int32), gcol=(ekey % nv).to(torch.int32).contiguous(),
                                       gmeta=(mask | (within << 8)).to(torch.int32).contiguous(), gbase=gbase.to(torch.int32).contiguous(),
                                       kperm=order.to(torch.int32).contiguous(), max_entries=int(ne_g.max()))
         return cache[group_nodes]
@@ -298,7 +302,7 @@ class _HipBlockOps:
         d.degree, d.lmax, d.lmin = int(degree), float(lmax), float(lmin)
         mt = self._mfma
         if mt is not None and self.kc is not None:  # the level's bf16 terms run on the matrix cores (ds_spmm_union16m)
-            d.mf_group_nodes, d.mf_max_entries = mt["G"], mt["max_entries"]
+            d.mf_group_nodes, d.mf_max_entries, d.mf_max_batch_blocks = mt["G"], mt["max_entries"], mt["max_batch_blocks"]
             d.mf_gptr, d.mf_gcol, d.mf_gmeta, d.mf_gbase = (mt[k].data_ptr() for k in ("gptr", "gcol", "gmeta", "gbase"))
             d.mf_kc = self.kc.data_ptr()
         else:
@@ -554,8 +558,8 @@ class _HipBlockOps:
         mt = self._mfma
         if mt is not None and self.kc is not None:
             _hip.check(self._L.ds_spmm_union16m(1, mt["G"], pp(mt["gptr"]), pp(mt["gcol"]), pp(mt["gmeta"]), pp(mt["gbase"]),
-                                                pp(self.kc), self.kc.shape[0], mt["ngroups"], mt["max_entries"], self.nv, pp(Wk),
-                                                _ld(Wk), pp(Wprev), _ld(Wprev), 0, pp(R0), _ld(R0), pp(self.dinv), Wk.shape[1],
+                                                pp(self.kc), self.kc.shape[0], mt["ngroups"], mt["max_entries"], mt["max_batch_blocks"],
+                                                self.nv, pp(Wk), _ld(Wk), pp(Wprev), _ld(Wprev), 0, pp(R0), _ld(R0), pp(self.dinv), Wk.shape[1],
                                                 float(c1), float(c2), int(bool(first)), None, 0, _hip.stream_ptr()),
                        "ds_spmm_union16m")
             return

@@ -435,7 +435,7 @@ def test_mfma_union_terms_match_valu_terms(dev, mesh, ncols, G):
 
     def mfma(epi, out, y32, first, wprev=None):
         _hip.check(L.ds_spmm_union16m(epi, G, p(mt["gptr"]), p(mt["gcol"]), p(mt["gmeta"]), p(mt["gbase"]), p(kc), sysd.nnzb,
-                                      mt["ngroups"], mt["max_entries"], sysd.nv, p(X), ncols, p(out), out.stride(0), int(y32), p(R0),
+                                      mt["ngroups"], mt["max_entries"], mt["max_batch_blocks"], sysd.nv, p(X), ncols, p(out), out.stride(0), int(y32), p(R0),
                                       ncols, p(ops.dinv), ncols, 0.31, 0.77, int(first), p(wprev), 0 if wprev is None else ncols,
                                       _hip.stream_ptr()), "ds_spmm_union16m")
 

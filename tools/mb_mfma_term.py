@@ -24,7 +24,7 @@ ut = None if u["single"] else p(u["utab"])
 G = int(sys.argv[3]) if len(sys.argv) > 3 else 8
 mt = sysd.mfma_tables(G)
 kc = torch.empty((sysd.nnzb, 3, 4), dtype=torch.bfloat16, device=dev)
-print(f"groups of {G}: {mt['ngroups']}, entries {mt['gcol'].numel()}, kc {kc.numel() * 2 / 1e6:.0f} MB, max entries {mt['max_entries']}")
+print(f"groups of {G}: {mt['ngroups']}, entries {mt['gcol'].numel()}, kc {kc.numel() * 2 / 1e6:.0f} MB, max entries {mt['max_entries']}, max blocks per batch {mt['max_batch_blocks']}")
 
 
 def pack():
@@ -39,7 +39,7 @@ def valu():
 
 def mfma():
     _hip.check(L.ds_spmm_union16m(1, G, p(mt["gptr"]), p(mt["gcol"]), p(mt["gmeta"]), p(mt["gbase"]), p(kc), sysd.nnzb, mt["ngroups"],
-                                  mt["max_entries"], sysd.nv, p(X), ncols, p(W), ncols, 0, p(R0), ncols, p(ops.dinv), ncols, 0.3, 0.7,
+                                  mt["max_entries"], mt["max_batch_blocks"], sysd.nv, p(X), ncols, p(W), ncols, 0, p(R0), ncols, p(ops.dinv), ncols, 0.3, 0.7,
                                   0, None, 0, _hip.stream_ptr()), "ds_spmm_union16m")
 
 
