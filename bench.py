@@ -77,7 +77,7 @@ def parse():
                          "(needs --dist-backend gloo: RCCL refuses two ranks on one device)")
     ap.add_argument("--mfma-groups", default="8,0",
                     help="nodes per wavefront of the MFMA form of the preconditioner's bf16 terms on the fine and on the "
-                         "corner-node level (4 or 8; 0 = the VALU kernel on that level)")
+                         "corner-node level (8, or 0 = the VALU kernel on that level)")
     ap.add_argument("--loss", default="mse", choices=["mse", "mss"],
                     help="scalar loss head: mse = the headline metric's; mss = the reference experiments' multi-scale "
                          "spectral loss (MSSLoss [1024..64], 'l1_loss', material_sync_train.py:124) on the STFT kernels")

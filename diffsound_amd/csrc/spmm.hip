@@ -801,7 +801,8 @@ extern "C" int ds_spmm_union16m(int epilogue, int group_nodes, const int32_t* gp
     DS_REQUIRE(gptr && gcol && gmeta && gbase && kc && X && Y && R0, "ds_spmm_union16m: null pointer");
     DS_REQUIRE(epilogue == 1 || epilogue == 2, "ds_spmm_union16m: epilogue must be 1 (Chebyshev term) or 2 (residual)");
     DS_REQUIRE(epilogue != 1 || dinv, "ds_spmm_union16m: the Chebyshev epilogue needs dinv");
-    DS_REQUIRE(group_nodes == 4 || group_nodes == 8, "ds_spmm_union16m: groups of 4 or 8 nodes");
+    // (4-node groups were slower on both levels; only the 8-node kernel is built)
+    DS_REQUIRE(group_nodes == 8, "ds_spmm_union16m: groups of 8 nodes");
     DS_REQUIRE(nv > 0 && ngroups == (nv + group_nodes - 1) / group_nodes && ncols > 0 && ncols % 4 == 0 && ncols <= 84,
                "ds_spmm_union16m: ncols must be a multiple of 4 <= 84 and ngroups = ceil(nv / group_nodes)");
     DS_REQUIRE(max_entries > 0 && max_entries <= 256, "ds_spmm_union16m: a group with %d union entries exceeds 256", max_entries);
@@ -831,12 +832,6 @@ extern "C" int ds_spmm_union16m(int epilogue, int group_nodes, const int32_t* gp
     const int nt = (ncols + 15) / 16;
 #define DS_MF_GO(GG, N) return launch_mfma<GG, N>(epilogue, y_f32, gptr, gcol, gmeta, gbase, kc, nnzb, ngroups, nv, Xf, ldx, Yf, ldy, lpn, acap, st, epi)
     auto go = [&]() -> int {
-        if (group_nodes == 4) {
-            switch (nt) {
-                case 1: DS_MF_GO(4, 1); case 2: DS_MF_GO(4, 2); case 3: DS_MF_GO(4, 3);
-                case 4: DS_MF_GO(4, 4); case 5: DS_MF_GO(4, 5); default: DS_MF_GO(4, 6);
-            }
-        }
         switch (nt) {
             case 1: DS_MF_GO(8, 1); case 2: DS_MF_GO(8, 2); case 3: DS_MF_GO(8, 3);
             case 4: DS_MF_GO(8, 4); case 5: DS_MF_GO(8, 5); default: DS_MF_GO(8, 6);

@@ -94,7 +94,7 @@ class TetSystem:
         self.assemble()
 
     def mfma_tables(self, group_nodes=8):
-        """Topology tables of the MFMA form of the bf16 terms (ds_spmm_union16m) for groups of 4 or 8 consecutive nodes:
+        """Topology tables of the MFMA form of the bf16 terms (ds_spmm_union16m) for groups of 8 consecutive nodes:
         gptr / gcol = the sorted union of the column ids of each group's rows; gmeta per entry = presence mask of the
         group's nodes | (first block of the entry inside the group) << 8; gbase = first block of each group; kperm = BSR
         block of every position of the (group, entry, node) order.  Built once per topology with device sorts."""
@@ -660,8 +660,9 @@ class _HipBlockOps:
 class HipModalOps(_HipBlockOps):
     """One material hypothesis (lam, mu) on a TetSystem."""
 
-    # nodes per wavefront of the MFMA form of the preconditioner's bf16 terms on (fine level, corner-node level); 0 keeps
-    # a level on the VALU kernel (ds_spmm_union16)
+    # nodes per wavefront of the MFMA form of the preconditioner's bf16 terms on (fine level, corner-node level): 8, or 0 =
+    # the VALU kernel (ds_spmm_union16).  The corner-node level stays on the VALU kernel (its launches are too short to
+    # gain: 36.0 against 35.8 passes/s with both levels on the matrix cores).
     mfma_groups = (8, 0)
 
     def __init__(self, system: TetSystem, lam, mu, two_level=None, _level=0, mfma_groups=None):
@@ -683,6 +684,8 @@ class HipModalOps(_HipBlockOps):
                 self._xfer = lvl
                 self.coarse = HipModalOps(lvl["sys"], lam, mu, two_level=False, _level=1, mfma_groups=self.mfma_groups)
         G = self.mfma_groups[min(_level, 1)]
+        if G not in (0, 8):
+            raise ValueError("mfma_groups: 8 nodes per wavefront, or 0 for the VALU kernel")
         if G and system.groups is not None and system.nnzb * 24 < 0x7F000000:
             mt = system.mfma_tables(G)
             if mt["max_entries"] <= 256:

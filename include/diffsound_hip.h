@@ -235,7 +235,7 @@ typedef struct {
     int64_t nv;
     const float* dinv;     /* (nv x 9) inverse diagonal blocks */
     double lmax, lmin;     /* the polynomial targets [lmin, lmax] of T K */
-    /* bf16 cycles only: mf_group_nodes = 4 or 8 sends the level's bf16 terms to ds_spmm_union16m (tables and the packed
+    /* bf16 cycles only: mf_group_nodes = 8 sends the level's bf16 terms to ds_spmm_union16m (tables and the packed
      * blocks as described there); 0: ds_spmm_union16 */
     int32_t mf_group_nodes;
     int32_t mf_max_entries;
@@ -288,7 +288,7 @@ int ds_spmm_union16(int epilogue, const int32_t* utab, const int32_t* ctab, int6
                     float c1, float c2, int first, const void* Wprev, int64_t ldp, ds_stream_t stream);
 /* MFMA form of ds_spmm_union16 (csrc/spmm_mfma.inc): the same two epilogues on the same bf16 blocks, the block
  * products on the matrix cores (v_mfma_f32_16x16x32_bf16; the 3x3 blocks rounded to bf16, fp32 accumulation), one
- * wavefront per group of group_nodes = 4 or 8 consecutive nodes.  Topology tables (device): gptr (ngroups + 1) / gcol =
+ * wavefront per group of group_nodes = 8 consecutive nodes.  Topology tables (device): gptr (ngroups + 1) / gcol =
  * the sorted union of the column ids of each group's rows; gmeta per entry = presence mask of the group's nodes |
  * (index of the entry's first block inside the group) << 8; gbase (ngroups) = first block of each group; kperm = the
  * BSR block of every position of the group / entry / node order.  ds_pack_kc writes kc (nnzb x 3 x 4 bf16: the rows of

@@ -400,21 +400,22 @@ def test_bf16_union_terms_match_fp32_terms(dev, ncols):
     assert torch.equal(W16, Wf.bfloat16())
 
 
-@pytest.mark.parametrize("mesh,ncols,G", [(6, 80, 8), (6, 40, 8), (6, 84, 8), (6, 52, 4), (3, 80, 8), (10, 80, 8), (10, 80, 4),
-                                          (5, 16, 8)])
-def test_mfma_union_terms_match_valu_terms(dev, mesh, ncols, G):
+@pytest.mark.parametrize("mesh,ncols,G,order", [(6, 80, 8, 2), (6, 40, 8, 2), (6, 84, 8, 2), (6, 52, 8, 2), (3, 80, 8, 2), (10, 80, 8, 2),
+                                                (5, 16, 8, 2), (12, 80, 8, 1), (26, 80, 8, 1)])
+def test_mfma_union_terms_match_valu_terms(dev, mesh, ncols, G, order):
     """ds_spmm_union16m (block products on the matrix cores, 3x3 blocks rounded to bf16 and packed by ds_pack_kc, one
-    wave per 4 or 8 nodes) against ds_spmm_union16 fed the same bf16-rounded blocks: the two differ
+    wave per 8 nodes) against ds_spmm_union16 fed the same bf16-rounded blocks: the two differ
     by the order of the fp32 accumulation only.  Chebyshev term with fp32 and bf16 output, first term, out-of-place
-    W_prev, residual; meshes whose last group is incomplete and with several batches of entries per group."""
+    W_prev, residual; meshes whose last group is incomplete and with several batches of entries per group, ord-1 meshes
+    (the corner-node level's kind)."""
     from diffsound_amd import _hip, meshgen
     from diffsound_amd.diffelastic.mesh import TetMesh
     from diffsound_amd.modal_ops import HipModalOps, TetSystem
 
     v, t = meshgen.kuhn_box(mesh)
-    tm = TetMesh(torch.from_numpy(v).to(dev), torch.from_numpy(t).long().to(dev)).to_high_order(2)
-    sysd = TetSystem(tm.vertices, tm.tets, 2, 2700.0)
-    ops = HipModalOps(sysd, 2e10, 2e10)
+    tm = TetMesh(torch.from_numpy(v).to(dev), torch.from_numpy(t).long().to(dev)).to_high_order(order)
+    sysd = TetSystem(tm.vertices, tm.tets, order, 2700.0)
+    ops = HipModalOps(sysd, 2e10, 2e10, two_level=False)
     g = torch.Generator(device=dev).manual_seed(ncols + mesh)
     mk = lambda scale=1.0: (torch.randn((sysd.n, ncols), generator=g, device=dev) * scale).bfloat16()
     X, Wp, R0 = mk(), mk(), mk(1e10)
@@ -461,6 +462,53 @@ def test_mfma_union_terms_match_valu_terms(dev, mesh, ncols, G):
     br2 = torch.empty_like(X)
     mfma(2, br2, False, False)
     assert torch.equal(br, br2)  # deterministic
+
+
+def test_mfma_terms_beside_other_kernels_are_repeatable(dev):
+    """The MFMA term on one stream and the VALU kernels (the eigensolver's fp32 K X, the bf16 term of the corner-node
+    level) on another, as the hypothesis lanes run them: every result of either stream equals its solo result bit for
+    bit.  With v_mfma_f32_16x16x32_bf16 in the MFMA kernel this failed - the packed-FMA kernels beside it returned
+    changed results - hence its 16x16x16 instructions (csrc/spmm_mfma.inc; tools/stress_mix.py is the longer form)."""
+    from diffsound_amd import meshgen
+    from diffsound_amd.diffelastic.mesh import TetMesh
+    from diffsound_amd.modal_ops import HipModalOps, TetSystem
+
+    def make(cells, order, G, seed):
+        v, t = meshgen.kuhn_box(cells)
+        tm = TetMesh(torch.from_numpy(v).to(dev), torch.from_numpy(t).long().to(dev)).to_high_order(order)
+        sysd = TetSystem(tm.vertices, tm.tets, order, 2700.0)
+        ops = HipModalOps(sysd, 2e10, 2e10, two_level=False, mfma_groups=(max(G, 0), 0))
+        g = torch.Generator(device=dev).manual_seed(seed)
+        mk = lambda: torch.randn(sysd.n, 80, generator=g, device=dev).bfloat16()
+        return dict(ops=ops, X=mk(), W=mk(), R=mk(), G=G)
+
+    def term(c, out):
+        if c["G"] < 0:
+            c["ops"].apply_K(c["X32"], out)
+            return
+        out.copy_(c["W"])
+        c["ops"].cheb_spmm16(c["X"], out, c["R"], 0.3, 0.7, False)
+
+    mf = make(14, 2, 8, 1)
+    assert mf["ops"]._mfma is not None and mf["ops"].kc is not None
+    for other in (make(14, 2, -1, 2), make(16, 1, 0, 3)):
+        if other["G"] < 0:
+            other["X32"], other["W"] = other["X"].float(), other["W"].float()
+        pair = (mf, other)
+        for c in pair:
+            c["ref"] = torch.empty_like(c["W"])
+            term(c, c["ref"])
+            c["outs"] = [torch.empty_like(c["W"]) for _ in range(16)]
+            c["stream"] = torch.cuda.Stream()
+        torch.cuda.synchronize()
+        for _ in range(3):
+            for c in pair:
+                with torch.cuda.stream(c["stream"]):
+                    for o in c["outs"]:
+                        term(c, o)
+            torch.cuda.synchronize()
+            for c in pair:
+                assert all(torch.equal(o, c["ref"]) for o in c["outs"]), c["G"]
 
 
 def test_polish_products(case, dev):
