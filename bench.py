@@ -401,15 +401,20 @@ def main():
         pmc = os.path.join(ROOT, "profiles", "spmm_pmc_bytes_per_launch.json")
         if os.path.exists(pmc):
             try:
-                traffic = json.load(open(pmc)).get(f"cells{a.cells}_cols{a.block}_{'bf16' if bf else 'fp32'}")
+                mf = bf and getattr(ops0, "_mfma", None) is not None and ops0.kc is not None
+                traffic = json.load(open(pmc)).get(f"cells{a.cells}_cols{a.block}_{'mfma' if mf else ('bf16' if bf else 'fp32')}")
             except Exception:
                 traffic = None
         roof = {"bound": "hbm", "achieved": solo, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": solo / HBM_PEAK_GBS, "traffic": traffic,
                 "stream_triad": stream_gbs, "frac_of_stream": solo / stream_gbs,
-                "kernel": (f"spmm_union_kernel<{a.block // 4},1,...,{'bf16' if bf else 'fp32'} blocks>: W' = W + c1(W - W_prev) + "
-                           f"c2 T(R0 - K W) on a {a.block}-column block, fine level (fp32 K blocks, "
-                           f"{'bf16' if bf else 'fp32'} iterates, fp32 arithmetic)"),
+                "kernel": ((f"spmm_union_mfma_kernel<8,{(a.block + 15) // 16},1>: W' = W + c1(W - W_prev) + c2 T(R0 - K W) on a "
+                            f"{a.block}-column block, fine level (bf16 K blocks and iterates, block products on the matrix "
+                            "cores with fp32 accumulation, fp32 epilogue)")
+                           if bf and getattr(ops0, "_mfma", None) is not None and ops0.kc is not None else
+                           (f"spmm_union_kernel<{a.block // 4},1,...,{'bf16' if bf else 'fp32'} blocks>: W' = W + c1(W - W_prev) + "
+                            f"c2 T(R0 - K W) on a {a.block}-column block, fine level (fp32 K blocks, "
+                            f"{'bf16' if bf else 'fp32'} iterates, fp32 arithmetic)")),
                 "algorithmic_bytes_per_launch": fine_bytes, "avg_launch_ms": solo_ms,
                 "how": ("'achieved' = algorithmic bytes of ONE fine-level fused-term launch / its HIP-event time with the "
                         "kernel alone on the device, on the compact blocks the V-cycle runs it on, right after the timed "

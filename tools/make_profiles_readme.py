@@ -41,7 +41,8 @@ GPU, cold-start eigensolve and numeric assembly in every pass.  Collected by `to
 | `r02_bench_kernel_stats.csv` | `rocprofv3 --kernel-trace --stats` of `python bench.py --no-cpu-baseline` (4 hypothesis lanes overlap: durations stretched by sharing) |
 | `r02_bench_lanes1_kernel_stats.csv` | the same with `--lanes 1 --hyp-per-gpu 2 --steps 4`: one hypothesis at a time, every kernel alone on the device — the table to read kernel durations from |
 | `r02_gpu_busy.txt` | device-busy fraction of the timed window from the kernel trace of the profiled default run (`tools/gpu_busy.py`; the profiler inflates the host side) |
-| `r02_spmm_pmc_fp32.json`, `r02_spmm_pmc_bf16.json`, `spmm_pmc_bytes_per_launch.json` | HBM-side traffic of the fused Chebyshev-term SpMM (fine level, 80 columns) from separate `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes; bytes = (2·FETCH + WRITE)·1024 (gfx950 correction of `guides/MI355X_MICROARCH.md`): fp32 blocks {pmc["cells26_cols80_fp32"] / 1e6:.0f} MB (743.1 MB algorithmic), **bf16 blocks {pmc["cells26_cols80_bf16"] / 1e6:.0f} MB (457.3 MB algorithmic, {pmc["cells26_cols80_bf16"] / 457.3e6:.2f} ×)** |
+| `r02_spmm_pmc_fp32.json`, `r02_spmm_pmc_bf16.json`, `r02_spmm_pmc_mfma.json`, `spmm_pmc_bytes_per_launch.json` | HBM-side traffic of the fused Chebyshev-term SpMM (fine level, 80 columns) from separate `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes; bytes = (2·FETCH + WRITE)·1024 (gfx950 correction of `guides/MI355X_MICROARCH.md`): VALU kernel on fp32 blocks {pmc["cells26_cols80_fp32"] / 1e6:.0f} MB (743.1 MB algorithmic), on bf16 blocks {pmc["cells26_cols80_bf16"] / 1e6:.0f} MB (457.3 MB algorithmic), **MFMA kernel (production) {pmc["cells26_cols80_mfma"] / 1e6:.0f} MB ({r["algorithmic_bytes_per_launch"] / 1e6:.1f} MB algorithmic, {pmc["cells26_cols80_mfma"] / r["algorithmic_bytes_per_launch"]:.2f} ×)** |
+| `r02_mfma_interference.txt` | why the MFMA kernel issues `v_mfma_f32_16x16x16_bf16`: with `v_mfma_f32_16x16x32_bf16` the packed-FMA kernels of OTHER streams returned changed results while it ran beside them (`tools/stress_mix.py`: paired launches on two streams compared bit for bit with solo results; bisection; bench loss sums of repeated runs) |
 | `r02_gram_mix.txt` | Gram / `mix` timings at the solver's shapes (`tools/mb_gram_mix.py`) |
 | `r02_gram_mix_pmc.json` | `--pmc SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE` over the same script: MFMA utilisation = busy cycles ÷ (GRBM_GUI_ACTIVE / 8 XCDs × 1024 SIMDs) = ''' + ", ".join(f"{k.split('(')[0]} {100 * v:.0f} %" for k, v in util.items()) + f''' |
 | `r02_stream_probe.txt` | STREAM triad / copy variants on the device (`tools/stream_probe.hip`): one 16-byte piece per thread reaches 6.1–6.4 TB/s, grid-stride loops 4.5–5.3 TB/s |
@@ -59,10 +60,11 @@ GPU, cold-start eigensolve and numeric assembly in every pass.  Collected by `to
 
 {table("r02_bench_lanes1_kernel_stats.csv", 22)}
 
-`spmm_union_kernel<20|0, EPI, 116, BIG, BF, OUT32>`: LPN 20 = full 80-column blocks, 0 = the narrower blocks after
-locking; EPI 0 K·W, 1 fused Chebyshev term, 2 residual handed to the corner-node level, 3 mass product; BF `true` = bf16
-blocks (the preconditioner), OUT32 `true` with BF = the term that leaves the V-cycle (fp32 result).  Fine-level and
-corner-node launches share a name (the corner-node ones are ten times more numerous and ~7× shorter).
+`spmm_union_mfma_kernel<8, NT, EPI, OUT32>`: the fine level's bf16 terms on the matrix cores (8 nodes per wavefront, NT
+16-column tiles: 5 = the full 80-column block, fewer after locking; EPI 1 fused Chebyshev term, 2 residual handed to the
+corner-node level; OUT32 = the term that leaves the V-cycle).  `spmm_union_kernel<20|0, EPI, 116, BIG, BF, OUT32>`: the
+VALU kernel - LPN 20 = full 80-column blocks, 0 = the narrower blocks after locking; EPI 0 K·W, 1 fused Chebyshev term
+(with BF `true`: the corner-node level's, ~23 us each), 3 mass product.
 
 ## Default run, 4 lanes (`r02_bench_kernel_stats.csv`)
 

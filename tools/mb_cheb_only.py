@@ -9,9 +9,10 @@ dev = torch.device('cuda')
 v, t = meshgen.kuhn_box(26)
 mesh = TetMesh(torch.from_numpy(v).to(dev), torch.from_numpy(t).long().to(dev)).to_high_order(2)
 sysd = TetSystem(mesh.vertices, mesh.tets, 2, 2700.0)
-ops = HipModalOps(sysd, 2e10, 2e10, two_level=False)
+kind = sys.argv[2] if len(sys.argv) > 2 else "fp32"  # fp32 | bf16 (VALU kernel on bf16 blocks) | mfma (ds_spmm_union16m)
+ops = HipModalOps(sysd, 2e10, 2e10, two_level=False, mfma_groups=(8, 0) if kind == "mfma" else (0, 0))
 X = torch.randn(sysd.n, 80, device=dev); W = torch.randn(sysd.n, 80, device=dev); R0 = torch.randn(sysd.n, 80, device=dev)
-bf = len(sys.argv) > 2 and sys.argv[2] == "bf16"
+bf = kind in ("bf16", "mfma")
 if bf:
     X, W, R0 = X.bfloat16(), W.bfloat16(), R0.bfloat16()
 for _ in range(int(sys.argv[1]) if len(sys.argv) > 1 else 4):
