@@ -17,6 +17,9 @@ import torch
 from . import _hip, fem_tables
 
 DS_F32, DS_F64 = 0, 1
+import threading
+
+_MFMA_TABLES_LOCK = threading.Lock()
 UNION_CAP = 116  # blocks per chunk of the neighbour-union tables (the kernel's smallest LDS image)
 
 
@@ -99,29 +102,36 @@ class TetSystem:
         group's nodes | (first block of the entry inside the group) << 8; gbase = first block of each group; kperm = BSR
         block of every position of the (group, entry, node) order.  Built once per topology with device sorts."""
         cache = self.__dict__.setdefault("_mfma_tables", {})
-        if group_nodes not in cache:
-            G, nv, dev = int(group_nodes), self.nv, self.device
-            rows = torch.repeat_interleave(torch.arange(nv, device=dev), (self.rowptr[1:] - self.rowptr[:-1]).long())
-            key = ((rows // G) * nv + self.colidx.long()) * G + rows % G
-            key, order = torch.sort(key)
-            ekey, inv, counts = torch.unique_consecutive(key // G, return_inverse=True, return_counts=True)
-            ng = (nv + G - 1) // G
-            gptr = torch.searchsorted(ekey // nv, torch.arange(ng + 1, device=dev))
-            goff = torch.zeros(ekey.numel() + 1, dtype=torch.int64, device=dev)
-            goff[1:] = torch.cumsum(counts, 0)
-            mask = torch.zeros(ekey.numel(), dtype=torch.int64, device=dev)
-            mask.scatter_add_(0, inv, torch.ones_like(key) << (key % G))
-            gbase = goff[gptr[:-1].clamp(max=ekey.numel())]
-            within = goff[:-1] - torch.repeat_interleave(gbase, gptr[1:] - gptr[:-1])
-            ne_g = gptr[1:] - gptr[:-1]
-            # blocks per batch of 32 entries (counted from each group's first entry): sizes the kernel's LDS
-            eidx = torch.arange(ekey.numel(), device=dev)
-            batch = (ekey // nv) * 8 + (eidx - torch.repeat_interleave(gptr[:-1], ne_g)) // 32
-            per_batch = torch.zeros(ng * 8, dtype=torch.int64, device=dev).scatter_add_(0, batch, counts)
-            cache[group_nodes] = dict(G=G, max_batch_blocks=int(per_batch.max()), ngroups=ng, gptr=gptr.to(torch.int32), gcol=(ekey % nv).to(torch.int32).contiguous(),
-                                      gmeta=(mask | (within << 8)).to(torch.int32).contiguous(), gbase=gbase.to(torch.int32).contiguous(),
-                                      kperm=order.to(torch.int32).contiguous(), max_entries=int(ne_g.max()))
+        with _MFMA_TABLES_LOCK:  # hypothesis lanes share the cache (with_own_values copies the dict reference)
+            if group_nodes not in cache:
+                cache[group_nodes] = self._build_mfma_tables(group_nodes)
+                torch.cuda.current_stream(self.device).synchronize()  # other lanes use the tables on their own streams
         return cache[group_nodes]
+
+    def _build_mfma_tables(self, group_nodes):
+        G, nv, dev = int(group_nodes), self.nv, self.device
+        rows = torch.repeat_interleave(torch.arange(nv, device=dev), (self.rowptr[1:] - self.rowptr[:-1]).long())
+        key = ((rows // G) * nv + self.colidx.long()) * G + rows % G
+        key, order = torch.sort(key)
+        ekey, inv, counts = torch.unique_consecutive(key // G, return_inverse=True, return_counts=True)
+        ng = (nv + G - 1) // G
+        gptr = torch.searchsorted(ekey // nv, torch.arange(ng + 1, device=dev))
+        goff = torch.zeros(ekey.numel() + 1, dtype=torch.int64, device=dev)
+        goff[1:] = torch.cumsum(counts, 0)
+        mask = torch.zeros(ekey.numel(), dtype=torch.int64, device=dev)
+        mask.scatter_add_(0, inv, torch.ones_like(key) << (key % G))
+        gbase = goff[gptr[:-1].clamp(max=ekey.numel())]
+        within = goff[:-1] - torch.repeat_interleave(gbase, gptr[1:] - gptr[:-1])
+        ne_g = gptr[1:] - gptr[:-1]
+        # blocks per batch of 32 entries (counted from each group's first entry): sizes the kernel's LDS
+        eidx = torch.arange(ekey.numel(), device=dev)
+        # (a group of more than 256 entries is not served by the kernel; its tail is lumped into the last slot here)
+        batch = (ekey // nv) * 8 + ((eidx - torch.repeat_interleave(gptr[:-1], ne_g)) // 32).clamp(max=7)
+        per_batch = torch.zeros(ng * 8, dtype=torch.int64, device=dev).scatter_add_(0, batch, counts)
+        return dict(G=G, ngroups=ng, max_entries=int(ne_g.max()), max_batch_blocks=int(per_batch.max()),
+                    gptr=gptr.to(torch.int32), gcol=(ekey % nv).to(torch.int32).contiguous(),
+                    gmeta=(mask | (within << 8)).to(torch.int32).contiguous(), gbase=gbase.to(torch.int32).contiguous(),
+                    kperm=order.to(torch.int32).contiguous())
 
     def with_own_values(self):
         """A view of this system that shares the mesh, pattern and tables but OWNS its assembled values
@@ -688,7 +698,7 @@ class HipModalOps(_HipBlockOps):
             raise ValueError("mfma_groups: 8 nodes per wavefront, or 0 for the VALU kernel")
         if G and system.groups is not None and system.nnzb * 24 < 0x7F000000:
             mt = system.mfma_tables(G)
-            if mt["max_entries"] <= 256:
+            if mt["max_entries"] <= 256 and mt["max_batch_blocks"] <= 32 * G:  # what ds_spmm_union16m serves
                 self._mfma = mt
         self.set_material(lam, mu)
         self.rigid = self._rigid_basis() if _level == 0 else None

@@ -464,6 +464,35 @@ def test_mfma_union_terms_match_valu_terms(dev, mesh, ncols, G, order):
     assert torch.equal(br, br2)  # deterministic
 
 
+def test_mfma_entry_point_refuses_what_it_does_not_serve(dev):
+    """ds_spmm_union16m validates on the host before any launch: group size, table limits, aliasing, alignment."""
+    from diffsound_amd import _hip, meshgen
+    from diffsound_amd.diffelastic.mesh import TetMesh
+    from diffsound_amd.modal_ops import HipModalOps, TetSystem
+
+    v, t = meshgen.kuhn_box(4)
+    tm = TetMesh(torch.from_numpy(v).to(dev), torch.from_numpy(t).long().to(dev)).to_high_order(2)
+    sysd = TetSystem(tm.vertices, tm.tets, 2, 2700.0)
+    ops = HipModalOps(sysd, 2e10, 2e10, two_level=False, mfma_groups=(8, 0))
+    mt, L, p = ops._mfma, _hip.lib(), _hip.ptr
+    X = torch.randn(sysd.n, 80, device=dev).bfloat16()
+    Y, R0 = torch.empty_like(X), torch.empty_like(X)
+
+    def call(G=8, max_entries=None, mbb=None, x=X, y=Y, ncols=80, epi=1, dinv=ops.dinv, y32=0):
+        return L.ds_spmm_union16m(epi, G, p(mt["gptr"]), p(mt["gcol"]), p(mt["gmeta"]), p(mt["gbase"]), p(ops.kc), sysd.nnzb,
+                                  (sysd.nv + G - 1) // G, mt["max_entries"] if max_entries is None else max_entries,
+                                  mt["max_batch_blocks"] if mbb is None else mbb, sysd.nv, p(x), x.stride(0), p(y), y.stride(0), y32,
+                                  p(R0), 80, None if dinv is None else p(dinv), ncols, 0.3, 0.7, 0, None, 0, _hip.stream_ptr())
+
+    assert call() == 0
+    for bad in (dict(G=4), dict(G=16), dict(max_entries=257), dict(mbb=0), dict(mbb=257), dict(y=X), dict(ncols=88), dict(ncols=78),
+                dict(epi=0), dict(epi=3), dict(dinv=None), dict(y32=1, epi=2), dict(x=X[:, 1:])):
+        assert call(**bad) != 0, bad
+        assert L.ds_last_error()
+    with pytest.raises(ValueError, match="mfma_groups"):
+        HipModalOps(sysd, 2e10, 2e10, two_level=False, mfma_groups=(4, 0))
+
+
 def test_mfma_terms_beside_other_kernels_are_repeatable(dev):
     """The MFMA term on one stream and the VALU kernels (the eigensolver's fp32 K X, the bf16 term of the corner-node
     level) on another, as the hypothesis lanes run them: every result of either stream equals its solo result bit for
