@@ -24,4 +24,6 @@ for c in (80, 40):
     X = torch.randn(sysd.n, c, device=dev); Y = torch.empty_like(X); Wp = torch.randn_like(X); R0 = torch.randn_like(X)
     out.append(f"c={c}: K {tm(lambda: ops.apply_K(X, Y)):.1f} us  fused {tm(lambda: ops._cheb_spmm_launch(X, Wp, R0, 0.3, 0.7, False)):.1f} us  "
                f"bytes(fused) {ops.cheb_term_bytes(c)/1e6:.1f} MB")
+Xb, Wb, Rb = (torch.randn(sysd.n, 80, device=dev).bfloat16() for _ in range(3))
+out.append(f"bf16 fused term (80 columns): {tm(lambda: ops.cheb_spmm16(Xb, Wb, Rb, 0.3, 0.7, False)):.1f} us")
 print("  ".join(out), flush=True)
