@@ -12,7 +12,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libdiffsound_hip.so")
-ABI_VERSION = 22  # DS_ABI_VERSION of include/diffsound_hip.h
+ABI_VERSION = 23  # DS_ABI_VERSION of include/diffsound_hip.h
 
 c_i32p = ctypes.POINTER(ctypes.c_int32)
 _P = ctypes.c_void_p
@@ -33,6 +33,7 @@ _SIGNATURES = {
                                ctypes.POINTER(_I64)]),
     "ds_dpattern_export": (_I, [_P] * 13),
     "ds_dpattern_free": (None, [_P]),
+    "ds_spmm_f64_polish": (_I, [_P, _P, _P, _P, _P, _I64, _P, _I64, _P, _P, _P, _I64, _I, _P]),
     "ds_pack_kc": (_I, [_P, _P, _I64, _P, _P]),
     "ds_spmm_union16m": (_I, [_I, _I, _P, _P, _P, _P, _P, _I64, _I64, _I, _I, _I64, _P, _I64, _P, _I64, _I, _P, _I64, _P, _I, _F,
                               _F, _I, _P, _I64, _P]),

@@ -467,6 +467,85 @@ __global__ void __launch_bounds__(256)
     }
 }
 
+// The read-out's three fp64-value products in ONE walk of the pattern: Ya = A X, Yb = B X (3x3 fp64 blocks: K_lambda and
+// K_mu) and Ym = (m (x) I3) X (the node-scalar mass values) share every gathered panel of the fp32 block X.  Three
+// launches of spmm_f64_node_kernel are bound by exactly those gathers (3.2 GB out of L2 per 64-column product at the
+// benchmark size: 0.63 + 0.63 + 0.22 ms); per output the arithmetic and its order are theirs, so the results are
+// bit-identical.
+__global__ void __launch_bounds__(256)
+    spmm_f64_polish_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx,
+                           const double* __restrict__ va, const double* __restrict__ vb, const double* __restrict__ vm,
+                           int64_t nv, const float* __restrict__ X, int64_t ldx, double* __restrict__ Ya,
+                           double* __restrict__ Yb, double* __restrict__ Ym, int64_t ldy, int lpn, unsigned nblk) {
+    using d2 = __attribute__((ext_vector_type(2))) double;
+    using xv4 = __attribute__((ext_vector_type(4))) float;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t node = (int64_t)ds::xcd_remap(blockIdx.x, nblk) * 4 + wave;
+    if (node >= nv) return;  // wave-uniform
+    const int g = lane / lpn, cl = lane - g * lpn;
+    const bool active = g < 3;
+    const int ga = active ? g : 0;
+    const int kb = __builtin_amdgcn_readfirstlane(rowptr[node]), ke = __builtin_amdgcn_readfirstlane(rowptr[node + 1]);
+    const float* xb = X + (int64_t)ga * ldx + cl * 4;
+    double aa[3][4], ab[3][4], am[4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        am[v] = 0.0;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) aa[r][v] = ab[r][v] = 0.0;
+    }
+#pragma unroll 4
+    for (int k = kb; k < ke; ++k) {
+        const int64_t col = colidx[k];
+        const xv4 x = *reinterpret_cast<const xv4*>(xb + col * 3 * ldx);
+        const double* pa = va + (int64_t)k * 9 + ga;  // column g of the blocks
+        const double* pb = vb + (int64_t)k * 9 + ga;
+        const double a0 = pa[0], a1 = pa[3], a2 = pa[6], b0 = pb[0], b1 = pb[3], b2 = pb[6], m = vm[k];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const double xv = (double)x[v];
+            aa[0][v] = fma(a0, xv, aa[0][v]);
+            aa[1][v] = fma(a1, xv, aa[1][v]);
+            aa[2][v] = fma(a2, xv, aa[2][v]);
+            ab[0][v] = fma(b0, xv, ab[0][v]);
+            ab[1][v] = fma(b1, xv, ab[1][v]);
+            ab[2][v] = fma(b2, xv, ab[2][v]);
+            am[v] = fma(m, xv, am[v]);
+        }
+    }
+    // lane (g, cl) ends with output row g: its own share plus the shares of the two other groups (as the node kernel)
+    double oa[4], ob[4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        oa[v] = ga == 0 ? aa[0][v] : (ga == 1 ? aa[1][v] : aa[2][v]);
+        ob[v] = ga == 0 ? ab[0][v] : (ga == 1 ? ab[1][v] : ab[2][v]);
+    }
+#pragma unroll
+    for (int s_ = 1; s_ <= 2; ++s_) {
+        const int to_row = (ga + s_) % 3;
+        int src_g = ga - s_;
+        if (src_g < 0) src_g += 3;
+        const int src_lane = active ? src_g * lpn + cl : lane;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const double sa = to_row == 0 ? aa[0][v] : (to_row == 1 ? aa[1][v] : aa[2][v]);
+            const double sb = to_row == 0 ? ab[0][v] : (to_row == 1 ? ab[1][v] : ab[2][v]);
+            oa[v] += __shfl(sa, src_lane, 64);
+            ob[v] += __shfl(sb, src_lane, 64);
+        }
+    }
+    if (active) {
+        const int64_t o = (node * 3 + g) * ldy + cl * 4;
+        *reinterpret_cast<d2*>(Ya + o) = d2{oa[0], oa[1]};
+        *reinterpret_cast<d2*>(Ya + o + 2) = d2{oa[2], oa[3]};
+        *reinterpret_cast<d2*>(Yb + o) = d2{ob[0], ob[1]};
+        *reinterpret_cast<d2*>(Yb + o + 2) = d2{ob[2], ob[3]};
+        *reinterpret_cast<d2*>(Ym + o) = d2{am[0], am[1]};
+        *reinterpret_cast<d2*>(Ym + o + 2) = d2{am[2], am[3]};
+    }
+}
+
 }  // namespace
 
 extern "C" int ds_spmm_bsr3(int kind, const int32_t* rowptr, const int32_t* colidx, const void* vals,
@@ -843,4 +922,23 @@ extern "C" int ds_spmm_union16m(int epilogue, int group_nodes, const int32_t* gp
         if (profiled_launch(stream, st, nv, nnzb, ncols, first, 2, go, rc)) return rc;
     }
     return go();
+}
+
+// Ya = A X, Yb = B X (fp64 3x3 block values), Ym = (m (x) I3) X (fp64 node scalars) for one fp32 block X in one walk.
+extern "C" int ds_spmm_f64_polish(const int32_t* rowptr, const int32_t* colidx, const double* a, const double* b,
+                                  const double* m, int64_t nv, const float* X, int64_t ldx, double* Ya, double* Yb,
+                                  double* Ym, int64_t ldy, int ncols, ds_stream_t stream) {
+    DS_REQUIRE(rowptr && colidx && a && b && m && X && Ya && Yb && Ym, "ds_spmm_f64_polish: null pointer");
+    DS_REQUIRE(nv > 0 && ncols > 0 && ncols % 4 == 0 && ncols <= 84, "ds_spmm_f64_polish: ncols must be a multiple of 4 <= 84");
+    DS_REQUIRE(ldx >= ncols && ldy >= ncols, "ds_spmm_f64_polish: leading dimension smaller than ncols");
+    const uintptr_t ya = reinterpret_cast<uintptr_t>(Ya) | reinterpret_cast<uintptr_t>(Yb) | reinterpret_cast<uintptr_t>(Ym) |
+                         (uintptr_t)(ldy * 8);
+    DS_REQUIRE(((reinterpret_cast<uintptr_t>(X) | (uintptr_t)(ldx * 4) | ya) & 15) == 0,
+               "ds_spmm_f64_polish: rows must be 16-byte aligned");
+    DS_REQUIRE(Ya != Yb && Ya != Ym && Yb != Ym, "ds_spmm_f64_polish: the three results must be different buffers");
+    const unsigned nblk = (unsigned)ds::ceil_div(nv, 4);
+    spmm_f64_polish_kernel<<<nblk, 256, 0, ds::as_stream(stream)>>>(rowptr, colidx, a, b, m, nv, X, ldx, Ya, Yb, Ym, ldy,
+                                                                    ncols / 4, nblk);
+    DS_LAUNCH_CHECK("spmm_f64_polish_kernel");
+    return DS_OK;
 }

@@ -40,7 +40,7 @@ enum { DS_OK = 0, DS_ERR_ARG = 1, DS_ERR_HIP = 2, DS_ERR_NOMEM = 3 };
 /* Thread-local text of the last error returned on this thread ("" if none). */
 const char* ds_last_error(void);
 /* Library ABI version (bumped on any signature change); ds_abi_version() returns the value the library was built with. */
-#define DS_ABI_VERSION 22
+#define DS_ABI_VERSION 23
 int ds_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------------
@@ -195,6 +195,13 @@ int ds_scalar_csr_spmm(const int32_t* rowptr, const int32_t* colidx, const float
                        const float* X, int64_t ldx, float* Y, int64_t ldy, int ncols, float beta,
                        ds_stream_t stream);
 /* kgrp: (nnzb x 9) f32 = the TRANSPOSED blocks in group order, kgrp[p] = vals_t[kperm[p]] (tables of ds_groups_build). */
+/* The three fp64-value products of the read-out in one walk of the pattern (the panels of X are gathered once instead of
+ * three times): Ya = A X, Yb = B X with (nnzb x 9) fp64 blocks (K_lambda, K_mu), Ym = (m (x) I3) X with nnzb fp64 node
+ * scalars (M_s); X fp32, results fp64, ncols a multiple of 4 <= 84, 16-byte aligned rows.  Bit-identical to ds_spmm_bsr3
+ * kinds 2, 2, 3.  (reference: the autograd read-out of get_undamped_freqs, src/diffelastic/diff_model.py:371-388) */
+int ds_spmm_f64_polish(const int32_t* rowptr, const int32_t* colidx, const double* a, const double* b, const double* m,
+                       int64_t nv, const float* X, int64_t ldx, double* Ya, double* Yb, double* Ym, int64_t ldy, int ncols,
+                       ds_stream_t stream);
 int ds_pack_groups(const float* vals_t, const int32_t* kperm, int64_t nnzb, float* kgrp, ds_stream_t stream);
 /* Neighbour-union form of ds_spmm_bsr3 / ds_cheb_spmm / ds_spmm_residual for ncols <= 84 (the eigensolver's
  * b-column products and every preconditioner term): one wavefront per group of 4 consecutive nodes walks the UNION

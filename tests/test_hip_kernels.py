@@ -540,6 +540,38 @@ def test_mfma_terms_beside_other_kernels_are_repeatable(dev):
                 assert all(torch.equal(o, c["ref"]) for o in c["outs"]), c["G"]
 
 
+def test_fused_polish_products_match_separate_launches(dev):
+    """ds_spmm_f64_polish (K_lambda X, K_mu X, M_s X in one walk) against three ds_spmm_bsr3 launches: bit-identical."""
+    from diffsound_amd import _hip, meshgen
+    from diffsound_amd.diffelastic.mesh import TetMesh
+    from diffsound_amd.modal_ops import HipModalOps, TetSystem
+
+    v, t = meshgen.kuhn_box(7)
+    tm = TetMesh(torch.from_numpy(v).to(dev), torch.from_numpy(t).long().to(dev)).to_high_order(2)
+    sysd = TetSystem(tm.vertices, tm.tets, 2, 2700.0)
+    ops = HipModalOps(sysd, 2e10, 3e10, two_level=False)
+    L, p = _hip.lib(), _hip.ptr
+    for c in (64, 84, 4):
+        Xw = torch.randn((sysd.n, c + 8), generator=torch.Generator(device=dev).manual_seed(c), device=dev)
+        X = Xw[:, 4:4 + c]  # a column range of a wider block
+        ref = [torch.empty((sysd.n, c), dtype=torch.float64, device=dev) for _ in range(3)]
+        for (kind, vals), out in zip(((2, sysd.klam), (2, sysd.kmu), (3, sysd.ms)), ref):
+            ops._spmm(kind, vals, X, out)
+        got = torch.full((3, sysd.n, c), float("nan"), dtype=torch.float64, device=dev)
+        _hip.check(L.ds_spmm_f64_polish(p(sysd.rowptr), p(sysd.colidx), p(sysd.klam), p(sysd.kmu), p(sysd.ms), sysd.nv, p(X),
+                                        X.stride(0), p(got[0]), p(got[1]), p(got[2]), c, c, _hip.stream_ptr()), "ds_spmm_f64_polish")
+        for a, b in zip(got, ref):
+            assert torch.equal(a, b)
+    # and through the ops: the read-out's Gram matrices are what the separate launches gave
+    X = torch.randn((sysd.n, 64), generator=torch.Generator(device=dev).manual_seed(1), device=dev)
+    GK, coef, GM = ops.polish_products(X)
+    Y = torch.empty((sysd.n, 64), dtype=torch.float64, device=dev)
+    for (kind, vals), G in zip(((2, sysd.klam), (2, sysd.kmu), (3, sysd.ms)), GK + [GM]):
+        ops._spmm(kind, vals, X, Y)
+        assert torch.equal(G, ops.gram(X, Y))
+    assert coef == list(ops.lame)
+
+
 def test_polish_products(case, dev):
     h, c = case["hops"], case["cops"]
     g = torch.Generator().manual_seed(9)
