@@ -1,1 +1,1 @@
-from diffsound_amd.utils.utils import LOBPCG_solver_freq  # noqa: F401
+from diffsound_amd.utils.utils import LOBPCG_solver_freq, plot_spec, resample  # noqa: F401
