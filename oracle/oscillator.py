@@ -3,7 +3,12 @@
 Follows /root/reference/src/ddsp/oscillator.py:
   TraditionalDampedOscillator.forward :282-310
   DampedOscillator.forward            :113-141
+  DampedOscillator.early / forward_curve :85-109, :143-176
+  GTDampedOscillator.forward          :217-243
   WeightedSum / DirectValue           :23-46   and  src/ddsp/utils.py:6-9
+  FilteredNoise.forward               src/ddsp/filtered_noise.py:20-67
+Pinned by tests/golden/g5_oscillator.npz and g7_real_audio.npz (outputs of the imported reference,
+tests/golden/make_golden.py) in tests/test_oracle_golden.py.
 """
 import numpy as np
 import torch
@@ -107,3 +112,25 @@ def filtered_noise(coefficient_bank, noise, sample_num, frame_length=64, attenua
     for i in range(nf):                                         # overlap-add, stride frame_length (:61-65)
         out[:, i * frame_length:i * frame_length + nfft] += frames[:, i]
     return out[:, :sample_num]
+
+
+def bank_curve(freq_linear, damp_per_mode, forces, sample_num, sr, normalise):
+    """DampedOscillator.early (oscillator.py:85-109; normalise False) / forward_curve (:143-176; True): the damping
+    of every mode is a GIVEN number (the reference evaluates a host callback on the detached frequency, :89-93 /
+    :150-154), unit amplitudes; fp32 cumsum path as in the reference.  freq_linear (m, 1) torch (autograd ok),
+    damp_per_mode (m,) array.  Returns (signal (A, S), damped_freq (m,))."""
+    A = forces.shape[0]
+    m = freq_linear.shape[0]
+    d_ = torch.as_tensor(np.asarray(damp_per_mode), dtype=torch.float32).reshape(1, m, 1)
+    damp = d_.repeat(A, 1, sample_num)
+    lbd = (freq_linear * 2 * np.pi) ** 2
+    damped_freq = (lbd - d_ ** 2) ** 0.5 / (2 * np.pi)
+    freq = (lbd - damp ** 2) ** 0.5 / (2 * np.pi)
+    D = torch.cumsum(damp / sr, dim=2)
+    P = torch.cumsum(freq / sr, dim=2)
+    signal = (torch.exp(-D) * torch.sin(2 * np.pi * P)).sum(1).unsqueeze(0)
+    w = torch.flip(forces.reshape(A, 1, -1), [-1])
+    signal = F.conv1d(signal, w, groups=A, padding=forces.shape[-1] - 1).squeeze(0)[:, :sample_num]
+    if normalise:
+        signal = signal / torch.max(torch.abs(signal), dim=1, keepdim=True)[0]
+    return signal, damped_freq.reshape(-1)

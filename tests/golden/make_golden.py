@@ -30,7 +30,8 @@ from src.diffelastic.gauss import generate_gauss_points_weights  # noqa: E402
 from src.diffelastic.shape_func import get_shape_function, get_shape_function_grad  # noqa: E402
 from src.diffelastic.mass_matrix import get_elememt_mass_matrix  # noqa: E402
 from src.diffelastic.material_model import Material  # noqa: E402
-from src.ddsp.oscillator import TraditionalDampedOscillator, DampedOscillator  # noqa: E402
+from src.ddsp.oscillator import TraditionalDampedOscillator, DampedOscillator, GTDampedOscillator  # noqa: E402
+from src.ddsp.filtered_noise import FilteredNoise  # noqa: E402
 from src.lobpcg import lobpcg_func  # noqa: E402
 
 MAT = (2700.0, 5e10, 0.25, 6.0, 1e-7)
@@ -282,6 +283,81 @@ def oscillator():
     print("g5 done")
 
 
+def real_audio_front_half():
+    """G7: src/ddsp/oscillator.py:178-243 (GTDampedOscillator.forward with and without
+    the per-sample frequency offsets and the noise branch, damping()), :85-109 (DampedOscillator.early), :143-176
+    (forward_curve), src/ddsp/filtered_noise.py:7-67 (FilteredNoise).  Inputs are stored or - the one large
+    parameter, freq_nonlinear (A, m, S, bins) - regenerated from a stored NumPy seed."""
+    A, m, S, sr = 2, 16, 4000, 32000
+    f_range = [400.0, 1500.0, 4000.0, 9000.0]
+    out = {"mat": np.asarray(MAT), "A": A, "m": m, "S": S, "sr": sr, "f_range": np.asarray(f_range)}
+    g = torch.Generator().manual_seed(17)
+    forces = torch.randn((A, 150), generator=g)
+    out["forces"] = forces.numpy()
+    torch.manual_seed(23)
+    osc = GTDampedOscillator(forces, A, m, S, sr, f_range, Material(MAT))
+    osc.noise.device = "cpu"  # (the reference's default device string is 'cuda')
+    out["nl_seed"] = 99
+    nl = np.random.default_rng(99).uniform(-4, 4, size=(A, m, S, len(f_range))).astype(np.float32)
+    osc.freq_nonlinear.params.data.copy_(torch.from_numpy(nl))
+    for k in ("freq_linear", "alpha", "beta"):
+        out[f"gt_{k}_params"] = getattr(osc, k).params.detach().numpy().copy()
+        out[f"gt_{k}_values"] = getattr(osc, k).values_list.numpy().copy()
+    out["gt_amp_value"] = osc.amp.value.detach().numpy().copy()
+    out["gt_noise_bank"] = osc.noise.coefficient_bank.detach().numpy().copy()
+    out["gt_damping"] = osc.damping().detach().numpy()
+    out["gt_freq_linear"] = osc.freq_linear().detach().numpy()
+    nf = S // 64 + 1
+    for tag, rate, nrate in (("lin", 0.0, 0.0), ("tv", 0.3, 0.0), ("tvn", 0.3, 1.0)):
+        osc.zero_grad()
+        torch.manual_seed(31)
+        sig = osc(rate, nrate)
+        out[f"gt_{tag}_signal"] = sig.detach().numpy()
+        out[f"gt_{tag}_undamped_freq_mean"] = osc.undamped_freq.detach().mean(-1).numpy()
+        (sig ** 2).mean().backward()
+        for k in ("freq_linear", "alpha", "beta"):
+            out[f"gt_{tag}_grad_{k}"] = getattr(osc, k).params.grad.numpy().copy()
+        out[f"gt_{tag}_grad_amp"] = osc.amp.value.grad.numpy().copy()
+        gnl = osc.freq_nonlinear.params.grad
+        if gnl is not None and rate != 0.0:  # (A, m, S, bins): a strided sample and its sums over time
+            out[f"gt_{tag}_grad_nl_sample"] = gnl[:, :, ::40, :].numpy().copy()
+            out[f"gt_{tag}_grad_nl_tsum"] = gnl.double().sum(2).numpy()
+        if nrate != 0.0:
+            out[f"gt_{tag}_grad_noise_bank"] = osc.noise.coefficient_bank.grad.numpy().copy()
+            torch.manual_seed(31)  # the draw FilteredNoise.forward made (filtered_noise.py:49-50)
+            out[f"gt_{tag}_noise"] = (torch.rand(A, nf, 64, dtype=torch.float32) * 2 - 1).numpy()
+    # FilteredNoise alone
+    torch.manual_seed(41)
+    fn = FilteredNoise(3, 8000, device="cpu")
+    torch.manual_seed(43)
+    y = fn()
+    torch.manual_seed(43)
+    out["fn_noise"] = (torch.rand(3, 8000 // 64 + 1, 64, dtype=torch.float32) * 2 - 1).numpy()
+    out["fn_bank"] = fn.coefficient_bank.detach().numpy().copy()
+    out["fn_signal"] = y.detach().numpy()
+    (y ** 2).mean().backward()
+    out["fn_grad_bank"] = fn.coefficient_bank.grad.numpy().copy()
+    # DampedOscillator.early / forward_curve with a piecewise-linear damping table (material_real_train.py:151)
+    from scipy import interpolate
+    xs = np.array([270.0, 770.0, 1270.0, 5020.0, 9020.0])
+    ys = np.array([3.0, 5.5, 4.0, 40.0, 90.0])
+    table = interpolate.interp1d(xs, ys, fill_value="extrapolate")
+    out["curve_x"], out["curve_y"] = xs, ys
+    torch.manual_seed(47)
+    dosc = DampedOscillator(forces, A, m, S, sr, [0.0, 1.0], Material(MAT))
+    fl = torch.sort(torch.rand(m, generator=g) * 8000 + 300)[0].reshape(m, 1)
+    out["curve_freqs"] = fl.numpy()
+    for tag, fn_ in (("early", dosc.early), ("curve", dosc.forward_curve)):
+        f = fl.clone().requires_grad_(True)
+        sig = fn_(f, table)
+        out[f"{tag}_signal"] = sig.detach().numpy()
+        out[f"{tag}_damped_freq"] = dosc.damped_freq.detach().reshape(-1).numpy()
+        (sig ** 2).mean().backward()
+        out[f"{tag}_grad_f"] = f.grad.numpy()
+    np.savez_compressed(os.path.join(HERE, "g7_real_audio.npz"), **out)
+    print("g7 done", {k: v.shape for k, v in out.items() if hasattr(v, "shape") and v.size > 1000})
+
+
 def lobpcg_trajectory():
     """G6: reference lobpcg_func on the 2^3 cube ord-2 matrices (restatement check only)."""
     verts, tets = kuhn_cube(2)
@@ -310,7 +386,7 @@ if __name__ == "__main__":
     ap.add_argument("--only", default="")
     ap.add_argument("--skip-ord2-bowl", action="store_true")
     a = ap.parse_args()
-    todo = a.only.split(",") if a.only else ["g1", "g2", "g3o1", "g3o2", "g4", "g5", "g6"]
+    todo = a.only.split(",") if a.only else ["g1", "g2", "g3o1", "g3o2", "g4", "g5", "g6", "g7"]
     torch.set_num_threads(8)
     if "g1" in todo:
         constants()
@@ -320,6 +396,8 @@ if __name__ == "__main__":
         oscillator()
     if "g6" in todo:
         lobpcg_trajectory()
+    if "g7" in todo:
+        real_audio_front_half()
     if "g4" in todo:
         geometry_backward()
     if "g3o1" in todo:

@@ -207,3 +207,69 @@ def test_oscillator_damped(golden):
     assert rel(ap.grad.numpy(), g["damped_grad_alpha_params"]) < 1e-4
     assert rel(bp.grad.numpy(), g["damped_grad_beta_params"]) < 1e-4
     assert rel(av.grad.numpy(), g["damped_grad_amp_value"]) < 1e-4
+
+
+# ---------------------------------------------------------------- G7 real-audio front half (row f4)
+def _g7_leaves(g):
+    A, m, S = int(g["A"]), int(g["m"]), int(g["S"])
+    nl = np.random.default_rng(int(g["nl_seed"])).uniform(-4, 4, size=(A, m, S, len(g["f_range"]))).astype(np.float32)
+    leaf = {k: torch.from_numpy(g[f"gt_{k}_params"]).clone().requires_grad_(True) for k in ("freq_linear", "alpha", "beta")}
+    leaf["freq_nonlinear"] = torch.from_numpy(nl).requires_grad_(True)
+    leaf["amp"] = torch.from_numpy(g["gt_amp_value"]).clone().requires_grad_(True)
+    leaf["noise_bank"] = torch.from_numpy(g["gt_noise_bank"]).clone().requires_grad_(True)
+    return leaf
+
+
+@pytest.mark.parametrize("tag,rate,nrate", [("lin", 0.0, 0.0), ("tv", 0.3, 0.0), ("tvn", 0.3, 1.0)])
+def test_gt_oscillator_restatement_against_reference(golden, tag, rate, nrate):
+    """oracle.bank_time_varying (+ filtered_noise) against GTDampedOscillator.forward of the imported reference
+    (oscillator.py:217-243): signal, undamped_freq read-out, gradients of mean(sig^2) w.r.t. every parameter."""
+    g = golden("g7_real_audio.npz")
+    A, m, S, sr = int(g["A"]), int(g["m"]), int(g["S"]), int(g["sr"])
+    leaf = _g7_leaves(g)
+    fr = torch.from_numpy(g["f_range"]).float()
+    fl = oosc.weighted_sum(fr, leaf["freq_linear"])
+    fnl = oosc.weighted_sum(fr, leaf["freq_nonlinear"])
+    alpha = oosc.weighted_sum(torch.from_numpy(g["gt_alpha_values"]), leaf["alpha"])
+    beta = oosc.weighted_sum(torch.from_numpy(g["gt_beta_values"]), leaf["beta"])
+    assert rel(fl.detach().numpy(), g["gt_freq_linear"]) < 1e-6
+    assert rel((0.5 * (alpha + beta * (fl * 2 * np.pi) ** 2)).detach().numpy(), g["gt_damping"]) < 1e-6
+    forces = torch.from_numpy(g["forces"])
+    sig, und = oosc.bank_time_varying(fl, fnl, rate, alpha, beta, oosc.modified_sigmoid(leaf["amp"]), forces, S, sr)
+    if nrate:
+        # FilteredNoise with the draw the reference made; torch twin of oracle.filtered_noise for the gradient
+        nz = oosc.filtered_noise(leaf["noise_bank"].detach().numpy(), g[f"gt_{tag}_noise"], S)
+        sig = sig + torch.from_numpy(nz).float() * nrate
+    assert rel(sig.detach().numpy(), g[f"gt_{tag}_signal"]) < 2e-5
+    assert rel(und.detach().mean(-1).numpy(), g[f"gt_{tag}_undamped_freq_mean"]) < 1e-6
+    (sig ** 2).mean().backward()
+    for k in ("freq_linear", "alpha", "beta"):
+        assert rel(leaf[k].grad.numpy(), g[f"gt_{tag}_grad_{k}"]) < 2e-4, k
+    assert rel(leaf["amp"].grad.numpy(), g[f"gt_{tag}_grad_amp"]) < 2e-4
+    if rate:
+        gnl = leaf["freq_nonlinear"].grad
+        assert rel(gnl[:, :, ::40, :].numpy(), g[f"gt_{tag}_grad_nl_sample"]) < 2e-4
+        assert rel(gnl.double().sum(2).numpy(), g[f"gt_{tag}_grad_nl_tsum"]) < 2e-4
+
+
+def test_filtered_noise_restatement_against_reference(golden):
+    g = golden("g7_real_audio.npz")
+    out = oosc.filtered_noise(g["fn_bank"], g["fn_noise"], 8000)
+    assert out.shape == g["fn_signal"].shape
+    assert rel(out, g["fn_signal"]) < 2e-6
+    # the noise branch inside GTDampedOscillator.forward(0.3, 1.0): signal difference to the noise-free render
+    nz = oosc.filtered_noise(g["gt_noise_bank"], g["gt_tvn_noise"], int(g["S"]))
+    assert rel(nz, g["gt_tvn_signal"] - g["gt_tv_signal"]) < 2e-5
+
+
+@pytest.mark.parametrize("tag", ["early", "curve"])
+def test_curve_bank_restatement_against_reference(golden, tag):
+    """DampedOscillator.early / forward_curve (oscillator.py:85-109, 143-176) with the piecewise-linear damping table."""
+    g = golden("g7_real_audio.npz")
+    f = torch.from_numpy(g["curve_freqs"]).clone().requires_grad_(True)
+    d = np.interp(g["curve_freqs"].reshape(-1).astype(np.float64), g["curve_x"], g["curve_y"])  # inside the knots
+    sig, dfreq = oosc.bank_curve(f, d, torch.from_numpy(g["forces"]), int(g["S"]), int(g["sr"]), tag == "curve")
+    assert rel(sig.detach().numpy(), g[f"{tag}_signal"]) < 2e-5
+    assert rel(dfreq.detach().numpy(), g[f"{tag}_damped_freq"]) < 1e-6
+    (sig ** 2).mean().backward()
+    assert rel(f.grad.numpy(), g[f"{tag}_grad_f"]) < 2e-4
