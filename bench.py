@@ -87,6 +87,8 @@ def parse():
                     help="scalar loss head: mse = the headline metric's; mss = the reference experiments' multi-scale "
                          "spectral loss (MSSLoss [1024..64], 'l1_loss', material_sync_train.py:124) on the STFT kernels")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-reps", type=int, default=3, help="full passes of the CPU oracle (a fresh process each)")
     ap.add_argument("--cpu-sample-cells", type=int, default=8,
                     help="the CPU oracle runs ONE full pass on a Kuhn box of this many cells per edge (8 -> 3072 tets, the "
                          "smallest ord-2 size of BASELINE.md section 3; 12 takes several minutes)")
@@ -154,7 +156,31 @@ def relaunch_as_ranks(a):
     sys.exit(subprocess.call(cmd, env=env))
 
 
-def cpu_baseline(sample_cells, order, modes, full_tets):
+def cpu_baseline(sample_cells, order, modes, full_tets, reps=3):
+    """The CPU oracle timed in a FRESH CHILD PROCESS (its own BLAS / OpenMP state: nothing the GPU run did to the
+    process - thread limits, pinned memory, lane threads - can skew it), ``reps`` full passes; ``value`` = 1 / median."""
+    nthreads = min(os.cpu_count() or 1, 16)
+    env = dict(os.environ)
+    env["OMP_NUM_THREADS"] = env["OPENBLAS_NUM_THREADS"] = env["MKL_NUM_THREADS"] = str(nthreads)
+    env["HIP_VISIBLE_DEVICES"] = env["CUDA_VISIBLE_DEVICES"] = ""  # the child never touches the GPU
+    runs = []
+    for _ in range(max(1, reps)):
+        out = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-child", "--cpu-sample-cells",
+                              str(sample_cells), "--order", str(order), "--modes", str(modes), "--cells",
+                              str(round((full_tets / 6) ** (1 / 3)))], capture_output=True, text=True, env=env, cwd=ROOT)
+        if out.returncode != 0:
+            raise SystemExit("bench.py: CPU baseline child failed:\n" + out.stderr[-2000:])
+        runs.append(json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]))
+    secs = sorted(r["sample_seconds"] for r in runs)
+    med = runs[[r["sample_seconds"] for r in runs].index(secs[len(secs) // 2])]
+    med = dict(med)
+    med["repetitions"] = len(runs)
+    med["sample_seconds_all"] = [round(r["sample_seconds"], 3) for r in runs]
+    med["sample"] = med["sample"] + f" (median of {len(runs)} passes, each in a fresh process: {med['sample_seconds_all']} s)"
+    return med
+
+
+def cpu_baseline_pass(sample_cells, order, modes, full_tets):
     """The CPU oracle (faithful restatement of the reference loop body) MEASURED on one full
     fwd+bwd pass at a stated size, with per-stage times.  ``value`` is passes/s AT THAT SIZE; the linear extrapolation
     to the benchmark mesh is reported separately (optimistic for the CPU: the reference's assembly and ARPACK's LU are
@@ -167,6 +193,13 @@ def cpu_baseline(sample_cells, order, modes, full_tets):
     # 2.9 s, all 256 hardware threads 18.2 s on the 750-tet sample (oversubscribed: every small op forks a big team)
     nthreads = min(os.cpu_count() or 1, 16)
     torch.set_num_threads(nthreads)
+    blas_threads = None
+    try:
+        from threadpoolctl import threadpool_info
+
+        blas_threads = {i.get("internal_api", i.get("user_api")): i.get("num_threads") for i in threadpool_info()}
+    except Exception:
+        pass
     v, t = meshgen.kuhn_box(sample_cells)
     stages = {}
     clock = [time.time()]
@@ -212,6 +245,7 @@ def cpu_baseline(sample_cells, order, modes, full_tets):
         "value": 1.0 / dt,
         "unit": f"passes/s at {ntets} tets (NOT the benchmark mesh)",
         "cores": nthreads,
+        "thread_pools": blas_threads,
         "cpu_model": cpu_model,
         "host_hardware_threads": os.cpu_count(),
         "kind": "port",
@@ -227,6 +261,9 @@ def cpu_baseline(sample_cells, order, modes, full_tets):
 
 def main():
     a = parse()
+    if a.cpu_baseline_child:  # one pass of the CPU oracle, nothing else (no GPU, no torch.distributed)
+        print(json.dumps(cpu_baseline_pass(a.cpu_sample_cells, a.order, a.modes, 6 * a.cells ** 3)))
+        return
     relaunch_as_ranks(a)  # N > 1: becomes N ranks under torch.distributed.run (never a silent single rank)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -244,10 +281,17 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(a.dist_backend, rank=rank, world_size=world)
 
+    def barrier():
+        if world > 1:
+            if a.dist_backend == "nccl":
+                dist.barrier(device_ids=[local_rank])  # RCCL: on this rank's own device, not a guessed one
+            else:
+                dist.barrier()
+
     from diffsound_amd import meshgen
     from diffsound_amd.diffelastic.mesh import TetMesh
     from diffsound_amd.lobpcg.modal_solver import SolverConfig
-    from diffsound_amd.pipeline import ModalPipeline, all_reduce_loss, shard_hypotheses
+    from diffsound_amd.pipeline import ModalPipeline, all_reduce_loss, gather_rank_stats, shard_hypotheses
 
     # ---- synthetic inputs, resident in HBM before timing -------------------------------------
     v, t = meshgen.kuhn_box(a.cells)
@@ -316,9 +360,9 @@ def main():
     lane_ops = [ln.ops for ln in pipe._lanes if ln.ops is not None] or [pipe.ops]
     prof_stream = pipe._lanes[0].stream.cuda_stream if pipe._lanes else torch.cuda.current_stream(dev).cuda_stream
     PROF_CAP = 20000
-    _hip.check(_hip.lib().ds_profile_stream(prof_stream, PROF_CAP), "ds_profile_stream")
-    if world > 1:
-        dist.barrier()
+    if rank == 0:
+        _hip.check(_hip.lib().ds_profile_stream(prof_stream, PROF_CAP), "ds_profile_stream")
+    barrier()
     torch.cuda.synchronize()
     t0 = time.time()
     iters = []
@@ -326,19 +370,30 @@ def main():
         total, its = step(warm)
         iters += its
     torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
+    own_dt = time.time() - t0  # this rank's own work, before it waits for the slowest one
+    barrier()
     dt = time.time() - t0
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev if a.dist_backend == "nccl" else "cpu")
+    cdev = dev if (world > 1 and a.dist_backend == "nccl") else torch.device("cpu")
+    tmax = torch.tensor([dt], dtype=torch.float64, device=cdev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax[0])
+    # per-rank view of the step: the only expected scaling loss is the imbalance of iteration counts between the
+    # ranks' hypotheses; one small all-gather AFTER the timed region makes it visible
+    free_b, total_b = torch.cuda.mem_get_info(dev)
+    gathered = gather_rank_stats([len(mine), np.sum(iters), np.max(iters), own_dt,
+                                  torch.cuda.max_memory_allocated(dev) / 2 ** 30, (total_b - free_b) / 2 ** 30, local_rank], dev)
+    per_rank = [{"rank": r, "device": int(g[6]), "hypotheses_per_step": int(g[0]), "fine_iterations": int(g[1]),
+                 "max_iterations_of_a_pass": int(g[2]), "busy_seconds": round(float(g[3]), 4),
+                 "idle_fraction": round(max(0.0, 1 - float(g[3]) / dt), 4),
+                 "hbm_peak_allocated_gib": round(float(g[4]), 3), "hbm_in_use_on_device_gib": round(float(g[5]), 3)}
+                for r, g in enumerate(gathered)]
 
     import ctypes
     pms = (ctypes.c_float * PROF_CAP)()
     pnv, pnz = (ctypes.c_int64 * PROF_CAP)(), (ctypes.c_int64 * PROF_CAP)()
     pnc, pfi = (ctypes.c_int32 * PROF_CAP)(), (ctypes.c_int32 * PROF_CAP)()
-    nrec = int(_hip.lib().ds_profile_collect(pms, pnv, pnz, pnc, pfi, PROF_CAP))
+    nrec = int(_hip.lib().ds_profile_collect(pms, pnv, pnz, pnc, pfi, PROF_CAP)) if rank == 0 else 0
     sysd = pipe.system
     roof = None
     if nrec:
@@ -483,12 +538,14 @@ def main():
             },
             "roofline": roof,
             "loss_sum_last_step": total,
+            "ranks": per_rank,
             "collective": (f"{a.dist_backend} all-reduce of the scalar loss over {world} ranks" if world > 1 else "none (1 rank)"),
         }
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(a.cpu_sample_cells, a.order, a.modes, sysd.T)
+            out["cpu_baseline"] = cpu_baseline(a.cpu_sample_cells, a.order, a.modes, sysd.T, a.cpu_reps)
         print(json.dumps(out))
     if world > 1:
+        barrier()  # rank 0's solo kernel timings above ran while the others wait here (a shared device stays quiet)
         dist.destroy_process_group()
 
 

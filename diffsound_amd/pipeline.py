@@ -201,3 +201,21 @@ def all_reduce_loss(loss_sum, device):
     if on:
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return float(t[0])
+
+
+def gather_rank_stats(values, device):
+    """Every rank's small vector of step statistics (hypotheses, iteration counts, busy seconds, memory) on every
+    rank - one all-gather of a few doubles AFTER the timed region, so that load imbalance between the ranks'
+    hypotheses (the only expected scaling loss) shows in the benchmark line.  Returns a list of
+    lists, one per rank (a single entry without torch.distributed)."""
+    import torch.distributed as dist
+
+    on = dist.is_available() and dist.is_initialized()
+    if on and dist.get_backend() != "nccl":
+        device = "cpu"
+    t = torch.tensor([float(v) for v in values], dtype=torch.float64, device=device)
+    if not on:
+        return [t.tolist()]
+    out = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return [o.tolist() for o in out]
