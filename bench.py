@@ -31,6 +31,21 @@ MAT = (2700.0, 5e10, 0.25, 6.0, 1e-7)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md); the STREAM triad below is MEASURED in the run
 
 
+SPMM_SOURCES = ("spmm.hip", "spmm_union.inc", "spmm_mfma.inc", "ds_common.h")
+
+
+def spmm_source_hash():
+    """sha256 (16 hex digits) over the sources of the SpMM kernels: the key that ties a PMC traffic figure under
+    profiles/ to the kernel it was measured on (tools/pmc_bytes.py records it; a figure with another key is stale)."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for name in SPMM_SOURCES:
+        with open(os.path.join(ROOT, "diffsound_amd", "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -461,16 +476,25 @@ def main():
         torch.cuda.synchronize()
         stream_gbs = 3.0 * ne * 4 / (e0.elapsed_time(e1) / 20 * 1e-3) / 1e9
         del ta, tb, tc
-        traffic = None
+        # PMC bytes of one such launch: a figure measured in its own rocprofv3 --pmc passes (tools/collect_profiles.sh)
+        # and valid ONLY for the kernel sources it was measured on - another source hash means stale, reported as null
+        traffic, traffic_note = None, "no PMC figure under profiles/ for this shape"
         pmc = os.path.join(ROOT, "profiles", "spmm_pmc_bytes_per_launch.json")
         if os.path.exists(pmc):
             try:
                 mf = bf and getattr(ops0, "_mfma", None) is not None and ops0.kc is not None
-                traffic = json.load(open(pmc)).get(f"cells{a.cells}_cols{a.block}_{'mfma' if mf else ('bf16' if bf else 'fp32')}")
-            except Exception:
-                traffic = None
+                doc = json.load(open(pmc))
+                rec = doc.get(f"cells{a.cells}_cols{a.block}_{'mfma' if mf else ('bf16' if bf else 'fp32')}")
+                if isinstance(rec, dict):
+                    if rec.get("spmm_source_sha16") == spmm_source_hash():
+                        traffic, traffic_note = rec["bytes"], f"PMC passes of {rec.get('measured', '?')} on these kernel sources"
+                    else:
+                        traffic_note = (f"stale: measured on kernel sources {rec.get('spmm_source_sha16')}, this run's are "
+                                        f"{spmm_source_hash()}")
+            except Exception as ex:
+                traffic_note = f"unreadable PMC record: {ex}"
         roof = {"bound": "hbm", "achieved": solo, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": solo / HBM_PEAK_GBS, "traffic": traffic,
+                "frac": solo / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,
                 "stream_triad": stream_gbs, "frac_of_stream": solo / stream_gbs,
                 "kernel": ((f"spmm_union_mfma_kernel<8,{(a.block + 15) // 16},1>: W' = W + c1(W - W_prev) + c2 T(R0 - K W) on a "
                             f"{a.block}-column block, fine level (bf16 K blocks and iterates, block products on the matrix "

@@ -855,18 +855,18 @@ extern "C" int ds_pack_kc(const float* k32, const int32_t* kperm, int64_t nnzb, 
     return DS_OK;
 }
 
-template <int G, int NT>
+template <int G, int NT, int BATCH>
 static int launch_mfma(int epilogue, int y_f32, const int32_t* gptr, const int32_t* gcol, const int32_t* gmeta,
                        const int32_t* gbase, const void* kc, int64_t nnzb, int64_t ngroups, int64_t nv, const float* X,
                        int64_t ldx, float* Y, int64_t ldy, int lpn, int acap, hipStream_t st, const ChebEpilogue& epi) {
     const char* kcp = static_cast<const char*>(kc);
-    const size_t lds = (size_t)mf_panel_bytes(lpn * 4, G) + (size_t)acap + 32;
+    const size_t lds = (size_t)mf_panel_bytes(lpn * 4, G, BATCH) + (size_t)acap + 32;
     if (epilogue == 2)
-        spmm_union_mfma_kernel<G, NT, 2, false><<<(unsigned)ngroups, 64, lds, st>>>(gptr, gcol, gmeta, gbase, kcp, nnzb, (unsigned)ngroups, nv, X, ldx, Y, ldy, lpn, acap, epi);
+        spmm_union_mfma_kernel<G, NT, 2, false, BATCH><<<(unsigned)ngroups, 64, lds, st>>>(gptr, gcol, gmeta, gbase, kcp, nnzb, (unsigned)ngroups, nv, X, ldx, Y, ldy, lpn, acap, epi);
     else if (y_f32)
-        spmm_union_mfma_kernel<G, NT, 1, true><<<(unsigned)ngroups, 64, lds, st>>>(gptr, gcol, gmeta, gbase, kcp, nnzb, (unsigned)ngroups, nv, X, ldx, Y, ldy, lpn, acap, epi);
+        spmm_union_mfma_kernel<G, NT, 1, true, BATCH><<<(unsigned)ngroups, 64, lds, st>>>(gptr, gcol, gmeta, gbase, kcp, nnzb, (unsigned)ngroups, nv, X, ldx, Y, ldy, lpn, acap, epi);
     else
-        spmm_union_mfma_kernel<G, NT, 1, false><<<(unsigned)ngroups, 64, lds, st>>>(gptr, gcol, gmeta, gbase, kcp, nnzb, (unsigned)ngroups, nv, X, ldx, Y, ldy, lpn, acap, epi);
+        spmm_union_mfma_kernel<G, NT, 1, false, BATCH><<<(unsigned)ngroups, 64, lds, st>>>(gptr, gcol, gmeta, gbase, kcp, nnzb, (unsigned)ngroups, nv, X, ldx, Y, ldy, lpn, acap, epi);
     DS_LAUNCH_CHECK("spmm_union_mfma_kernel");
     return DS_OK;
 }
@@ -885,8 +885,8 @@ extern "C" int ds_spmm_union16m(int epilogue, int group_nodes, const int32_t* gp
     DS_REQUIRE(nv > 0 && ngroups == (nv + group_nodes - 1) / group_nodes && ncols > 0 && ncols % 4 == 0 && ncols <= 84,
                "ds_spmm_union16m: ncols must be a multiple of 4 <= 84 and ngroups = ceil(nv / group_nodes)");
     DS_REQUIRE(max_entries > 0 && max_entries <= 256, "ds_spmm_union16m: a group with %d union entries exceeds 256", max_entries);
-    DS_REQUIRE(max_batch_blocks > 0 && max_batch_blocks <= 32 * group_nodes,
-               "ds_spmm_union16m: max_batch_blocks must be in (0, 32 x group_nodes]");
+    DS_REQUIRE(max_batch_blocks > 0 && max_batch_blocks <= DS_MF_BATCH * group_nodes,
+               "ds_spmm_union16m: max_batch_blocks must be in (0, DS_MF_BATCH x group_nodes]");
     const int acap = ((max_batch_blocks * 24 + 1023) / 1024) * 1024;  // whole 1 KiB staging pieces
     DS_REQUIRE(nnzb > 0 && nnzb * 24 < (int64_t)PIPE_OOB, "ds_spmm_union16m: the block array exceeds the descriptor range");
     DS_REQUIRE(ldx >= ncols && ldy >= ncols && ldr >= ncols, "ds_spmm_union16m: leading dimension smaller than ncols");
@@ -909,7 +909,7 @@ extern "C" int ds_spmm_union16m(int epilogue, int group_nodes, const int32_t* gp
     float* Yf = static_cast<float*>(Y);
     const int lpn = ncols / 4;
     const int nt = (ncols + 15) / 16;
-#define DS_MF_GO(GG, N) return launch_mfma<GG, N>(epilogue, y_f32, gptr, gcol, gmeta, gbase, kc, nnzb, ngroups, nv, Xf, ldx, Yf, ldy, lpn, acap, st, epi)
+#define DS_MF_GO(GG, N) return launch_mfma<GG, N, DS_MF_BATCH>(epilogue, y_f32, gptr, gcol, gmeta, gbase, kc, nnzb, ngroups, nv, Xf, ldx, Yf, ldy, lpn, acap, st, epi)
     auto go = [&]() -> int {
         switch (nt) {
             case 1: DS_MF_GO(8, 1); case 2: DS_MF_GO(8, 2); case 3: DS_MF_GO(8, 3);

@@ -19,6 +19,7 @@ from . import _hip, fem_tables
 DS_F32, DS_F64 = 0, 1
 import threading
 
+MF_BATCH = 16  # entries per LDS batch of the MFMA kernel (DS_MF_BATCH of include/diffsound_hip.h)
 _MFMA_TABLES_LOCK = threading.Lock()
 UNION_CAP = 116  # blocks per chunk of the neighbour-union tables (the kernel's smallest LDS image)
 
@@ -123,11 +124,12 @@ class TetSystem:
         gbase = goff[gptr[:-1].clamp(max=ekey.numel())]
         within = goff[:-1] - torch.repeat_interleave(gbase, gptr[1:] - gptr[:-1])
         ne_g = gptr[1:] - gptr[:-1]
-        # blocks per batch of 32 entries (counted from each group's first entry): sizes the kernel's LDS
+        # blocks per batch of MF_BATCH = 16 entries (counted from each group's first entry): sizes the kernel's LDS
         eidx = torch.arange(ekey.numel(), device=dev)
         # (a group of more than 256 entries is not served by the kernel; its tail is lumped into the last slot here)
-        batch = (ekey // nv) * 8 + ((eidx - torch.repeat_interleave(gptr[:-1], ne_g)) // 32).clamp(max=7)
-        per_batch = torch.zeros(ng * 8, dtype=torch.int64, device=dev).scatter_add_(0, batch, counts)
+        nslot = 256 // MF_BATCH
+        batch = (ekey // nv) * nslot + ((eidx - torch.repeat_interleave(gptr[:-1], ne_g)) // MF_BATCH).clamp(max=nslot - 1)
+        per_batch = torch.zeros(ng * nslot, dtype=torch.int64, device=dev).scatter_add_(0, batch, counts)
         return dict(G=G, ngroups=ng, max_entries=int(ne_g.max()), max_batch_blocks=int(per_batch.max()),
                     gptr=gptr.to(torch.int32), gcol=(ekey % nv).to(torch.int32).contiguous(),
                     gmeta=(mask | (within << 8)).to(torch.int32).contiguous(), gbase=gbase.to(torch.int32).contiguous(),
@@ -708,7 +710,7 @@ class HipModalOps(_HipBlockOps):
             raise ValueError("mfma_groups: 8 nodes per wavefront, or 0 for the VALU kernel")
         if G and system.groups is not None and system.nnzb * 24 < 0x7F000000:
             mt = system.mfma_tables(G)
-            if mt["max_entries"] <= 256 and mt["max_batch_blocks"] <= 32 * G:  # what ds_spmm_union16m serves
+            if mt["max_entries"] <= 256 and mt["max_batch_blocks"] <= MF_BATCH * G:  # what ds_spmm_union16m serves
                 self._mfma = mt
         self.set_material(lam, mu)
         self.rigid = self._rigid_basis() if _level == 0 else None

@@ -103,6 +103,18 @@ class ModalPipeline:
         else:
             holder.ops.set_material(lam_f, mu_f)
         res = ModalSolver(holder.ops, self.cfg).solve(self.modes, X0=warm)
+        return self._readout(holder, model, res, backward)
+
+    def run_cached_pass(self, res, youngs, poisson, backward=True, _lane=None):
+        """A pass BETWEEN eigendecompositions (reference experiments/material_sync_train.py:135-141 with
+        EIGEN_DECOMPOSE_CYCLE = 15: ``eigen_decomposition()`` only every 15th epoch, ``get_undamped_freqs()`` - the
+        first-order read-out on the kept eigenvectors - every epoch): steps 3-6 of a pass on the quadratic forms
+        a_i, b_i, m_i of an earlier solve ``res`` with the current (E, nu).  No assembly, no eigensolve."""
+        model = DirectLinear(youngs, poisson, self.mat)
+        return self._readout(self if _lane is None else _lane, model, res, backward)
+
+    def _readout(self, holder, model, res, backward):
+        lam, mu = model.lame()
         ev = res.eigenvalues
         dev = ev.device
         pred = ev + (lam.to(dev) * res.a_lambda + mu.to(dev) * res.b_mu) - ev * res.m_diag

@@ -40,7 +40,7 @@ enum { DS_OK = 0, DS_ERR_ARG = 1, DS_ERR_HIP = 2, DS_ERR_NOMEM = 3 };
 /* Thread-local text of the last error returned on this thread ("" if none). */
 const char* ds_last_error(void);
 /* Library ABI version (bumped on any signature change); ds_abi_version() returns the value the library was built with. */
-#define DS_ABI_VERSION 23
+#define DS_ABI_VERSION 24
 int ds_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------------
@@ -294,14 +294,15 @@ int ds_spmm_union16(int epilogue, const int32_t* utab, const int32_t* ctab, int6
                     void* Y, int64_t ldy, int y_f32, const void* R0, int64_t ldr, const float* dinv, int ncols,
                     float c1, float c2, int first, const void* Wprev, int64_t ldp, ds_stream_t stream);
 /* MFMA form of ds_spmm_union16 (csrc/spmm_mfma.inc): the same two epilogues on the same bf16 blocks, the block
- * products on the matrix cores (v_mfma_f32_16x16x32_bf16; the 3x3 blocks rounded to bf16, fp32 accumulation), one
+ * products on the matrix cores (v_mfma_f32_16x16x16_bf16; the 3x3 blocks rounded to bf16, fp32 accumulation), one
  * wavefront per group of group_nodes = 8 consecutive nodes.  Topology tables (device): gptr (ngroups + 1) / gcol =
  * the sorted union of the column ids of each group's rows; gmeta per entry = presence mask of the group's nodes |
  * (index of the entry's first block inside the group) << 8; gbase (ngroups) = first block of each group; kperm = the
  * BSR block of every position of the group / entry / node order.  ds_pack_kc writes kc (nnzb x 3 x 4 bf16: the rows of
  * the blocks in that order, padded to 8 bytes) from the BSR values k32 - once per material.  max_entries = the largest
- * group's entry count (<= 256); max_batch_blocks = the largest number of blocks in 32 consecutive entries of a group
- * (counted from the group's first entry; it sizes the wavefront's LDS). */
+ * group's entry count (<= 256); max_batch_blocks = the largest number of blocks in DS_MF_BATCH = 16 consecutive entries
+ * of a group (batches counted from the group's first entry; it sizes the wavefront's LDS). */
+#define DS_MF_BATCH 16
 int ds_pack_kc(const float* k32, const int32_t* kperm, int64_t nnzb, void* kc, ds_stream_t stream);
 int ds_spmm_union16m(int epilogue, int group_nodes, const int32_t* gptr, const int32_t* gcol, const int32_t* gmeta,
                      const int32_t* gbase, const void* kc, int64_t nnzb, int64_t ngroups, int max_entries,

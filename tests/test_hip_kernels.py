@@ -485,7 +485,7 @@ def test_mfma_entry_point_refuses_what_it_does_not_serve(dev):
                                   p(R0), 80, None if dinv is None else p(dinv), ncols, 0.3, 0.7, 0, None, 0, _hip.stream_ptr())
 
     assert call() == 0
-    for bad in (dict(G=4), dict(G=16), dict(max_entries=257), dict(mbb=0), dict(mbb=257), dict(y=X), dict(ncols=88), dict(ncols=78),
+    for bad in (dict(G=4), dict(G=16), dict(max_entries=257), dict(mbb=0), dict(mbb=129), dict(y=X), dict(ncols=88), dict(ncols=78),
                 dict(epi=0), dict(epi=3), dict(dinv=None), dict(y32=1, epi=2), dict(x=X[:, 1:])):
         assert call(**bad) != 0, bad
         assert L.ds_last_error()
