@@ -11,7 +11,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libdiffsound_hip.so")
+LIB_PATH = os.environ.get("DS_EXP_LIB") or os.path.join(_HERE, "csrc", "libdiffsound_hip.so")  # (DS_EXP_LIB: A/B builds, experiments)
 ABI_VERSION = 24  # DS_ABI_VERSION of include/diffsound_hip.h
 
 c_i32p = ctypes.POINTER(ctypes.c_int32)

@@ -496,8 +496,9 @@ def test_mfma_entry_point_refuses_what_it_does_not_serve(dev):
 def test_mfma_terms_beside_other_kernels_are_repeatable(dev):
     """The MFMA term on one stream and the VALU kernels (the eigensolver's fp32 K X, the bf16 term of the corner-node
     level) on another, as the hypothesis lanes run them: every result of either stream equals its solo result bit for
-    bit.  With v_mfma_f32_16x16x32_bf16 in the MFMA kernel this failed - the packed-FMA kernels beside it returned
-    changed results - hence its 16x16x16 instructions (csrc/spmm_mfma.inc; tools/stress_mix.py is the longer form)."""
+    bit.  With v_mfma_f32_16x16x32_bf16 in the MFMA kernel AND packed FMAs in the VALU kernels this failed - hence the
+    16x16x16 instructions of the one (csrc/spmm_mfma.inc) and the plain v_fma_f32 of the others (csrc/spmm_union.inc);
+    test_immunity_to_foreign_mfma_and_the_probe_itself below isolates the hardware interaction."""
     from diffsound_amd import meshgen
     from diffsound_amd.diffelastic.mesh import TetMesh
     from diffsound_amd.modal_ops import HipModalOps, TetSystem
@@ -538,6 +539,89 @@ def test_mfma_terms_beside_other_kernels_are_repeatable(dev):
             torch.cuda.synchronize()
             for c in pair:
                 assert all(torch.equal(o, c["ref"]) for o in c["outs"]), c["G"]
+
+
+def test_immunity_to_foreign_mfma_and_the_probe_itself(dev):
+    """The gfx950 finding behind the library's "no packed FP32" build (csrc/Makefile): a REGISTER-ONLY spin of
+    v_mfma_f32_16x16x32_bf16 (tests/probes/mfma_probe.hip: no memory, no LDS) on one stream changes results of a
+    REGISTER-ONLY chain of v_pk_fma_f32 on another, never of the same chain of v_fma_f32, and the 16x16x16 / fp32 MFMA
+    forms change nothing.  Asserted here: (a) the forms this library issues (bf16 16x16x16, fp32 16x16x4) leave both
+    chains bit-exact; (b) the library's own accumulating kernels - fp32 K X, the bf16 VALU term, the MFMA term - return
+    their solo results bit for bit beside the double-rate MFMA spin, the aggressor that corrupted 120 of 120 launches of
+    the packed-FMA build (profiles/r03_mfma_interference_matrix.txt).  How often the packed chain is hit by the
+    double-rate form is printed, not asserted (it is a property of the silicon, not of this library)."""
+    import ctypes
+    import os
+
+    from diffsound_amd import meshgen
+    from diffsound_amd.diffelastic.mesh import TetMesh
+    from diffsound_amd.modal_ops import HipModalOps, TetSystem
+
+    so = os.path.join(os.path.dirname(os.path.abspath(__file__)), "probes", "libmfma_probe.so")
+    if not os.path.exists(so):
+        pytest.skip("tests/probes/libmfma_probe.so not built (make -C diffsound_amd/csrc probe)")
+    P = ctypes.CDLL(so)
+    P.probe_mfma_spin.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    P.probe_fma_chain.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    ncu = torch.cuda.get_device_properties(0).multi_processor_count
+    sA, sB = torch.cuda.Stream(), torch.cuda.Stream()
+    spin_out = torch.empty(ncu * 4 * 64, device=dev)
+
+    def beside(form, victim, outs, ref, iters=150000):
+        assert P.probe_mfma_spin(form, iters, ncu * 4, spin_out.data_ptr(), sB.cuda_stream) == 0  # ~10 ms of MFMAs
+        with torch.cuda.stream(sA):
+            for o in outs:
+                victim(o)
+        torch.cuda.synchronize()
+        return sum(0 if torch.equal(o, ref) else 1 for o in outs)
+
+    seed = torch.rand(4096, device=dev) - 0.5
+    hits = {}
+    for packed in (1, 0):
+        ref = torch.empty(ncu * 4 * 256 * 12, device=dev)
+
+        def chain(o, packed=packed):
+            assert P.probe_fma_chain(packed, 3000, ncu * 4, seed.data_ptr(), o.data_ptr(),
+                                     torch.cuda.current_stream().cuda_stream) == 0
+
+        chain(ref)
+        torch.cuda.synchronize()
+        assert torch.isfinite(ref).all()
+        outs = [torch.empty_like(ref) for _ in range(30)]
+        for form in (16, 4):
+            assert beside(form, chain, outs, ref) == 0, (packed, form)
+        hits[packed] = sum(beside(32, chain, outs, ref) for _ in range(3))
+    print(f"register-only chains beside the double-rate bf16 MFMA spin: v_pk_fma_f32 {hits[1]} of 90 launches changed, "
+          f"v_fma_f32 {hits[0]} of 90")
+    assert hits[0] == 0
+
+    def make(cells, order, G, sd):
+        v, t = meshgen.kuhn_box(cells)
+        tm = TetMesh(torch.from_numpy(v).to(dev), torch.from_numpy(t).long().to(dev)).to_high_order(order)
+        sysd = TetSystem(tm.vertices, tm.tets, order, 2700.0)
+        ops = HipModalOps(sysd, 2e10, 2e10, two_level=False, mfma_groups=(max(G, 0), 0))
+        g = torch.Generator(device=dev).manual_seed(sd)
+        mk = lambda: torch.randn(sysd.n, 80, generator=g, device=dev).bfloat16()
+        c = dict(ops=ops, X=mk(), W=mk(), R=mk(), G=G)
+        if G < 0:
+            c["X32"], c["W"] = c["X"].float(), c["W"].float()
+        return c
+
+    def term(c, out):
+        if c["G"] < 0:
+            c["ops"].apply_K(c["X32"], out)
+            return
+        out.copy_(c["W"])
+        c["ops"].cheb_spmm16(c["X"], out, c["R"], 0.3, 0.7, False)
+
+    for cells, order, G in ((16, 2, -1), (18, 1, 0), (16, 2, 8)):
+        c = make(cells, order, G, 11)
+        ref = torch.empty_like(c["W"])
+        term(c, ref)
+        torch.cuda.synchronize()
+        outs = [torch.empty_like(ref) for _ in range(30)]
+        for form in (32, 16):
+            assert beside(form, lambda o, c=c: term(c, o), outs, ref) == 0, (G, form)
 
 
 def test_fused_polish_products_match_separate_launches(dev):
