@@ -95,7 +95,7 @@ def parse():
                          "(< 0: the library default 2e-6; on the benchmark the first sweep suffices either way - the launch "
                          "counts with 2e-6 and 1e-5 are identical)")
     ap.add_argument("--ortho-passes", type=int, default=-1)
-    ap.add_argument("--mfma-groups", default="8,0",
+    ap.add_argument("--mfma-groups", default="8,8",
                     help="nodes per wavefront of the MFMA form of the preconditioner's bf16 terms on the fine and on the "
                          "corner-node level (8, or 0 = the VALU kernel on that level)")
     ap.add_argument("--loss", default="mse", choices=["mse", "mss"],

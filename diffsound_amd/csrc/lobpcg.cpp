@@ -17,10 +17,19 @@
 #include <cstring>
 #include <limits>
 #include <vector>
+#include <chrono>
+#include <cstdlib>
 
 #include "ds_common.h"
 
 namespace {
+// EXPERIMENT: host-time breakdown of one solve (DS_EXP_TIMING=1)
+struct Tm {
+    double sync = 0, eigh = 0, dense = 0, total = 0;
+    int nsync = 0, neigh = 0;
+};
+thread_local Tm g_tm;
+inline double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 // ---------------------------------------------------------------------------------------------------------------
 // small dense algebra, row-major double
@@ -95,6 +104,7 @@ Mat lower_inverse(const Mat& L) {
 
 // eigenvalues ascending, Z columns = eigenvectors (row-major Z); returns false when LAPACK reports failure
 bool eigh(const ds_lapack_t& la, const Mat& Gsym, std::vector<double>& w, Mat& Z) {
+    struct T_ { double t0 = now_s(); ~T_() { g_tm.eigh += now_s() - t0; ++g_tm.neigh; } } t_;
     const int n = Gsym.r;
     std::vector<double> A = Gsym.a;  // symmetric: row-major == column-major
     w.assign(n, 0.0);
@@ -238,7 +248,7 @@ struct Ctx {
         rc = hip(hipMemcpyAsync(stage, p->gbuf, sizeof(double) * (size_t)pc * qc, hipMemcpyDeviceToHost, st),
                  "ds_lobpcg_iterate: Gram block to host");
         if (rc != DS_OK) return rc;
-        rc = hip(hipStreamSynchronize(st), "ds_lobpcg_iterate: stream synchronise");
+        { const double t0 = now_s(); rc = hip(hipStreamSynchronize(st), "ds_lobpcg_iterate: stream synchronise"); g_tm.sync += now_s() - t0; ++g_tm.nsync; }
         if (rc == DS_OK) std::memcpy(out.a.data(), stage, sizeof(double) * (size_t)pc * qc);
         return rc;
     }
@@ -391,6 +401,8 @@ extern "C" int ds_lobpcg_iterate(ds_lobpcg_t* p, const ds_lapack_t* lapack, ds_s
     }
     const int64_t n = p->n, lds = p->lds, ldks = p->ldks, ldr = p->ldr;
     int rc;
+    g_tm = Tm();
+    const double t_begin = now_s();
     std::vector<double> lam(p->lam, p->lam + b), rel(b, std::numeric_limits<double>::infinity());
     Mat Gxp(b, b);
     for (int i = 0; i < b; ++i) Gxp(i, i) = lam[i];
@@ -413,7 +425,8 @@ extern "C" int ds_lobpcg_iterate(ds_lobpcg_t* p, const ds_lapack_t* lapack, ds_s
         if ((rc = c.hip(hipMemcpyAsync(nrm, p->nrm, sizeof(double) * 2048, hipMemcpyDeviceToHost, c.st),
                         "ds_lobpcg_iterate: residual norms to host")) != DS_OK)
             return rc;
-        if ((rc = c.hip(hipStreamSynchronize(c.st), "ds_lobpcg_iterate: stream synchronise")) != DS_OK) return rc;
+        { const double t0 = now_s(); rc = c.hip(hipStreamSynchronize(c.st), "ds_lobpcg_iterate: stream synchronise"); g_tm.sync += now_s() - t0; ++g_tm.nsync; }
+        if (rc != DS_OK) return rc;
         for (int j = 0; j < na; ++j)
             rel[ncl + j] = std::sqrt(nrm[j] / nrm[1024 + j]) / (p->A_norm + std::fabs(lam[ncl + j]) * p->B_norm);
         int nconv = 0;
@@ -510,6 +523,12 @@ extern "C" int ds_lobpcg_iterate(ds_lobpcg_t* p, const ds_lapack_t* lapack, ds_s
         std::swap(c.KS, c.KS2);
         k0 = 0;
         npc = na;
+    }
+    if (getenv("DS_EXP_TIMING")) {
+        g_tm.total = now_s() - t_begin;
+        fprintf(stderr, "lobpcg n=%lld b=%d: %d iterations, host total %.2f ms: waiting for the stream %.2f ms (%d syncs), dsyevd %.2f ms (%d calls), rest (launch calls, Cholesky, gemm, copies) %.2f ms\n",
+                (long long)p->n, b, it, g_tm.total * 1e3, g_tm.sync * 1e3, g_tm.nsync, g_tm.eigh * 1e3, g_tm.neigh,
+                (g_tm.total - g_tm.sync - g_tm.eigh) * 1e3);
     }
     p->iterations = it;
     p->result_in_s2 = (c.S == p->S) ? 0 : 1;

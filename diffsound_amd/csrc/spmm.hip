@@ -910,13 +910,31 @@ extern "C" int ds_spmm_union16m(int epilogue, int group_nodes, const int32_t* gp
     const int lpn = ncols / 4;
     const int nt = (ncols + 15) / 16;
 #define DS_MF_GO(GG, N) return launch_mfma<GG, N, DS_MF_BATCH>(epilogue, y_f32, gptr, gcol, gmeta, gbase, kc, nnzb, ngroups, nv, Xf, ldx, Yf, ldy, lpn, acap, st, epi)
+#define DS_MF_GO32(GG, N) return launch_mfma<GG, N, 2 * DS_MF_BATCH>(epilogue, y_f32, gptr, gcol, gmeta, gbase, kc, nnzb, ngroups, nv, Xf, ldx, Yf, ldy, lpn, acap32, st, epi)
+    // A level with fewer groups than the device has wave slots at two waves per SIMD (the corner-node level: 2 461 groups
+    // on 1 024 SIMDs) is one wave's chain of dependent round trips, not an occupancy problem: batches of 32 entries halve
+    // the number of those round trips (two 16-entry batches never hold more blocks than 2 x max_batch_blocks)
+    static const int small_level = [] {
+        int dev = 0, cus = 256;
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        return cus * 8;
+    }();
+    const int acap32 = ((2 * max_batch_blocks * 24 + 1023) / 1024) * 1024;
     auto go = [&]() -> int {
+        if (ngroups <= small_level) {
+            switch (nt) {
+                case 1: DS_MF_GO32(8, 1); case 2: DS_MF_GO32(8, 2); case 3: DS_MF_GO32(8, 3);
+                case 4: DS_MF_GO32(8, 4); case 5: DS_MF_GO32(8, 5); default: DS_MF_GO32(8, 6);
+            }
+        }
         switch (nt) {
             case 1: DS_MF_GO(8, 1); case 2: DS_MF_GO(8, 2); case 3: DS_MF_GO(8, 3);
             case 4: DS_MF_GO(8, 4); case 5: DS_MF_GO(8, 5); default: DS_MF_GO(8, 6);
         }
     };
 #undef DS_MF_GO
+#undef DS_MF_GO32
     if (epilogue == 1 && !y_f32) {
         int rc = DS_OK;
         if (profiled_launch(stream, st, nv, nnzb, ncols, first, 2, go, rc)) return rc;

@@ -685,7 +685,7 @@ class HipModalOps(_HipBlockOps):
     # nodes per wavefront of the MFMA form of the preconditioner's bf16 terms on (fine level, corner-node level): 8, or 0 =
     # the VALU kernel (ds_spmm_union16).  The corner-node level stays on the VALU kernel (its launches are too short to
     # gain: 36.0 against 35.8 passes/s with both levels on the matrix cores).
-    mfma_groups = (8, 0)
+    mfma_groups = (8, 8)
 
     def __init__(self, system: TetSystem, lam, mu, two_level=None, _level=0, mfma_groups=None):
         """two_level: build the corner-node level for the two-level preconditioner (ord-2 meshes; default on)."""

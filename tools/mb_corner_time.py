@@ -6,6 +6,8 @@ from diffsound_amd import meshgen
 from diffsound_amd.diffelastic.mesh import TetMesh
 from diffsound_amd.modal_ops import TetSystem, HipModalOps
 dev = torch.device('cuda')
+if len(sys.argv) > 1:
+    HipModalOps.mfma_groups = tuple(int(x) for x in sys.argv[1].split(','))
 v, t = meshgen.kuhn_box(26)
 mesh = TetMesh(torch.from_numpy(v).to(dev), torch.from_numpy(t).long().to(dev)).to_high_order(2)
 fine = TetSystem(mesh.vertices, mesh.tets, 2, 2700.0)
@@ -18,7 +20,7 @@ def tm(fn, reps=200):
     for _ in range(reps): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps * 1e3
-tag = " ".join(f"{k}={v}" for k, v in os.environ.items() if k.startswith("DS_"))
+tag = "mfma_groups=" + str(HipModalOps.mfma_groups)
 out = [f"[{tag}] nv={sysd.nv} nnzb={sysd.nnzb}"]
 for c in (80, 40):
     X = torch.randn(sysd.n, c, device=dev); Y = torch.empty_like(X); Wp = torch.randn_like(X); R0 = torch.randn_like(X)
