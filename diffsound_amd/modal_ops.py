@@ -683,8 +683,8 @@ class HipModalOps(_HipBlockOps):
     """One material hypothesis (lam, mu) on a TetSystem."""
 
     # nodes per wavefront of the MFMA form of the preconditioner's bf16 terms on (fine level, corner-node level): 8, or 0 =
-    # the VALU kernel (ds_spmm_union16).  The corner-node level stays on the VALU kernel (its launches are too short to
-    # gain: 36.0 against 35.8 passes/s with both levels on the matrix cores).
+    # the VALU kernel (ds_spmm_union16).  Both levels since round 3: with 16-entry batches on the fine level and 32-entry
+    # batches on levels smaller than the device's wave slots, the corner-node level's term takes 17.7 us instead of 22.1.
     mfma_groups = (8, 8)
 
     def __init__(self, system: TetSystem, lam, mu, two_level=None, _level=0, mfma_groups=None):
