@@ -101,6 +101,10 @@ def parse():
     ap.add_argument("--loss", default="mse", choices=["mse", "mss"],
                     help="scalar loss head: mse = the headline metric's; mss = the reference experiments' multi-scale "
                          "spectral loss (MSSLoss [1024..64], 'l1_loss', material_sync_train.py:124) on the STFT kernels")
+    ap.add_argument("--workload", default="c3", choices=["c3", "c5"],
+                    help="c3 = the headline benchmark (BASELINE.json configs[2]); c5 = configs[4], the 1M-tet / 128-mode / fp64 "
+                         "stress (one rank): SpMM bandwidth of every product form at that size and the fp32 + fp64-refined "
+                         "solve - its own JSON line, not the headline metric")
     ap.add_argument("--amortised-cycle", type=int, default=15,
                     help="also time the amortised variant the reference trains with (eigendecomposition every this many "
                          "passes, material_sync_train.py:135-141: EIGEN_DECOMPOSE_CYCLE = 15); 0 = skip")
@@ -277,8 +281,112 @@ def cpu_baseline_pass(sample_cells, order, modes, full_tets):
     }
 
 
+def main_c5(a):
+    """BASELINE.json configs[4]: 55^3 Kuhn cells = 998 250 tets, ord-2 (n = 4.1 M, nnz = 0.34 G), 128 modes, fp64
+    eigenvalues - "HBM-roofline SpMM stress".  Times every product form of the solve alone on the device against its
+    algorithmic bytes and the measured STREAM triad, then the solve itself: fp32 iteration + fp64
+    Rayleigh-Ritz polish, and the fp64 refinement to a backward error < 1e-10 of all 128 pairs."""
+    from diffsound_amd import _hip, meshgen
+    from diffsound_amd.diffelastic.mesh import TetMesh
+    from diffsound_amd.lobpcg.modal_solver import ModalSolver, SolverConfig
+    from diffsound_amd.modal_ops import HipModalOps, TetSystem
+    from oracle import fem  # (Lame constants only)
+
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    cells, modes, block = (a.cells if a.cells != 26 else 55), (a.modes if a.modes != 64 else 128), (a.block if a.block != 80 else 136)
+    v, t = meshgen.kuhn_box(cells)
+    t0 = time.time()
+    mesh = TetMesh(torch.from_numpy(v).to(dev), torch.from_numpy(t).long().to(dev)).to_high_order(2)
+    sysd = TetSystem(mesh.vertices, mesh.tets, 2, MAT[0])
+    lam, mu = fem.lame(MAT[1], MAT[2])
+    ops = HipModalOps(sysd, lam, mu)
+    torch.cuda.synchronize()
+    t_setup = time.time() - t0
+    n, nv, nnzb = sysd.n, sysd.nv, sysd.nnzb
+    L = _hip.lib()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+    def timed(fn, reps):
+        fn()
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps * 1e-3
+
+    ne = 1 << 28
+    ta, tb, tc = (torch.empty(ne, device=dev) for _ in range(3))
+    tb.fill_(1.0), tc.fill_(2.0)
+    stream_gbs = 3.0 * ne * 4 / timed(lambda: _hip.check(L.ds_stream_triad(ta.data_ptr(), tb.data_ptr(), tc.data_ptr(), ne, 0.5,
+                                                                           _hip.stream_ptr()), "ds_stream_triad"), 10) / 1e9
+    del ta, tb, tc
+    products = []
+
+    def record(name, nbytes, secs, what):
+        products.append({"product": name, "what": what, "algorithmic_bytes": int(nbytes), "ms": secs * 1e3,
+                         "achieved_gbs": nbytes / secs / 1e9, "frac_of_peak": nbytes / secs / 1e9 / HBM_PEAK_GBS,
+                         "frac_of_stream": nbytes / secs / 1e9 / stream_gbs})
+
+    for c in (84, 68):  # the widths the neighbour-union kernels serve; a 136-column block is two launches of 68
+        X, Y = torch.randn((n, c), device=dev), torch.empty((n, c), device=dev)
+        record(f"K X fp32, {c} columns", nnzb * 40 + (nv + 1) * 4 + 2 * n * c * 4, timed(lambda: ops.apply_K(X, Y), 5),
+               "spmm_union_kernel<.,0>: fp32 3x3 blocks, the eigensolver's stiffness product")
+        record(f"M X fp32, {c} columns", nnzb * 8 + (nv + 1) * 4 + 2 * n * c * 4, timed(lambda: ops.apply_M(X, Y), 5),
+               "spmm_union_kernel<.,3>: node-scalar mass values")
+        del X, Y
+    c = 136
+    X, Y = torch.randn((n, c), device=dev), torch.empty((n, c), device=dev)
+    record("K X fp32, 136 columns", nnzb * 40 + (nv + 1) * 4 + 2 * n * c * 4, timed(lambda: ops.apply_K(X, Y), 3),
+           "the form the solve runs on its 136-column block")
+    del X, Y
+    Xb, Wb, Rb = (torch.randn((n, 84), device=dev).bfloat16() for _ in range(3))
+    record("fused Chebyshev term bf16, 84 columns", ops.cheb_term_bytes(84, elem_bytes=2),
+           timed(lambda: ops.cheb_spmm16(Xb, Wb, Rb, 0.3, 0.7, False), 5),
+           "spmm_union_mfma_kernel: the preconditioner's term on the matrix cores")
+    del Xb, Wb, Rb
+    X64, Y64 = torch.randn((n, 80), device=dev, dtype=torch.float64), torch.empty((n, 80), device=dev, dtype=torch.float64)
+    record("K X fp64 values and vectors, 80 columns", 2 * nnzb * 76 + 2 * (nv + 1) * 4 + 4 * n * 80 * 8,
+           timed(lambda: ops.apply_K64(X64, Y64), 2), "two spmm_f64_node launches (K_lambda, K_mu) + combination: the refinement's K W")
+    record("M X fp64 values and vectors, 80 columns", nnzb * 12 + (nv + 1) * 4 + 2 * n * 80 * 8,
+           timed(lambda: ops.apply_M64(X64, Y64), 2), "spmm_f64_node, node-scalar values")
+    del X64, Y64
+    torch.cuda.empty_cache()
+    # ---- the solve
+    torch.cuda.synchronize()
+    t0 = time.time()
+    res = ModalSolver(ops, SolverConfig(block=block, lmax_cap=10.0)).solve(modes)
+    torch.cuda.synchronize()
+    t32 = time.time() - t0
+    t0 = time.time()
+    r64 = ModalSolver(ops, SolverConfig(block=block, lmax_cap=10.0, refine_tol=1e-10)).solve(modes)
+    torch.cuda.synchronize()
+    t64 = time.time() - t0
+    if not (float(res.rerr.max()) < 2e-6 and float(r64.rerr.max()) < 1e-10):
+        raise SystemExit(f"bench.py --workload c5: not converged (fp32 {float(res.rerr.max()):.3g}, fp64 {float(r64.rerr.max()):.3g})")
+    free_b, total_b = torch.cuda.mem_get_info(dev)
+    print(json.dumps({
+        "metric": "seconds per eigensolve, 1M-tet ord-2 mesh, 128 modes, fp64 eigenvalues (BASELINE.json configs[4])",
+        "value": t64, "unit": "s", "n_gpus": 1, "higher_is_better": False, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": (f"Kuhn box {cells}^3 cells = {sysd.T} tets, ord-2 ({nv} nodes, n={n}, nnz={nnzb * 9}), {modes} modes, "
+                                f"block {block}; one eigensolve, no gradient (configs[4] is the SpMM stress, not a pass)"),
+                   "setup_seconds": t_setup},
+        "solve": {"fp32_iteration_plus_fp64_polish": {"seconds": t32, "iterations": res.iterations,
+                                                      "coarse_iterations": res.coarse_iterations,
+                                                      "worst_backward_error": float(res.rerr.max())},
+                  "with_fp64_refinement": {"seconds": t64, "fp32_iterations": r64.iterations,
+                                           "fp64_steps": r64.refine_iterations,
+                                           "worst_backward_error": float(r64.rerr.max()), "tolerance": 1e-10}},
+        "stream_triad_gbs": stream_gbs, "hbm_peak_gbs": HBM_PEAK_GBS, "spmm": products,
+        "hbm_in_use_gib": (total_b - free_b) / 2 ** 30}))
+
+
 def main():
     a = parse()
+    if a.workload == "c5":
+        return main_c5(a)
     if a.cpu_baseline_child:  # one pass of the CPU oracle, nothing else (no GPU, no torch.distributed)
         print(json.dumps(cpu_baseline_pass(a.cpu_sample_cells, a.order, a.modes, 6 * a.cells ** 3)))
         return

@@ -6,6 +6,8 @@
 #   <tag>_spmm_pmc.json                 FETCH_SIZE / WRITE_SIZE per fused Chebyshev-term launch (separate passes)
 #   <tag>_gram_mix.txt                  Gram / mix timings at the solver's shapes
 #   <tag>_gram_mix_pmc.json             MFMA counters of the Gram / mix kernels
+#   <tag>_symbolic_phase_timing.txt     tools/time_lift.py: ord-2 lifting + symbolic phase per topology, warm
+#   <tag>_c5_bench.json / _c5_kernel_stats.csv   bench.py --workload c5 (configs[4]) under rocprofv3 --kernel-trace --stats
 # Copy what is to be judged into profiles/.
 set -e
 tag=${1:-rXX}
@@ -30,8 +32,14 @@ for kind in fp32 bf16 mfma; do
   kname="spmm_union_kernel"; [ $kind = mfma ] && kname="spmm_union_mfma_kernel"
   python3 tools/pmc_summary.py /tmp/pmc_b "$kname" > $out/${tag}_spmm_pmc_$kind.json; cat $out/${tag}_spmm_pmc_$kind.json
 done
+python3 tools/pmc_bytes.py $tag > $out/${tag}_spmm_pmc_bytes_per_launch.json   # -> profiles/spmm_pmc_bytes_per_launch.json (keyed by the kernel-source hash)
+python3 tools/time_lift.py > $out/${tag}_symbolic_phase_timing.txt 2>&1; cat $out/${tag}_symbolic_phase_timing.txt
 python3 tools/mb_gram_mix.py > $out/${tag}_gram_mix.txt 2>&1; cat $out/${tag}_gram_mix.txt
 rm -rf /tmp/pmc_g
 timeout -k 10 300 rocprofv3 --kernel-include-regex "gram32_partial|mix_lds" --pmc SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d /tmp/pmc_g -o p -- python3 tools/mb_gram_mix.py > /tmp/pmc_log_g.txt 2>&1 || { tail -5 /tmp/pmc_log_g.txt; exit 1; }
 python3 tools/pmc_summary.py /tmp/pmc_g "gram32_partial_kernel" "mix_lds_kernel<10>" "mix_lds_kernel<5>" > $out/${tag}_gram_mix_pmc.json; cat $out/${tag}_gram_mix_pmc.json
+# configs[4]: the 1M-tet / 128-mode / fp64 stress with its kernel table
+rm -rf /tmp/prof_c5
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_c5 -o c5 -- python3 bench.py --workload c5 > $out/${tag}_c5_bench.json 2> $out/${tag}_c5_stderr.log
+python3 tools/summarize_prof.py /tmp/prof_c5 $out/${tag}_c5_kernel_stats.csv --top 40
 echo "all done"
