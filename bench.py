@@ -55,7 +55,7 @@ def parse():
     ap.add_argument("--order", type=int, default=2)
     ap.add_argument("--modes", type=int, default=64)
     ap.add_argument("--hyp-per-gpu", type=int, default=8, help="material hypotheses per GPU per step")
-    ap.add_argument("--lanes", type=int, default=4,
+    ap.add_argument("--lanes", type=int, default=8,
                     help="hypotheses in flight at once per GPU (own HIP stream + host thread each), so one lane's "
                          "host-side Rayleigh-Ritz step overlaps the other lane's kernels")
     ap.add_argument("--cheb-degree", type=int, default=48)
