@@ -79,7 +79,7 @@ def parse():
                     help="backward-error tolerance of the eigensolve, ||K u - lambda M u|| / (||u|| (||K|| + lambda ||M||)) "
                          "per wanted pair: 1e-5 is the tolerance the metric states for fp32 iterates (SURVEY.md 8(d)); "
                          "0 = the library default 2e-6")
-    ap.add_argument("--nested-tol", type=float, default=1e-2,
+    ap.add_argument("--nested-tol", type=float, default=3e-3,
                     help="> 0: nested iteration - the random start is first iterated on the corner-node level to this "
                          "backward error and prolongated (SolverConfig.nested_tol); 0 = start the fine level from the "
                          "random block directly")
