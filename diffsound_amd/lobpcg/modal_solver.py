@@ -76,6 +76,7 @@ class SolverConfig:
     # (1e-10).  0 = off (the fp64 Rayleigh-Ritz polish of the fp32 block is the result).
     refine_tol: float = 0.0
     refine_maxit: int = 40
+    refine_refresh: int = 8  # every this many fp64 steps all Gram blocks are recomputed from the vectors (else by recurrence)
     nested_tol: float = 0.0
     nested_maxit: int = 8
     nested_cheb_degree: int = 28
@@ -681,8 +682,12 @@ class ModalSolver:
         """Continue from the converged fp32 block with fp64 vectors (see SolverConfig.refine_tol): LOBPCG steps in
         fp64.  One step = K W, M W for the new block (fp64 SpMM), one Rayleigh-Ritz on S = [Y | X | P | W] through the
         generalised (3b + 6)-dimensional pencil (S^T K S, S^T M S) - the rigid modes come out as its six ~zero
-        eigenvalues and are dropped - and X, P and their products with K and M for the next step by linearity (dense
-        fp64 products through torch.matmul: a handful of steps per solve, not the hot path)."""
+        eigenvalues and are dropped - and X, P and their products with K and M for the next step by linearity.
+        RAYLEIGH-RITZ BY RECURRENCE, as in the fp32 iteration: only the NEW columns meet the vectors - the Gram blocks
+        S^T K W and S^T M W (8 tall-skinny products per step instead of 22) - while the blocks among Y, X and P follow
+        from the last step's eigenvector matrix by (3b + 6)-dimensional algebra; every ``refine_refresh``-th step
+        recomputes all blocks from the vectors.  The n x b updates accumulate in place (``addmm``): no temporaries of
+        the size of a block."""
         ops, cfg = self.ops, self.cfg
         dev = ops.device
         X = res.block_vectors.double()
@@ -691,28 +696,49 @@ class ModalSolver:
         ny = 0 if Y is None else 6
         f64 = dict(dtype=torch.float64, device=dev)
         KX, MX = torch.empty((n, b), **f64), torch.empty((n, b), **f64)
+        if hasattr(ops, "combined_k64"):
+            ops.combined_k64(True)  # one fp64 block array for K during the steps (released below)
         ops.apply_K64(X, KX)
         ops.apply_M64(X, MX)
         if ny:
             MY, KY = torch.empty_like(Y), torch.empty_like(Y)
             ops.apply_M64(Y, MY)
             ops.apply_K64(Y, KY)  # ~ eps ||K|| (the rigid modes are null vectors of K); kept, not assumed zero
-        lam = None
+            Y6, KY6, MY6 = Y[:, :6], KY[:, :6], MY[:, :6]
+
+        def gen_eigh(GA_, GB_):
+            L = torch.linalg.cholesky(_sym(GB_))
+            Li = torch.linalg.solve_triangular(L, torch.eye(L.shape[0], dtype=L.dtype), upper=False)
+            E_, Zt = torch.linalg.eigh(_sym(Li @ _sym(GA_) @ Li.transpose(0, 1)))
+            return E_, (Li.transpose(0, 1) @ Zt).contiguous()
+
+        def full_grams(blocks, kblocks, mblocks):
+            offs = [0]
+            for blk in blocks:
+                offs.append(offs[-1] + blk.shape[1])
+            m = offs[-1]
+            GA, GB = torch.zeros((m, m), **f64), torch.zeros((m, m), **f64)
+            for i_, Si in enumerate(blocks):
+                for j_ in range(i_, len(blocks)):
+                    for Gm, blks in ((GB, mblocks), (GA, kblocks)):
+                        G = ops.gram(Si, blks[j_])
+                        Gm[offs[i_]:offs[i_ + 1], offs[j_]:offs[j_ + 1]] = G
+                        if j_ > i_:
+                            Gm[offs[j_]:offs[j_ + 1], offs[i_]:offs[i_ + 1]] = G.transpose(0, 1)
+            return GA, GB
+
+        # Rayleigh-Ritz on the fp32 block alone: the pairs whose residual is tested first, and an X that is
+        # K-diagonal / M-orthonormal - which every later step's X is by construction
+        GA, GB = ops.gram(X, KX), ops.gram(X, MX)
+        lam, C = _small(gen_eigh, dev, GA, GB)
+        X, KX, MX = X @ C, KX @ C, MX @ C
         P = KP = MP = None
+        G0A = G0B = None  # Gram blocks among [Y | X | P] of the current basis (fp64, m0 x m0), by recurrence
+        refresh = max(1, int(getattr(cfg, "refine_refresh", 8)))
+        since = refresh  # the first step forms everything from the vectors
         hist = []
         for it in range(cfg.refine_maxit + 1):
-            # Rayleigh-Ritz on the current X alone gives the pairs whose residual is tested
-            GA, GB = ops.gram(X, KX), ops.gram(X, MX)
-
-            def gen_eigh(GA_, GB_):
-                L = torch.linalg.cholesky(_sym(GB_))
-                Li = torch.linalg.solve_triangular(L, torch.eye(L.shape[0], dtype=L.dtype), upper=False)
-                E_, Zt = torch.linalg.eigh(_sym(Li @ _sym(GA_) @ Li.transpose(0, 1)))
-                return E_, (Li.transpose(0, 1) @ Zt).contiguous()
-
-            lam, C = _small(gen_eigh, dev, GA, GB)
-            X, KX, MX = X @ C, KX @ C, MX @ C
-            R = KX - MX * lam[None, :]
+            R = torch.addcmul(KX, MX, lam[None, :], value=-1.0)
             rn = torch.linalg.vector_norm(R, dim=0)
             rel = rn / (torch.linalg.vector_norm(X, dim=0) * (A_norm + lam.abs() * B_norm))
             worst = float(rel[:k].max())
@@ -736,49 +762,76 @@ class ModalSolver:
             del R32, W32, R
             KW, MW = torch.empty_like(W), torch.empty_like(W)
             ops.apply_M64(W, MW)
-            wn = torch.sqrt((W * MW).sum(0).clamp(min=1e-300))  # unit M-norm columns: a well scaled pencil
-            W /= wn[None, :]
-            MW /= wn[None, :]
+            wn = torch.rsqrt((W * MW).sum(0).clamp(min=1e-300))  # unit M-norm columns: a well scaled pencil
+            W *= wn[None, :]
+            MW *= wn[None, :]
             ops.apply_K64(W, KW)
             # pencil on S = [Y | X | P | W]  (P: the previous step's update directions - the locally optimal 3-term
             # recurrence; without it the pairs next to the guard vectors crawl); should the Gram matrix of S be
             # numerically singular (P and W nearly dependent close to convergence), the step is repeated without P
-            for use_p in ((True, False) if P is not None else (False,)):
-                S_blocks = ([Y[:, :6]] if ny else []) + [X] + ([P] if use_p else []) + [W]
-                KS_blocks = ([KY[:, :6]] if ny else []) + [KX] + ([KP] if use_p else []) + [KW]
-                MS_blocks = ([MY[:, :6]] if ny else []) + [MX] + ([MP] if use_p else []) + [MW]
-                offs = [0]
-                for blk in S_blocks:
-                    offs.append(offs[-1] + blk.shape[1])
-                m = offs[-1]
-                GA = torch.zeros((m, m), **f64)
-                GB = torch.zeros((m, m), **f64)
-                for i, Si in enumerate(S_blocks):
-                    for j in range(i, len(S_blocks)):
-                        for Gm, blocks in ((GB, MS_blocks), (GA, KS_blocks)):
-                            G = ops.gram(Si, blocks[j])
-                            Gm[offs[i]:offs[i + 1], offs[j]:offs[j + 1]] = G
-                            if j > i:
-                                Gm[offs[j]:offs[j + 1], offs[i]:offs[i + 1]] = G.transpose(0, 1)
-                try:
-                    _, Z = _small(gen_eigh, dev, GA, GB)
-                    break
-                except torch.linalg.LinAlgError:
-                    if not use_p:
-                        raise
-            Zs = Z[:, ny:ny + b]  # the six lowest pairs are the rigid modes
-            Cx = Zs[ny:ny + b].contiguous()
-            # update directions: everything of the new X that is not the old X
-            rest = [(blk, kb, mb, Zs[offs[i]:offs[i + 1]].contiguous())
-                    for i, (blk, kb, mb) in enumerate(zip(S_blocks, KS_blocks, MS_blocks)) if blk is not X]
-            Pn = sum(blk @ c for blk, _, _, c in rest)
-            KPn = sum(kb @ c for _, kb, _, c in rest)
-            MPn = sum(mb @ c for _, _, mb, c in rest)
-            X, KX, MX = X @ Cx + Pn, KX @ Cx + KPn, MX @ Cx + MPn
-            Pn, KPn, MPn = Pn[:, idx], KPn[:, idx], MPn[:, idx]  # directions of the active pairs only
-            pn = torch.sqrt((Pn * MPn).sum(0).clamp(min=1e-300))
-            P, KP, MP = Pn / pn[None, :], KPn / pn[None, :], MPn / pn[None, :]
-            del W, KW, MW, Pn, KPn, MPn, rest
+            head = ([(Y6, KY6, MY6)] if ny else []) + [(X, KX, MX)] + ([(P, KP, MP)] if P is not None else [])
+            blocks = [h[0] for h in head] + [W]
+            offs = [0]
+            for blk in blocks:
+                offs.append(offs[-1] + blk.shape[1])
+            m, m0, na = offs[-1], offs[-2], W.shape[1]
+            if since >= refresh or G0A is None or G0A.shape[0] != m0:
+                GA, GB = full_grams(blocks, [h[1] for h in head] + [KW], [h[2] for h in head] + [MW])
+                since = 1
+            else:  # only the new columns meet the vectors
+                GA, GB = torch.zeros((m, m), **f64), torch.zeros((m, m), **f64)
+                GA[:m0, :m0], GB[:m0, :m0] = G0A, G0B
+                for i_, blk in enumerate(blocks):
+                    for Gm, Wp in ((GA, KW), (GB, MW)):
+                        G = ops.gram(blk, Wp)
+                        Gm[offs[i_]:offs[i_ + 1], m0:] = G
+                        if i_ < len(blocks) - 1:
+                            Gm[m0:, offs[i_]:offs[i_ + 1]] = G.transpose(0, 1)
+                since += 1
+            GA, GB = _sym(GA), _sym(GB)
+            use_p = P is not None
+            try:
+                E_, Z = _small(gen_eigh, dev, GA, GB)
+            except torch.linalg.LinAlgError:
+                if not use_p:
+                    raise
+                keep = torch.cat([torch.arange(0, offs[-3], device=dev), torch.arange(m0, m, device=dev)])  # without P
+                E_, Zk = _small(gen_eigh, dev, GA[keep][:, keep].contiguous(), GB[keep][:, keep].contiguous())
+                Z = torch.zeros((m, Zk.shape[1]), **f64)
+                Z[keep] = Zk
+            Zs = Z[:, ny:ny + b].contiguous()  # the six lowest pairs are the rigid modes
+            lam = E_[ny:ny + b].contiguous()
+            xo = ny  # row offset of X in S
+            Cx = Zs[xo:xo + b].contiguous()
+            # update directions: everything of the new X that is not the old X, accumulated in place
+            Zr = Zs.clone()
+            Zr[xo:xo + b] = 0.0
+            news = []
+            for which in range(3):  # the vectors, their K-products, their M-products
+                parts = [h[which] for h in head] + [(W, KW, MW)[which]]
+                Pn = None
+                for i_, blk in enumerate(parts):
+                    if blk is head[1 if ny else 0][which]:
+                        continue  # (the old X: it enters through Cx below)
+                    c = Zs[offs[i_]:offs[i_ + 1]]
+                    Pn = torch.mm(blk, c) if Pn is None else Pn.addmm_(blk, c)
+                news.append(Pn)
+            Pn, KPn, MPn = news
+            X, KX, MX = torch.addmm(Pn, X, Cx), torch.addmm(KPn, KX, Cx), torch.addmm(MPn, MX, Cx)
+            # directions of the active pairs only, unit M-norm (from the small algebra: Pn = S Zr)
+            pn2 = ((Zr.transpose(0, 1) @ GB) * Zr.transpose(0, 1)).sum(1)[idx].clamp(min=1e-300)
+            sc = torch.rsqrt(pn2)
+            P, KP, MP = Pn[:, idx] * sc[None, :], KPn[:, idx] * sc[None, :], MPn[:, idx] * sc[None, :]
+            # Gram blocks among [Y | X_new | P_new] for the next step: T^T G T with T the coefficients of that basis in S
+            T = torch.zeros((m, ny + b + idx.numel()), **f64)
+            if ny:
+                T[:ny, :ny] = torch.eye(ny, **f64)
+            T[:, ny:ny + b] = Zs
+            T[:, ny + b:] = Zr[:, idx] * sc[None, :]
+            G0A, G0B = _sym(T.transpose(0, 1) @ GA @ T), _sym(T.transpose(0, 1) @ GB @ T)
+            del W, KW, MW, Pn, KPn, MPn, news
+        if hasattr(ops, "combined_k64"):
+            ops.combined_k64(False)
         U = X[:, :k].contiguous()
         kparts = ops.apply_K64(U, torch.empty_like(U), terms=True)
         MU = torch.empty_like(U)

@@ -634,9 +634,26 @@ class _HipBlockOps:
             _hip.check(self._L.ds_spmm_bsr3(kind + 2, p(self.rowptr), p(self.colidx), p(vals), None, self.nv, p(xs),
                                             _ld(xs), p(os_), _ld(os_), c1 - c0, _hip.stream_ptr()), "ds_spmm_bsr3(f64)")
 
+    _k64 = None
+
+    def combined_k64(self, on):
+        """fp64 refinement: while ``on``, ``apply_K64`` multiplies by ONE fp64 block array K = sum c_i K_i, formed on the
+        first product (configs[4]: 2.7 GB), instead of one product per term - half the matrix traffic of every K W.
+        The caller brackets a phase in which neither the material nor the assembled terms change, and switches it off
+        afterwards (the array is released)."""
+        self._k64 = False if on else None
+
     def apply_K64(self, X, out, terms=False):
         """out <- K X, all fp64 (fp64 block values).  ``terms``: also return the list of the separate K_i X."""
         kterms, _ = self.polish_terms()
+        if self._k64 is not None and not terms and len({kt[0] for kt in kterms}) == 1:
+            if self._k64 is False:
+                k = kterms[0][1] * float(kterms[0][2])
+                for _, vals, c in kterms[1:]:
+                    k.add_(vals, alpha=float(c))
+                self._k64 = k
+            self._spmm64(kterms[0][0], self._k64, X, out)
+            return []
         tmp = self._scratch("k64tmp", X.shape, torch.float64)
         parts = []
         out.zero_()
