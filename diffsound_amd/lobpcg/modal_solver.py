@@ -77,6 +77,7 @@ class SolverConfig:
     refine_tol: float = 0.0
     refine_maxit: int = 40
     refine_refresh: int = 8  # every this many fp64 steps all Gram blocks are recomputed from the vectors (else by recurrence)
+    refine_sweeps: int = 2   # preconditioner sweeps per fp64 step (2: W = B R + B (R - K B R); C5: 21 -> 17 steps, 4.3 -> 3.8 s)
     nested_tol: float = 0.0
     nested_maxit: int = 8
     nested_cheb_degree: int = 28
@@ -758,6 +759,17 @@ class ModalSolver:
             R32 = (R[:, idx] / rn[idx].clamp(min=1e-300)[None, :]).float().contiguous()
             W32 = torch.empty_like(R32)
             self.precond_apply(R32, W32)
+            for _ in range(max(0, int(getattr(cfg, "refine_sweeps", 1)) - 1)):
+                # one more sweep of the preconditioned Richardson iteration: W <- W + B (R - K W), all fp32.  A step of
+                # the fp64 phase is dominated by its dense n x b products, not by the preconditioner: a stronger
+                # correction per step buys fewer steps
+                T32 = torch.empty_like(R32)
+                ops.apply_K(W32, T32)
+                T32 = R32 - T32
+                D32 = torch.empty_like(R32)
+                self.precond_apply(T32, D32)
+                W32 += D32
+                del T32, D32
             W = W32.double()
             del R32, W32, R
             KW, MW = torch.empty_like(W), torch.empty_like(W)
