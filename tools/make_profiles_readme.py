@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Regenerate profiles/README.md from the committed round-2 evidence (bench JSON, rocprofv3 kernel-stat summaries, PMC)."""
+"""Regenerate profiles/README.md from the committed round-3 evidence (bench JSON, rocprofv3 kernel-stat summaries, PMC)."""
 import csv, json, os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 P = lambda f: os.path.join(ROOT, "profiles", f)
@@ -22,53 +22,59 @@ def table(f, n=16):
     return "\n".join(out)
 
 
-d = json.load(open(P("r02_bench_n1.json")))
+d = json.load(open(P("r03_bench_n1.json")))
 r = d["roofline"]
 pmc = json.load(open(P("spmm_pmc_bytes_per_launch.json")))
-gm = json.load(open(P("r02_gram_mix_pmc.json")))
+gm = json.load(open(P("r03_gram_mix_pmc.json")))
 util = {k: v["SQ_VALU_MFMA_BUSY_CYCLES"]["mean"] / (v["GRBM_GUI_ACTIVE"]["mean"] / 8 * 1024) for k, v in gm.items()}
 cb = d["cpu_baseline"]
-lines = f'''# profiles/ — round 2 evidence (MI355X, gfx950, ROCm 7.2); round 1 under `r01/`
+c5 = json.load(open(P("r03_c5_bench_noprof.json")))
+am = d.get("amortised") or {}
+lines = f'''# profiles/ — round 3 evidence (MI355X, gfx950, ROCm 7.2); round 1 under `r01/`, round 2 as `r02_*`
 
 All runs: `bench.py` defaults = workload C3 (Kuhn box 26³ = 105 456 tets, ord-2, n = 446 631, nnz = 37.2 M, 64 modes,
-block 80, two-level preconditioner on bf16 blocks, nested start, tolerance 1e-5), 8 hypotheses per step, 4 in flight per
-GPU, cold-start eigensolve and numeric assembly in every pass.  Collected by `tools/collect_profiles.sh r02` on the GPU box
-(regenerate this file with `python tools/make_profiles_readme.py`).
+block 80, two-level preconditioner on bf16 blocks with both levels' terms on the matrix cores, nested start to 3e-3,
+tolerance 1e-5), 8 hypotheses per step, 8 in flight per GPU, cold-start eigensolve and numeric assembly in every pass.
+Collected by `tools/collect_profiles.sh r03` on the GPU box (regenerate this file with `python tools/make_profiles_readme.py`).
 
 | file | what |
 |---|---|
-| `r02_bench_n1.json` | the JSON line of `python bench.py` (N = 1, 3 steps, 1 warm-up, CPU baseline included): **{d["value"]:.1f} passes/s** |
-| `r02_bench_kernel_stats.csv` | `rocprofv3 --kernel-trace --stats` of `python bench.py --no-cpu-baseline` (4 hypothesis lanes overlap: durations stretched by sharing) |
-| `r02_bench_lanes1_kernel_stats.csv` | the same with `--lanes 1 --hyp-per-gpu 2 --steps 4`: one hypothesis at a time, every kernel alone on the device — the table to read kernel durations from |
-| `r02_gpu_busy.txt` | device-busy fraction of the timed window from the kernel trace of the profiled default run (`tools/gpu_busy.py`; the profiler inflates the host side) |
-| `r02_spmm_pmc_fp32.json`, `r02_spmm_pmc_bf16.json`, `r02_spmm_pmc_mfma.json`, `spmm_pmc_bytes_per_launch.json` | HBM-side traffic of the fused Chebyshev-term SpMM (fine level, 80 columns) from separate `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes; bytes = (2·FETCH + WRITE)·1024 (gfx950 correction of `guides/MI355X_MICROARCH.md`): VALU kernel on fp32 blocks {pmc["cells26_cols80_fp32"] / 1e6:.0f} MB (743.1 MB algorithmic), on bf16 blocks {pmc["cells26_cols80_bf16"] / 1e6:.0f} MB (457.3 MB algorithmic), **MFMA kernel (production) {pmc["cells26_cols80_mfma"] / 1e6:.0f} MB ({r["algorithmic_bytes_per_launch"] / 1e6:.1f} MB algorithmic, {pmc["cells26_cols80_mfma"] / r["algorithmic_bytes_per_launch"]:.2f} ×)** |
-| `r02_mfma_interference.txt` | why the MFMA kernel issues `v_mfma_f32_16x16x16_bf16`: with `v_mfma_f32_16x16x32_bf16` the packed-FMA kernels of OTHER streams returned changed results while it ran beside them (`tools/stress_mix.py`: paired launches on two streams compared bit for bit with solo results; bisection; bench loss sums of repeated runs) |
-| `r02_gram_mix.txt` | Gram / `mix` timings at the solver's shapes (`tools/mb_gram_mix.py`) |
-| `r02_gram_mix_pmc.json` | `--pmc SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE` over the same script: MFMA utilisation = busy cycles ÷ (GRBM_GUI_ACTIVE / 8 XCDs × 1024 SIMDs) = ''' + ", ".join(f"{k.split('(')[0]} {100 * v:.0f} %" for k, v in util.items()) + f''' |
-| `r02_stream_probe.txt` | STREAM triad / copy variants on the device (`tools/stream_probe.hip`): one 16-byte piece per thread reaches 6.1–6.4 TB/s, grid-stride loops 4.5–5.3 TB/s |
-| `r02_exp_tolerance.txt` | eigensolve tolerance vs iterations and accuracy on C3 (`tools/exp_tol.py`): what the benchmark's 1e-5 costs in eigenvalue / audio / gradient accuracy relative to a 5e-7 solve |
+| `r03_bench_n1.json` | the JSON line of `python bench.py` (N = 1, 3 steps, 1 warm-up, CPU baseline included): **{d["value"]:.1f} passes/s**; amortised variant (eigendecomposition every 15 passes) {am.get("value", float("nan")):.0f} passes/s |
+| `r03_bench_kernel_stats.csv` | `rocprofv3 --kernel-trace --stats` of `python bench.py --no-cpu-baseline --steps 8` (8 hypothesis lanes overlap: durations stretched by sharing) |
+| `r03_bench_lanes1_kernel_stats.csv` | the same with `--lanes 1 --hyp-per-gpu 2 --steps 4`: one hypothesis at a time, every kernel alone on the device — the table to read kernel durations from |
+| `r03_gpu_busy.txt`, `r03_concurrency_profile.txt` | device-busy fraction of the timed window (`tools/gpu_busy.py`) and the concurrency profile (`tools/gpu_timeline.py`: kernels in flight, busy share per stream, idle time by gap size, which kernels border the short gaps) |
+| `r03_spmm_pmc_fp32.json`, `r03_spmm_pmc_bf16.json`, `r03_spmm_pmc_mfma.json`, `spmm_pmc_bytes_per_launch.json` | HBM-side traffic of the fused Chebyshev-term SpMM (fine level, 80 columns) from separate `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes; bytes = (2·FETCH + WRITE)·1024 (gfx950 correction of `guides/MI355X_MICROARCH.md`): VALU kernel on fp32 blocks {pmc["cells26_cols80_fp32"]["bytes"] / 1e6:.0f} MB (743.1 MB algorithmic), on bf16 blocks {pmc["cells26_cols80_bf16"]["bytes"] / 1e6:.0f} MB (457.3 MB algorithmic), **MFMA kernel (production) {pmc["cells26_cols80_mfma"]["bytes"] / 1e6:.0f} MB ({r["algorithmic_bytes_per_launch"] / 1e6:.1f} MB algorithmic, {pmc["cells26_cols80_mfma"]["bytes"] / r["algorithmic_bytes_per_launch"]:.2f} ×)**; every record carries the hash of the SpMM sources it was measured on (`bench.py` reports a record with another hash as stale: `traffic: null`) |
+| `r03_mfma_interference_matrix.txt` | the gfx950 finding from the victim's side (`tools/mfma_interference.py`, `tests/probes/mfma_probe.hip`): register-only MFMA spins (x32 / x16 bf16, fp32, plain FMA) beside register-only chains of `v_pk_fma_f32` / `v_fma_f32` and beside the production kernels, every launch compared bit for bit with its solo result - taken with the packed-FMA build of round 2 as the production victim (120 of 120 launches changed beside the double-rate form) |
+| `r03_no_packed_fp32_ab.txt` | A/B of the build without packed FP32 (shipped) against the packed build: kernel timings, benchmark, bit-identical loss, and the same matrix with 0 of 120 for every production kernel |
+| `r03_mfma_batch_sizes.txt` | the fused term at C3 with LDS batches of 32 / 16 / 8 entries (2 / 3 / 4 waves per SIMD): 171 / 145 / 144 us |
+| `r03_lanes_sweep.txt`, `r03_exp_knobs.txt`, `r03_exp_nested_tol.txt` | throughput against lanes, block width, smoother / corner-level degree, nested-start tolerance (the re-tuning behind this round's defaults) |
+| `r03_host_time_one_lane.txt`, `r03_device_eigh_probe.txt` | host time of one solve by cause (`DS_EXP_TIMING=1`); the dense Rayleigh-Ritz steps through rocSOLVER on the device against one host core |
+| `r03_symbolic_phase_timing.txt` | `tools/time_lift.py`: ord-2 lifting and the symbolic phase per topology at C3 |
+| `r03_gram_mix.txt`, `r03_gram_mix_pmc.json` | Gram / `mix` timings at the solver's shapes and their MFMA counters: utilisation = busy cycles ÷ (GRBM_GUI_ACTIVE / 8 XCDs × 1024 SIMDs) = ''' + ", ".join(f"{k.split('(')[0]} {100 * v:.0f} %" for k, v in util.items()) + f''' |
+| `r03_c5_bench_noprof.json`, `r03_c5_bench.json`, `r03_c5_kernel_stats.csv` | **configs[4]** (`bench.py --workload c5`, plain and under `rocprofv3 --kernel-trace --stats`): 998 250 tets, n = 4.1 M, 128 modes - SpMM bandwidth of every product form against the in-run STREAM triad, fp32 solve {c5["solve"]["fp32_iteration_plus_fp64_polish"]["seconds"]:.1f} s, with the fp64 refinement to 1e-10 **{c5["solve"]["with_fp64_refinement"]["seconds"]:.1f} s** ({c5["solve"]["with_fp64_refinement"]["fp64_steps"]} fp64 steps; second solve of the process, figures of the plain run) |
 
-## Roofline figures of `r02_bench_n1.json`
+## Roofline figures of `r03_bench_n1.json`
 
 * dominant kernel `{r["kernel"]}`: {r["algorithmic_bytes_per_launch"] / 1e6:.1f} MB algorithmic per launch, {r["avg_launch_ms"]:.3f} ms alone on the device
-  → **{r["achieved"]:.0f} GB/s = {100 * r["frac"]:.1f} % of 8 TB/s, {100 * r["frac_of_stream"]:.1f} % of the STREAM triad measured in the same run ({r["stream_triad"]:.0f} GB/s)**;
-  in situ (4 lanes sharing the chip): fine {r["in_situ"]["levels"]["fine"]["avg_launch_ms"]:.3f} ms, corner-node {r["in_situ"]["levels"]["corner_node"]["avg_launch_ms"]:.3f} ms per launch;
-* the eigensolver's K·W: {r.get("lobpcg_spmm", {}).get("achieved", float("nan")):.0f} GB/s = {100 * r.get("lobpcg_spmm", {}).get("frac_of_stream", float("nan")):.0f} % of STREAM ({r.get("lobpcg_spmm", {}).get("avg_launch_ms", float("nan")):.3f} ms for 451.9 MB, fine level, alone on the device; in `r02_bench_lanes1_kernel_stats.csv` the name `spmm_union_kernel<20, 0, …>` also covers the short corner-level launches of the nested start);
-* CPU baseline: {cb["sample"]} on {cb["cores"]} threads of {cb["cpu_model"]} ({cb["host_hardware_threads"]} hardware threads on the host); stages {cb["stage_seconds"]}.
+  → **{r["achieved"]:.0f} GB/s = {100 * r["frac"]:.1f} % of 8 TB/s, {100 * r["frac_of_stream"]:.1f} % of the STREAM triad measured in the same run ({r["stream_triad"]:.0f} GB/s)**; PMC traffic {r["traffic"]} B ({r["traffic_note"]});
+  in situ (8 lanes sharing the chip): fine {r["in_situ"]["levels"]["fine"]["avg_launch_ms"]:.3f} ms, corner-node {r["in_situ"]["levels"]["corner_node"]["avg_launch_ms"]:.3f} ms per launch;
+* the eigensolver's K·W: {r.get("lobpcg_spmm", {}).get("achieved", float("nan")):.0f} GB/s = {100 * r.get("lobpcg_spmm", {}).get("frac_of_stream", float("nan")):.0f} % of STREAM ({r.get("lobpcg_spmm", {}).get("avg_launch_ms", float("nan")):.3f} ms for 451.9 MB, fine level, alone on the device);
+* CPU baseline: {cb["sample"]} on {cb["cores"]} threads of {cb["cpu_model"]} ({cb["host_hardware_threads"]} hardware threads on the host); stages of the median pass {cb["stage_seconds"]}.
 
-## One hypothesis at a time (`r02_bench_lanes1_kernel_stats.csv`; 11 passes incl. the target render and one warm-up step)
+## One hypothesis at a time (`r03_bench_lanes1_kernel_stats.csv`; 15 passes incl. the target render and one warm-up step)
 
-{table("r02_bench_lanes1_kernel_stats.csv", 22)}
+{table("r03_bench_lanes1_kernel_stats.csv", 22)}
 
-`spmm_union_mfma_kernel<8, NT, EPI, OUT32>`: the fine level's bf16 terms on the matrix cores (8 nodes per wavefront, NT
-16-column tiles: 5 = the full 80-column block, fewer after locking; EPI 1 fused Chebyshev term, 2 residual handed to the
-corner-node level; OUT32 = the term that leaves the V-cycle).  `spmm_union_kernel<20|0, EPI, 116, BIG, BF, OUT32>`: the
-VALU kernel - LPN 20 = full 80-column blocks, 0 = the narrower blocks after locking; EPI 0 K·W, 1 fused Chebyshev term
-(with BF `true`: the corner-node level's, ~23 us each), 3 mass product.
+`spmm_union_mfma_kernel<8, NT, EPI, OUT32, BATCH>`: the bf16 terms of both levels on the matrix cores (8 nodes per
+wavefront, NT 16-column tiles: 5 = the full 80-column block, fewer after locking; EPI 1 fused Chebyshev term, 2 residual
+handed to the corner-node level; OUT32 = the term that leaves the V-cycle; BATCH 16 on the fine level, 32 on levels smaller
+than the device's wave slots - the name covers the fine level's ~145 us launches and the corner-node level's ~18 us ones).
+`spmm_union_kernel<20|0, EPI, 116, BIG, BF, OUT32>`: the VALU kernel - LPN 20 = full 80-column blocks, 0 = the narrower
+blocks after locking; EPI 0 K·W, 3 mass product.
 
-## Default run, 4 lanes (`r02_bench_kernel_stats.csv`)
+## Default run, 8 lanes (`r03_bench_kernel_stats.csv`)
 
-{table("r02_bench_kernel_stats.csv", 16)}
+{table("r03_bench_kernel_stats.csv", 16)}
 '''
 open(P("README.md"), "w").write(lines)
 print("wrote profiles/README.md")
