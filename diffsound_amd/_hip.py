@@ -6,6 +6,7 @@ reference src/include/macro.h:75-83).  Tensors are passed as raw ``data_ptr()`` 
 kernels are enqueued on torch's current HIP stream.
 """
 import ctypes
+import threading
 import os
 
 import torch
@@ -113,8 +114,8 @@ _lapack = None
 
 def lapack_table():
     """ds_lapack_t filled with SciPy's LAPACK / BLAS entry points (scipy.linalg.cython_lapack / cython_blas export them
-    as PyCapsules).  The <= 3b x 3b problems are fastest on one thread and are solved by several lanes at once, so the
-    BLAS behind them is limited to one thread (threadpoolctl) the first time the table is built."""
+    as PyCapsules).  The table changes nothing in the process: the BLAS thread count is the caller's business
+    (``blas_one_thread`` below is what the native solve is wrapped in)."""
     global _lapack
     if _lapack is None:
         import scipy.linalg.cython_blas as cb
@@ -125,15 +126,39 @@ def lapack_table():
         get.restype, get.argtypes = ctypes.c_void_p, [ctypes.py_object, ctypes.c_char_p]
         name.restype, name.argtypes = ctypes.c_char_p, [ctypes.py_object]
         addr = lambda cap: get(cap, name(cap))
-        t = LapackTable(addr(cl.__pyx_capi__["dsyevd"]), addr(cb.__pyx_capi__["dgemm"]))
-        try:
-            from threadpoolctl import threadpool_limits
-
-            t._limits = threadpool_limits(limits=1, user_api="blas")
-        except Exception:  # threadpoolctl missing: the BLAS keeps its own thread count
-            t._limits = None
-        _lapack = t
+        _lapack = LapackTable(addr(cl.__pyx_capi__["dsyevd"]), addr(cb.__pyx_capi__["dgemm"]))
     return _lapack
+
+
+class blas_one_thread:
+    """The <= 3b x 3b problems of the native eigensolver loop are fastest on one BLAS thread and are solved by several
+    hypothesis lanes at once.  Context manager, re-entrant across threads: the first solve that enters limits the BLAS
+    behind SciPy to one thread (threadpoolctl), the last one that leaves restores what was there - nothing stays changed
+    in the host process (round 2 left the limit in place for good, which also skewed the CPU baseline)."""
+
+    _lock = threading.Lock()
+    _depth = 0
+    _ctl = None
+
+    def __enter__(self):
+        cls = blas_one_thread
+        with cls._lock:
+            if cls._depth == 0:
+                try:
+                    from threadpoolctl import threadpool_limits
+
+                    cls._ctl = threadpool_limits(limits=1, user_api="blas")
+                except Exception:  # threadpoolctl missing: the BLAS keeps its own thread count
+                    cls._ctl = None
+            cls._depth += 1
+
+    def __exit__(self, *a):
+        cls = blas_one_thread
+        with cls._lock:
+            cls._depth -= 1
+            if cls._depth == 0 and cls._ctl is not None:
+                cls._ctl.restore_original_limits()
+                cls._ctl = None
 
 
 _SIGNATURES["ds_twolevel_apply"] = (_I, [ctypes.POINTER(TwoLevelDesc), _P])

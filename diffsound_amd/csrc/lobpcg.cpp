@@ -203,7 +203,11 @@ bool orthonormal_columns(const ds_lapack_t& la, const Mat& Tm, Mat& Q) {
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int COEF_SLOTS = 8;
 
-struct PinnedRing {  // per host thread, grown on demand, kept for the life of the thread
+struct PinnedRing {  // per host thread, grown on demand, released when the thread ends
+    ~PinnedRing() {
+        if (host) (void)hipHostFree(host);
+        if (back) (void)hipHostFree(back);
+    }
     float* host = nullptr;
     size_t slot_floats = 0;
     double* back = nullptr;  // device-to-host staging (Gram blocks, residual norms): a pageable destination would
@@ -391,6 +395,10 @@ extern "C" int ds_lobpcg_iterate(ds_lobpcg_t* p, const ds_lapack_t* lapack, ds_s
                "ds_lobpcg_iterate: block width must be a multiple of 4 <= 84 (got %d)", p->b);
     DS_REQUIRE(p->n == 3 * p->nv && p->n >= 3 * p->b + p->ny, "ds_lobpcg_iterate: bad problem size");
     DS_REQUIRE(p->twolevel || (p->pa && p->pb), "ds_lobpcg_iterate: no preconditioner scratch");
+    // the periodic full refresh multiplies K by [X P W] (up to 3 b columns): wider than 84 it goes through ds_spmm_bsr3,
+    // which needs the plain BSR arrays - asked for here, not at the 8th iteration
+    DS_REQUIRE(p->rr_refresh <= 0 || 3 * p->b <= 84 || (p->rowptr && p->colidx && p->k32 && p->k32t),
+               "ds_lobpcg_iterate: rowptr / colidx / k32 / k32t are needed for the full refresh of a block wider than 28");
     Ctx c{p, ds::as_stream(stream), stream, *lapack, p->S, p->S2, p->KS, p->KS2};
     const int b = p->b, k = p->k, ny = p->ny;
     {   // cbuf holds COEF_SLOTS slots of (ny + 3 b) x 2 b floats

@@ -448,8 +448,9 @@ class _HipBlockOps:
         rerr_h = (ctypes.c_double * b)()
         hist_h = (ctypes.c_double * (cfg.maxit + 1))()
         d.lam, d.rerr, d.history, d.history_cap = lam_h, rerr_h, hist_h, cfg.maxit + 1
-        _hip.check(self._L.ds_lobpcg_iterate(ctypes.byref(d), ctypes.byref(_hip.lapack_table()), _hip.stream_ptr()),
-                   "ds_lobpcg_iterate")
+        with _hip.blas_one_thread():
+            _hip.check(self._L.ds_lobpcg_iterate(ctypes.byref(d), ctypes.byref(_hip.lapack_table()), _hip.stream_ptr()),
+                       "ds_lobpcg_iterate")
         it = int(d.iterations)
         lam_t = torch.tensor(list(lam_h), dtype=torch.float64, device=dev)
         rel_t = torch.tensor(list(rerr_h), dtype=torch.float64, device=dev)
