@@ -57,6 +57,17 @@ def test_bench_line_contract(one_rank):
     assert 3000 < r["stream_triad"] < 8000 and r["in_situ"]["launches_timed"] > 0
 
 
+def test_loss_is_bit_identical_across_runs(ndev, one_rank):
+    """Concurrent hypothesis lanes on separate streams must not change a single bit of any pass: the loss sum of a
+    second, identical run equals the first exactly (the check that exposed the MFMA / packed-FMA interaction of
+    DESIGN.md 5b in round 2), here with 4 lanes on a mesh large enough for the lanes' kernels to overlap."""
+    args = ["--gpus", "1", "--hyp-per-gpu", "8", "--lanes", "4", "--steps", "2", "--warmup", "0", "--cells", "12", "--modes", "32",
+            "--block", "40", "--no-cpu-baseline", "--amortised-cycle", "0"]
+    a, b = _bench(*args), _bench(*args)
+    assert a["loss_sum_last_step"] == b["loss_sum_last_step"]
+    assert [r["fine_iterations"] for r in a["ranks"]] == [r["fine_iterations"] for r in b["ranks"]]
+
+
 def test_two_ranks_sharing_one_device_gloo(ndev, one_rank):
     two = _bench("--gpus", "2", "--hyp-per-gpu", "2", "--lanes", "2", "--dist-backend", "gloo", "--share-devices", *SMALL)
     assert two["n_gpus"] == 2 and "gloo" in two["collective"]
