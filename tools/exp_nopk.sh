@@ -1,4 +1,7 @@
 #!/bin/bash
+# (round 3; the A/B library tools/libds_nopk.so was `make -C diffsound_amd/csrc BUILD=build_nopk LIB=../../tools/libds_nopk.so` of the
+# tree BEFORE plain FMAs became the only form - with `EXTRA="-DDS_PLAIN_FMA=1 -Xclang -target-feature -Xclang -packed-fp32-ops"` - loaded
+# through DS_EXP_LIB; kept as the record of how profiles/r03_no_packed_fp32_ab.txt was taken)
 # A/B: the production library against the build without packed FP32 (tools/libds_nopk.so: -DDS_PLAIN_FMA=1 and the
 # compiler's packed-fp32-ops feature off)
 for lib in "" "tools/libds_nopk.so"; do
