@@ -57,6 +57,51 @@ __global__ void __launch_bounds__(256) probe(const int32_t* __restrict__ gptr, c
                 }
             }
         }
+    } else if (MODE == 6) {
+        // outer-product layout with the columns split over TWO waves (blockIdx.y = column half of 40): per entry three
+        // dword loads of 40 lanes (160 bytes each)
+        const int c0 = blockIdx.y * 40;
+        for (int b = 0; b < ne; b += 64) {
+            const int mine = (b + lane < ne) ? (gent[e0 + b + lane] & 0x0fffffff) : -1;
+            const int cnt = min(64, ne - b);
+            for (int q = 0; q < cnt; q += 8) {
+                int x[24];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int e = __builtin_amdgcn_readlane(mine, (q + u) & 63);
+                    const int so = e < 0 ? 0 : e * panel_bytes;
+                    const int bad = (e < 0 || lane >= 40) ? 0x7f000000 : 0;
+#pragma unroll
+                    for (int g = 0; g < 3; ++g)
+                        x[3 * u + g] = __builtin_amdgcn_raw_buffer_load_b32(rs, (bad ? bad : (c0 + lane) * 4 + g * row_bytes), so, 0);
+                }
+#pragma unroll
+                for (int u = 0; u < 24; ++u) acc ^= x[u];
+            }
+        }
+    } else if (MODE == 5) {
+        // fp32 panels in the OUTER-PRODUCT layout (one column per lane: the B operand of v_mfma_f32_4x4x1_16B_f32): per
+        // entry three dword loads (row g, columns 0..63) and one for the tails (lane l: row l >> 4, column 64 + (l & 15))
+        const int tvoff = lane < 48 ? (lane >> 4) * row_bytes + (64 + (lane & 15)) * 4 : 0x7f000000;
+        for (int b = 0; b < ne; b += 64) {
+            const int mine = (b + lane < ne) ? (gent[e0 + b + lane] & 0x0fffffff) : -1;
+            const int cnt = min(64, ne - b);
+            for (int q = 0; q < cnt; q += 4) {
+                int x[16];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int e = __builtin_amdgcn_readlane(mine, (q + u) & 63);
+                    const int so = e < 0 ? 0 : e * panel_bytes;
+                    const int bad = e < 0 ? 0x7f000000 : 0;
+#pragma unroll
+                    for (int g = 0; g < 3; ++g)
+                        x[4 * u + g] = __builtin_amdgcn_raw_buffer_load_b32(rs, (bad ? bad : lane * 4 + g * row_bytes), so, 0);
+                    x[4 * u + 3] = __builtin_amdgcn_raw_buffer_load_b32(rs, bad ? bad : tvoff, so, 0);
+                }
+#pragma unroll
+                for (int u = 0; u < 16; ++u) acc ^= x[u];
+            }
+        }
     } else {  // MODE 1: 30 lanes x 16 B = one 480-byte bf16 panel; two panels per instruction
         const int half = lane >= 30 ? 1 : 0;
         const int l30 = lane - 30 * half;
@@ -125,11 +170,13 @@ extern "C" float gather_probe(int mode, const int32_t* gptr, const int32_t* gent
     float best = 1e30f;
     for (int r = 0; r < reps + 1; ++r) {
         hipEventRecord(a, 0);
-        const int eb = mode == 2 ? 4 : 2;
+        const int eb = (mode == 2 || mode == 5 || mode == 6) ? 4 : 2;
         const int row_bytes = ld_elems * eb, panel_bytes = 3 * row_bytes;
         if (mode == 0) probe<0><<<nwg, 256>>>(gptr, gent, ngroups, (const char*)X, xbytes, panel_bytes, row_bytes, ld_elems / 4, out);
         else if (mode == 1) probe<1><<<nwg, 256>>>(gptr, gent, ngroups, (const char*)X, xbytes, panel_bytes, row_bytes, 0, out);
         else if (mode == 2) probe<2><<<nwg, 256>>>(gptr, gent, ngroups, (const char*)X, xbytes, panel_bytes, row_bytes, ld_elems / 4, out);
+        else if (mode == 5) probe<5><<<nwg, 256>>>(gptr, gent, ngroups, (const char*)X, xbytes, panel_bytes, row_bytes, ld_elems / 4, out);
+        else if (mode == 6) probe<6><<<dim3(nwg, 2), 256>>>(gptr, gent, ngroups, (const char*)X, xbytes, panel_bytes, row_bytes, ld_elems / 4, out);
         else probe16<<<ngroups, 256>>>(gptr, gent, ngroups, (const char*)X, xbytes, panel_bytes, out);
         hipEventRecord(b, 0);
         hipEventSynchronize(b);

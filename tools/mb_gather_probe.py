@@ -53,3 +53,14 @@ for G in (8, 16, 32):
     gptr = torch.searchsorted(key // nv, torch.arange(ng + 1, device=dev)).to(torch.int32).contiguous()
     gent = (key % nv).to(torch.int32).contiguous()
     run(3, gptr, gent, ng, X16, key.numel(), 480, f"bf16, 16 B/lane, workgroup-wide union of {G} nodes ({key.numel() / pat.nnzb:.3f})")
+# fp32 panels, one wave per group of G nodes: the production load (16 B per lane, one instruction per panel) against the
+# outer-product layout (one column per lane: 3 + 1 dword loads per panel)
+run(5, pat.gptr, pat.gent, pat.ngroups, X32, ne, 960, "fp32 panels, 4-node unions, 4 dword loads per panel")
+for G in (8, 16):
+    key = torch.unique((rows // G) * nv + pat.colidx.long())
+    ng = (nv + G - 1) // G
+    gptr = torch.searchsorted(key // nv, torch.arange(ng + 1, device=dev)).to(torch.int32).contiguous()
+    gent = (key % nv).to(torch.int32).contiguous()
+    run(2, gptr, gent, ng, X32, key.numel(), 960, f"fp32 panels, one wave per {G}-node union, 16 B/lane")
+    run(5, gptr, gent, ng, X32, key.numel(), 960, f"fp32 panels, one wave per {G}-node union, 4 dword loads per panel")
+    run(6, gptr, gent, ng, X32, key.numel(), 960, f"fp32 panels, two waves (40 columns each) per {G}-node union, 3 dword loads per half panel")
