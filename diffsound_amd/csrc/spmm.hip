@@ -370,7 +370,6 @@ int launch_wn(const int32_t* rowptr, const int32_t* colidx, const void* vals, co
 
 #include "spmm_union.inc"
 #include "spmm_mfma.inc"
-#include "spmm_op.inc"
 
 template <int KIND>
 int launch_fast(const int32_t* rowptr, const int32_t* colidx, const void* vals, const void* vals_t, int64_t nv,
@@ -941,45 +940,6 @@ extern "C" int ds_spmm_union16m(int epilogue, int group_nodes, const int32_t* gp
         if (profiled_launch(stream, st, nv, nnzb, ncols, first, 2, go, rc)) return rc;
     }
     return go();
-}
-
-// ------------------------------------------------------------------------------------------------
-// Outer-product form of the eigensolver's fp32 products on 8-node unions (spmm_op.inc)
-extern "C" int ds_pack_op(const float* k32, const float* ms32, const int32_t* kperm, int64_t nnzb, float* kop, float* mop,
-                          ds_stream_t stream) {
-    DS_REQUIRE(k32 && kperm && kop && nnzb > 0 && (!mop || ms32), "ds_pack_op: bad argument");
-    DS_REQUIRE((reinterpret_cast<uintptr_t>(kop) & 15) == 0 && (reinterpret_cast<uintptr_t>(mop) & 15) == 0,
-               "ds_pack_op: kop / mop must be 16-byte aligned");
-    pack_op_kernel<<<(unsigned)ds::ceil_div(nnzb * 9, 256), 256, 0, ds::as_stream(stream)>>>(k32, ms32, kperm, nnzb, kop, mop);
-    DS_LAUNCH_CHECK("pack_op_kernel");
-    return DS_OK;
-}
-
-extern "C" int ds_spmm_union8(int kind, const int32_t* gptr, const int32_t* gcol, const int32_t* gmeta,
-                              const int32_t* gbase, const float* vals, int64_t nnzb, int64_t ngroups, int max_entries,
-                              int max_group_blocks, int64_t nv, const float* X, int64_t ldx, float* Y, int64_t ldy,
-                              int ncols, ds_stream_t stream) {
-    DS_REQUIRE(gptr && gcol && gmeta && gbase && vals && X && Y, "ds_spmm_union8: null pointer");
-    DS_REQUIRE(kind == 0 || kind == 3, "ds_spmm_union8: kind must be 0 (3x3 blocks) or 3 (node scalars)");
-    DS_REQUIRE(nv > 0 && ngroups == (nv + 7) / 8 && ncols > 0 && ncols % 4 == 0 && ncols <= 84,
-               "ds_spmm_union8: ncols must be a multiple of 4 <= 84 and ngroups = ceil(nv / 8)");
-    DS_REQUIRE(max_entries > 0 && max_entries <= 256, "ds_spmm_union8: a group with %d union entries exceeds 256", max_entries);
-    DS_REQUIRE(max_group_blocks > 0 && max_group_blocks <= 8 * 256, "ds_spmm_union8: bad max_group_blocks");
-    DS_REQUIRE(ldx >= ncols && ldy >= ncols && X != Y, "ds_spmm_union8: bad blocks");
-    DS_REQUIRE(3 * nv * ldx * 4 < (int64_t)PIPE_OOB, "ds_spmm_union8: X exceeds the range of one descriptor");
-    DS_REQUIRE((reinterpret_cast<uintptr_t>(vals) & 15) == 0 && ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(Y)) & 3) == 0,
-               "ds_spmm_union8: values must be 16-byte aligned");
-    const size_t lds = (size_t)ds::ceil_div((int64_t)max_group_blocks * (kind == 0 ? 36 : 4), 1024) * 1024;  // whole 1 KiB pieces
-    DS_REQUIRE(lds <= 64 * 1024, "ds_spmm_union8: a group of %d blocks does not fit the LDS image", max_group_blocks);
-    hipStream_t st = ds::as_stream(stream);
-    if (kind == 0)
-        spmm_union_op_kernel<8, 0><<<(unsigned)ngroups, 64, lds, st>>>(gptr, gcol, gmeta, gbase, vals, nnzb, (unsigned)ngroups,
-                                                                        nv, X, ldx, Y, ldy, ncols);
-    else
-        spmm_union_op_kernel<8, 3><<<(unsigned)ngroups, 64, lds, st>>>(gptr, gcol, gmeta, gbase, vals, nnzb, (unsigned)ngroups,
-                                                                        nv, X, ldx, Y, ldy, ncols);
-    DS_LAUNCH_CHECK("spmm_union_op_kernel");
-    return DS_OK;
 }
 
 // Ya = A X, Yb = B X (fp64 3x3 block values), Ym = (m (x) I3) X (fp64 node scalars) for one fp32 block X in one walk.

@@ -130,9 +130,7 @@ class TetSystem:
         nslot = 256 // MF_BATCH
         batch = (ekey // nv) * nslot + ((eidx - torch.repeat_interleave(gptr[:-1], ne_g)) // MF_BATCH).clamp(max=nslot - 1)
         per_batch = torch.zeros(ng * nslot, dtype=torch.int64, device=dev).scatter_add_(0, batch, counts)
-        nb_g = torch.diff(torch.cat([gbase, gbase.new_tensor([goff[-1]])]))  # blocks per group
         return dict(G=G, ngroups=ng, max_entries=int(ne_g.max()), max_batch_blocks=int(per_batch.max()),
-                    max_group_blocks=int(nb_g.max()),
                     gptr=gptr.to(torch.int32), gcol=(ekey % nv).to(torch.int32).contiguous(),
                     gmeta=(mask | (within << 8)).to(torch.int32).contiguous(), gbase=gbase.to(torch.int32).contiguous(),
                     kperm=order.to(torch.int32).contiguous())

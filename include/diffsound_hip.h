@@ -40,7 +40,7 @@ enum { DS_OK = 0, DS_ERR_ARG = 1, DS_ERR_HIP = 2, DS_ERR_NOMEM = 3 };
 /* Thread-local text of the last error returned on this thread ("" if none). */
 const char* ds_last_error(void);
 /* Library ABI version (bumped on any signature change); ds_abi_version() returns the value the library was built with. */
-#define DS_ABI_VERSION 25
+#define DS_ABI_VERSION 24
 int ds_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------------
@@ -310,18 +310,6 @@ int ds_spmm_union16m(int epilogue, int group_nodes, const int32_t* gptr, const i
                      const void* R0, int64_t ldr,
                      const float* dinv, int ncols, float c1, float c2, int first, const void* Wprev, int64_t ldp,
                      ds_stream_t stream);
-/* Outer-product form of the eigensolver's fp32 products on the same 8-node tables (csrc/spmm_op.inc): Y = K X
- * (kind 0, vals = kop: the 3x3 blocks row-major in group / entry / node order) and Y = (m (x) I3) X (kind 3, vals = mop: the
- * node-scalar mass values in that order) for a <= 84-column fp32 block; block products as v_mfma_f32_4x4x1_16B_f32 outer
- * products (exact fp32 FMAs) with the accumulators in the accumulation registers, one wavefront per group.  ds_pack_op
- * writes kop (nnzb x 9) and mop (nnzb, may be NULL) from the BSR values - once per material.  max_group_blocks = the
- * largest number of blocks of a group (it sizes the wavefront's LDS image).  Replaces, for the eigensolver, the products
- * of the reference's _linalg_utils.py:27-39 (A @ X for a sparse A) - as ds_spmm_union does on 4-node unions. */
-int ds_pack_op(const float* k32, const float* ms32, const int32_t* kperm, int64_t nnzb, float* kop, float* mop,
-               ds_stream_t stream);
-int ds_spmm_union8(int kind, const int32_t* gptr, const int32_t* gcol, const int32_t* gmeta, const int32_t* gbase,
-                   const float* vals, int64_t nnzb, int64_t ngroups, int max_entries, int max_group_blocks, int64_t nv,
-                   const float* X, int64_t ldx, float* Y, int64_t ldy, int ncols, ds_stream_t stream);
 int ds_cheb_init16(const void* R, int r_f32, int64_t ldr, void* W, int64_t ldw, void* Rcopy, int64_t ldc,
                    const float* dinv, int64_t nv, int ncols, float c, ds_stream_t stream);
 int ds_scalar_csr_spmm16(const int32_t* rowptr, const int32_t* colidx, const float* w, int64_t nrows, const void* X,
