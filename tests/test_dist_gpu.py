@@ -57,6 +57,22 @@ def test_bench_line_contract(one_rank):
     assert 3000 < r["stream_triad"] < 8000 and r["in_situ"]["launches_timed"] > 0
 
 
+def test_c5_workload_line(ndev):
+    """`bench.py --workload c5` (configs[4]: SpMM stress + fp64-refined solve) on a small stand-in mesh: one JSON line,
+    every product form with its algorithmic bytes and bandwidth fractions, both solves converged."""
+    d = _bench("--workload", "c5", "--cells", "10", "--modes", "16", "--block", "24")
+    assert d["unit"] == "s" and d["higher_is_better"] is False and d["dtype"] == "f64" and d["n_gpus"] == 1
+    assert "6000 tets" in d["config"]["workload"]
+    s32, s64 = d["solve"]["fp32_iteration_plus_fp64_polish"], d["solve"]["with_fp64_refinement"]
+    assert s32["worst_backward_error"] < 2e-6 and s64["worst_backward_error"] < 1e-10 and 1 <= s64["fp64_steps"] <= 40
+    assert abs(d["value"] - s64["seconds"]) < 1e-12
+    names = [p["product"] for p in d["spmm"]]
+    assert any("fp32, 84" in n for n in names) and any("bf16" in n for n in names) and any("fp64" in n for n in names)
+    for p in d["spmm"]:
+        assert p["algorithmic_bytes"] > 0 and p["ms"] > 0 and 0 < p["frac_of_peak"] < 1
+        assert abs(p["frac_of_stream"] - p["achieved_gbs"] / d["stream_triad_gbs"]) < 1e-9
+
+
 def test_loss_is_bit_identical_across_runs(ndev, one_rank):
     """Concurrent hypothesis lanes on separate streams must not change a single bit of any pass: the loss sum of a
     second, identical run equals the first exactly (the check that exposed the MFMA / packed-FMA interaction of
