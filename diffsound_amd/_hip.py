@@ -139,17 +139,22 @@ class blas_one_thread:
     _lock = threading.Lock()
     _depth = 0
     _ctl = None
+    _controller = False  # threadpoolctl's view of the loaded BLAS libraries, built once (a scan of every loaded library:
+                         # ~1 ms, too much to pay on every solve)
 
     def __enter__(self):
         cls = blas_one_thread
         with cls._lock:
             if cls._depth == 0:
-                try:
-                    from threadpoolctl import threadpool_limits
+                if cls._controller is False:
+                    lapack_table()  # (loads SciPy's BLAS: the controller only knows the libraries loaded when it is built)
+                    try:
+                        from threadpoolctl import ThreadpoolController
 
-                    cls._ctl = threadpool_limits(limits=1, user_api="blas")
-                except Exception:  # threadpoolctl missing: the BLAS keeps its own thread count
-                    cls._ctl = None
+                        cls._controller = ThreadpoolController()
+                    except Exception:  # threadpoolctl missing: the BLAS keeps its own thread count
+                        cls._controller = None
+                cls._ctl = None if cls._controller is None else cls._controller.limit(limits=1, user_api="blas")
             cls._depth += 1
 
     def __exit__(self, *a):

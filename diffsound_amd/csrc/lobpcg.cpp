@@ -484,6 +484,8 @@ extern "C" int ds_lobpcg_iterate(ds_lobpcg_t* p, const ds_lapack_t* lapack, ds_s
         }
         symmetrize(G);
         // Rayleigh-Ritz: lowest na pairs, and P = the part of the old active X that left the new Ritz block
+        // (dsyevr on the index range 1..na - the same tridiagonalisation, a third of the vectors - was measured: 3.3 ms per
+        // 240 x 240 problem with SciPy's OpenBLAS against 1.45 ms for the full dsyevd; not used)
         std::vector<double> E;
         Mat Z;
         if (!eigh(*lapack, G, E, Z)) {
