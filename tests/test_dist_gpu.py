@@ -55,6 +55,11 @@ def test_bench_line_contract(one_rank):
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and 0 < r["frac"] < 1
     assert 3000 < r["stream_triad"] < 8000 and r["in_situ"]["launches_timed"] > 0
+    assert "traffic_note" in r and (r["traffic"] is None or r["traffic"] > 0)
+    # the amortised variant (eigendecomposition every 15 passes) beside the headline, and the per-rank view of the step
+    am = d["amortised"]
+    assert am["eigen_decompose_cycle"] == 15 and am["unit"] == "passes/s" and am["value"] > d["value"]
+    assert len(d["ranks"]) == 1 and d["ranks"][0]["hypotheses_per_step"] == 4 and d["ranks"][0]["fine_iterations"] >= 4
 
 
 def test_c5_workload_line(ndev):
