@@ -65,7 +65,8 @@ __global__ void __launch_bounds__(256)
                         const float* __restrict__ w, int64_t nrows, const uint16_t* __restrict__ X, int64_t ldx,
                         uint16_t* __restrict__ Y, int64_t ldy, int lpn, float beta) {
     const int cpn = 3 * lpn;  // 8-byte pieces per node panel
-    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // (each XCD a contiguous range of rows: neighbouring rows gather overlapping panels, which then meet in one L2)
+    const int64_t gid = (int64_t)ds::xcd_remap(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
     const int64_t node = gid / cpn;
     if (node >= nrows) return;
     const int c = (int)(gid - node * cpn);

@@ -129,6 +129,71 @@ __global__ void __launch_bounds__(256) probe(const int32_t* __restrict__ gptr, c
     if (acc == 0x12345678) out[grp] = acc;  // keeps the loads alive, (almost) never writes
 }
 
+// mode 7: the production fp32 load (mode 2) with knobs: DEPTH loads in flight per wave, the workgroup -> group mapping of the
+// library (each XCD a contiguous range of groups) or the plain one, WPG groups walked by every wave one after the other, and
+// `colmask` != 0 folds every panel index into a table of colmask + 1 panels (the ceiling of the load shape out of the L2)
+__device__ __forceinline__ unsigned probe_xcd_remap(unsigned bid, unsigned nblk) {
+    const unsigned q = nblk >> 3, r = nblk & 7, x = bid & 7, k = bid >> 3;
+    return x < r ? x * (q + 1) + k : r * (q + 1) + (x - r) * q + k;
+}
+template <int DEPTH>
+__global__ void __launch_bounds__(256) probe7(const int32_t* __restrict__ gptr, const int32_t* __restrict__ gent, unsigned ngroups,
+                                              const char* __restrict__ X, unsigned xbytes, int panel_bytes, int row_bytes,
+                                              int lanes_per_row, int remap, int colmask, unsigned nwg, int* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const unsigned grp = (remap ? probe_xcd_remap(blockIdx.x, nwg) : blockIdx.x) * 4 + wave;
+    if (grp >= ngroups) return;
+    const int e0 = __builtin_amdgcn_readfirstlane(gptr[grp]);
+    const int ne = __builtin_amdgcn_readfirstlane(gptr[grp + 1]) - e0;
+    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)X, 0, (int)xbytes, 0x00020000);
+    int acc = 0;
+    const int g = lane / lanes_per_row, cl = lane - g * lanes_per_row;
+    const int voff = g < 3 ? g * row_bytes + cl * 16 : 0x7f000000;
+    for (int b = 0; b < ne; b += 64) {
+        int mine = (b + lane < ne) ? (gent[e0 + b + lane] & 0x0fffffff) : -1;
+        if (colmask && mine >= 0) mine &= colmask;
+        const int cnt = min(64, ne - b);
+        for (int q = 0; q < cnt; q += DEPTH) {
+            i4v x[DEPTH];
+#pragma unroll
+            for (int u = 0; u < DEPTH; ++u) {
+                const int e = __builtin_amdgcn_readlane(mine, (q + u) & 63);
+                const int so = e < 0 ? 0 : e * panel_bytes;
+                x[u] = __builtin_bit_cast(i4v, __builtin_amdgcn_raw_buffer_load_b128(rs, e < 0 ? 0x7f000000 : voff, so, 0));
+            }
+#pragma unroll
+            for (int u = 0; u < DEPTH; ++u) acc ^= x[u].x ^ x[u].y ^ x[u].z ^ x[u].w;
+        }
+    }
+    if (acc == 0x12345678) out[grp] = acc;
+}
+
+extern "C" float gather_probe7(int depth, int remap, int colmask, const int32_t* gptr, const int32_t* gent, unsigned ngroups,
+                               const void* X, unsigned xbytes, int ld_elems, int* out, int reps) {
+    hipEvent_t a, b;
+    hipEventCreate(&a);
+    hipEventCreate(&b);
+    const unsigned nwg = (ngroups + 3) / 4;
+    const int row_bytes = ld_elems * 4, panel_bytes = 3 * row_bytes;
+    float best = 1e30f;
+    for (int r = 0; r < reps + 1; ++r) {
+        hipEventRecord(a, 0);
+        if (depth == 4) probe7<4><<<nwg, 256>>>(gptr, gent, ngroups, (const char*)X, xbytes, panel_bytes, row_bytes, ld_elems / 4, remap, colmask, nwg, out);
+        else if (depth == 8) probe7<8><<<nwg, 256>>>(gptr, gent, ngroups, (const char*)X, xbytes, panel_bytes, row_bytes, ld_elems / 4, remap, colmask, nwg, out);
+        else probe7<16><<<nwg, 256>>>(gptr, gent, ngroups, (const char*)X, xbytes, panel_bytes, row_bytes, ld_elems / 4, remap, colmask, nwg, out);
+        hipEventRecord(b, 0);
+        hipEventSynchronize(b);
+        float ms;
+        hipEventElapsedTime(&ms, a, b);
+        if (r > 0 && ms < best) best = ms;
+    }
+    hipEventDestroy(a);
+    hipEventDestroy(b);
+    if (hipGetLastError() != hipSuccess) return -1.f;
+    return best;
+}
+
 // mode 3: gptr / gent describe 16-node groups; the 4 waves of a workgroup split the entries of ONE group
 __global__ void __launch_bounds__(256) probe16(const int32_t* __restrict__ gptr, const int32_t* __restrict__ gent,
                                                unsigned ngroups, const char* __restrict__ X, unsigned xbytes, int panel_bytes,

@@ -36,6 +36,19 @@ ne = pat.ne
 print(f"nv {nv}, groups of 4: {pat.ngroups}, union entries {ne} ({ne / pat.nnzb:.3f} of the blocks)")
 
 
+L.gather_probe7.restype = ctypes.c_float
+L.gather_probe7.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint, ctypes.c_void_p,
+                            ctypes.c_uint, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
+
+
+def run7(depth, remap, colmask, gptr, gent, ng, X, panels, label):
+    ms = L.gather_probe7(depth, remap, colmask, gptr.data_ptr(), gent.data_ptr(), ng, X.data_ptr(), X.numel() * X.element_size(), ld,
+                         out.data_ptr(), 5)
+    gb = panels * 960 / 1e9
+    print(f"mode 7 depth {depth:2d} remap {remap} table {'all' if not colmask else colmask + 1:>6} panels, {label}: {ms * 1e3:.1f} us, "
+          f"{gb / ms:.2f} TB/s gathered", flush=True)
+
+
 def run(mode, gptr, gent, ng, X, panels, pbytes, label):
     ms = L.gather_probe(mode, gptr.data_ptr(), gent.data_ptr(), ng, X.data_ptr(), X.numel() * X.element_size(), ld, out.data_ptr(), 5)
     gb = panels * pbytes / 1e9
@@ -64,3 +77,20 @@ for G in (8, 16):
     run(2, gptr, gent, ng, X32, key.numel(), 960, f"fp32 panels, one wave per {G}-node union, 16 B/lane")
     run(5, gptr, gent, ng, X32, key.numel(), 960, f"fp32 panels, one wave per {G}-node union, 4 dword loads per panel")
     run(6, gptr, gent, ng, X32, key.numel(), 960, f"fp32 panels, two waves (40 columns each) per {G}-node union, 3 dword loads per half panel")
+
+# the knobs of the fp32 load: loads in flight, XCD-contiguous group ranges, and the ceiling of the load shape (small tables)
+if os.environ.get("PROBE_KNOBS", "1") == "1":
+    for G in (4, 8, 16):
+        if G == 4:
+            gptr, gent, ng, n_ent = pat.gptr, pat.gent, pat.ngroups, ne
+        else:
+            key = torch.unique((rows // G) * nv + pat.colidx.long())
+            ng = (nv + G - 1) // G
+            gptr = torch.searchsorted(key // nv, torch.arange(ng + 1, device=dev)).to(torch.int32).contiguous()
+            gent = (key % nv).to(torch.int32).contiguous()
+            n_ent = key.numel()
+        for depth in (4, 8, 16):
+            for remap in (0, 1):
+                run7(depth, remap, 0, gptr, gent, ng, X32, n_ent, f"{G}-node unions")
+        for colmask in (2047, 32767):
+            run7(8, 1, colmask, gptr, gent, ng, X32, n_ent, f"{G}-node unions")
