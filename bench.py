@@ -640,6 +640,13 @@ def main():
                                         f"{spmm_source_hash()}")
             except Exception as ex:
                 traffic_note = f"unreadable PMC record: {ex}"
+        kw_traffic = None  # the same for the eigensolver's Y = K X (record "kx")
+        try:
+            rec = json.load(open(pmc)).get(f"cells{a.cells}_cols{a.block}_kx") if os.path.exists(pmc) else None
+            if isinstance(rec, dict) and rec.get("spmm_source_sha16") == spmm_source_hash():
+                kw_traffic = rec["bytes"]
+        except Exception:
+            pass
         roof = {"bound": "hbm", "achieved": solo, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": solo / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,
                 "stream_triad": stream_gbs, "frac_of_stream": solo / stream_gbs,
@@ -658,7 +665,7 @@ def main():
                 "lobpcg_spmm": {"kernel": f"spmm_union_kernel<{a.block // 4},0>: Y = K X on a {a.block}-column fp32 block (K W of the iteration)",
                                 "algorithmic_bytes_per_launch": kw_bytes, "avg_launch_ms": kw_ms,
                                 "achieved": kw_bytes / (kw_ms * 1e-3) / 1e9, "frac": kw_bytes / (kw_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                "frac_of_stream": kw_bytes / (kw_ms * 1e-3) / 1e9 / stream_gbs},
+                                "frac_of_stream": kw_bytes / (kw_ms * 1e-3) / 1e9 / stream_gbs, "traffic": kw_traffic},
                 "in_situ": {"achieved": achieved, "frac": achieved / HBM_PEAK_GBS,
                             "algorithmic_bytes_per_launch": float(nbytes.mean()), "avg_launch_ms": float(ms.mean()),
                             "launches_timed": int(len(ms)), "levels": levels, "all_block_widths": all_widths,

@@ -23,7 +23,7 @@ python3 tools/gpu_busy.py /tmp/prof_b 0.4 > $out/${tag}_gpu_busy.txt; cat $out/$
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_l1 -o bench -- python3 bench.py --no-cpu-baseline --lanes 1 --hyp-per-gpu 2 --steps 4 --warmup 1 > $out/${tag}_bench_prof_l1.log 2>&1
 python3 tools/summarize_prof.py /tmp/prof_l1 $out/${tag}_bench_lanes1_kernel_stats.csv --top 45
 # PMC bytes of the fused term (two passes: the TCC counters do not fit one)
-for kind in fp32 bf16 mfma; do
+for kind in fp32 bf16 mfma kx; do
   rm -rf /tmp/pmc_b
   for c in FETCH_SIZE WRITE_SIZE; do
     timeout -k 10 200 rocprofv3 --kernel-include-regex "spmm_union" --pmc $c --output-format csv -d /tmp/pmc_b/$c -o p -- python3 tools/mb_cheb_only.py 6 $kind > /tmp/pmc_log_$c.txt 2>&1 || { tail -5 /tmp/pmc_log_$c.txt; exit 1; }

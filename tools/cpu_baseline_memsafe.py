@@ -89,5 +89,5 @@ print(json.dumps({
     "n": int(3 * v.shape[0]), "modes": modes, "seconds": round(dt, 1), "passes_per_s": 1.0 / dt, "stage_seconds": stages,
     "threads": nthreads, "cpu_model": cpu_model, "host_hardware_threads": os.cpu_count(),
     "peak_rss_gb": round(resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1e6, 1),
-    "loss": float(loss), "dloss_dE": float(E.grad), "dloss_dnu": float(nu.grad),
+    "loss": float(loss.detach()), "dloss_dE": float(E.grad), "dloss_dnu": float(nu.grad),
     "lowest_eigenvalues": [float(x) for x in ev[:4]]}, indent=1))

@@ -9,13 +9,17 @@ dev = torch.device('cuda')
 v, t = meshgen.kuhn_box(26)
 mesh = TetMesh(torch.from_numpy(v).to(dev), torch.from_numpy(t).long().to(dev)).to_high_order(2)
 sysd = TetSystem(mesh.vertices, mesh.tets, 2, 2700.0)
-kind = sys.argv[2] if len(sys.argv) > 2 else "fp32"  # fp32 | bf16 (VALU kernel on bf16 blocks) | mfma (ds_spmm_union16m)
+kind = sys.argv[2] if len(sys.argv) > 2 else "fp32"  # fp32 | bf16 (VALU kernel on bf16 blocks) | mfma (ds_spmm_union16m) | kx (Y = K X, fp32)
 ops = HipModalOps(sysd, 2e10, 2e10, two_level=False, mfma_groups=(8, 0) if kind == "mfma" else (0, 0))
 X = torch.randn(sysd.n, 80, device=dev); W = torch.randn(sysd.n, 80, device=dev); R0 = torch.randn(sysd.n, 80, device=dev)
 bf = kind in ("bf16", "mfma")
 if bf:
     X, W, R0 = X.bfloat16(), W.bfloat16(), R0.bfloat16()
+Yk = torch.empty(sysd.n, 80, device=dev) if kind == "kx" else None
 for _ in range(int(sys.argv[1]) if len(sys.argv) > 1 else 4):
-    (ops.cheb_spmm16 if bf else ops.cheb_spmm)(X, W, R0, 0.3, 0.7, False)
+    if kind == "kx":  # the eigensolver's own product Y = K X (fp32)
+        ops.apply_K(X, Yk)
+    else:
+        (ops.cheb_spmm16 if bf else ops.cheb_spmm)(X, W, R0, 0.3, 0.7, False)
 torch.cuda.synchronize()
 print("done", flush=True)

@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """profiles/spmm_pmc_bytes_per_launch.json from the per-kind PMC summaries of tools/collect_profiles.sh:
 
-    python tools/pmc_bytes.py <tag>     reads gpurun_out/<tag>_spmm_pmc_{fp32,bf16,mfma}.json (tools/pmc_summary.py)
+    python tools/pmc_bytes.py <tag>     reads gpurun_out/<tag>_spmm_pmc_{fp32,bf16,mfma,kx}.json (tools/pmc_summary.py)
 
-HBM-side bytes per fused-term launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 - separate rocprofv3 --pmc passes; the
+HBM-side bytes per launch of the fused term (fp32 / bf16 / mfma) and of the eigensolver's Y = K X (kx) = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 - separate rocprofv3 --pmc passes; the
 gfx950 correction of guides/MI355X_MICROARCH.md: FETCH_SIZE counts 64 of every 128 bytes of a wide streaming read.
 Every record carries the hash of the SpMM kernel sources it was measured on; bench.py reports a record with another
 hash as stale (traffic: null)."""
@@ -18,7 +18,7 @@ import bench  # noqa: E402
 
 tag = sys.argv[1]
 out = {"_comment": __doc__.split("\n\n")[1].replace("\n", " ")}
-for kind in ("fp32", "bf16", "mfma"):
+for kind in ("fp32", "bf16", "mfma", "kx"):
     path = os.path.join(ROOT, "gpurun_out", f"{tag}_spmm_pmc_{kind}.json")
     if not os.path.exists(path):
         continue
