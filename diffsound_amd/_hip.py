@@ -13,7 +13,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DS_EXP_LIB") or os.path.join(_HERE, "csrc", "libdiffsound_hip.so")  # (DS_EXP_LIB: A/B builds, experiments)
-ABI_VERSION = 24  # DS_ABI_VERSION of include/diffsound_hip.h
+ABI_VERSION = 25  # DS_ABI_VERSION of include/diffsound_hip.h
 
 c_i32p = ctypes.POINTER(ctypes.c_int32)
 _P = ctypes.c_void_p
@@ -62,6 +62,7 @@ _SIGNATURES = {
     "ds_mix": (_I, [_P, _I64, _I, _P, _I, _P, _I64, _I64, _F, _F, _P]),
     "ds_osc_bank_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _D, _P, _P]),
     "ds_osc_bank_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _D, _P, _P, _P, _P, _P]),
+    "ds_readout_pass": (_I, [_P, _P, _P, _P, _I, _D, _D, _D, _D, _D, _D, _D, _D, _P, _I, _I, _D, _P, _I, _P, _P, _P, _P, _P, _P]),
     "ds_osc_tv_workspace_floats": (_I64, [_I, _I, _I]),
     "ds_osc_tv_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _D, _P, _P, _P]),
     "ds_osc_tv_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _D, _P, _P, _P, _P, _P]),

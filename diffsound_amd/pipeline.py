@@ -114,6 +114,12 @@ class ModalPipeline:
         return self._readout(self if _lane is None else _lane, model, res, backward)
 
     def _readout(self, holder, model, res, backward):
+        if self.loss_fn is None and type(holder.osc) is TraditionalDampedOscillator and holder.osc.audio_num == 1:
+            return self._readout_native(holder, model, res, backward)
+        return self._readout_torch(holder, model, res, backward)
+
+    def _readout_torch(self, holder, model, res, backward):
+        """Steps 3-6 as torch operations with autograd (any loss head, e.g. MSSLoss; also the cross-check of the native path)."""
         lam, mu = model.lame()
         ev = res.eigenvalues
         dev = ev.device
@@ -133,6 +139,53 @@ class ModalPipeline:
         rerr = float(res.rerr.max()) if res.rerr is not None else float("nan")
         return (PassResult(float(loss.detach()), gE, gnu, freqs.detach(), res.iterations, ev, res.coarse_iterations, rerr),
                 res, audio.detach())
+
+
+    def _readout_native(self, holder, model, res, backward):
+        """Steps 3-6 with the headline's MSE loss as ONE native call (``ds_readout_pass``: three small kernels around the two
+        oscillator launches) and one 24-byte copy back - the torch formulation below it is ~45 element-wise launches on
+        64-element vectors plus the autograd engine, 0.83 ms of host time per pass.  Same arithmetic (reference
+        diff_model.py:371-388, oscillator.py:282-310); gradients by the chain rule in closed form."""
+        from . import _hip
+
+        E, nu = float(model.E.detach()), float(model.nu.detach())
+        lam, mu = E * nu / ((1 + nu) * (1 - 2 * nu)), E / (2 * (1 + nu))
+        dlam_dE, dlam_dnu = nu / ((1 + nu) * (1 - 2 * nu)), E * (1 + 2 * nu * nu) / ((1 + nu) ** 2 * (1 - 2 * nu) ** 2)
+        dmu_dE, dmu_dnu = 1 / (2 * (1 + nu)), -E / (2 * (1 + nu) ** 2)
+        osc = holder.osc
+        ev = res.eigenvalues
+        dev = ev.device
+        m, S = int(ev.shape[0]), int(osc.sample_num)
+        buf = getattr(holder, "_readout_buf", None)
+        if buf is None or buf[0].shape[0] != 6 * m or buf[1].shape[0] != 2 * S or buf[0].device != dev:
+            buf = (torch.empty(6 * m, dtype=torch.float64, device=dev), torch.empty(2 * S, dtype=torch.float32, device=dev),
+                   torch.empty(3, dtype=torch.float64, device=dev))
+            holder._readout_buf = buf
+        work, fwork, out = buf
+        if osc._force.device != dev:
+            osc._force = osc._force.to(dev)
+        audio = torch.empty((1, S), dtype=torch.float32, device=dev)
+        freqs = torch.empty(m, dtype=torch.float32, device=dev)
+        tgt = None if self.target is None else self.target.reshape(-1).float().contiguous()
+        if tgt is not None and tgt.shape[0] != S:
+            raise ValueError("target clip length differs from the oscillator's sample_num")
+        a, b, md = res.a_lambda.double().contiguous(), res.b_mu.double().contiguous(), res.m_diag.double().contiguous()
+        p = _hip.ptr
+        _hip.check(_hip.lib().ds_readout_pass(p(ev.double().contiguous()), p(a), p(b), p(md), m, lam, mu, dlam_dE, dlam_dnu,
+                                              dmu_dE, dmu_dnu, float(osc.alpha), float(osc.beta), p(osc._force),
+                                              int(osc._force.shape[1]), S, float(osc.sr), p(tgt), 1 if backward else 0,
+                                              p(audio), p(freqs), p(work), p(fwork), p(out), _hip.stream_ptr()),
+                   "ds_readout_pass")
+        host = out.tolist()  # the pass's one synchronisation
+        gE, gnu = (host[1], host[2]) if backward else (float("nan"), float("nan"))
+        rerr = getattr(res, "_rerr_max", None)
+        if rerr is None:
+            rerr = float(res.rerr.max()) if res.rerr is not None else float("nan")
+            try:
+                res._rerr_max = rerr
+            except AttributeError:
+                pass
+        return (PassResult(host[0], gE, gnu, freqs.unsqueeze(1), res.iterations, ev, res.coarse_iterations, rerr), res, audio)
 
 
 class _Lane:

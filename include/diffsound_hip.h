@@ -40,7 +40,7 @@ enum { DS_OK = 0, DS_ERR_ARG = 1, DS_ERR_HIP = 2, DS_ERR_NOMEM = 3 };
 /* Thread-local text of the last error returned on this thread ("" if none). */
 const char* ds_last_error(void);
 /* Library ABI version (bumped on any signature change); ds_abi_version() returns the value the library was built with. */
-#define DS_ABI_VERSION 24
+#define DS_ABI_VERSION 25
 int ds_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------------
@@ -397,6 +397,25 @@ int ds_osc_bank_fwd(const double* d, const double* w, const float* amp, const fl
 int ds_osc_bank_bwd(const float* gy, const double* d, const double* w, const float* amp,
                     const float* force, int A, int m, int F, int S, double sr, float* gs,
                     double* gd, double* gw, float* gamp, ds_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Read-out + render + loss + backward of a pass in one call: steps 3-6 of the reference's training-loop body, the part it
+ * runs EVERY epoch (the eigendecomposition only every EIGEN_DECOMPOSE_CYCLE-th: experiments/material_sync_train.py:135-167):
+ *   pred_i = ev_i + (lam a_i + mu b_i) - ev_i m_i        get_undamped_freqs, src/diffelastic/diff_model.py:371-388
+ *   f_i = float(sqrt(pred_i) / 2 / pi);  w0sq = (2 pi f)^2, d = (alpha + beta w0sq) / 2, w = sqrt(w0sq - d^2)
+ *   audio = oscillator bank of (d, w), unit amplitudes, A = 1          TraditionalDampedOscillator, src/ddsp/oscillator.py:282-310
+ *   loss = mean((audio - target)^2)   (target NULL: mean(audio^2))
+ *   backward != 0: dloss/dE, dloss/dnu through the bank, the damping model and lam(E, nu), mu(E, nu), whose partial
+ *   derivatives the caller passes (dlam_dE, dlam_dnu, dmu_dE, dmu_dnu).
+ * ev, a_lam, b_mu, m_diag: (m) f64 - eigenvalues and the quadratic forms u^T K_lambda u, u^T K_mu u, u^T M u of the kept
+ * eigenvectors; force (F) f32; target (S) f32 or NULL; audio (S) f32 out; freqs (m) f32 out; work: 6 m doubles, fwork: 2 S
+ * floats (scratch); out: 3 doubles on the device (loss, dloss/dE, dloss/dnu; the last two only with backward).
+ * ---------------------------------------------------------------------------------------------- */
+int ds_readout_pass(const double* ev, const double* a_lam, const double* b_mu, const double* m_diag, int m,
+                    double lam, double mu, double dlam_dE, double dlam_dnu, double dmu_dE, double dmu_dnu,
+                    double alpha, double beta, const float* force, int F, int S, double sr, const float* target,
+                    int backward, float* audio, float* freqs, double* work, float* fwork, double* out,
+                    ds_stream_t stream);
 
 /* Time-varying bank (reference GTDampedOscillator.forward with non_linear_rate != 0, oscillator.py:217-243):
  *   s[a,t] = sum_m amp[a,m] exp(-D[a,m,t]) sin(2 pi P[a,m,t]),  D = cumsum_t(dmp / sr),  P = cumsum_t(frq / sr)

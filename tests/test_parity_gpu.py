@@ -70,6 +70,37 @@ def test_ord2_pass_with_bench_settings_matches_oracle(dev):
     assert abs(r.grad_nu / gnu - 1) < 2e-3, (r.grad_nu, gnu)
 
 
+def test_native_readout_pass_matches_the_torch_autograd_formulation(dev):
+    """ds_readout_pass (steps 3-6 of a pass in one call; what the reference runs every epoch between eigendecompositions,
+    experiments/material_sync_train.py:135-167) against the same steps written as torch operations with autograd: frequencies
+    and audio bit-identical, loss and both gradients to rounding - with a target, without one, and forward only."""
+    from diffsound_amd import meshgen
+    from diffsound_amd.diffelastic.mesh import TetMesh
+    from diffsound_amd.pipeline import DirectLinear, ModalPipeline
+
+    modes = 24
+    v, t = meshgen.kuhn_box(5)
+    mesh = TetMesh(torch.from_numpy(v).to(dev), torch.from_numpy(t).long().to(dev)).to_high_order(2)
+    pipe = ModalPipeline(mesh.vertices, mesh.tets, 2, modes, MAT, solver_config=bench.solver_config(block=32, order=2))
+    _, res, audio0 = pipe.run_pass(MAT[1], MAT[2], backward=False)
+    for target in (audio0 * 0.9, None):
+        pipe.target = None if target is None else target.detach()
+        for E, nu in ((MAT[1] * 1.07, MAT[2] * 0.96), (4.1e10, 0.21)):
+            rn, _, an = pipe._readout_native(pipe, DirectLinear(E, nu, pipe.mat), res, True)
+            rt, _, at = pipe._readout_torch(pipe, DirectLinear(E, nu, pipe.mat), res, True)
+            assert torch.equal(rn.freqs, rt.freqs)
+            assert torch.equal(an, at)
+            assert abs(rn.loss / rt.loss - 1) < 1e-6, (rn.loss, rt.loss)
+            # (fp32 gy = 2 diff / S is rounded in another order by autograd; dloss/dE is a sum with cancellation: 2e-6 seen)
+            assert abs(rn.grad_E / rt.grad_E - 1) < 2e-5, (rn.grad_E, rt.grad_E)
+            assert abs(rn.grad_nu / rt.grad_nu - 1) < 2e-5, (rn.grad_nu, rt.grad_nu)
+            rf, _, af = pipe._readout_native(pipe, DirectLinear(E, nu, pipe.mat), res, False)
+            assert torch.equal(af, an) and rf.loss == rn.loss and np.isnan(rf.grad_E)
+    # the dispatcher takes the native path for the headline's loss and the torch path for a loss module
+    r1, _, _ = pipe.run_cached_pass(res, 4.1e10, 0.21)
+    assert r1.loss == rn.loss and r1.grad_E == rn.grad_E
+
+
 def test_c3_full_pass_with_bench_settings_converges_and_matches_finite_difference(dev):
     """configs[2] with the benchmark's own settings: fwd+bwd, every pair converged, finite gradients, and
     d loss / dE against (loss(E(1+h)) - loss(E(1-h))) / (2 E h).  h = 5e-5: the lowest modes ring for ~0.2 s, so the
