@@ -58,6 +58,11 @@ def parse():
     ap.add_argument("--lanes", type=int, default=8,
                     help="hypotheses in flight at once per GPU (own HIP stream + host thread each), so one lane's "
                          "host-side Rayleigh-Ritz step overlaps the other lane's kernels")
+    ap.add_argument("--step-barrier", action="store_true",
+                    help="join all hypothesis lanes after every step (the schedule of rounds 1-2). Default: a lane runs its "
+                         "hypotheses' passes of consecutive steps back to back - a hypothesis' next step depends on its own "
+                         "previous one only - and the per-step loss all-reduce is issued as soon as every lane has finished "
+                         "that step")
     ap.add_argument("--cheb-degree", type=int, default=48)
     ap.add_argument("--cheb-ratio", type=float, default=800.0)
     ap.add_argument("--block", type=int, default=80)
@@ -461,14 +466,14 @@ def main():
     worst = [0.0]
     cits = []
 
-    def step(warm):
-        loss_sum = 0.0  # (every pass runs its own numeric assembly: ModalPipeline.run_pass)
-        its = []
-        outs = pipe.run_batch([(float(Es[h]), float(nus[h])) for h in mine], lanes=a.lanes,
-                              warm=[warm.get(h) for h in mine] if a.warm_start else None)
+    hyps = [(float(Es[h]), float(nus[h])) for h in mine]
+    its_all = []
+
+    def on_step(s, outs):
+        """Called once per step, as soon as every lane has finished it (the lanes run on): the convergence gate of each
+        pass and the step's ONE collective, the all-reduce of the scalar loss."""
+        loss_sum = 0.0
         for h, (r, res, _) in zip(mine, outs):
-            if a.warm_start:
-                warm[h] = res.block_vectors
             # convergence gate (BASELINE.md section 3): an unconverged pass is not a pass
             if not (r.iterations < cfg.maxit and r.max_rerr < tol and np.isfinite(r.loss)
                     and np.isfinite(r.grad_E) and np.isfinite(r.grad_nu)):
@@ -477,16 +482,28 @@ def main():
                                  f"loss {r.loss}, grad ({r.grad_E}, {r.grad_nu})")
             worst[0] = max(worst[0], r.max_rerr)
             loss_sum += r.loss
-            its.append(r.iterations)
+            its_all.append(r.iterations)
             cits.append(r.coarse_iterations)
-        total = all_reduce_loss(loss_sum, dev)
-        return total, its
+        on_step.total = all_reduce_loss(loss_sum, dev)
 
-    warm = {}
-    for _ in range(max(a.warmup, 0)):
-        step(warm)
-        if not a.warm_start:
-            warm.clear()
+    def run_steps(nsteps, warm):
+        """``nsteps`` steps (one pass of every hypothesis of this rank per step; every pass runs its own numeric assembly).
+        Default: the hypothesis lanes run their passes of consecutive steps back to back (ModalPipeline.run_steps - a
+        hypothesis' next step depends on its own previous one only); --step-barrier: all lanes join after every step."""
+        if nsteps <= 0:
+            return warm
+        if a.step_barrier:
+            for s in range(nsteps):
+                outs = pipe.run_batch(hyps, lanes=a.lanes, warm=warm if a.warm_start else None)
+                if a.warm_start:
+                    warm = [res.block_vectors for _, res, _ in outs]
+                on_step(s, outs)
+            return warm
+        outs = pipe.run_steps(hyps, nsteps, lanes=a.lanes, on_step=on_step, warm_start=a.warm_start,
+                              warm_init=warm if a.warm_start else None)
+        return [res.block_vectors for _, res, _ in outs[-1]] if a.warm_start else None
+
+    warm = run_steps(max(a.warmup, 0), None)
     if a.warmup <= 0 and a.lanes > 1 and len(mine) > 1:
         # --warmup 0: the lanes' streams, operators and value arrays are set-up, not part of a step
         pipe.run_batch([(MAT[1], MAT[2])] * min(a.lanes, len(mine)), lanes=a.lanes, backward=False)
@@ -503,10 +520,9 @@ def main():
     barrier()
     torch.cuda.synchronize()
     t0 = time.time()
-    iters = []
-    for _ in range(a.steps):
-        total, its = step(warm)
-        iters += its
+    del its_all[:]
+    run_steps(a.steps, warm)
+    iters, total = list(its_all), on_step.total
     torch.cuda.synchronize()
     own_dt = time.time() - t0  # this rank's own work, before it waits for the slowest one
     barrier()
@@ -701,6 +717,10 @@ def main():
                 "loss": "MSE against a fixed target clip" if a.loss == "mse" else "MSSLoss [1024..64] l1_loss (STFT kernels)",
                 "parallelism": (f"dp{world} over material hypotheses, scalar loss all-reduce; {min(a.lanes, a.hyp_per_gpu)} "
                                 "hypotheses in flight per GPU (one HIP stream + host thread each)"),
+                "step_schedule": ("all lanes join after every step" if a.step_barrier else
+                                  "no join between steps: a lane runs its hypotheses' passes of consecutive steps back to back (a "
+                                  "hypothesis' next step depends on its own previous one only); the step's loss all-reduce is issued "
+                                  "as soon as every lane of the rank has finished that step"),
                 "precision": ("fp32 block vectors and SpMM, fp64 Gram accumulation / Rayleigh-Ritz / read-out; the preconditioner's "
                               f"internal blocks in {cfg.precond_storage}"),
                 "eigensolver": (f"LOBPCG(ortho) block {a.block}, {precond_desc}, "

@@ -255,6 +255,87 @@ def _run_batch(pipe, hyps, lanes=2, warm=None, backward=True):
 ModalPipeline.run_batch = _run_batch
 
 
+def _run_steps(pipe, hyps, steps, lanes=2, on_step=None, warm_start=False, backward=True, warm_init=None):
+    """``steps`` consecutive passes of every hypothesis WITHOUT a join between the steps: lane ``li`` owns the hypotheses
+    ``li, li + lanes, ...`` and runs their passes of step 0, then of step 1, ... back to back on its own stream and thread.
+    A hypothesis' step s + 1 depends on nothing but its own step s (the inverse-rendering batch of the reference has one
+    optimiser state per material hypothesis, experiments/material_sync_train.py:137-167), so the lanes need not wait for
+    each other: joined per step (``run_batch`` in a loop) the 8 lanes of the benchmark finish between 90 and 195 ms of a
+    195 ms step - 14 % of the lane time is the tail of the step (tools/lane_tail.py).
+    ``on_step(s, results_of_step_s)`` is called on the CALLER's thread as soon as every lane has finished step s (in step
+    order; the lanes keep running meanwhile): that is where the per-step scalar all-reduce of the loss goes.
+    ``warm_start``: a hypothesis' step s + 1 starts from the block its step s ended with (``warm_init``: optional list of
+    start blocks for step 0).  Returns ``out[s][i]``."""
+    import threading
+
+    n = len(hyps)
+    if steps <= 0 or n == 0:
+        return []
+    lanes = max(1, min(lanes, n))
+    while len(pipe._lanes) < lanes:
+        pipe._lanes.append(_Lane(pipe, ops=pipe.ops if not pipe._lanes else None))
+    main = torch.cuda.current_stream(pipe.device)
+    ready = torch.cuda.Event()
+    ready.record(main)
+    out = [[None] * n for _ in range(steps)]
+    finished = [0] * steps  # lanes that have completed step s
+    cond = threading.Condition()
+    errs, done = [], []
+
+    def work(li):
+        lane = pipe._lanes[li]
+        try:
+            torch.cuda.set_device(pipe.device)
+            with torch.cuda.stream(lane.stream):
+                lane.stream.wait_event(ready)
+                warm = {} if warm_init is None else {i: warm_init[i] for i in range(li, n, lanes)}
+                for s in range(steps):
+                    for i in range(li, n, lanes):
+                        E, nu = hyps[i]
+                        out[s][i] = pipe.run_pass(E, nu, warm=warm.get(i), backward=backward, _lane=lane)
+                        if warm_start:
+                            warm[i] = out[s][i][1].block_vectors
+                    with cond:
+                        finished[s] += 1
+                        cond.notify_all()
+                e = torch.cuda.Event()
+                e.record(lane.stream)
+                done.append(e)
+        except BaseException as ex:  # surfaced in the caller's thread
+            with cond:
+                errs.append(ex)
+                cond.notify_all()
+
+    pool = getattr(pipe, "_lane_pool", None)
+    if pool is None or pool._max_workers < lanes:
+        from concurrent.futures import ThreadPoolExecutor
+
+        pool = pipe._lane_pool = ThreadPoolExecutor(max_workers=lanes, thread_name_prefix="ds-lane")
+    futures = [pool.submit(work, li) for li in range(lanes)]
+    try:
+        for s in range(steps):
+            with cond:
+                while finished[s] < lanes and not errs:
+                    cond.wait()
+            if errs:
+                break
+            if on_step is not None:
+                on_step(s, out[s])
+    finally:
+        for f in futures:
+            f.result()
+    if errs:
+        raise errs[0]
+    for e in done:
+        main.wait_event(e)
+    if pipe.ops is None:
+        pipe.ops = pipe._lanes[0].ops
+    return out
+
+
+ModalPipeline.run_steps = _run_steps
+
+
 def all_reduce_loss(loss_sum, device):
     """Sum of per-rank loss sums.  The data path has no other collective."""
     import torch.distributed as dist

@@ -89,6 +89,19 @@ def test_loss_is_bit_identical_across_runs(ndev, one_rank):
     assert [r["fine_iterations"] for r in a["ranks"]] == [r["fine_iterations"] for r in b["ranks"]]
 
 
+def test_steps_without_a_join_give_the_joined_schedule_s_results(ndev, one_rank):
+    """bench.py's default schedule (ModalPipeline.run_steps: a lane runs its hypotheses' consecutive steps back to back) against
+    --step-barrier (all lanes join after every step): the same passes, so the same loss sum to the last bit; three steps, four
+    hypotheses on two lanes (two hypotheses per lane and step)."""
+    args = ["--gpus", "1", "--hyp-per-gpu", "4", "--lanes", "2", *SMALL]
+    args[args.index("--steps") + 1] = "3"
+    free = _bench(*args)
+    joined = _bench(*args, "--step-barrier")
+    assert free["loss_sum_last_step"] == joined["loss_sum_last_step"] == one_rank["loss_sum_last_step"]
+    assert "no join between steps" in free["config"]["step_schedule"] and "join after every step" in joined["config"]["step_schedule"]
+    assert free["steps"] == joined["steps"] == 3
+
+
 def test_two_ranks_sharing_one_device_gloo(ndev, one_rank):
     two = _bench("--gpus", "2", "--hyp-per-gpu", "2", "--lanes", "2", "--dist-backend", "gloo", "--share-devices", *SMALL)
     assert two["n_gpus"] == 2 and "gloo" in two["collective"]
