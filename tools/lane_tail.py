@@ -48,3 +48,25 @@ for s in range(8):
 mean_end = np.mean([np.mean(r[1]) for r in rows])
 last = np.mean([r[0] for r in rows])
 print(f"mean lane finish {1e3 * mean_end:.1f} ms of a {1e3 * last:.1f} ms step: {100 * (1 - mean_end / last):.1f} % of the lane-time is tail")
+
+# the same without the join per step (ModalPipeline.run_steps): when does each hypothesis' LAST step end?
+K = 10
+stamps.clear()
+last = {}
+
+
+def timed2(self, E, nu, **kw):
+    r = orig(self, E, nu, **kw)
+    last[(E, nu)] = time.time()
+    return r
+
+
+pipeline.ModalPipeline.run_pass = timed2
+torch.cuda.synchronize()
+t0 = time.time()
+pipe.run_steps(hyps, K, lanes=8)
+torch.cuda.synchronize()
+t1 = time.time()
+ends = sorted(last[h] - t0 for h in hyps)
+print(f"{K} steps without a join: {1e3 * (t1 - t0):.1f} ms = {1e3 * (t1 - t0) / K:.1f} ms per step; the lanes' last passes end at "
+      + " ".join(f"{1e3 * e:.0f}" for e in ends) + f" ms: {100 * (1 - np.mean(ends) / (t1 - t0)):.1f} % of the lane-time is tail")
