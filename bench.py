@@ -49,8 +49,8 @@ def spmm_source_hash():
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--cells", type=int, default=26, help="Kuhn box cells per edge (26 -> 105 456 tets)")
     ap.add_argument("--order", type=int, default=2)
     ap.add_argument("--modes", type=int, default=64)

@@ -39,7 +39,7 @@ Collected by `tools/collect_profiles.sh r03` on the GPU box (regenerate this fil
 
 | file | what |
 |---|---|
-| `r03_bench_n1.json` | the JSON line of `python bench.py` (N = 1, 3 steps, 1 warm-up, CPU baseline included): **{d["value"]:.1f} passes/s**; amortised variant (eigendecomposition every 15 passes) {am.get("value", float("nan")):.0f} passes/s |
+| `r03_bench_n1.json` | the JSON line of `python bench.py` (N = 1, {d["steps"]} steps, {d["warmup"]} warm-up, CPU baseline included): **{d["value"]:.1f} passes/s**; amortised variant (eigendecomposition every 15 passes) {am.get("value", float("nan")):.0f} passes/s |
 | `r03_bench_kernel_stats.csv` | `rocprofv3 --kernel-trace --stats` of `python bench.py --no-cpu-baseline --steps 8` (8 hypothesis lanes overlap: durations stretched by sharing) |
 | `r03_bench_lanes1_kernel_stats.csv` | the same with `--lanes 1 --hyp-per-gpu 2 --steps 4`: one hypothesis at a time, every kernel alone on the device — the table to read kernel durations from |
 | `r03_gpu_busy.txt`, `r03_concurrency_profile.txt` | device-busy fraction of the timed window (`tools/gpu_busy.py`) and the concurrency profile (`tools/gpu_timeline.py`: kernels in flight, busy share per stream, idle time by gap size, which kernels border the short gaps) |
