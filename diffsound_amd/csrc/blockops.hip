@@ -220,7 +220,7 @@ int launch_mix(const float* A, int64_t lda, int p, const float* C, int q, float*
 // DS_KOM: knock-out builds for tools/exp_knockout_mix.sh (1 no loads of A after the first two k-steps, 2 no LDS reads of the
 // coefficients after them, 4 no MFMAs); 0 in the product.  Result (profiles/r03_mix_knockout.txt): 240 -> 80 whole 0.207 ms,
 // MFMAs alone 0.194, loads alone 0.160; 240 -> 160 whole 0.370, MFMAs alone 0.337, loads alone 0.222 - the kernel runs at the
-// rate its MFMAs issue alone (88-102 TF/s of v_mfma_f32_16x16x4_f32 at the clock the device holds under this load)
+// rate its MFMA loop issues alone (88-102 TF/s; the instruction sustains 134-138 TF/s in tools/mfma_rate_probe.hip)
 #ifndef DS_KOM
 #define DS_KOM 0
 #endif

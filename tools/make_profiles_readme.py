@@ -49,7 +49,7 @@ Collected by `tools/collect_profiles.sh r03` on the GPU box (regenerate this fil
 | `r03_mfma_batch_sizes.txt` | the fused term at C3 with LDS batches of 32 / 16 / 8 entries (2 / 3 / 4 waves per SIMD): 171 / 145 / 144 us |
 | `r03_union_knockout.txt`, `r03_union_prefetch_ab.txt` | knock-out builds of the neighbour-union kernel (`tools/exp_knockout.sh`, `-DDS_KO=bits`): K X 248 us whole, 201 without FMAs, 221 without coefficient reads, 174 without gathers, 92 with none of the three, 78 skeleton - the parts add up (a wave's chain, no saturated unit); the A/B of what followed (coefficients one block ahead, 84 VGPRs): K W 231 -> 220 us in the bench |
 | `r03_gather_probe.txt` | `tools/gather_probe.hip` on the real C3 union tables: the panels of every group pulled into registers with no arithmetic. Mode 7 (added late in the round) maps workgroups to groups as the library does (each XCD a contiguous range): **94 us = 24 TB/s** for the 4-node fp32 unions, 82 / 86 us for 8- / 16-node unions, against 220 / 180 / 146 us with workgroups dealt round-robin over the XCDs (modes 0-6, which the round first read as the bound of K W); tail: the outer-product MFMA experiment |
-| `r03_gram_knockout.txt`, `r03_mix_knockout.txt` | knock-out builds of the Gram and `mix` kernels (`-DDS_KOG`, `-DDS_KOM`): Gram 240x80 0.225-0.234 ms whole, MFMAs alone 0.168, operand loads alone 0.208 (B through LDS measured: -4.5 %, not adopted); `mix` 240->80 0.207 whole / 0.194 MFMAs alone / 0.160 loads alone, 240->160 0.370 / 0.337 / 0.222: `mix` runs at the rate its MFMAs issue (88-102 TF/s of `v_mfma_f32_16x16x4_f32` sustained on this device) |
+| `r03_gram_knockout.txt`, `r03_mix_knockout.txt` | knock-out builds of the Gram and `mix` kernels (`-DDS_KOG`, `-DDS_KOM`): Gram 240x80 0.225-0.234 ms whole, MFMAs alone 0.168, operand loads alone 0.208 (B through LDS measured: -4.5 %, not adopted); `mix` 240->80 0.207 whole / 0.194 MFMAs alone / 0.160 loads alone, 240->160 0.370 / 0.337 / 0.222: `mix` runs at the rate its MFMA loop issues (88-102 TF/s; the instruction alone sustains 134-138 TF/s at 2.3-2.4 GHz, `tools/mfma_rate_probe.hip`) |
 | `r03_cpu_memsafe_8_container.json`, `r03_cpu_memsafe_12_container.json`, `r03_cpu_memsafe_16_container.json` | BASELINE.md section 3 (i)/(ii): the memory-safe CPU restatement (`tools/cpu_baseline_memsafe.py`) on the build container's 8 cores: 23.5 s / 181.5 s / 1 025 s per pass at 3 072 / 10 368 / 24 576 tets; ARPACK's shift-invert 11.7 / 100 / 776 s (n^2.5): about 7 hours at the benchmark mesh, which is why (i) is not measured |
 | `r03_cached_pass_profile.txt` | `tools/prof_cached_pass.py`: host profile of the pass between eigendecompositions as torch operations (0.83 ms: autograd engine 0.43, ~45 element-wise launches) and its time as one native call (`ds_readout_pass`): 0.11 ms |
 | `r03_bench_step_barrier.json` | the same run with `--step-barrier` (all lanes join after every step: the schedule up to the middle of round 3), same box and call as `r03_bench_n1.json`: 40.3 against 44.6 passes/s |
