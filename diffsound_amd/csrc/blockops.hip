@@ -240,10 +240,20 @@ __global__ void __launch_bounds__(64 * MIX_NW)
     extern __shared__ __attribute__((aligned(16))) float s_c[];  // [p16 / 4][JT * 16][4], rows >= p and columns >= q zero
     constexpr int W = JT * 16;
     const int p16 = (p + 15) & ~15;
-    for (int t = threadIdx.x; t < p16 * W; t += 64 * MIX_NW) {
-        const int kq = t / (W * 4), rem = t - kq * (W * 4), pos = rem >> 2;
-        const int r = kq * 4 + (rem & 3), c = (pos & 15) * JT + (pos >> 4);
-        s_c[t] = (r < p && c < q) ? C[r * q + c] : 0.f;
+    // (eight independent loads per thread and round: one load per trip cost a workgroup ~25 k cycles before its first MFMA)
+    constexpr int NTHR = 64 * MIX_NW, STG = 8;
+    for (int t0 = threadIdx.x; t0 < p16 * W; t0 += NTHR * STG) {
+        float v[STG];
+#pragma unroll
+        for (int u = 0; u < STG; ++u) {
+            const int t = t0 + u * NTHR;
+            const int kq = t / (W * 4), rem = t - kq * (W * 4), pos = rem >> 2;
+            const int r = kq * 4 + (rem & 3), c = (pos & 15) * JT + (pos >> 4);
+            v[u] = (t < p16 * W && r < p && c < q) ? C[r * q + c] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < STG; ++u)
+            if (t0 + u * NTHR < p16 * W) s_c[t0 + u * NTHR] = v[u];
     }
     __syncthreads();
     const f4* sc4 = reinterpret_cast<const f4*>(s_c);
