@@ -60,6 +60,14 @@ Collected by `tools/collect_profiles.sh r03` on the GPU box (regenerate this fil
 | `r03_gram_mix.txt`, `r03_gram_mix_pmc.json` | Gram / `mix` timings at the solver's shapes and their MFMA counters: utilisation = busy cycles ÷ (GRBM_GUI_ACTIVE / 8 XCDs × 1024 SIMDs) = ''' + ", ".join(f"{k.split('(')[0]} {100 * v:.0f} %" for k, v in util.items()) + f''' |
 | `r03_c5_bench_noprof.json`, `r03_c5_bench.json`, `r03_c5_kernel_stats.csv` | **configs[4]** (`bench.py --workload c5`, plain and under `rocprofv3 --kernel-trace --stats`): 998 250 tets, n = 4.1 M, 128 modes - SpMM bandwidth of every product form against the in-run STREAM triad, fp32 solve {c5["solve"]["fp32_iteration_plus_fp64_polish"]["seconds"]:.1f} s, with the fp64 refinement to 1e-10 **{c5["solve"]["with_fp64_refinement"]["seconds"]:.1f} s** ({c5["solve"]["with_fp64_refinement"]["fp64_steps"]} fp64 steps; second solve of the process, figures of the plain run) |
 
+## A note on the profiled runs
+
+One of about ten `rocprofv3 --kernel-trace --stats -- python3 bench.py ...` runs of this round ended in a host SIGSEGV inside the HIP
+runtime's launch path under the profiler's hooks (a hypothesis lane's thread, first seconds of the run; `ds_spmm_union16m` happened to be
+the caller). Two immediate reruns of the same command on fresh boxes were clean, no unprofiled run or test has ever shown it, and the
+stack ends in runtime / profiler frames, not in this library: recorded here as a profiler-side flake of concurrent launches from eight
+threads, not investigated further.
+
 ## Roofline figures of `r03_bench_n1.json`
 
 * dominant kernel `{r["kernel"]}`: {r["algorithmic_bytes_per_launch"] / 1e6:.1f} MB algorithmic per launch, {r["avg_launch_ms"]:.3f} ms alone on the device
