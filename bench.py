@@ -485,6 +485,9 @@ def main():
             its_all.append(r.iterations)
             cits.append(r.coarse_iterations)
         on_step.total = all_reduce_loss(loss_sum, dev)
+        on_step.stamps.append(time.time())
+
+    on_step.stamps = []
 
     def run_steps(nsteps, warm):
         """``nsteps`` steps (one pass of every hypothesis of this rank per step; every pass runs its own numeric assembly).
@@ -737,6 +740,9 @@ def main():
             "roofline": roof,
             "loss_sum_last_step": total,
             "ranks": per_rank,
+            # wall-clock seconds between the completions of consecutive steps on rank 0 (warm-up steps first): shows whether the
+            # timed steps ran in a steady state
+            "step_completion_intervals_s": [round(b - a_, 4) for a_, b in zip(on_step.stamps[:-1], on_step.stamps[1:])],
             "amortised": amortised,
             "collective": (f"{a.dist_backend} all-reduce of the scalar loss over {world} ranks" if world > 1 else "none (1 rank)"),
         }
