@@ -52,7 +52,7 @@ Collected by `tools/collect_profiles.sh r03` on the GPU box (regenerate this fil
 | `r03_gram_knockout.txt`, `r03_mix_knockout.txt` | knock-out builds of the Gram and `mix` kernels (`-DDS_KOG`, `-DDS_KOM`): Gram 240x80 0.225-0.234 ms whole, MFMAs alone 0.168, operand loads alone 0.208 (B through LDS measured: -4.5 %, not adopted); `mix` 240->80 0.207 whole / 0.194 MFMAs alone / 0.160 loads alone, 240->160 0.370 / 0.337 / 0.222: `mix` runs at the rate its MFMA loop issues (88-102 TF/s; the instruction alone sustains 134-138 TF/s at 2.3-2.4 GHz, `tools/mfma_rate_probe.hip`) |
 | `r03_cpu_memsafe_8_container.json`, `r03_cpu_memsafe_12_container.json`, `r03_cpu_memsafe_16_container.json` | BASELINE.md section 3 (i)/(ii): the memory-safe CPU restatement (`tools/cpu_baseline_memsafe.py`) on the build container's 8 cores: 23.5 s / 181.5 s / 1 025 s per pass at 3 072 / 10 368 / 24 576 tets; ARPACK's shift-invert 11.7 / 100 / 776 s (n^2.5): about 7 hours at the benchmark mesh, which is why (i) is not measured |
 | `r03_cached_pass_profile.txt` | `tools/prof_cached_pass.py`: host profile of the pass between eigendecompositions as torch operations (0.83 ms: autograd engine 0.43, ~45 element-wise launches) and its time as one native call (`ds_readout_pass`): 0.11 ms |
-| `r03_bench_step_barrier.json` | the same run with `--step-barrier` (all lanes join after every step: the schedule up to the middle of round 3), same box as `r03_bench_n1.json`: 42.3 against 45.4 passes/s |
+| `r03_bench_step_barrier.json` | the same run with `--step-barrier` (all lanes join after every step: the schedule up to the middle of round 3), same call as `r03_bench_n1.json`: 42.8 against 44.9 passes/s |
 | `r03_lane_tail.txt` | `tools/lane_tail.py`: when each of the 8 hypothesis lanes finishes inside a step joined at its end (90 ... 195 ms of 195: 14-15 % of the lane time is tail) and when each hypothesis' last step ends without the join (10 %: the hypotheses themselves cost differently; 8 hardware queues instead of 4 change nothing) |
 | `r03_lanes_sweep.txt`, `r03_exp_knobs.txt`, `r03_exp_nested_tol.txt` | throughput against lanes, block width, smoother / corner-level degree, nested-start tolerance (the re-tuning behind this round's defaults) |
 | `r03_host_time_one_lane.txt`, `r03_device_eigh_probe.txt` | host time of one solve by cause (`DS_EXP_TIMING=1`); the dense Rayleigh-Ritz steps through rocSOLVER on the device against one host core |
