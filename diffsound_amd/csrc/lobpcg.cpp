@@ -275,6 +275,10 @@ struct Ctx {
 
     int apply_K(const float* X, int64_t ldx, float* Y, int64_t ldy, int ncols) {
         const ds_level_t& L = p->level;
+        if (ncols <= 84 && ncols % 4 == 0 && L.m32_gptr && L.m32_k && 3 * L.nv * ldx * 4 < (int64_t)0x7f000000)
+            return ds_spmm_union32m(0, L.level_tag, L.m32_gptr, L.m32_gcol, L.m32_gmeta, L.m32_gbase, L.m32_k, L.nnzb * 36 + 16,
+                                    L.nnzb, (L.nv + 3) / 4, L.m32_max_entries, L.m32_max_batch_blocks, L.nv, X, ldx, Y, ldy,
+                                    ncols, stream);
         if (ncols <= 84 && ncols % 4 == 0)
             return ds_spmm_union(0, L.utab, L.ctab, L.ngroups, L.cap_blocks, L.gent, L.kgrp, L.nnzb, L.nv, X, ldx, Y, ldy,
                                  nullptr, 0, nullptr, ncols, 0.f, 0.f, 0, nullptr, 0, stream);
@@ -288,6 +292,10 @@ struct Ctx {
 
     int apply_M(const float* X, int64_t ldx, float* Y, int64_t ldy, int ncols) {
         const ds_level_t& L = p->level;
+        if (L.m32_gptr && L.m32_m && 3 * L.nv * ldx * 4 < (int64_t)0x7f000000)
+            return ds_spmm_union32m(3, L.level_tag, L.m32_gptr, L.m32_gcol, L.m32_gmeta, L.m32_gbase, L.m32_m, L.nnzb * 4 + 16,
+                                    L.nnzb, (L.nv + 3) / 4, L.m32_max_entries, L.m32_max_batch_blocks, L.nv, X, ldx, Y, ldy,
+                                    ncols, stream);
         return ds_spmm_union(3, L.utab, L.ctab, L.ngroups, L.cap_blocks, L.gent, p->mgrp, L.nnzb, L.nv, X, ldx, Y, ldy,
                              nullptr, 0, nullptr, ncols, 0.f, 0.f, 0, nullptr, 0, stream);
     }
@@ -397,7 +405,7 @@ extern "C" int ds_lobpcg_iterate(ds_lobpcg_t* p, const ds_lapack_t* lapack, ds_s
     DS_REQUIRE(p->twolevel || (p->pa && p->pb), "ds_lobpcg_iterate: no preconditioner scratch");
     // the periodic full refresh multiplies K by [X P W] (up to 3 b columns): wider than 84 it goes through ds_spmm_bsr3,
     // which needs the plain BSR arrays - asked for here, not at the 8th iteration
-    DS_REQUIRE(p->rr_refresh <= 0 || 3 * p->b <= 84 || (p->rowptr && p->colidx && p->k32 && p->k32t),
+    DS_REQUIRE(3 * p->b <= 84 || (p->rowptr && p->colidx && p->k32 && p->k32t),
                "ds_lobpcg_iterate: rowptr / colidx / k32 / k32t are needed for the full refresh of a block wider than 28");
     Ctx c{p, ds::as_stream(stream), stream, *lapack, p->S, p->S2, p->KS, p->KS2};
     const int b = p->b, k = p->k, ny = p->ny;

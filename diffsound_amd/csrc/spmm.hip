@@ -370,6 +370,7 @@ int launch_wn(const int32_t* rowptr, const int32_t* colidx, const void* vals, co
 
 #include "spmm_union.inc"
 #include "spmm_mfma.inc"
+#include "spmm_mfma32.inc"
 
 template <int KIND>
 int launch_fast(const int32_t* rowptr, const int32_t* colidx, const void* vals, const void* vals_t, int64_t nv,
@@ -855,23 +856,30 @@ extern "C" int ds_pack_kc(const float* k32, const int32_t* kperm, int64_t nnzb, 
     return DS_OK;
 }
 
-template <int G, int NT, int BATCH>
+template <int G, int NT, int BATCH, int LVL>
 static int launch_mfma(int epilogue, int y_f32, const int32_t* gptr, const int32_t* gcol, const int32_t* gmeta,
                        const int32_t* gbase, const void* kc, int64_t nnzb, int64_t ngroups, int64_t nv, const float* X,
                        int64_t ldx, float* Y, int64_t ldy, int lpn, int acap, hipStream_t st, const ChebEpilogue& epi) {
     const char* kcp = static_cast<const char*>(kc);
     const size_t lds = (size_t)mf_panel_bytes(lpn * 4, G, BATCH) + (size_t)acap + 32;
     if (epilogue == 2)
-        spmm_union_mfma_kernel<G, NT, 2, false, BATCH><<<(unsigned)ngroups, 64, lds, st>>>(gptr, gcol, gmeta, gbase, kcp, nnzb, (unsigned)ngroups, nv, X, ldx, Y, ldy, lpn, acap, epi);
+        spmm_union_mfma_kernel<G, NT, 2, false, BATCH, LVL><<<(unsigned)ngroups, 64, lds, st>>>(gptr, gcol, gmeta, gbase, kcp, nnzb, (unsigned)ngroups, nv, X, ldx, Y, ldy, lpn, acap, epi);
     else if (y_f32)
-        spmm_union_mfma_kernel<G, NT, 1, true, BATCH><<<(unsigned)ngroups, 64, lds, st>>>(gptr, gcol, gmeta, gbase, kcp, nnzb, (unsigned)ngroups, nv, X, ldx, Y, ldy, lpn, acap, epi);
+        spmm_union_mfma_kernel<G, NT, 1, true, BATCH, LVL><<<(unsigned)ngroups, 64, lds, st>>>(gptr, gcol, gmeta, gbase, kcp, nnzb, (unsigned)ngroups, nv, X, ldx, Y, ldy, lpn, acap, epi);
     else
-        spmm_union_mfma_kernel<G, NT, 1, false, BATCH><<<(unsigned)ngroups, 64, lds, st>>>(gptr, gcol, gmeta, gbase, kcp, nnzb, (unsigned)ngroups, nv, X, ldx, Y, ldy, lpn, acap, epi);
+        spmm_union_mfma_kernel<G, NT, 1, false, BATCH, LVL><<<(unsigned)ngroups, 64, lds, st>>>(gptr, gcol, gmeta, gbase, kcp, nnzb, (unsigned)ngroups, nv, X, ldx, Y, ldy, lpn, acap, epi);
     DS_LAUNCH_CHECK("spmm_union_mfma_kernel");
     return DS_OK;
 }
 
-extern "C" int ds_spmm_union16m(int epilogue, int group_nodes, const int32_t* gptr, const int32_t* gcol,
+// entries per batch on the corner-node level (level_tag 1): DS_MF_BATCH, or twice that (one wave's chain of dependent round
+// trips is what a level with about as many groups as the device has wave slots is made of; measured at C3's corner level,
+// 2 461 groups: see DESIGN.md section 6)
+#ifndef DS_MF_CORNER_BATCH
+#define DS_MF_CORNER_BATCH DS_MF_BATCH
+#endif
+
+extern "C" int ds_spmm_union16m(int epilogue, int group_nodes, int level_tag, const int32_t* gptr, const int32_t* gcol,
                                 const int32_t* gmeta, const int32_t* gbase, const void* kc, int64_t nnzb,
                                 int64_t ngroups, int max_entries, int max_batch_blocks, int64_t nv, const void* X,
                                 int64_t ldx, void* Y,
@@ -882,12 +890,12 @@ extern "C" int ds_spmm_union16m(int epilogue, int group_nodes, const int32_t* gp
     DS_REQUIRE(epilogue != 1 || dinv, "ds_spmm_union16m: the Chebyshev epilogue needs dinv");
     // (4-node groups were slower on both levels; only the 8-node kernel is built)
     DS_REQUIRE(group_nodes == 8, "ds_spmm_union16m: groups of 8 nodes");
+    DS_REQUIRE(level_tag == 0 || level_tag == 1, "ds_spmm_union16m: level_tag must be 0 (fine) or 1 (corner-node level)");
     DS_REQUIRE(nv > 0 && ngroups == (nv + group_nodes - 1) / group_nodes && ncols > 0 && ncols % 4 == 0 && ncols <= 84,
                "ds_spmm_union16m: ncols must be a multiple of 4 <= 84 and ngroups = ceil(nv / group_nodes)");
     DS_REQUIRE(max_entries > 0 && max_entries <= 256, "ds_spmm_union16m: a group with %d union entries exceeds 256", max_entries);
     DS_REQUIRE(max_batch_blocks > 0 && max_batch_blocks <= DS_MF_BATCH * group_nodes,
                "ds_spmm_union16m: max_batch_blocks must be in (0, DS_MF_BATCH x group_nodes]");
-    const int acap = ((max_batch_blocks * 24 + 1023) / 1024) * 1024;  // whole 1 KiB staging pieces
     DS_REQUIRE(nnzb > 0 && nnzb * 24 < (int64_t)PIPE_OOB, "ds_spmm_union16m: the block array exceeds the descriptor range");
     DS_REQUIRE(ldx >= ncols && ldy >= ncols && ldr >= ncols, "ds_spmm_union16m: leading dimension smaller than ncols");
     DS_REQUIRE(X != Y, "ds_spmm_union16m: X and Y must be different buffers");
@@ -909,38 +917,95 @@ extern "C" int ds_spmm_union16m(int epilogue, int group_nodes, const int32_t* gp
     float* Yf = static_cast<float*>(Y);
     const int lpn = ncols / 4;
     const int nt = (ncols + 15) / 16;
-#define DS_MF_GO(GG, N) return launch_mfma<GG, N, DS_MF_BATCH>(epilogue, y_f32, gptr, gcol, gmeta, gbase, kc, nnzb, ngroups, nv, Xf, ldx, Yf, ldy, lpn, acap, st, epi)
-#define DS_MF_GO32(GG, N) return launch_mfma<GG, N, 2 * DS_MF_BATCH>(epilogue, y_f32, gptr, gcol, gmeta, gbase, kc, nnzb, ngroups, nv, Xf, ldx, Yf, ldy, lpn, acap32, st, epi)
-    // A level with fewer groups than the device has wave slots at two waves per SIMD (the corner-node level: 2 461 groups
-    // on 1 024 SIMDs) is one wave's chain of dependent round trips, not an occupancy problem: batches of 32 entries halve
-    // the number of those round trips (two 16-entry batches never hold more blocks than 2 x max_batch_blocks)
-    static const int small_level = [] {
-        int dev = 0, cus = 256;
-        (void)hipGetDevice(&dev);
-        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        return cus * 8;
-    }();
-    const int acap32 = ((2 * max_batch_blocks * 24 + 1023) / 1024) * 1024;
+    // two batches of DS_MF_BATCH entries never hold more blocks than 2 x max_batch_blocks
+    constexpr int CB = DS_MF_CORNER_BATCH;
+    const int acap = ((max_batch_blocks * 24 + 1023) / 1024) * 1024;  // whole 1 KiB staging pieces
+    const int acapc = (((CB / DS_MF_BATCH) * max_batch_blocks * 24 + 1023) / 1024) * 1024;
+#define DS_MF_GO(N) return launch_mfma<8, N, DS_MF_BATCH, 0>(epilogue, y_f32, gptr, gcol, gmeta, gbase, kc, nnzb, ngroups, nv, Xf, ldx, Yf, ldy, lpn, acap, st, epi)
+#define DS_MF_GOC(N) return launch_mfma<8, N, CB, 1>(epilogue, y_f32, gptr, gcol, gmeta, gbase, kc, nnzb, ngroups, nv, Xf, ldx, Yf, ldy, lpn, acapc, st, epi)
     auto go = [&]() -> int {
-        if (ngroups <= small_level) {
+        if (level_tag == 1) {
             switch (nt) {
-                case 1: DS_MF_GO32(8, 1); case 2: DS_MF_GO32(8, 2); case 3: DS_MF_GO32(8, 3);
-                case 4: DS_MF_GO32(8, 4); case 5: DS_MF_GO32(8, 5); default: DS_MF_GO32(8, 6);
+                case 1: DS_MF_GOC(1); case 2: DS_MF_GOC(2); case 3: DS_MF_GOC(3);
+                case 4: DS_MF_GOC(4); case 5: DS_MF_GOC(5); default: DS_MF_GOC(6);
             }
         }
         switch (nt) {
-            case 1: DS_MF_GO(8, 1); case 2: DS_MF_GO(8, 2); case 3: DS_MF_GO(8, 3);
-            case 4: DS_MF_GO(8, 4); case 5: DS_MF_GO(8, 5); default: DS_MF_GO(8, 6);
+            case 1: DS_MF_GO(1); case 2: DS_MF_GO(2); case 3: DS_MF_GO(3);
+            case 4: DS_MF_GO(4); case 5: DS_MF_GO(5); default: DS_MF_GO(6);
         }
     };
 #undef DS_MF_GO
-#undef DS_MF_GO32
+#undef DS_MF_GOC
     if (epilogue == 1 && !y_f32) {
         int rc = DS_OK;
         if (profiled_launch(stream, st, nv, nnzb, ncols, first, 2, go, rc)) return rc;
     }
     return go();
 }
+
+// ------------------------------------------------------------------------------------------------
+// fp32 matrix-core form of the eigensolver's own products (spmm_mfma32.inc)
+#ifndef DS_MF32_BATCH
+#define DS_MF32_BATCH 8
+#endif
+template <int NT, int EPI, int LVL>
+static int launch_mfma32(const int32_t* gptr, const int32_t* gcol, const int32_t* gmeta, const int32_t* gbase, const float* vals,
+                         unsigned vals_bytes, int64_t ngroups, int64_t nv, const float* X, int64_t ldx, float* Y, int64_t ldy,
+                         int lpn, hipStream_t st) {
+    constexpr int EB = DS_MF32_BATCH;
+    constexpr int acap = ((EB * MF32_G * (EPI == 3 ? 4 : 36) + 1023) / 1024) * 1024;  // whole 1 KiB staging pieces
+    const size_t lds = (size_t)mf32_panel_bytes(NT, EB) + acap + 48;
+    spmm_union_mfma32_kernel<NT, EPI, EB, LVL><<<(unsigned)ngroups, 64, lds, st>>>(gptr, gcol, gmeta, gbase, vals, vals_bytes,
+                                                                                  (unsigned)ngroups, nv, X, ldx, Y, ldy, lpn, acap);
+    DS_LAUNCH_CHECK("spmm_union_mfma32_kernel");
+    return DS_OK;
+}
+
+extern "C" int ds_spmm_union32m(int epilogue, int level_tag, const int32_t* gptr, const int32_t* gcol, const int32_t* gmeta,
+                                const int32_t* gbase, const float* vals, int64_t vals_bytes, int64_t nblocks, int64_t ngroups,
+                                int max_entries, int max_batch_blocks, int64_t nv, const float* X, int64_t ldx, float* Y,
+                                int64_t ldy, int ncols, ds_stream_t stream) {
+    DS_REQUIRE(gptr && gcol && gmeta && gbase && vals && X && Y, "ds_spmm_union32m: null pointer");
+    DS_REQUIRE(epilogue == 0 || epilogue == 3, "ds_spmm_union32m: epilogue must be 0 (3x3 blocks) or 3 (node-scalar values)");
+    DS_REQUIRE(level_tag == 0 || level_tag == 1, "ds_spmm_union32m: level_tag must be 0 (fine) or 1 (corner-node level)");
+    DS_REQUIRE(nv > 0 && ngroups == (nv + MF32_G - 1) / MF32_G && ncols > 0 && ncols % 4 == 0 && ncols <= 84,
+               "ds_spmm_union32m: ncols must be a multiple of 4 <= 84 and ngroups = ceil(nv / 4)");
+    DS_REQUIRE(max_entries > 0 && max_entries <= 256, "ds_spmm_union32m: a group with %d union entries exceeds 256", max_entries);
+    DS_REQUIRE(max_batch_blocks > 0 && max_batch_blocks <= DS_MF32_BATCH * MF32_G,
+               "ds_spmm_union32m: max_batch_blocks must be in (0, DS_MF32_BATCH x 4]");
+    const int64_t vb = epilogue == 3 ? 4 : 36;
+    // (the value stream is read in 16-byte pieces: the array carries 16 bytes of slack behind its last block)
+    DS_REQUIRE(nblocks > 0 && vals_bytes >= nblocks * vb + 16 && vals_bytes < (int64_t)PIPE_OOB,
+               "ds_spmm_union32m: the value array must hold nblocks x %d bytes + 16 of slack, under the descriptor range", (int)vb);
+    DS_REQUIRE(ldx >= ncols && ldy >= ncols, "ds_spmm_union32m: leading dimension smaller than ncols");
+    DS_REQUIRE(X != Y, "ds_spmm_union32m: X and Y must be different buffers");
+    DS_REQUIRE(3 * nv * ldx * 4 < (int64_t)PIPE_OOB, "ds_spmm_union32m: the operand block exceeds the descriptor range");
+    const uintptr_t al = reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(Y) | (uintptr_t)(ldx * 4) | (uintptr_t)(ldy * 4);
+    DS_REQUIRE((al & 15) == 0 && (reinterpret_cast<uintptr_t>(vals) & 3) == 0, "ds_spmm_union32m: rows must be 16-byte aligned");
+    hipStream_t st = ds::as_stream(stream);
+    const int lpn = ncols / 4, nt = (ncols + 15) / 16;
+#define DS_M32_GO(N, E, L) return launch_mfma32<N, E, L>(gptr, gcol, gmeta, gbase, vals, (unsigned)vals_bytes, ngroups, nv, X, ldx, Y, ldy, lpn, st)
+#define DS_M32_NT(E, L)                                                                     \
+    switch (nt) {                                                                           \
+        case 1: DS_M32_GO(1, E, L); case 2: DS_M32_GO(2, E, L); case 3: DS_M32_GO(3, E, L); \
+        case 4: DS_M32_GO(4, E, L); case 5: DS_M32_GO(5, E, L); default: DS_M32_GO(6, E, L); \
+    }
+    if (epilogue == 0) {
+        if (level_tag == 0) DS_M32_NT(0, 0)
+        DS_M32_NT(0, 1)
+    }
+    if (level_tag == 0) DS_M32_NT(3, 0)
+    DS_M32_NT(3, 1)
+#undef DS_M32_NT
+#undef DS_M32_GO
+}
+
+#ifdef DS_M32_DIAG
+extern "C" int ds_m32_diag(unsigned long long* out, int nwaves) {  // diagnostic build only: out[nwaves][8]
+    return ds::check_hip(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_m32_dbg), (size_t)nwaves * 8 * sizeof(unsigned long long)), "ds_m32_diag read");
+}
+#endif
 
 // Ya = A X, Yb = B X (fp64 3x3 block values), Ym = (m (x) I3) X (fp64 node scalars) for one fp32 block X in one walk.
 extern "C" int ds_spmm_f64_polish(const int32_t* rowptr, const int32_t* colidx, const double* a, const double* b,

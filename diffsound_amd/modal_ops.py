@@ -20,6 +20,8 @@ DS_F32, DS_F64 = 0, 1
 import threading
 
 MF_BATCH = 16  # entries per LDS batch of the MFMA kernel (DS_MF_BATCH of include/diffsound_hip.h)
+MF32_BATCH = 8  # entries per LDS batch of the fp32 MFMA kernel (DS_MF32_BATCH), groups of MF32_G = 4 nodes
+MF32_G = 4
 _MFMA_TABLES_LOCK = threading.Lock()
 UNION_CAP = 116  # blocks per chunk of the neighbour-union tables (the kernel's smallest LDS image)
 
@@ -97,19 +99,21 @@ class TetSystem:
         self._coarse = None
         self.assemble()
 
-    def mfma_tables(self, group_nodes=8):
-        """Topology tables of the MFMA form of the bf16 terms (ds_spmm_union16m) for groups of 8 consecutive nodes:
+    def mfma_tables(self, group_nodes=8, batch=MF_BATCH):
+        """Topology tables of the MFMA forms - of the bf16 terms (ds_spmm_union16m, groups of 8 consecutive nodes, batches of
+        16 entries) and of the eigensolver's fp32 products (ds_spmm_union32m, groups of 4, batches of 8):
         gptr / gcol = the sorted union of the column ids of each group's rows; gmeta per entry = presence mask of the
         group's nodes | (first block of the entry inside the group) << 8; gbase = first block of each group; kperm = BSR
         block of every position of the (group, entry, node) order.  Built once per topology with device sorts."""
         cache = self.__dict__.setdefault("_mfma_tables", {})
         with _MFMA_TABLES_LOCK:  # hypothesis lanes share the cache (with_own_values copies the dict reference)
-            if group_nodes not in cache:
-                cache[group_nodes] = self._build_mfma_tables(group_nodes)
+            key_ = (int(group_nodes), int(batch))
+            if key_ not in cache:
+                cache[key_] = self._build_mfma_tables(*key_)
                 torch.cuda.current_stream(self.device).synchronize()  # other lanes use the tables on their own streams
-        return cache[group_nodes]
+        return cache[key_]
 
-    def _build_mfma_tables(self, group_nodes):
+    def _build_mfma_tables(self, group_nodes, mf_batch):
         G, nv, dev = int(group_nodes), self.nv, self.device
         rows = torch.repeat_interleave(torch.arange(nv, device=dev), (self.rowptr[1:] - self.rowptr[:-1]).long())
         key = ((rows // G) * nv + self.colidx.long()) * G + rows % G
@@ -124,13 +128,13 @@ class TetSystem:
         gbase = goff[gptr[:-1].clamp(max=ekey.numel())]
         within = goff[:-1] - torch.repeat_interleave(gbase, gptr[1:] - gptr[:-1])
         ne_g = gptr[1:] - gptr[:-1]
-        # blocks per batch of MF_BATCH = 16 entries (counted from each group's first entry): sizes the kernel's LDS
+        # blocks per batch of mf_batch entries (counted from each group's first entry): sizes the kernel's LDS
         eidx = torch.arange(ekey.numel(), device=dev)
         # (a group of more than 256 entries is not served by the kernel; its tail is lumped into the last slot here)
-        nslot = 256 // MF_BATCH
-        batch = (ekey // nv) * nslot + ((eidx - torch.repeat_interleave(gptr[:-1], ne_g)) // MF_BATCH).clamp(max=nslot - 1)
+        nslot = 256 // mf_batch
+        batch = (ekey // nv) * nslot + ((eidx - torch.repeat_interleave(gptr[:-1], ne_g)) // mf_batch).clamp(max=nslot - 1)
         per_batch = torch.zeros(ng * nslot, dtype=torch.int64, device=dev).scatter_add_(0, batch, counts)
-        return dict(G=G, ngroups=ng, max_entries=int(ne_g.max()), max_batch_blocks=int(per_batch.max()),
+        return dict(G=G, batch=mf_batch, ngroups=ng, max_entries=int(ne_g.max()), max_batch_blocks=int(per_batch.max()),
                     gptr=gptr.to(torch.int32), gcol=(ekey % nv).to(torch.int32).contiguous(),
                     gmeta=(mask | (within << 8)).to(torch.int32).contiguous(), gbase=gbase.to(torch.int32).contiguous(),
                     kperm=order.to(torch.int32).contiguous())
@@ -312,6 +316,7 @@ class _HipBlockOps:
         d.utab, d.ctab, d.ngroups, d.cap_blocks = (None if u.get("single") else u["utab"].data_ptr()), u["ctab"].data_ptr(), u["ngroups"], u["capb"]
         d.gent, d.kgrp, d.nnzb, d.nv, d.dinv = g["gent"].data_ptr(), self.kgrp.data_ptr(), self.kgrp.shape[0], self.nv, self.dinv.data_ptr()
         d.degree, d.lmax, d.lmin = int(degree), float(lmax), float(lmin)
+        d.level_tag = self._level_tag
         mt = self._mfma
         if mt is not None and self.kc is not None:  # the level's bf16 terms run on the matrix cores (ds_spmm_union16m)
             d.mf_group_nodes, d.mf_max_entries, d.mf_max_batch_blocks = mt["G"], mt["max_entries"], mt["max_batch_blocks"]
@@ -319,10 +324,35 @@ class _HipBlockOps:
             d.mf_kc = self.kc.data_ptr()
         else:
             d.mf_group_nodes = 0
+        m4 = self._mfma32
+        if m4 is not None and self.k4 is not None:  # the level's own fp32 products run on the matrix cores (ds_spmm_union32m)
+            d.m32_max_entries, d.m32_max_batch_blocks = m4["max_entries"], m4["max_batch_blocks"]
+            d.m32_gptr, d.m32_gcol, d.m32_gmeta, d.m32_gbase = (m4[k].data_ptr() for k in ("gptr", "gcol", "gmeta", "gbase"))
+            d.m32_k = self.k4.data_ptr()
+            d.m32_m = None if self.m4 is None else self.m4.data_ptr()
+        else:
+            d.m32_gptr = None
         return d
 
     _mfma = None  # tables of the MFMA form of the bf16 terms (TetSystem.mfma_tables), None: the VALU kernel
     kc = None     # (nnzb, 3, 4) bf16: the 3x3 blocks in the order of those tables (ds_pack_kc)
+    _mfma32 = None  # tables of the fp32 MFMA form of the level's own products K X / M X (groups of 4 nodes), None: VALU
+    k4 = None     # (nnzb * 9 + 4,) fp32: the 3x3 blocks (row-major) in the order of those tables, 16 bytes of slack
+    m4 = None     # (nnzb + 4,) fp32: the node-scalar mass values in that order
+    _level_tag = 0  # 0: fine level, 1: corner-node level (selects kernel symbols, nothing else)
+
+    def _union32_ok(self, X, out):
+        return (self._mfma32 is not None and self.k4 is not None and self._union_ok(X, out)
+                and 3 * self.nv * X.stride(0) * 4 < 0x7F000000)
+
+    def _union32(self, epilogue, X, Y):
+        pp = _hip.ptr
+        m4 = self._mfma32
+        vals = self.m4 if epilogue == 3 else self.k4
+        _hip.check(self._L.ds_spmm_union32m(epilogue, self._level_tag, pp(m4["gptr"]), pp(m4["gcol"]), pp(m4["gmeta"]),
+                                            pp(m4["gbase"]), pp(vals), vals.numel() * 4, self.colidx.shape[0], m4["ngroups"],
+                                            m4["max_entries"], m4["max_batch_blocks"], self.nv, pp(X), _ld(X), pp(Y), _ld(Y),
+                                            X.shape[1], _hip.stream_ptr()), "ds_spmm_union32m")
 
     def twolevel_apply(self, smooth, coarse, R, W, D, AD, Rr, Rc, Ec, Dc, ADc, Wc, R16=None):
         """The whole two-level V-cycle W = B R through the native driver (ds_twolevel_apply): one call instead of
@@ -471,14 +501,18 @@ class _HipBlockOps:
                    "ds_spmm_union")
 
     def apply_K(self, X, out):
-        if self._union_ok(X, out):
+        if self._union32_ok(X, out):
+            self._union32(0, X, out)
+        elif self._union_ok(X, out):
             self._union(0, X, out)
         else:
             self._spmm(0, self.k32, X, out)
         self.counts["apply_K_cols"] += X.shape[1]
 
     def apply_M(self, X, out):
-        if self.m_kind == 1 and self.mgrp is not None and self._union_ok(X, out):
+        if self.m_kind == 1 and self.m4 is not None and self._union32_ok(X, out):
+            self._union32(3, X, out)
+        elif self.m_kind == 1 and self.mgrp is not None and self._union_ok(X, out):
             self._union(3, X, out)
         else:
             self._spmm(self.m_kind, self.ms32, X, out)
@@ -570,7 +604,7 @@ class _HipBlockOps:
         pp = _hip.ptr
         mt = self._mfma
         if mt is not None and self.kc is not None:
-            _hip.check(self._L.ds_spmm_union16m(1, mt["G"], pp(mt["gptr"]), pp(mt["gcol"]), pp(mt["gmeta"]), pp(mt["gbase"]),
+            _hip.check(self._L.ds_spmm_union16m(1, mt["G"], self._level_tag, pp(mt["gptr"]), pp(mt["gcol"]), pp(mt["gmeta"]), pp(mt["gbase"]),
                                                 pp(self.kc), self.kc.shape[0], mt["ngroups"], mt["max_entries"], mt["max_batch_blocks"],
                                                 self.nv, pp(Wk), _ld(Wk), pp(Wprev), _ld(Wprev), 0, pp(R0), _ld(R0), pp(self.dinv), Wk.shape[1],
                                                 float(c1), float(c2), int(bool(first)), None, 0, _hip.stream_ptr()),
@@ -705,11 +739,21 @@ class HipModalOps(_HipBlockOps):
     # batches on levels smaller than the device's wave slots, the corner-node level's term takes 17.7 us instead of 22.1.
     mfma_groups = (8, 8)
 
-    def __init__(self, system: TetSystem, lam, mu, two_level=None, _level=0, mfma_groups=None):
+    # the level's own fp32 products (K W, M W, M X of the eigensolver) on the matrix cores (ds_spmm_union32m) instead of
+    # the VALU neighbour-union kernel.  OFF: built, parity-green and measured in round 4 - at C3 K X takes 263 us against
+    # 229 us (M X 246 against 151): v_mfma_f32_16x16x4_f32 runs at the fp32 VECTOR rate and the 16 x 4 tile of 3x3 blocks on
+    # a 4-node union is 3/4 x 0.43 full, so the matrix pipe needs 125-150 us for what the VALU does in 40, on top of the
+    # LDS staging the form requires (profiles/r04_mfma32_*.txt)
+    mfma32 = False
+
+    def __init__(self, system: TetSystem, lam, mu, two_level=None, _level=0, mfma_groups=None, mfma32=None):
         """two_level: build the corner-node level for the two-level preconditioner (ord-2 meshes; default on)."""
         self.sys = system
+        self._level_tag = min(int(_level), 1)
         if mfma_groups is not None:
             self.mfma_groups = tuple(mfma_groups)
+        if mfma32 is not None:
+            self.mfma32 = bool(mfma32)
         self._init_common(system.rowptr, system.colidx, system.nv, system.device)
         dev = self.device
         self.k32 = torch.empty((system.nnzb, 9), dtype=torch.float32, device=dev)
@@ -722,7 +766,8 @@ class HipModalOps(_HipBlockOps):
             lvl = system.coarse_level()
             if lvl is not None:
                 self._xfer = lvl
-                self.coarse = HipModalOps(lvl["sys"], lam, mu, two_level=False, _level=1, mfma_groups=self.mfma_groups)
+                self.coarse = HipModalOps(lvl["sys"], lam, mu, two_level=False, _level=1, mfma_groups=self.mfma_groups,
+                                          mfma32=self.mfma32)
         G = self.mfma_groups[min(_level, 1)]
         if G not in (0, 8):
             raise ValueError("mfma_groups: 8 nodes per wavefront, or 0 for the VALU kernel")
@@ -730,6 +775,10 @@ class HipModalOps(_HipBlockOps):
             mt = system.mfma_tables(G)
             if mt["max_entries"] <= 256 and mt["max_batch_blocks"] <= MF_BATCH * G:  # what ds_spmm_union16m serves
                 self._mfma = mt
+        if self.mfma32 and system.groups is not None and system.nnzb * 36 + 16 < 0x7F000000:
+            m4 = system.mfma_tables(MF32_G, MF32_BATCH)
+            if m4["max_entries"] <= 256 and m4["max_batch_blocks"] <= MF32_BATCH * MF32_G:  # what ds_spmm_union32m serves
+                self._mfma32 = m4
         self.set_material(lam, mu)
         self.rigid = self._rigid_basis() if _level == 0 else None
 
@@ -754,6 +803,16 @@ class HipModalOps(_HipBlockOps):
                     self.kc = torch.empty((s.nnzb, 3, 4), dtype=torch.bfloat16, device=self.device)
                 _hip.check(self._L.ds_pack_kc(p(self.k32), p(self._mfma["kperm"]), s.nnzb, p(self.kc), _hip.stream_ptr()),
                            "ds_pack_kc")
+            if self._mfma32 is not None:
+                if self.k4 is None:  # (zeros: the 16 bytes of slack behind the last block are read and must be finite)
+                    self.k4 = torch.zeros((s.nnzb * 9 + 4,), dtype=torch.float32, device=self.device)
+                    self._kperm4 = self._mfma32["kperm"].long()
+                _hip.check(self._L.ds_pack_groups(p(self.k32), p(self._mfma32["kperm"]), s.nnzb, p(self.k4),
+                                                  _hip.stream_ptr()), "ds_pack_groups")
+                if self.m_kind == 1:
+                    if self.m4 is None:
+                        self.m4 = torch.zeros((s.nnzb + 4,), dtype=torch.float32, device=self.device)
+                    torch.index_select(self.ms32, 0, self._kperm4, out=self.m4[:s.nnzb])
 
     def _rigid_basis(self):
         """Translations + rotations about the centroid, M-orthonormalised in fp64; stored (n, 8) fp32 with

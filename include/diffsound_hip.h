@@ -40,7 +40,7 @@ enum { DS_OK = 0, DS_ERR_ARG = 1, DS_ERR_HIP = 2, DS_ERR_NOMEM = 3 };
 /* Thread-local text of the last error returned on this thread ("" if none). */
 const char* ds_last_error(void);
 /* Library ABI version (bumped on any signature change); ds_abi_version() returns the value the library was built with. */
-#define DS_ABI_VERSION 25
+#define DS_ABI_VERSION 26
 int ds_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------------
@@ -247,9 +247,18 @@ typedef struct {
     int32_t mf_group_nodes;
     int32_t mf_max_entries;
     int32_t mf_max_batch_blocks;
-    int32_t mf_reserved;
+    int32_t level_tag;     /* 0: fine level, 1: corner-node level - selects kernel instantiations whose SYMBOLS differ, so
+                              that a rocprofv3 kernel table separates the two levels' launches (same code otherwise) */
     const int32_t *mf_gptr, *mf_gcol, *mf_gmeta, *mf_gbase;
     const void* mf_kc;
+    /* fp32 matrix-core form of the level's own products K X / M X (ds_spmm_union32m): m32_gptr != NULL enables it in
+     * ds_lobpcg_iterate; tables for groups of 4 nodes, m32_k / m32_m the values in the tables' order (with 16 bytes of
+     * slack behind the last block), m32_m may be NULL (mass matrix not node-scalar) */
+    int32_t m32_max_entries;
+    int32_t m32_max_batch_blocks;
+    const int32_t *m32_gptr, *m32_gcol, *m32_gmeta, *m32_gbase;
+    const float* m32_k;
+    const float* m32_m;
 } ds_level_t;
 typedef struct {
     ds_level_t fine, coarse;
@@ -304,12 +313,28 @@ int ds_spmm_union16(int epilogue, const int32_t* utab, const int32_t* ctab, int6
  * of a group (batches counted from the group's first entry; it sizes the wavefront's LDS). */
 #define DS_MF_BATCH 16
 int ds_pack_kc(const float* k32, const int32_t* kperm, int64_t nnzb, void* kc, ds_stream_t stream);
-int ds_spmm_union16m(int epilogue, int group_nodes, const int32_t* gptr, const int32_t* gcol, const int32_t* gmeta,
-                     const int32_t* gbase, const void* kc, int64_t nnzb, int64_t ngroups, int max_entries,
+int ds_spmm_union16m(int epilogue, int group_nodes, int level_tag, const int32_t* gptr, const int32_t* gcol,
+                     const int32_t* gmeta, const int32_t* gbase, const void* kc, int64_t nnzb, int64_t ngroups, int max_entries,
                      int max_batch_blocks, int64_t nv, const void* X, int64_t ldx, void* Y, int64_t ldy, int y_f32,
                      const void* R0, int64_t ldr,
                      const float* dinv, int ncols, float c1, float c2, int first, const void* Wprev, int64_t ldp,
                      ds_stream_t stream);
+/* fp32 matrix-core form of ds_spmm_union epilogues 0 and 3 (csrc/spmm_mfma32.inc) - the eigensolver's own products
+ * K W, M W, M X on fp32 blocks of <= 84 columns (reference: torch.sparse.mm in src/lobpcg/_linalg_utils.py:36-37):
+ * one wavefront per group of 4 consecutive nodes, the gathered panels of a batch of DS_MF32_BATCH union entries staged
+ * in LDS as the B operand of v_mfma_f32_16x16x4_f32 (exact fp32: one rounding per product), the 3x3 blocks (epilogue 0:
+ * `vals` = nblocks x 9 floats, row-major blocks) or node-scalar values (epilogue 3: nblocks floats) of the batch staged
+ * beside them and spread over the 16 x 4 A tile.  Tables as for ds_spmm_union16m but for groups of 4 nodes (gmeta = 4-bit
+ * presence mask | first block inside the group << 8), values in the tables' (group, entry, node) order with at least 16
+ * bytes of slack behind the last block (vals_bytes = the readable size); max_batch_blocks = the largest number of blocks
+ * in DS_MF32_BATCH consecutive entries of a group (batches counted from the group's first entry).  Per output element
+ * the products are summed in ONE chain in entry order - the same precision as ds_spmm_union, whose three chains (one per
+ * panel row) are added at the end: results agree to fp32 rounding, not bit for bit.  level_tag as in ds_level_t. */
+#define DS_MF32_BATCH 8
+int ds_spmm_union32m(int epilogue, int level_tag, const int32_t* gptr, const int32_t* gcol, const int32_t* gmeta,
+                     const int32_t* gbase, const float* vals, int64_t vals_bytes, int64_t nblocks, int64_t ngroups,
+                     int max_entries, int max_batch_blocks, int64_t nv, const float* X, int64_t ldx, float* Y, int64_t ldy,
+                     int ncols, ds_stream_t stream);
 int ds_cheb_init16(const void* R, int r_f32, int64_t ldr, void* W, int64_t ldw, void* Rcopy, int64_t ldc,
                    const float* dinv, int64_t nv, int ncols, float c, ds_stream_t stream);
 int ds_scalar_csr_spmm16(const int32_t* rowptr, const int32_t* colidx, const float* w, int64_t nrows, const void* X,

@@ -435,7 +435,7 @@ def test_mfma_union_terms_match_valu_terms(dev, mesh, ncols, G, order):
                                      0.77, int(first), p(wprev), 0 if wprev is None else ncols, _hip.stream_ptr()), "ds_spmm_union16")
 
     def mfma(epi, out, y32, first, wprev=None):
-        _hip.check(L.ds_spmm_union16m(epi, G, p(mt["gptr"]), p(mt["gcol"]), p(mt["gmeta"]), p(mt["gbase"]), p(kc), sysd.nnzb,
+        _hip.check(L.ds_spmm_union16m(epi, G, 0, p(mt["gptr"]), p(mt["gcol"]), p(mt["gmeta"]), p(mt["gbase"]), p(kc), sysd.nnzb,
                                       mt["ngroups"], mt["max_entries"], mt["max_batch_blocks"], sysd.nv, p(X), ncols, p(out), out.stride(0), int(y32), p(R0),
                                       ncols, p(ops.dinv), ncols, 0.31, 0.77, int(first), p(wprev), 0 if wprev is None else ncols,
                                       _hip.stream_ptr()), "ds_spmm_union16m")
@@ -464,6 +464,92 @@ def test_mfma_union_terms_match_valu_terms(dev, mesh, ncols, G, order):
     assert torch.equal(br, br2)  # deterministic
 
 
+@pytest.mark.parametrize("mesh,order,ncols", [(6, 2, 80), (6, 2, 40), (6, 2, 84), (6, 2, 52), (3, 2, 80), (10, 2, 80), (5, 2, 16),
+                                              (12, 1, 80), (26, 1, 80), (2, 1, 8), (3, 1, 4)])
+def test_mfma32_products_match_fp64_product_and_valu_kernel(dev, mesh, order, ncols):
+    """ds_spmm_union32m (the eigensolver's own fp32 products on v_mfma_f32_16x16x4_f32, one wave per 4 nodes, batches of 8
+    union entries) against an fp64-value / fp64-accumulation product of the same fp32 operands, beside the VALU
+    neighbour-union kernel it replaces: K X (3x3 blocks) and M X (node-scalar values), strided views of a wider buffer
+    whose margins must stay untouched, meshes whose last group is incomplete, groups with one and with many batches,
+    ord-1 meshes (the corner-node level's kind).  The MFMA form sums each output in ONE fp32 chain (entry order), the VALU
+    form in three (one per panel row): same precision, not the same bits."""
+    from diffsound_amd import _hip, meshgen
+    from diffsound_amd.diffelastic.mesh import TetMesh
+    from diffsound_amd.modal_ops import HipModalOps, TetSystem
+
+    v, t = meshgen.kuhn_box(mesh)
+    tm = TetMesh(torch.from_numpy(v).to(dev), torch.from_numpy(t).long().to(dev)).to_high_order(order)
+    sysd = TetSystem(tm.vertices, tm.tets, order, 2700.0)
+    lam, mu = 2e10, 3e10
+    ops = HipModalOps(sysd, lam, mu, two_level=False, mfma32=True)
+    m4 = ops._mfma32
+    assert m4 is not None and m4["G"] == 4 and m4["batch"] == 8 and m4["ngroups"] == (sysd.nv + 3) // 4
+    assert int(m4["gptr"][-1]) == m4["gcol"].numel()
+    # the packed values: blocks (row-major, NOT transposed) and node scalars in the tables' order, finite slack behind them
+    kp = m4["kperm"].long()
+    assert torch.equal(ops.k4[:sysd.nnzb * 9].view(-1, 9), ops.k32[kp]) and torch.equal(ops.m4[:sysd.nnzb], ops.ms32[kp])
+    assert float(ops.k4[sysd.nnzb * 9:].abs().max()) == 0.0 and float(ops.m4[sysd.nnzb:].abs().max()) == 0.0
+    g = torch.Generator(device=dev).manual_seed(ncols + mesh)
+    big = torch.full((sysd.n, ncols + 12), float("nan"), device=dev)
+    X = big[:, 8:8 + ncols]
+    X.copy_(torch.randn((sysd.n, ncols), generator=g, device=dev))
+    Xc = X.contiguous()
+    # reference: the fp32 values both kernels multiply by, products and sums in fp64 (ds_spmm_bsr3 kinds 2 / 3)
+    for epi, vals64, kind in ((0, ops.k32.double().contiguous(), 2), (3, ops.ms32.double().contiguous(), 3)):
+        ref = torch.empty((sysd.n, ncols), dtype=torch.float64, device=dev)
+        ops._spmm(kind, vals64, Xc, ref)
+        scale = float(ref.abs().max())
+        outs = {}
+        for name, fn in (("mfma", ops._union32), ("valu", ops._union)):
+            wide = torch.full((sysd.n, ncols + 8), float("nan"), device=dev)
+            fn(epi, X, wide[:, 4:4 + ncols])
+            assert bool(torch.isnan(wide[:, :4]).all()) and bool(torch.isnan(wide[:, 4 + ncols:]).all()), name
+            outs[name] = wide[:, 4:4 + ncols].double()
+            assert bool(torch.isfinite(outs[name]).all()), name
+        e_m = float((outs["mfma"] - ref).abs().max()) / scale
+        e_v = float((outs["valu"] - ref).abs().max()) / scale
+        assert e_m < 1e-6 and e_m < 3 * e_v + 1e-7, (epi, e_m, e_v)
+        again = torch.empty((sysd.n, ncols), device=dev)
+        ops._union32(epi, X, again)
+        assert torch.equal(again.double(), outs["mfma"])  # deterministic
+    # the ops' own entry points take the matrix-core form
+    Y = torch.empty((sysd.n, ncols), device=dev)
+    ops.apply_K(X, Y)
+    Y2 = torch.empty_like(Y)
+    ops._union32(0, X, Y2)
+    assert torch.equal(Y, Y2)
+
+
+def test_mfma32_entry_point_refuses_what_it_does_not_serve(dev):
+    """ds_spmm_union32m validates on the host before any launch."""
+    from diffsound_amd import _hip, meshgen
+    from diffsound_amd.diffelastic.mesh import TetMesh
+    from diffsound_amd.modal_ops import HipModalOps, TetSystem
+
+    v, t = meshgen.kuhn_box(4)
+    tm = TetMesh(torch.from_numpy(v).to(dev), torch.from_numpy(t).long().to(dev)).to_high_order(2)
+    sysd = TetSystem(tm.vertices, tm.tets, 2, 2700.0)
+    ops = HipModalOps(sysd, 2e10, 2e10, two_level=False, mfma32=True)
+    m4, L, p = ops._mfma32, _hip.lib(), _hip.ptr
+    X = torch.randn(sysd.n, 80, device=dev)
+    Y = torch.empty_like(X)
+
+    def call(epi=0, tag=0, vals=None, vbytes=None, ngroups=None, max_entries=None, mbb=None, x=X, y=Y, ncols=80):
+        vals = (ops.m4 if epi == 3 else ops.k4) if vals is None else vals
+        return L.ds_spmm_union32m(epi, tag, p(m4["gptr"]), p(m4["gcol"]), p(m4["gmeta"]), p(m4["gbase"]), p(vals),
+                                  vals.numel() * 4 if vbytes is None else vbytes, sysd.nnzb,
+                                  m4["ngroups"] if ngroups is None else ngroups, m4["max_entries"] if max_entries is None else max_entries,
+                                  m4["max_batch_blocks"] if mbb is None else mbb, sysd.nv, p(x), x.stride(0), p(y), y.stride(0), ncols,
+                                  _hip.stream_ptr())
+
+    assert call() == 0 and call(epi=3) == 0 and call(tag=1) == 0
+    for bad in (dict(epi=1), dict(epi=2), dict(tag=2), dict(vbytes=sysd.nnzb * 36), dict(ngroups=m4["ngroups"] + 1), dict(max_entries=257),
+                dict(mbb=0), dict(mbb=33), dict(y=X), dict(ncols=88), dict(ncols=78), dict(x=X[:, 1:])):
+        assert call(**bad) != 0, bad
+        assert L.ds_last_error()
+    torch.cuda.synchronize()
+
+
 def test_mfma_entry_point_refuses_what_it_does_not_serve(dev):
     """ds_spmm_union16m validates on the host before any launch: group size, table limits, aliasing, alignment."""
     from diffsound_amd import _hip, meshgen
@@ -479,7 +565,7 @@ def test_mfma_entry_point_refuses_what_it_does_not_serve(dev):
     Y, R0 = torch.empty_like(X), torch.empty_like(X)
 
     def call(G=8, max_entries=None, mbb=None, x=X, y=Y, ncols=80, epi=1, dinv=ops.dinv, y32=0):
-        return L.ds_spmm_union16m(epi, G, p(mt["gptr"]), p(mt["gcol"]), p(mt["gmeta"]), p(mt["gbase"]), p(ops.kc), sysd.nnzb,
+        return L.ds_spmm_union16m(epi, G, 0, p(mt["gptr"]), p(mt["gcol"]), p(mt["gmeta"]), p(mt["gbase"]), p(ops.kc), sysd.nnzb,
                                   (sysd.nv + G - 1) // G, mt["max_entries"] if max_entries is None else max_entries,
                                   mt["max_batch_blocks"] if mbb is None else mbb, sysd.nv, p(x), x.stride(0), p(y), y.stride(0), y32,
                                   p(R0), 80, None if dinv is None else p(dinv), ncols, 0.3, 0.7, 0, None, 0, _hip.stream_ptr())

@@ -15,7 +15,7 @@ cells = int(sys.argv[1]) if len(sys.argv) > 1 else 26
 v, t = meshgen.kuhn_box(cells)
 mesh = TetMesh(torch.from_numpy(v).to(dev), torch.from_numpy(t).long().to(dev)).to_high_order(2)
 sysd = TetSystem(mesh.vertices, mesh.tets, 2, 2700.0)
-ops = HipModalOps(sysd, 2e10, 2e10, two_level=False, mfma_groups=(0, 0))
+ops = HipModalOps(sysd, 2e10, 2e10, two_level=False, mfma_groups=(0, 0), mfma32=True)
 X, Y = torch.randn(sysd.n, 80, device=dev), torch.empty(sysd.n, 80, device=dev)
 W, R0 = torch.randn(sysd.n, 80, device=dev), torch.randn(sysd.n, 80, device=dev)
 
@@ -32,6 +32,12 @@ def timeit(fn, label, reps=30):
     print(f"{label}: {e0.elapsed_time(e1) / reps * 1e3:.1f} us", flush=True)
 
 
-timeit(lambda: ops.apply_K(X, Y), "K X  (80 columns, fp32)")
-timeit(lambda: ops.apply_M(X, Y), "M X  (80 columns, fp32)")
+timeit(lambda: ops._union(0, X, Y), "K X  (80 columns, fp32, VALU union kernel)")
+timeit(lambda: ops._union(3, X, Y), "M X  (80 columns, fp32, VALU union kernel)")
+if ops._mfma32 is not None:
+    timeit(lambda: ops._union32(0, X, Y), "K X  (80 columns, fp32, matrix cores)")
+    timeit(lambda: ops._union32(3, X, Y), "M X  (80 columns, fp32, matrix cores)")
+    m4 = ops._mfma32
+    print("4-node unions: entries", m4["gcol"].numel(), "blocks", sysd.nnzb, "max entries / group", m4["max_entries"],
+          "max blocks / batch", m4["max_batch_blocks"], flush=True)
 timeit(lambda: ops._cheb_spmm_launch(X, W, R0, 0.3, 0.7, False), "fused Chebyshev term (fp32)")

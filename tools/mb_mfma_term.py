@@ -38,7 +38,7 @@ def valu():
 
 
 def mfma():
-    _hip.check(L.ds_spmm_union16m(1, G, p(mt["gptr"]), p(mt["gcol"]), p(mt["gmeta"]), p(mt["gbase"]), p(kc), sysd.nnzb, mt["ngroups"],
+    _hip.check(L.ds_spmm_union16m(1, G, 0, p(mt["gptr"]), p(mt["gcol"]), p(mt["gmeta"]), p(mt["gbase"]), p(kc), sysd.nnzb, mt["ngroups"],
                                   mt["max_entries"], mt["max_batch_blocks"], sysd.nv, p(X), ncols, p(W), ncols, 0, p(R0), ncols, p(ops.dinv), ncols, 0.3, 0.7,
                                   0, None, 0, _hip.stream_ptr()), "ds_spmm_union16m")
 
