@@ -119,6 +119,10 @@ def parse():
     ap.add_argument("--cpu-sample-cells", type=int, default=8,
                     help="the CPU oracle runs ONE full pass on a Kuhn box of this many cells per edge (8 -> 3072 tets, the "
                          "smallest ord-2 size of BASELINE.md section 3; 12 takes several minutes)")
+    ap.add_argument("--cpu-second-cells", type=int, default=12,
+                    help="a SECOND measured size of the CPU oracle (one pass; 12 -> 10 368 tets, about a minute on the GPU box's "
+                         "host): the line then carries a measured scaling exponent between the two sizes instead of only the "
+                         "linear extrapolation; 0 = skip")
     return ap.parse_args()
 
 
@@ -183,27 +187,49 @@ def relaunch_as_ranks(a):
     sys.exit(subprocess.call(cmd, env=env))
 
 
-def cpu_baseline(sample_cells, order, modes, full_tets, reps=3):
+def cpu_baseline(sample_cells, order, modes, full_tets, reps=3, second_cells=0):
     """The CPU oracle timed in a FRESH CHILD PROCESS (its own BLAS / OpenMP state: nothing the GPU run did to the
     process - thread limits, pinned memory, lane threads - can skew it), ``reps`` full passes; ``value`` = 1 / median."""
     nthreads = min(os.cpu_count() or 1, 16)
     env = dict(os.environ)
     env["OMP_NUM_THREADS"] = env["OPENBLAS_NUM_THREADS"] = env["MKL_NUM_THREADS"] = str(nthreads)
     env["HIP_VISIBLE_DEVICES"] = env["CUDA_VISIBLE_DEVICES"] = ""  # the child never touches the GPU
-    runs = []
-    for _ in range(max(1, reps)):
+    def child(cells):
         out = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-child", "--cpu-sample-cells",
-                              str(sample_cells), "--order", str(order), "--modes", str(modes), "--cells",
+                              str(cells), "--order", str(order), "--modes", str(modes), "--cells",
                               str(round((full_tets / 6) ** (1 / 3)))], capture_output=True, text=True, env=env, cwd=ROOT)
         if out.returncode != 0:
             raise SystemExit("bench.py: CPU baseline child failed:\n" + out.stderr[-2000:])
-        runs.append(json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]))
+        return json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+
+    runs = [child(sample_cells) for _ in range(max(1, reps))]
     secs = sorted(r["sample_seconds"] for r in runs)
     med = runs[[r["sample_seconds"] for r in runs].index(secs[len(secs) // 2])]
     med = dict(med)
     med["repetitions"] = len(runs)
     med["sample_seconds_all"] = [round(r["sample_seconds"], 3) for r in runs]
     med["sample"] = med["sample"] + f" (median of {len(runs)} passes, each in a fresh process: {med['sample_seconds_all']} s)"
+    if second_cells and second_cells > sample_cells:
+        # BASELINE.md section 3 (ii): the FAITHFUL restatement's measured scaling between two sizes on this host, and the
+        # benchmark-mesh time extrapolated with the measured exponent (still optimistic: ARPACK's LU grows as n^2.5 between
+        # 10k and 25k tets, profiles/r03_cpu_memsafe_*_container.json); (i) - a measured pass at the benchmark mesh - is about
+        # 7 hours of shift-invert alone and is not attempted
+        big = child(second_cells)
+        n0 = int(med["unit"].split(" at ")[1].split(" tets")[0])
+        n1 = int(big["unit"].split(" at ")[1].split(" tets")[0])
+        p = float(np.log(big["sample_seconds"] / med["sample_seconds"]) / np.log(n1 / n0))
+        t_full = big["sample_seconds"] * (full_tets / n1) ** max(p, 1.0)
+        med["second_size"] = {"tets": n1, "sample_seconds": big["sample_seconds"], "stage_seconds": big["stage_seconds"],
+                              "value": big["value"], "unit": big["unit"]}
+        med["measured_exponent"] = {"value": p, "between_tets": [n0, n1],
+                                    "what": "d log(seconds per pass) / d log(tets) of the faithful CPU restatement on this host"}
+        med["extrapolated_to_benchmark_mesh_measured_exponent"] = {
+            "value": 1.0 / t_full, "unit": "passes/s", "seconds_per_pass": t_full,
+            "how": (f"{big['sample_seconds']:.1f} s at {n1} tets x ({full_tets} / {n1}) ^ {max(p, 1.0):.2f} - BASELINE.md section 3 (ii), "
+                    "the faithful restatement's curve; (i), a measured pass at the benchmark mesh, is infeasible (hours of "
+                    "shift-invert LU, > 58 GB)")}
+        med["sample"] += (f"; second size {second_cells}^3 cells ({n1} tets): {big['sample_seconds']:.1f} s -> measured exponent "
+                          f"{p:.2f} in the tet count")
     return med
 
 
@@ -295,7 +321,7 @@ def main_c5(a):
     from diffsound_amd.diffelastic.mesh import TetMesh
     from diffsound_amd.lobpcg.modal_solver import ModalSolver, SolverConfig
     from diffsound_amd.modal_ops import HipModalOps, TetSystem
-    from oracle import fem  # (Lame constants only)
+    from diffsound_amd.diffelastic.diff_model import _lame
 
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
@@ -304,7 +330,7 @@ def main_c5(a):
     t0 = time.time()
     mesh = TetMesh(torch.from_numpy(v).to(dev), torch.from_numpy(t).long().to(dev)).to_high_order(2)
     sysd = TetSystem(mesh.vertices, mesh.tets, 2, MAT[0])
-    lam, mu = fem.lame(MAT[1], MAT[2])
+    lam, mu = (float(x) for x in _lame(MAT[1], MAT[2]))
     ops = HipModalOps(sysd, lam, mu)
     torch.cuda.synchronize()
     t_setup = time.time() - t0
@@ -353,8 +379,15 @@ def main_c5(a):
            "spmm_union_mfma_kernel: the preconditioner's term on the matrix cores")
     del Xb, Wb, Rb
     X64, Y64 = torch.randn((n, 80), device=dev, dtype=torch.float64), torch.empty((n, 80), device=dev, dtype=torch.float64)
-    record("K X fp64 values and vectors, 80 columns", 2 * nnzb * 76 + 2 * (nv + 1) * 4 + 4 * n * 80 * 8,
-           timed(lambda: ops.apply_K64(X64, Y64), 2), "two spmm_f64_node launches (K_lambda, K_mu) + combination: the refinement's K W")
+    record("K X fp64 values and vectors, 80 columns, term by term", 2 * nnzb * 76 + 2 * (nv + 1) * 4 + 4 * n * 80 * 8,
+           timed(lambda: ops.apply_K64(X64, Y64), 2), "two spmm_f64_node launches (K_lambda, K_mu) + combination")
+    ops.combined_k64(True)
+    try:
+        ops.apply_K64(X64, Y64)  # (forms the combined array)
+        record("K X fp64 values and vectors, 80 columns", nnzb * 76 + (nv + 1) * 4 + 2 * n * 80 * 8,
+               timed(lambda: ops.apply_K64(X64, Y64), 2), "one spmm_f64_node launch on the combined fp64 K array: the refinement's K W")
+    finally:
+        ops.combined_k64(False)
     record("M X fp64 values and vectors, 80 columns", nnzb * 12 + (nv + 1) * 4 + 2 * n * 80 * 8,
            timed(lambda: ops.apply_M64(X64, Y64), 2), "spmm_f64_node, node-scalar values")
     del X64, Y64
@@ -585,7 +618,12 @@ def main():
         fi_a, eb_a = (fl_a & 1).astype(np.float64), (fl_a >> 8).astype(np.float64)  # `first` flag, bytes per vector element
         # algorithmic bytes of a fused term (HipModalOps.cheb_term_bytes): values + ids, row pointers, block-Jacobi blocks,
         # W_k gathered, R0 and W_{k-1} read (not when `first`), W_{k+1} written
-        by_all = nz_a * 40 + (nv_a + 1) * 4 + nv_a * 36 + (4 - fi_a) * 3 * nv_a * nc_a * eb_a
+        # (9 values + one int32 id per block; the values count 2 bytes each where the level's bf16 term
+        # runs on the matrix cores - the same rule as cheb_term_bytes)
+        mf_levels = {int(o.nv) for o in (lane_ops[0], getattr(lane_ops[0], "coarse", None))
+                     if o is not None and o._mfma is not None and o.kc is not None}
+        vb_a = np.where((eb_a == 2) & np.isin(nv_a.astype(np.int64), sorted(mf_levels)), 2.0, 4.0)
+        by_all = nz_a * (9 * vb_a + 4) + (nv_a + 1) * 4 + nv_a * 36 + (4 - fi_a) * 3 * nv_a * nc_a * eb_a
         full = nc_a == a.block  # full-width blocks (after locking the narrower ones run another instantiation)
         ms, nbytes = ms_all[full], by_all[full]
         achieved = float(nbytes.sum() / (ms.sum() * 1e-3) / 1e9)
@@ -747,7 +785,7 @@ def main():
             "collective": (f"{a.dist_backend} all-reduce of the scalar loss over {world} ranks" if world > 1 else "none (1 rank)"),
         }
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(a.cpu_sample_cells, a.order, a.modes, sysd.T, a.cpu_reps)
+            out["cpu_baseline"] = cpu_baseline(a.cpu_sample_cells, a.order, a.modes, sysd.T, a.cpu_reps, a.cpu_second_cells)
         print(json.dumps(out))
     if world > 1:
         barrier()  # rank 0's solo kernel timings above ran while the others wait here (a shared device stays quiet)

@@ -217,13 +217,10 @@ int launch_mix(const float* A, int64_t lda, int p, const float* C, int q, float*
         __builtin_amdgcn_sched_barrier(0);  \
     } while (0)
 
-// DS_KOM: knock-out builds for tools/exp_knockout_mix.sh (1 no loads of A after the first two k-steps, 2 no LDS reads of the
-// coefficients after them, 4 no MFMAs); 0 in the product.  Result (profiles/r03_mix_knockout.txt): 240 -> 80 whole 0.207 ms,
-// MFMAs alone 0.194, loads alone 0.160; 240 -> 160 whole 0.370, MFMAs alone 0.337, loads alone 0.222 - the kernel runs at the
-// rate its MFMA loop issues alone (88-102 TF/s; the instruction sustains 134-138 TF/s in tools/mfma_rate_probe.hip)
-#ifndef DS_KOM
-#define DS_KOM 0
-#endif
+// (knock-out builds of round 3 - no loads of A / no LDS reads of the coefficients / no MFMAs, profiles/r03_mix_knockout.txt,
+// made from the sources of commit 81379de: 240 -> 80 whole 0.207 ms, MFMAs alone 0.194, loads alone 0.160; 240 -> 160 whole
+// 0.370, MFMAs alone 0.337, loads alone 0.222 - the kernel runs at the rate its MFMA loop issues alone, 88-102 TF/s; the
+// instruction sustains 134-138 TF/s in tools/mfma_rate_probe.hip)
 constexpr int MIX_NW = 8;  // waves per workgroup sharing one LDS copy of C (2 workgroups per CU -> 4 waves per SIMD)
 
 using u4 = __attribute__((ext_vector_type(4))) unsigned;
@@ -281,14 +278,12 @@ __global__ void __launch_bounds__(64 * MIX_NW)
         auto fetch = [&](f4 (&a)[RT], f4 (&b)[JT], int step) {
 #pragma unroll
             for (int t = 0; t < RT; ++t) {
-                if ((DS_KOM & 1) && step > 1) { asm volatile("" : "+v"(a[t])); continue; }
                 const u4 raw = __builtin_amdgcn_raw_buffer_load_b128(rs, voff[t] + (unsigned)step * 64u, 0, 0);
                 a[t] = __builtin_bit_cast(f4, raw);
             }
             const int sb = min(step, nstep - 1);  // the fetch past the last step re-reads it (never used)
 #pragma unroll
             for (int j = 0; j < JT; ++j) {
-                if ((DS_KOM & 2) && step > 1) { asm volatile("" : "+v"(b[j])); continue; }
                 b[j] = sc4[(sb * 4 + lq) * W + j * 16 + li];
             }
         };
@@ -299,13 +294,6 @@ __global__ void __launch_bounds__(64 * MIX_NW)
             f4 am[RT];
 #pragma unroll
             for (int t = 0; t < RT; ++t) am[t] = kv ? a[t] : f4{0.f, 0.f, 0.f, 0.f};
-            if (DS_KOM & 4) {
-#pragma unroll
-                for (int t = 0; t < RT; ++t) asm volatile("" :: "v"(am[t]));
-#pragma unroll
-                for (int j = 0; j < JT; ++j) asm volatile("" :: "v"(b[j]));
-                return;
-            }
 #pragma unroll
             for (int s_ = 0; s_ < 4; ++s_)
 #pragma unroll
@@ -316,7 +304,6 @@ __global__ void __launch_bounds__(64 * MIX_NW)
         };
         f4 a0[RT], a1[RT], b0[JT], b1[JT];
         fetch(a0, b0, 0);
-        if (DS_KOM) fetch(a1, b1, 1);
         // scheduling barriers: the operands of step + 1 are requested BEFORE the MFMAs of step issue and waited
         // for after them (left alone, the compiler gathered the requests of two steps behind the MFMAs and met
         // them with vmcnt(0) at the loop head)

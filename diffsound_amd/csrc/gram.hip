@@ -260,33 +260,26 @@ __device__ __forceinline__ void gram32_tile(__amdgpu_buffer_rsrc_t ra, __amdgpu_
     // the reloads in between the MFMAs and the entry/back-edge merge then produced vmcnt(8): the ring drained
     // once per turn, 75 TF/s).
     __builtin_amdgcn_sched_barrier(0);
-    // DS_KOG: knock-out builds for tools/exp_knockout_gram.sh (1 no folds in the loop, 2 no operand loads in the loop, 4 no MFMAs);
-    // 0 in the product.  Result at 240 x 80 (profiles/r03_gram_knockout.txt): whole 0.225-0.234 ms, MFMAs alone 0.168, loads
-    // alone 0.208 - the operand loads (every wave reads its own copy of B: 896 floats per mesh row against 320) are the bound,
-    // the folds are hidden; keeping the four waves of a workgroup in step with a barrier per ring turn changed nothing
-#ifndef DS_KOG
-#define DS_KOG 0
-#endif
-#define KOG_LOAD(t_, b_) do { if (!(DS_KOG & 2)) load(t_, b_); else asm volatile("" : "+v"(t_.a[0][0]), "+v"(t_.b[0][0])); } while (0)
-#define KOG_MFMA(t_) do { if (!(DS_KOG & 4)) mfma(t_); else { asm volatile("" :: "v"(t_.a[0][0]), "v"(t_.b[KS-1][0]), "v"(t_.a[KS-1][NA-1])); for (int s_ = 0; s_ < KS; ++s_) { asm volatile("" :: "v"(t_.a[s_][0]), "v"(t_.b[s_][0]), "v"(t_.b[s_][NB1-1]), "v"(t_.c[s_][0])); } } } while (0)
-    if (DS_KOG & 2) load(t2, 2);
+    // (knock-out builds of round 3 - no folds / no operand loads / no MFMAs, profiles/r03_gram_knockout.txt, made from the
+    // sources of commit 81379de - at 240 x 80: whole 0.225-0.234 ms, MFMAs alone 0.168, loads alone 0.208: the operand loads
+    // (every wave reads its own copy of B: 896 floats per mesh row against 320) are the bound, the folds are hidden; keeping
+    // the four waves of a workgroup in step with a barrier per ring turn changed nothing)
     for (int t = 0; t < nbatch; t += 3) {
-        KOG_LOAD(t2, t + 2);
+        load(t2, t + 2);
         __builtin_amdgcn_sched_barrier(0);
-        KOG_MFMA(t0);
+        mfma(t0);
         __builtin_amdgcn_sched_barrier(0);
-        KOG_LOAD(t0, t + 3);
+        load(t0, t + 3);
         __builtin_amdgcn_sched_barrier(0);
-        KOG_MFMA(t1);
+        mfma(t1);
         __builtin_amdgcn_sched_barrier(0);
-        KOG_LOAD(t1, t + 4);
+        load(t1, t + 4);
         __builtin_amdgcn_sched_barrier(0);
-        KOG_MFMA(t2);
+        mfma(t2);
         __builtin_amdgcn_sched_barrier(0);
-        if (!(DS_KOG & 1)) fold();  // every 48 rows
+        fold();  // every 48 rows
         __builtin_amdgcn_sched_barrier(0);
     }
-    if (DS_KOG & 1) fold();
     // fp32 C/D map: lane holds rows 4*(lane>>4) + g, column lane&15 of each MFMA tile
 #pragma unroll
     for (int a = 0; a < NA; ++a)

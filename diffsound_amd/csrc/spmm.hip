@@ -19,6 +19,7 @@
 #include <vector>
 
 #include "ds_common.h"
+#include "ds_diag.h"
 
 namespace {
 
@@ -1001,9 +1002,12 @@ extern "C" int ds_spmm_union32m(int epilogue, int level_tag, const int32_t* gptr
 #undef DS_M32_GO
 }
 
-#ifdef DS_M32_DIAG
+#ifdef DS_DIAG
 extern "C" int ds_m32_diag(unsigned long long* out, int nwaves) {  // diagnostic build only: out[nwaves][8]
     return ds::check_hip(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_m32_dbg), (size_t)nwaves * 8 * sizeof(unsigned long long)), "ds_m32_diag read");
+}
+extern "C" int ds_mf_diag(unsigned long long* out, int nwaves) {  // the bf16 term kernel's records
+    return ds::check_hip(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_mf_dbg), (size_t)nwaves * 8 * sizeof(unsigned long long)), "ds_mf_diag read");
 }
 #endif
 

@@ -160,8 +160,13 @@ def _orthonormal_columns(Tm):
 class _one_thread:
     """LAPACK on <= 3b x 3b matrices is fastest single-threaded (measured on the MI355X host: 240 x 240
     fp64 eigh 2.5 ms with 1 thread, no faster with 2-8, 150 ms with the default 128 threads; rocSOLVER's
-    launch-bound syevd takes 5.7 ms).  Re-entrant across the worker threads of concurrent solves: the
-    process-wide thread count is lowered by the first solve that enters and restored by the last that leaves."""
+    launch-bound syevd takes 5.7 ms).  Re-entrant across the worker threads of concurrent solves.
+    ``torch.set_num_threads`` is PER CALLING THREAD for what matters here (omp_set_num_threads and
+    mkl_set_num_threads_local): every thread that enters lowers ITS OWN count; the last one that leaves restores the
+    saved value (for itself and as torch's process-wide default).  Until round 4 only the first thread to enter lowered
+    a count - its own - and the other hypothesis lanes ran their small LAPACK steps on however many threads they happened
+    to have: slow, and the reason two identical 8-lane runs could differ in the last bits of a gradient
+    (tests/test_fullsize_gpu.py::test_c3_eight_lanes_are_bit_identical_from_run_to_run)."""
 
     _lock = threading.Lock()
     _depth = 0
@@ -172,8 +177,8 @@ class _one_thread:
         with cls._lock:
             if cls._depth == 0:
                 cls._saved = torch.get_num_threads()
-                torch.set_num_threads(1)
             cls._depth += 1
+        torch.set_num_threads(1)
 
     def __exit__(self, *a):
         cls = _one_thread
@@ -675,7 +680,11 @@ class ModalSolver:
         res = self._polish(X, k, it, rel[:k].clone(), history)
         res.coarse_iterations = self.nested_iterations
         if cfg.refine_tol > 0.0:
-            res = self.refine64(res, k, float(A_norm), float(B_norm))
+            try:
+                res = self.refine64(res, k, float(A_norm), float(B_norm))
+            finally:  # (a step that raises must not leave the combined fp64 K array cached for a later material)
+                if hasattr(self.ops, "combined_k64"):
+                    self.ops.combined_k64(False)
         return res
 
     # ------------------------------------------------------------------ fp64 refinement

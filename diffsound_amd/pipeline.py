@@ -118,6 +118,21 @@ class ModalPipeline:
             return self._readout_native(holder, model, res, backward)
         return self._readout_torch(holder, model, res, backward)
 
+    def _call_loss(self, audio, damped_freq):
+        import inspect
+
+        takes = getattr(self, "_loss_takes_freq", None)
+        if takes is None:
+            try:
+                params = inspect.signature(self.loss_fn.forward if isinstance(self.loss_fn, nn.Module) else self.loss_fn).parameters
+                takes = "freq" in params
+            except (TypeError, ValueError):
+                takes = False
+            self._loss_takes_freq = takes
+        if takes and damped_freq is not None:
+            return self.loss_fn(audio, self.target, freq=damped_freq)
+        return self.loss_fn(audio, self.target)
+
     def _readout_torch(self, holder, model, res, backward):
         """Steps 3-6 as torch operations with autograd (any loss head, e.g. MSSLoss; also the cross-check of the native path)."""
         lam, mu = model.lame()
@@ -129,7 +144,9 @@ class ModalPipeline:
         if self.target is None:
             loss = (audio ** 2).mean()
         elif self.loss_fn is not None:
-            loss = self.loss_fn(audio, self.target)
+            # (the Sinkhorn head of the reference's MSSLoss wants the damped frequencies beside the audio:
+            # src/ddsp/mss_loss.py:104-117; the l1 / rmse heads ignore them)
+            loss = self._call_loss(audio, getattr(holder.osc, "damped_freq", None))
         else:
             loss = ((audio - self.target) ** 2).mean()
         gE = gnu = float("nan")
@@ -156,6 +173,8 @@ class ModalPipeline:
         ev = res.eigenvalues
         dev = ev.device
         m, S = int(ev.shape[0]), int(osc.sample_num)
+        if m != int(osc.mode_num):  # (the torch path fails the same way, in the bank's reshape)
+            raise ValueError(f"the solve returned {m} modes, the oscillator bank was built for {osc.mode_num}")
         buf = getattr(holder, "_readout_buf", None)
         if buf is None or buf[0].shape[0] != 6 * m or buf[1].shape[0] != 2 * S or buf[0].device != dev:
             buf = (torch.empty(6 * m, dtype=torch.float64, device=dev), torch.empty(2 * S, dtype=torch.float32, device=dev),
@@ -177,6 +196,10 @@ class ModalPipeline:
                                               p(audio), p(freqs), p(work), p(fwork), p(out), _hip.stream_ptr()),
                    "ds_readout_pass")
         host = out.tolist()  # the pass's one synchronisation
+        # what code written against the reference reads off the bank after a forward (oscillator.py:303-305; e.g.
+        # experiments/material_sync_train.py:167): the undamped and damped frequencies of this pass
+        osc.undamped_freq = freqs.reshape(1, m, 1)
+        osc.damped_freq = (work[m:2 * m] / (2 * np.pi)).float().reshape(1, m, 1)  # (work[m:2m]: damped angular frequencies)
         gE, gnu = (host[1], host[2]) if backward else (float("nan"), float("nan"))
         rerr = getattr(res, "_rerr_max", None)
         if rerr is None:
@@ -198,6 +221,19 @@ class _Lane:
         self.stream = torch.cuda.Stream(device=pipe.device)
         self.osc = TraditionalDampedOscillator(pipe.osc._force.clone(), 1, pipe.modes, pipe.osc.sample_num, pipe.osc.sr,
                                                pipe.mat)
+
+
+def _lane_pool(pipe, lanes):
+    """The pipeline's persistent lane threads; a pool that is too small is shut down (its threads and their thread-local
+    pinned staging rings released) before a larger one replaces it."""
+    pool = getattr(pipe, "_lane_pool", None)
+    if pool is None or pool._max_workers < lanes:
+        from concurrent.futures import ThreadPoolExecutor
+
+        if pool is not None:
+            pool.shutdown(wait=True)
+        pool = pipe._lane_pool = ThreadPoolExecutor(max_workers=lanes, thread_name_prefix="ds-lane")
+    return pool
 
 
 def _run_batch(pipe, hyps, lanes=2, warm=None, backward=True):
@@ -235,11 +271,7 @@ def _run_batch(pipe, hyps, lanes=2, warm=None, backward=True):
 
     # persistent worker threads: starting three threads per batch cost 2-9 ms of interpreter-lock hand-offs before the
     # first lane reached its first launch (device idle at every step boundary in the kernel trace)
-    pool = getattr(pipe, "_lane_pool", None)
-    if pool is None or pool._max_workers < lanes:
-        from concurrent.futures import ThreadPoolExecutor
-
-        pool = pipe._lane_pool = ThreadPoolExecutor(max_workers=lanes, thread_name_prefix="ds-lane")
+    pool = _lane_pool(pipe, lanes)
     futures = [pool.submit(work, li) for li in range(min(lanes, n))]
     for f in futures:
         f.result()
@@ -291,6 +323,8 @@ def _run_steps(pipe, hyps, steps, lanes=2, on_step=None, warm_start=False, backw
                 warm = {} if warm_init is None else {i: warm_init[i] for i in range(li, n, lanes)}
                 for s in range(steps):
                     for i in range(li, n, lanes):
+                        if errs:  # another lane failed: stop here instead of running every remaining step first
+                            return
                         E, nu = hyps[i]
                         out[s][i] = pipe.run_pass(E, nu, warm=warm.get(i), backward=backward, _lane=lane)
                         if warm_start:
@@ -306,11 +340,7 @@ def _run_steps(pipe, hyps, steps, lanes=2, on_step=None, warm_start=False, backw
                 errs.append(ex)
                 cond.notify_all()
 
-    pool = getattr(pipe, "_lane_pool", None)
-    if pool is None or pool._max_workers < lanes:
-        from concurrent.futures import ThreadPoolExecutor
-
-        pool = pipe._lane_pool = ThreadPoolExecutor(max_workers=lanes, thread_name_prefix="ds-lane")
+    pool = _lane_pool(pipe, lanes)
     futures = [pool.submit(work, li) for li in range(lanes)]
     try:
         for s in range(steps):

@@ -216,6 +216,45 @@ def test_c3_reproducible(c3):
     assert float((cold.eigenvalues / ref - 1).abs().max()) < 1e-9
 
 
+def test_c3_eight_lanes_are_bit_identical_from_run_to_run(dev):
+    """THE concurrency guard at the benchmark's own shape: the C3 mesh, the benchmark's solver settings, 8 hypotheses on 8
+    lanes (8 streams, 8 host threads, the lanes' kernels sharing the chip), 2 steps without a join - run twice from
+    identical fresh state.  Hypotheses are independent and every kernel is deterministic, so NOTHING may differ: per pass
+    the 64 eigenvalues, the loss, both gradients and the iteration counts are compared bit for bit.  (Round 2's silicon
+    interaction - a foreign MFMA disturbing packed-FP32 arithmetic - showed as exactly this kind of difference.  The
+    looser lanes-against-sequential comparison of tests/test_modal_gpu.py cannot be bit-exact by design: a lane's
+    Chebyshev interval starts from the previous hypothesis ON THAT LANE.)"""
+    import bench
+    from diffsound_amd import meshgen
+    from diffsound_amd.diffelastic.mesh import TetMesh
+    from diffsound_amd.pipeline import ModalPipeline
+
+    v, t = meshgen.kuhn_box(26)
+    mesh = TetMesh(torch.from_numpy(v).to(dev), torch.from_numpy(t).long().to(dev)).to_high_order(2)
+    rng = np.random.default_rng(2024)
+    hyps = [(float(E), float(nu)) for E, nu in zip(rng.uniform(1e10, 1e11, 8), rng.uniform(0.1, 0.4, 8))]
+    runs = []
+    for _ in range(2):
+        pipe = ModalPipeline(mesh.vertices, mesh.tets, 2, 64, MAT, solver_config=bench.solver_config())
+        pipe.assemble()
+        _, _, target = pipe.run_pass(MAT[1], MAT[2], backward=False)
+        pipe.set_target(target)
+        out = pipe.run_steps(hyps, 2, lanes=8)
+        torch.cuda.synchronize()
+        runs.append([[(r.loss, r.grad_E, r.grad_nu, r.iterations, r.coarse_iterations, res.eigenvalues.clone())
+                      for (r, res, _) in step] for step in out])
+        assert len(pipe._lanes) == 8
+        del pipe, out
+        torch.cuda.empty_cache()
+    a, b = runs
+    for s in range(2):
+        for i in range(8):
+            la, lb = a[s][i], b[s][i]
+            assert la[:5] == lb[:5], (s, i, la[:5], lb[:5])
+            assert torch.equal(la[5], lb[5]), (s, i)
+            assert np.isfinite(la[0]) and la[3] < bench.solver_config().maxit
+
+
 @pytest.fixture(scope="module")
 def c5(dev):
     """BASELINE.json configs[4]: 1M-tet ord-2 mesh (55^3 Kuhn cells = 998 250 tets, n = 4.1 M), 128 modes."""

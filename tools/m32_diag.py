@@ -46,3 +46,33 @@ for epi, name in ((0, "K X"), (3, "M X")):
           f"({conc / 1024:.2f} per SIMD)")
     print(f"   cycles per wave {life.mean():.0f} ({life.mean() / clock:.1f} us): head {head.mean():.0f}, per-batch wait + LDS writes + issue "
           f"{wait.mean():.0f}, fragments + MFMAs {m.mean():.0f}, epilogue {tail.mean():.0f}", flush=True)
+
+# the bf16 fused Chebyshev term on the matrix cores (ds_spmm_union16m, groups of 8 nodes), the benchmark's dominant kernel
+from diffsound_amd.modal_ops import MF_BATCH  # noqa: E402
+
+ops8 = HipModalOps(sysd, 2e10, 2e10, two_level=False, mfma_groups=(8, 8))
+mk = lambda: torch.randn(sysd.n, 80, device=dev).bfloat16()
+Wk, Wp, R0 = mk(), mk(), mk()
+L.ds_mf_diag.restype = ctypes.c_int
+L.ds_mf_diag.argtypes = [ctypes.c_void_p, ctypes.c_int]
+for _ in range(20):
+    ops8.cheb_spmm16(Wk, Wp, R0, 0.3, 0.7, False)
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+ops8.cheb_spmm16(Wk, Wp, R0, 0.3, 0.7, False)
+e1.record()
+torch.cuda.synchronize()
+n = ops8._mfma["ngroups"]
+rec = np.zeros((n, 8), dtype=np.uint64)
+L.ds_mf_diag(rec.ctypes.data, n)
+t0, t1, rt, wait, a, m, head, tail = rec.astype(np.float64).T
+life = t1 - t0
+clock = life.sum() / rt.sum() * 100.0
+us = e0.elapsed_time(e1) * 1e3
+conc = life.sum() / clock / us
+print(f"bf16 term (8-node groups, batches of {MF_BATCH}): launch {us:.1f} us by events; in-kernel clock {clock:.0f} MHz; {conc:.0f} waves resident "
+      f"on average ({conc / 1024:.2f} per SIMD)")
+print(f"   cycles per wave {life.mean():.0f} ({life.mean() / clock:.1f} us): head {head.mean():.0f}, per-batch wait + LDS writes + issue "
+      f"{wait.mean():.0f}, fragments + MFMAs {m.mean():.0f}, epilogue {tail.mean():.0f}; batches per group {ops8._mfma['gcol'].numel() / n / MF_BATCH:.1f}",
+      flush=True)
