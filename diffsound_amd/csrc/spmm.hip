@@ -746,7 +746,7 @@ extern "C" int ds_spmm_union(int epilogue, const int32_t* utab, const int32_t* c
     DS_REQUIRE(epilogue != 1 || dinv, "ds_spmm_union: the Chebyshev epilogue needs dinv");
     DS_REQUIRE(nv > 0 && ngroups == (nv + 3) / 4 && nnzb > 0 && ncols > 0 && ncols % 4 == 0 && ncols <= 84,
                "ds_spmm_union: ncols must be a multiple of 4 <= 84 and ngroups = ceil(nv / 4)");
-    DS_REQUIRE(cap_blocks > 0 && cap_blocks <= UN_CAPB, "ds_spmm_union: a chunk of %d blocks exceeds the LDS image (116)", cap_blocks);
+    DS_REQUIRE(cap_blocks > 0 && cap_blocks <= UN_CAPB, "ds_spmm_union: a chunk of %d blocks exceeds the LDS image (DS_UNION_CAP = 140)", cap_blocks);
     DS_REQUIRE(ldx >= ncols && ldy >= ncols && (epilogue == 0 || epilogue == 3 || ldr >= ncols),
                "ds_spmm_union: leading dimension smaller than ncols");
     DS_REQUIRE(X != Y, "ds_spmm_union: X and Y must be different buffers");

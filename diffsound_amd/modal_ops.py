@@ -23,7 +23,7 @@ MF_BATCH = 16  # entries per LDS batch of the MFMA kernel (DS_MF_BATCH of includ
 MF32_BATCH = 8  # entries per LDS batch of the fp32 MFMA kernel (DS_MF32_BATCH), groups of MF32_G = 4 nodes
 MF32_G = 4
 _MFMA_TABLES_LOCK = threading.Lock()
-UNION_CAP = 116  # blocks per chunk of the neighbour-union tables (the kernel's smallest LDS image)
+UNION_CAP = int(os.environ.get("DS_EXP_UNION_CAP", 140))  # (DS_EXP_UNION_CAP: A/B on one box) blocks per chunk of the neighbour-union tables (the kernel's LDS image; DS_UNION_CAP of the header)
 
 
 def _ld(t):

@@ -208,7 +208,7 @@ int ds_pack_groups(const float* vals_t, const int32_t* kperm, int64_t nnzb, floa
  * of their neighbours, so a neighbour panel shared inside the group is gathered once (Morton order: 0.58 x the
  * panel loads of one wavefront per node).  Tables from ds_groups_build - gent (union entries col | mask << 28),
  * kgrp (TRANSPOSED 3x3 blocks in group order, ds_pack_groups) - cut into chunks of whole entries with at most
- * cap_blocks (<= 116) blocks: ctab (nchunks x 4) = (e0, e1, b0, b1), utab (ngroups x 2) = chunk range of each
+ * cap_blocks (<= DS_UNION_CAP = 140) blocks: ctab (nchunks x 4) = (e0, e1, b0, b1), utab (ngroups x 2) = chunk range of each
  * group, ngroups = ceil(nv / 4); utab may be NULL when every group is exactly one chunk (ctab has ngroups rows).
  * epilogue 0: Y <- A X ; 1: Y (= W_prev) <- X + c1 (X - Y) + c2 T (R0 - A X) (first != 0: Y not read) ;
  * (Wprev != NULL, epilogue 1 only: W_prev is read from there and Y is only written - out-of-place form) ;
@@ -216,6 +216,7 @@ int ds_pack_groups(const float* vals_t, const int32_t* kperm, int64_t nnzb, floa
  * matrix).  X and Y distinct, 16-byte aligned rows; operand blocks of 2 GB and more (3 nv ld 4 >= 0x7f000000 bytes)
  * take a variant that builds one buffer descriptor per panel load.
  * (reference: torch.sparse.mm in src/lobpcg/_linalg_utils.py:36-37 and the iK callable of _lobpcg.py:441) */
+#define DS_UNION_CAP 140
 int ds_spmm_union(int epilogue, const int32_t* utab, const int32_t* ctab, int64_t ngroups, int cap_blocks,
                   const int32_t* gent, const float* kgrp, int64_t nnzb, int64_t nv, const float* X, int64_t ldx,
                   float* Y, int64_t ldy, const float* R0, int64_t ldr, const float* dinv, int ncols, float c1, float c2,
