@@ -104,7 +104,8 @@ class LobpcgDesc(ctypes.Structure):
     """ds_lobpcg_t of include/diffsound_hip.h."""
     _i32 = ctypes.c_int32
     _fields_ = [("n", _I64), ("nv", _I64), ("b", _i32), ("k", _i32), ("ny", _i32), ("maxit", _i32), ("lock", _i32),
-                ("ortho_passes", _i32), ("rr_refresh", _i32), ("gram_exact", _i32), ("tol", _D), ("ortho_tol", _D),
+                ("ortho_passes", _i32), ("rr_refresh", _i32), ("gram_exact", _i32), ("kx_fresh", _i32), ("reserved0", _i32),
+                ("tol", _D), ("ortho_tol", _D),
                 ("A_norm", _D), ("B_norm", _D), ("S", _P), ("S2", _P), ("KS", _P), ("KS2", _P), ("R", _P), ("MX", _P),
                 ("MW", _P), ("lds", _I64), ("ldks", _I64), ("ldr", _I64), ("level", LevelDesc), ("mgrp", _P),
                 ("rowptr", _P), ("colidx", _P), ("k32", _P), ("k32t", _P), ("twolevel", ctypes.POINTER(TwoLevelDesc)),

@@ -530,13 +530,17 @@ extern "C" int ds_lobpcg_iterate(ds_lobpcg_t* p, const ds_lapack_t* lapack, ds_s
         if (ncl && (rc = c.copy_cols(c.S2 + ny, lds, c.S + ny, lds, ncl)) != DS_OK) return rc;
         if (2 * na <= 160) {
             if ((rc = c.mix(Sa, lds, sz, ZZ, c.S2 + ny + ncl, lds)) != DS_OK) return rc;
-            if ((rc = c.mix(KSa, ldks, sz, ZZ, c.KS2, ldks)) != DS_OK) return rc;
+            if (!p->kx_fresh && (rc = c.mix(KSa, ldks, sz, ZZ, c.KS2, ldks)) != DS_OK) return rc;
         } else {
             if ((rc = c.mix(Sa, lds, sz, Z1, c.S2 + ny + ncl, lds)) != DS_OK) return rc;
             if ((rc = c.mix(Sa, lds, sz, Zp, c.S2 + ny + b, lds)) != DS_OK) return rc;
-            if ((rc = c.mix(KSa, ldks, sz, Z1, c.KS2, ldks)) != DS_OK) return rc;
-            if ((rc = c.mix(KSa, ldks, sz, Zp, c.KS2 + na, ldks)) != DS_OK) return rc;
+            if (!p->kx_fresh) {
+                if ((rc = c.mix(KSa, ldks, sz, Z1, c.KS2, ldks)) != DS_OK) return rc;
+                if ((rc = c.mix(KSa, ldks, sz, Zp, c.KS2 + na, ldks)) != DS_OK) return rc;
+            }
         }
+        // K X' fresh: one b-column product instead of the 3b -> 2b column update of K [X P W] (K P' is never needed)
+        if (p->kx_fresh && (rc = c.apply_K(c.S2 + ny + ncl, lds, c.KS2, ldks, na)) != DS_OK) return rc;
         std::swap(c.S, c.S2);
         std::swap(c.KS, c.KS2);
         k0 = 0;

@@ -61,6 +61,10 @@ class SolverConfig:
     # the Gram matrix (a third of the SpMM columns, half of the Gram flops).  Every ``rr_refresh``-th
     # iteration recomputes K [X P W] and the whole Gram matrix from the vectors (0 = every iteration).
     rr_refresh: int = 8
+    # K X' of the new Ritz block by ONE product K X' (b columns, 0.19 ms at the benchmark size) instead of the update
+    # [K X' | K P'] = K [X P W] [Z1 Zp] (a 3b -> 2b column mix, 0.37 ms): K P is then never formed - the Gram blocks among X
+    # and P come from the small Ritz algebra and only the residual needs K X - and K X' carries no recurrence error
+    kx_fresh: bool = True
     # storage of the preconditioner's internal blocks (V-cycle iterates, residuals, corner-level vectors): "bf16" halves
     # the bytes of every fused term - the cycle is bound by them - and leaves the outer iteration counts unchanged
     # (fp32 arithmetic in registers; the cycle's input R and output W stay fp32); "fp32" keeps everything in fp32
@@ -659,13 +663,17 @@ class ModalSolver:
             # 240 x 160 coefficient image; with the first, register-only kernel one wide launch was slower than two)
             if 2 * na <= 160:
                 ops.mix(Sa, ZZ, S2[:, ny + ncl:ny + b + na])
-                ops.mix(KSa, ZZ, KS2[:, :2 * na])
+                if not cfg.kx_fresh:
+                    ops.mix(KSa, ZZ, KS2[:, :2 * na])
             else:
                 Z1, Zp = ZZ[:, :na], ZZ[:, na:]
                 ops.mix(Sa, Z1, S2[:, ny + ncl:ny + b])
                 ops.mix(Sa, Zp, S2[:, ny + b:ny + b + na])
-                ops.mix(KSa, Z1, KS2[:, :na])  # K X_new
-                ops.mix(KSa, Zp, KS2[:, na:2 * na])  # K P_new
+                if not cfg.kx_fresh:
+                    ops.mix(KSa, Z1, KS2[:, :na])  # K X_new
+                    ops.mix(KSa, Zp, KS2[:, na:2 * na])  # K P_new
+            if cfg.kx_fresh:
+                ops.apply_K(S2[:, ny + ncl:ny + b], KS2[:, :na])  # K X_new, fresh (K P_new is never needed)
             S, S2 = S2, S
             KS, KS2 = KS2, KS
             k0 = 0

@@ -23,7 +23,7 @@ MF_BATCH = 16  # entries per LDS batch of the MFMA kernel (DS_MF_BATCH of includ
 MF32_BATCH = 8  # entries per LDS batch of the fp32 MFMA kernel (DS_MF32_BATCH), groups of MF32_G = 4 nodes
 MF32_G = 4
 _MFMA_TABLES_LOCK = threading.Lock()
-UNION_CAP = int(os.environ.get("DS_EXP_UNION_CAP", 140))  # (DS_EXP_UNION_CAP: A/B on one box) blocks per chunk of the neighbour-union tables (the kernel's LDS image; DS_UNION_CAP of the header)
+UNION_CAP = 140  # blocks per chunk of the neighbour-union tables (the kernel's LDS image; DS_UNION_CAP of the header)
 
 
 def _ld(t):
@@ -73,15 +73,6 @@ def morton_order(vertices):
     with bricks aligned to the node planes 0.461 / 0.282 (unstructured meshes: unchanged within 1 %)."""
     v = vertices.detach().double()
     nv = v.shape[0]
-    if os.environ.get("DS_EXP_ORDER") == "abs":  # EXPERIMENT (A/B on one box): the curve over raw coordinates, as until round 3
-        lo = v.min(0).values
-        span = (v.max(0).values - lo).max().clamp(min=1e-300)
-        qq = ((v - lo) / span * 1023).round().to(torch.int64).clamp_(0, 1023)
-        key = torch.zeros(nv, dtype=torch.int64, device=v.device)
-        for b in range(10):
-            for a in range(3):
-                key |= ((qq[:, a] >> b) & 1) << (3 * b + a)
-        return torch.argsort(key, stable=True)
     ext = (v.max(0).values - v.min(0).values).clamp(min=1e-300)
     vol = float(ext.prod())
     q, bits = [], 1
@@ -501,6 +492,7 @@ class _HipBlockOps:
         d.n, d.nv, d.b, d.k, d.ny = self.n, self.nv, b, k, ny
         d.maxit, d.lock, d.ortho_passes, d.rr_refresh = cfg.maxit, int(cfg.lock), cfg.ortho_passes, cfg.rr_refresh
         d.gram_exact = int(bool(self.gram_exact))
+        d.kx_fresh = int(bool(getattr(cfg, "kx_fresh", False)))
         d.tol, d.ortho_tol, d.A_norm, d.B_norm = float(tol), float(cfg.ortho_tol), A_norm, B_norm
         d.S, d.S2, d.KS, d.KS2 = S.data_ptr(), S2.data_ptr(), KS.data_ptr(), KS2.data_ptr()
         d.R, d.MX, d.MW = R.data_ptr(), MX.data_ptr(), MW.data_ptr()

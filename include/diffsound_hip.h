@@ -362,6 +362,10 @@ typedef struct {
     int64_t n, nv;            /* n = 3 nv rows */
     int32_t b, k, ny;         /* block width (multiple of 4, <= 84), wanted pairs, rigid columns */
     int32_t maxit, lock, ortho_passes, rr_refresh, gram_exact;
+    int32_t kx_fresh;         /* != 0: K X' of the new Ritz block by ONE product K X' (b columns) instead of the update
+                                 [K X' | K P'] = K [X P W] [Z1 Zp] (3b -> 2b columns) - K P is then never formed: the Gram
+                                 blocks among X and P come from the small Ritz algebra, only the residual needs K X */
+    int32_t reserved0;
     double tol, ortho_tol, A_norm, B_norm;
     float *S, *S2;            /* (n x (ny + 3 b)), leading dimension lds */
     float *KS, *KS2;          /* (n x 3 b), leading dimension ldks */
