@@ -31,7 +31,8 @@ MAT = (2700.0, 5e10, 0.25, 6.0, 1e-7)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md); the STREAM triad below is MEASURED in the run
 
 
-SPMM_SOURCES = ("spmm.hip", "spmm_union.inc", "spmm_mfma.inc", "ds_common.h")
+# (the node ordering and the union tables decide the traffic as much as the kernels do: modal_ops.py is part of the key)
+SPMM_SOURCES = ("spmm.hip", "spmm_union.inc", "spmm_mfma.inc", "spmm_mfma32.inc", "ds_common.h", "ds_diag.h", "../modal_ops.py")
 
 
 def spmm_source_hash():

@@ -757,13 +757,18 @@ class _HipBlockOps:
         c = X.shape[1]
         if (len(kterms) == 2 and kterms[0][0] == 2 and kterms[1][0] == 2 and mkind == 3 and X.dtype == torch.float32
                 and c % 4 == 0 and c <= 84 and X.stride(1) == 1 and (X.data_ptr() | (X.stride(0) * 4)) % 16 == 0):
-            # K_lambda X, K_mu X and M_s X in one walk of the pattern (ds_spmm_f64_polish): one gather of X instead of three
-            Y3 = self._scratch("polish3", (3,) + tuple(X.shape), torch.float64)
+            # K_lambda X, K_mu X and M_s X in one walk of the pattern (ds_spmm_f64_polish): one gather of X instead of three;
+            # the three results sit side by side in ONE (n x 3c) block, so their Gram products with X are one launch that
+            # reads X once (round 4; three launches before)
+            Y3 = self._scratch("polish3", (X.shape[0], 3 * c), torch.float64)
             p = _hip.ptr
+            ya, yb, ym = Y3[:, :c], Y3[:, c:2 * c], Y3[:, 2 * c:]
             _hip.check(self._L.ds_spmm_f64_polish(p(self.rowptr), p(self.colidx), p(kterms[0][1]), p(kterms[1][1]), p(mvals),
-                                                  self.nv, p(X), _ld(X), p(Y3[0]), p(Y3[1]), p(Y3[2]), c, c, _hip.stream_ptr()),
+                                                  self.nv, p(X), _ld(X), p(ya), p(yb), p(ym), 3 * c, c, _hip.stream_ptr()),
                        "ds_spmm_f64_polish")
-            return [self.gram(X, Y3[0]), self.gram(X, Y3[1])], [kterms[0][2], kterms[1][2]], self.gram(X, Y3[2])
+            G3 = self.gram(X, Y3)
+            return ([G3[:, :c].contiguous(), G3[:, c:2 * c].contiguous()], [kterms[0][2], kterms[1][2]],
+                    G3[:, 2 * c:].contiguous())
         Y = self._scratch("polish", X.shape, torch.float64)
         GK, coef = [], []
         for kind, vals, c in kterms:

@@ -8,20 +8,31 @@
 #   <tag>_gram_mix_pmc.json             MFMA counters of the Gram / mix kernels
 #   <tag>_symbolic_phase_timing.txt     tools/time_lift.py: ord-2 lifting + symbolic phase per topology, warm
 #   <tag>_c5_bench.json / _c5_kernel_stats.csv   bench.py --workload c5 (configs[4]) under rocprofv3 --kernel-trace --stats
+#   <tag>_mb_kx.txt / _mb_corner.txt / _m32_diag.txt   the eigensolver's own products alone, the corner-node level, per-wave cycles
 # Copy what is to be judged into profiles/.
+# A gpurun call is capped at 20 minutes: tools/collect_profiles.sh <tag> <part>, part = 1 (bench line + kernel tables + busy
+# fraction), 2 (PMC passes, microbenchmarks, diagnostics), 3 (configs[4]) or all.
 set -e
 tag=${1:-rXX}
+part=${2:-all}
 export TMPDIR=/tmp
 out=gpurun_out
 mkdir -p $out
+if [ $part = 1 ] || [ $part = all ]; then
 python3 bench.py > $out/${tag}_bench_n1.json 2> $out/${tag}_bench_stderr.log
 echo "bench done"; tail -c 300 $out/${tag}_bench_n1.json; echo
+fi
+if [ $part = 1b ] || [ $part = all ]; then
 rm -rf /tmp/prof_b /tmp/prof_l1
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_b -o bench -- python3 bench.py --no-cpu-baseline --steps 8 > $out/${tag}_bench_prof.log 2>&1
+# (about one in ten profiled 8-lane runs ends in a SIGSEGV inside the runtime's launch path under the profiler's hooks -
+# profiles/README.md, "A note on the profiled runs" - so this step gets one more try)
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_b -o bench -- python3 bench.py --no-cpu-baseline --steps 8 > $out/${tag}_bench_prof.log 2>&1 || { echo "profiled run failed, once more"; rm -rf /tmp/prof_b; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_b -o bench -- python3 bench.py --no-cpu-baseline --steps 8 > $out/${tag}_bench_prof.log 2>&1; }
 python3 tools/summarize_prof.py /tmp/prof_b $out/${tag}_bench_kernel_stats.csv --top 45
 python3 tools/gpu_busy.py /tmp/prof_b 0.4 > $out/${tag}_gpu_busy.txt; cat $out/${tag}_gpu_busy.txt  # last 40 % of the run: timed steps only
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_l1 -o bench -- python3 bench.py --no-cpu-baseline --lanes 1 --hyp-per-gpu 2 --steps 4 --warmup 1 > $out/${tag}_bench_prof_l1.log 2>&1
 python3 tools/summarize_prof.py /tmp/prof_l1 $out/${tag}_bench_lanes1_kernel_stats.csv --top 45
+fi
+if [ $part = 2 ] || [ $part = all ]; then
 # PMC bytes of the fused term (two passes: the TCC counters do not fit one)
 for kind in fp32 bf16 mfma kx; do
   rm -rf /tmp/pmc_b
@@ -34,12 +45,23 @@ for kind in fp32 bf16 mfma kx; do
 done
 python3 tools/pmc_bytes.py $tag > $out/${tag}_spmm_pmc_bytes_per_launch.json   # -> profiles/spmm_pmc_bytes_per_launch.json (keyed by the kernel-source hash)
 python3 tools/time_lift.py > $out/${tag}_symbolic_phase_timing.txt 2>&1; cat $out/${tag}_symbolic_phase_timing.txt
+# the eigensolver's own products alone on the device (VALU union kernel and the fp32 matrix-core form), the corner-node level,
+# and the per-wave cycle breakdown of a diagnostic build (make -C diffsound_amd/csrc BUILD=/tmp/build_diag LIB=libds_m32diag.so
+# EXTRA=-DDS_DIAG libds_m32diag.so - built in the container, it travels with the snapshot)
+python3 tools/mb_kx.py 2>&1 | grep -v amdgpu.ids > $out/${tag}_mb_kx.txt; cat $out/${tag}_mb_kx.txt
+python3 tools/mb_corner_time.py 2>&1 | grep -v amdgpu.ids > $out/${tag}_mb_corner.txt; cat $out/${tag}_mb_corner.txt
+if [ -f diffsound_amd/csrc/libds_m32diag.so ]; then
+  DS_EXP_LIB=$PWD/diffsound_amd/csrc/libds_m32diag.so python3 tools/m32_diag.py 2>&1 | grep -v amdgpu.ids > $out/${tag}_m32_diag.txt; cat $out/${tag}_m32_diag.txt
+fi
 python3 tools/mb_gram_mix.py > $out/${tag}_gram_mix.txt 2>&1; cat $out/${tag}_gram_mix.txt
 rm -rf /tmp/pmc_g
 timeout -k 10 300 rocprofv3 --kernel-include-regex "gram32_partial|mix_lds" --pmc SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d /tmp/pmc_g -o p -- python3 tools/mb_gram_mix.py > /tmp/pmc_log_g.txt 2>&1 || { tail -5 /tmp/pmc_log_g.txt; exit 1; }
 python3 tools/pmc_summary.py /tmp/pmc_g "gram32_partial_kernel" "mix_lds_kernel<10>" "mix_lds_kernel<5>" > $out/${tag}_gram_mix_pmc.json; cat $out/${tag}_gram_mix_pmc.json
+fi
+if [ $part = 3 ] || [ $part = all ]; then
 # configs[4]: the 1M-tet / 128-mode / fp64 stress with its kernel table
 rm -rf /tmp/prof_c5
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_c5 -o c5 -- python3 bench.py --workload c5 > $out/${tag}_c5_bench.json 2> $out/${tag}_c5_stderr.log
 python3 tools/summarize_prof.py /tmp/prof_c5 $out/${tag}_c5_kernel_stats.csv --top 40
+fi
 echo "all done"
