@@ -280,7 +280,7 @@ struct Ctx {
                                     L.nnzb, (L.nv + 3) / 4, L.m32_max_entries, L.m32_max_batch_blocks, L.nv, X, ldx, Y, ldy,
                                     ncols, stream);
         if (ncols <= 84 && ncols % 4 == 0)
-            return ds_spmm_union(0, L.utab, L.ctab, L.ngroups, L.cap_blocks, L.gent, L.kgrp, L.nnzb, L.nv, X, ldx, Y, ldy,
+            return ds_spmm_union(0, L.level_tag, L.utab, L.ctab, L.ngroups, L.cap_blocks, L.gent, L.kgrp, L.nnzb, L.nv, X, ldx, Y, ldy,
                                  nullptr, 0, nullptr, ncols, 0.f, 0.f, 0, nullptr, 0, stream);
         for (int c0 = 0; c0 < ncols; c0 += 256) {  // wide blocks (the periodic full refresh): wave-per-node kernels
             const int c1 = std::min(ncols, c0 + 256);
@@ -296,7 +296,7 @@ struct Ctx {
             return ds_spmm_union32m(3, L.level_tag, L.m32_gptr, L.m32_gcol, L.m32_gmeta, L.m32_gbase, L.m32_m, L.nnzb * 4 + 16,
                                     L.nnzb, (L.nv + 3) / 4, L.m32_max_entries, L.m32_max_batch_blocks, L.nv, X, ldx, Y, ldy,
                                     ncols, stream);
-        return ds_spmm_union(3, L.utab, L.ctab, L.ngroups, L.cap_blocks, L.gent, p->mgrp, L.nnzb, L.nv, X, ldx, Y, ldy,
+        return ds_spmm_union(3, L.level_tag, L.utab, L.ctab, L.ngroups, L.cap_blocks, L.gent, p->mgrp, L.nnzb, L.nv, X, ldx, Y, ldy,
                              nullptr, 0, nullptr, ncols, 0.f, 0.f, 0, nullptr, 0, stream);
     }
 

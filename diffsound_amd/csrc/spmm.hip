@@ -735,13 +735,14 @@ extern "C" int64_t ds_profile_collect(float* ms, int64_t* nv, int64_t* nnzb, int
     return n;
 }
 
-extern "C" int ds_spmm_union(int epilogue, const int32_t* utab, const int32_t* ctab, int64_t ngroups, int cap_blocks,
+extern "C" int ds_spmm_union(int epilogue, int level_tag, const int32_t* utab, const int32_t* ctab, int64_t ngroups, int cap_blocks,
                              const int32_t* gent,
                              const float* kgrp, int64_t nnzb, int64_t nv, const float* X, int64_t ldx, float* Y,
                              int64_t ldy, const float* R0, int64_t ldr, const float* dinv, int ncols, float c1, float c2,
                              int first, const float* Wprev, int64_t ldp, ds_stream_t stream) {
     DS_REQUIRE(ctab && gent && kgrp && X && Y, "ds_spmm_union: null pointer");
     DS_REQUIRE(epilogue >= 0 && epilogue <= 3, "ds_spmm_union: bad epilogue %d", epilogue);
+    DS_REQUIRE(level_tag == 0 || level_tag == 1, "ds_spmm_union: level_tag must be 0 (fine) or 1 (corner-node level)");
     DS_REQUIRE(epilogue == 0 || epilogue == 3 || R0, "ds_spmm_union: the epilogue needs R0");
     DS_REQUIRE(epilogue != 1 || dinv, "ds_spmm_union: the Chebyshev epilogue needs dinv");
     DS_REQUIRE(nv > 0 && ngroups == (nv + 3) / 4 && nnzb > 0 && ncols > 0 && ncols % 4 == 0 && ncols <= 84,
@@ -776,16 +777,19 @@ extern "C" int ds_spmm_union(int epilogue, const int32_t* utab, const int32_t* c
             return rc;
     }
 #define DS_U(L, E) return launch_union<L, E>(utab, ctab, ngroups, cap_blocks, gent, kgrp, nnzb, nv, X, ldx, Y, ldy, lpn, st, epi)
+#define DS_UL(L, E) do { if (level_tag == 1) return launch_union<L, E, false, true, 1>(utab, ctab, ngroups, cap_blocks, gent, kgrp, nnzb, nv, X, ldx, Y, ldy, lpn, st, epi); \
+                         return launch_union<L, E, false, true, 0>(utab, ctab, ngroups, cap_blocks, gent, kgrp, nnzb, nv, X, ldx, Y, ldy, lpn, st, epi); } while (0)
     if (lpn == 20) {
         if (epilogue == 1) DS_U(20, 1);
         if (epilogue == 2) DS_U(20, 2);
-        if (epilogue == 3) DS_U(20, 3);
-        DS_U(20, 0);
+        if (epilogue == 3) DS_UL(20, 3);
+        DS_UL(20, 0);
     }
     if (epilogue == 1) DS_U(0, 1);
     if (epilogue == 2) DS_U(0, 2);
-    if (epilogue == 3) DS_U(0, 3);
-    DS_U(0, 0);
+    if (epilogue == 3) DS_UL(0, 3);
+    DS_UL(0, 0);
+#undef DS_UL
 #undef DS_U
 }
 

@@ -42,7 +42,7 @@ int chebyshev(const ds_level_t& L, const float* R, int64_t ldr, float* Wout, int
         }
         const bool last = k == terms - 1;
         // W_{k+1} overwrites W_{k-1} (oth) - except the last one, which reads oth and lands in Wout
-        int rc = ds_spmm_union(1, L.utab, L.ctab, L.ngroups, L.cap_blocks, L.gent, L.kgrp, L.nnzb, L.nv, cur, lds,
+        int rc = ds_spmm_union(1, L.level_tag, L.utab, L.ctab, L.ngroups, L.cap_blocks, L.gent, L.kgrp, L.nnzb, L.nv, cur, lds,
                                last ? Wout : oth, last ? ldw : lds, R, ldr, L.dinv, ncols, c1, c2, k == 0 ? 1 : 0,
                                last ? oth : nullptr, last ? lds : 0, stream);
         if (rc != DS_OK) return rc;
@@ -158,7 +158,7 @@ extern "C" int ds_twolevel_apply(const ds_twolevel_t* p, ds_stream_t stream) {
     int rc = chebyshev(p->fine, p->R, p->ldr, p->Wc, p->ldwc, p->D, p->AD, p->ldd, c, false, stream);  // W1 = S R
     if (rc != DS_OK) return rc;
     // Rr = R - K W1 ;  Rc = P^T Rr
-    rc = ds_spmm_union(2, p->fine.utab, p->fine.ctab, p->fine.ngroups, p->fine.cap_blocks, p->fine.gent, p->fine.kgrp,
+    rc = ds_spmm_union(2, p->fine.level_tag, p->fine.utab, p->fine.ctab, p->fine.ngroups, p->fine.cap_blocks, p->fine.gent, p->fine.kgrp,
                        p->fine.nnzb, p->fine.nv, p->Wc, p->ldwc, p->Rr, p->ldrr, p->R, p->ldr, nullptr, c, 0.f, 0.f, 0,
                        nullptr, 0, stream);
     if (rc != DS_OK) return rc;

@@ -535,7 +535,7 @@ class _HipBlockOps:
         g = self.sys.groups
         u = g["union"]
         vals = self.mgrp if epilogue == 3 else self.kgrp
-        _hip.check(self._L.ds_spmm_union(epilogue, None if u.get("single") else pp(u["utab"]), pp(u["ctab"]), u["ngroups"], u["capb"], pp(g["gent"]), pp(vals),
+        _hip.check(self._L.ds_spmm_union(epilogue, self._level_tag, None if u.get("single") else pp(u["utab"]), pp(u["ctab"]), u["ngroups"], u["capb"], pp(g["gent"]), pp(vals),
                                          vals.shape[0], self.nv, pp(X), _ld(X), pp(Y), _ld(Y), pp(R0),
                                          0 if R0 is None else _ld(R0), pp(self.dinv) if epilogue == 1 else None,
                                          X.shape[1], float(c1), float(c2), int(bool(first)), pp(Wprev),

@@ -215,9 +215,10 @@ int ds_pack_groups(const float* vals_t, const int32_t* kperm, int64_t nnzb, floa
  * 2: Y <- R0 - A X ; 3: Y <- (A_s (x) I3) X with kgrp = the node-SCALAR values in group order (nnzb floats: the mass
  * matrix).  X and Y distinct, 16-byte aligned rows; operand blocks of 2 GB and more (3 nv ld 4 >= 0x7f000000 bytes)
  * take a variant that builds one buffer descriptor per panel load.
+ * level_tag (0 fine, 1 corner-node level) selects instantiations of epilogues 0 and 3 whose kernel symbols differ - nothing else.
  * (reference: torch.sparse.mm in src/lobpcg/_linalg_utils.py:36-37 and the iK callable of _lobpcg.py:441) */
 #define DS_UNION_CAP 140
-int ds_spmm_union(int epilogue, const int32_t* utab, const int32_t* ctab, int64_t ngroups, int cap_blocks,
+int ds_spmm_union(int epilogue, int level_tag, const int32_t* utab, const int32_t* ctab, int64_t ngroups, int cap_blocks,
                   const int32_t* gent, const float* kgrp, int64_t nnzb, int64_t nv, const float* X, int64_t ldx,
                   float* Y, int64_t ldy, const float* R0, int64_t ldr, const float* dinv, int ncols, float c1, float c2,
                   int first, const float* Wprev, int64_t ldp, ds_stream_t stream);
