@@ -659,16 +659,27 @@ def main():
         fine_bytes = ops0.cheb_term_bytes(a.block, elem_bytes=2 if bf else 4)
         solo = fine_bytes / (solo_ms * 1e-3) / 1e9
         del Wk, Wp, R0
-        # the eigensolver's own stiffness product K W (fp32 blocks, the "LOBPCG SpMM" of the north star), alone as well
-        Xk, Yk = torch.randn((sysd.n, a.block), device=dev), torch.empty((sysd.n, a.block), device=dev)
-        for _ in range(3):
-            ops0.apply_K(Xk, Yk)
-        e0.record()
-        for _ in range(30):
-            ops0.apply_K(Xk, Yk)
-        e1.record()
-        torch.cuda.synchronize()
-        kw_ms = e0.elapsed_time(e1) / 30
+        # the eigensolver's own stiffness product K W (fp32 blocks, the "LOBPCG SpMM" of the north star), alone as well - ON THE
+        # OPERANDS THE ITERATION GIVES IT: W = the last b columns of the solver's [Y | X | P | W] basis buffer, K W = the last b
+        # columns of its K [X P W] buffer (both with rows 1 KiB apart, lobpcg/modal_solver.py), and beside it on compact blocks
+        ny_, pitch = 8, -(-(8 + 3 * a.block) // 256) * 256
+        Sb, KSb = torch.randn((sysd.n, pitch), device=dev), torch.empty((sysd.n, pitch), device=dev)
+        Xk, Yk = Sb[:, ny_ + 2 * a.block:ny_ + 3 * a.block], KSb[:, 2 * a.block:3 * a.block]
+
+        def time_kx(x_, y_):
+            for _ in range(3):
+                ops0.apply_K(x_, y_)
+            e0.record()
+            for _ in range(30):
+                ops0.apply_K(x_, y_)
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / 30
+
+        kw_ms = time_kx(Xk, Yk)
+        Xc, Yc = torch.randn((sysd.n, a.block), device=dev), torch.empty((sysd.n, a.block), device=dev)
+        kw_ms_compact = time_kx(Xc, Yc)
+        del Sb, KSb, Xc, Yc
         kw_bytes = sysd.nnzb * 40 + (sysd.nv + 1) * 4 + 2 * sysd.n * a.block * 4
         del Xk, Yk
         # STREAM triad a = b + s c on the same device, right here: 3 arrays of 1 GiB (4x the Infinity Cache)
@@ -724,8 +735,12 @@ def main():
                         "kernel alone on the device, on the compact blocks the V-cycle runs it on, right after the timed "
                         "region (30 back-to-back launches); 'stream_triad' = ds_stream_triad on 3 x 1 GiB arrays, same "
                         "device, same run; 'traffic' = PMC bytes of one such launch (profiles/)"),
-                "lobpcg_spmm": {"kernel": f"spmm_union_kernel<{a.block // 4},0>: Y = K X on a {a.block}-column fp32 block (K W of the iteration)",
+                "lobpcg_spmm": {"kernel": (f"spmm_union_kernel<{a.block // 4},0,140,...,0>: Y = K X on a {a.block}-column fp32 block (K W of the "
+                                           f"iteration), on the iteration's own operands: W = columns {ny_ + 2 * a.block}..{ny_ + 3 * a.block} of the "
+                                           f"[Y | X | P | W] basis buffer, K W = columns {2 * a.block}..{3 * a.block} of the K [X P W] buffer, rows "
+                                           f"{pitch * 4} bytes apart; alone on the device, 30 back-to-back launches, HIP events"),
                                 "algorithmic_bytes_per_launch": kw_bytes, "avg_launch_ms": kw_ms,
+                                "avg_launch_ms_on_compact_blocks": kw_ms_compact,
                                 "achieved": kw_bytes / (kw_ms * 1e-3) / 1e9, "frac": kw_bytes / (kw_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                 "frac_of_stream": kw_bytes / (kw_ms * 1e-3) / 1e9 / stream_gbs, "traffic": kw_traffic},
                 "in_situ": {"achieved": achieved, "frac": achieved / HBM_PEAK_GBS,

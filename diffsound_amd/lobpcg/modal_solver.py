@@ -21,6 +21,7 @@ The ``ops`` protocol (see ``diffsound_amd/modal_ops.py`` for the HIP implementat
   n, device, dtype, rigid (n x 6, M-orthonormal), apply_K, apply_M, gram, mix, residual,
   precond, polish_products.
 """
+import os
 import threading
 from dataclasses import dataclass, field
 from typing import Callable, Optional
@@ -525,12 +526,21 @@ class ModalSolver:
         # projection against [Y, X, P] is ONE Gram + ONE update launch; the active basis S[:, ny:] is what
         # the stiffness SpMM and the Rayleigh-Ritz Gram see.
         ny = 0 if Y is None else Y.shape[1]
-        S = torch.empty((n, ny + 3 * b), dtype=dt, device=dev)
-        S2 = torch.empty((n, ny + 3 * b), dtype=dt, device=dev)
+
+        def wide(cols):
+            """(n x cols) block inside a buffer whose rows are a multiple of 1 KiB apart (fp32 on the device): every 3-row
+            panel of a column range then starts at the same offset inside a cache line - the neighbour-union products gather
+            such panels, and on the benchmark mesh K X takes 186 us on an 80-column range of a 256-column buffer against 196 us
+            with 248 columns (M X 152 against 164; profiles/r04_mb_kx_strided.txt)."""
+            ld = cols if (dev.type != "cuda" or dt != torch.float32 or os.environ.get("DS_EXP_LD") == "0") else -(-cols // 256) * 256
+            return torch.empty((n, ld), dtype=dt, device=dev)[:, :cols]
+
+        S = wide(ny + 3 * b)
+        S2 = wide(ny + 3 * b)
         if ny:
             S[:, :ny].copy_(Y)
             S2[:, :ny].copy_(Y)
-        KS = torch.empty((n, 3 * b), dtype=dt, device=dev)
+        KS = wide(3 * b)
         R = torch.empty((n, b), dtype=dt, device=dev)
         MX = torch.empty((n, b), dtype=dt, device=dev)
         MW = torch.empty((n, b), dtype=dt, device=dev)
@@ -553,7 +563,7 @@ class ModalSolver:
         state.fvars.update(A_norm=float(A_norm), B_norm=float(B_norm))
         tol = cfg.tol or (2e-6 if dt == torch.float32 else 1e-10)
         self._orthonormalize(X, S[:, :ny], MW, VW=S[:, :ny + b] if ny else None)
-        KS2 = torch.empty((n, 3 * b), dtype=dt, device=dev)
+        KS2 = wide(3 * b)
         ops.apply_K(X, KS[:, :b])
         lam, Z = _small(lambda G: torch.linalg.eigh(_sym(G)), dev, ops.gram(X, KS[:, :b], symmetric=True))
         lam = lam.clone()

@@ -15,7 +15,9 @@ X = torch.randn(sysd.n, 80, device=dev); W = torch.randn(sysd.n, 80, device=dev)
 bf = kind in ("bf16", "mfma")
 if bf:
     X, W, R0 = X.bfloat16(), W.bfloat16(), R0.bfloat16()
-Yk = torch.empty(sysd.n, 80, device=dev) if kind == "kx" else None
+if kind == "kx":  # the iteration's own operands: column ranges of 256-column buffers (rows 1 KiB apart), as bench.py times it
+    Sb, KSb = torch.randn(sysd.n, 256, device=dev), torch.empty(sysd.n, 256, device=dev)
+    X, Yk = Sb[:, 168:248], KSb[:, 160:240]
 for _ in range(int(sys.argv[1]) if len(sys.argv) > 1 else 4):
     if kind == "kx":  # the eigensolver's own product Y = K X (fp32)
         ops.apply_K(X, Yk)

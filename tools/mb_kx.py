@@ -41,3 +41,12 @@ if ops._mfma32 is not None:
     print("4-node unions: entries", m4["gcol"].numel(), "blocks", sysd.nnzb, "max entries / group", m4["max_entries"],
           "max blocks / batch", m4["max_batch_blocks"], flush=True)
 timeit(lambda: ops._cheb_spmm_launch(X, W, R0, 0.3, 0.7, False), "fused Chebyshev term (fp32)")
+
+# the same products on column ranges of a wider buffer, as the solver calls them: leading dimension 248 (its [Y | X | P | W]
+# basis: rows 992 bytes apart) and 256 (rows 1 024 bytes apart: every panel row starts at the same offset inside a cache line)
+for ld in (248, 256):
+    big = torch.randn(sysd.n, ld, device=dev)
+    for c0 in (8, 168):
+        Xs = big[:, c0:c0 + 80]
+        timeit(lambda: ops._union(0, Xs, Y), f"K X  (80 columns at column {c0} of a {ld}-column buffer, VALU)")
+        timeit(lambda: ops._union(3, Xs, Y), f"M X  (80 columns at column {c0} of a {ld}-column buffer, VALU)")
