@@ -532,7 +532,7 @@ class ModalSolver:
             panel of a column range then starts at the same offset inside a cache line - the neighbour-union products gather
             such panels, and on the benchmark mesh K X takes 186 us on an 80-column range of a 256-column buffer against 196 us
             with 248 columns (M X 152 against 164; profiles/r04_mb_kx_strided.txt)."""
-            ld = cols if (dev.type != "cuda" or dt != torch.float32 or os.environ.get("DS_EXP_LD") == "0") else -(-cols // 256) * 256
+            ld = cols if (dev.type != "cuda" or dt != torch.float32) else -(-cols // 256) * 256
             return torch.empty((n, ld), dtype=dt, device=dev)[:, :cols]
 
         S = wide(ny + 3 * b)
