@@ -83,6 +83,8 @@ def parse():
                     help="recompute K [X P W] and the whole Gram matrix every this many iterations (-1 = solver default)")
     ap.add_argument("--kx-fresh", type=int, default=-1,
                     help="1: K X' of every new Ritz block by one product (solver default), 0: by the update of K [X P W]")
+    ap.add_argument("--fused-residual", type=int, default=-1,
+                    help="1: the residual of every iteration in one walk of the unions (solver default), 0: K X', M X', residual")
     ap.add_argument("--tol", type=float, default=1e-5,
                     help="backward-error tolerance of the eigensolve, ||K u - lambda M u|| / (||u|| (||K|| + lambda ||M||)) "
                          "per wanted pair: 1e-5 is the tolerance the metric states for fp32 iterates (SURVEY.md 8(d)); "
@@ -149,6 +151,8 @@ def solver_config(a=None, **over):
         cfg.rr_refresh = a.rr_refresh
     if getattr(a, "kx_fresh", -1) >= 0:
         cfg.kx_fresh = bool(a.kx_fresh)
+    if getattr(a, "fused_residual", -1) >= 0:
+        cfg.fused_residual = bool(a.fused_residual)
     cfg.tol = a.tol
     cfg.power_iters = a.power_iters
     if a.warm_power_iters > 0:

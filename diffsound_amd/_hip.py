@@ -60,6 +60,8 @@ _SIGNATURES = {
     "ds_geometry_grad": (_I, [_P, _I64, _I, _I64, _P, _P, _I64, _I, _P, _P, _D, _D, _P, _P, _I, _P, _P, _P]),
     "ds_spmm_union": (_I, [_I, _I, _P, _P, _I64, _I, _P, _P, _I64, _I64, _P, _I64, _P, _I64, _P, _I64, _P, _I, _F, _F, _I, _P,
                           _I64, _P]),
+    "ds_union_residual_workspace_bytes": (_I64, [_I64, _I]),
+    "ds_union_residual": (_I, [_I, _P, _P, _I64, _I, _P, _P, _P, _I64, _I64, _P, _I64, _P, _P, _I64, _I, _P, _I64, _P, _P, _P]),
     "ds_mix": (_I, [_P, _I64, _I, _P, _I, _P, _I64, _I64, _F, _F, _P]),
     "ds_osc_bank_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _D, _P, _P]),
     "ds_osc_bank_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _D, _P, _P, _P, _P, _P]),
@@ -110,7 +112,7 @@ class LobpcgDesc(ctypes.Structure):
                 ("MW", _P), ("lds", _I64), ("ldks", _I64), ("ldr", _I64), ("level", LevelDesc), ("mgrp", _P),
                 ("rowptr", _P), ("colidx", _P), ("k32", _P), ("k32t", _P), ("twolevel", ctypes.POINTER(TwoLevelDesc)),
                 ("pa", _P), ("pb", _P), ("ldp", _I64), ("pr16", _P), ("gbuf", _P), ("cbuf", _P), ("nrm", _P), ("lam_dev", _P),
-                ("gram_work", _P), ("gram_work_bytes", _I64), ("lam", ctypes.POINTER(_D)), ("rerr", ctypes.POINTER(_D)),
+                ("res_work", _P), ("res_work_bytes", _I64), ("gram_work", _P), ("gram_work_bytes", _I64), ("lam", ctypes.POINTER(_D)), ("rerr", ctypes.POINTER(_D)),
                 ("history", ctypes.POINTER(_D)), ("history_cap", _i32), ("iterations", _i32), ("result_in_s2", _i32)]
 
 

@@ -423,20 +423,32 @@ extern "C" int ds_lobpcg_iterate(ds_lobpcg_t* p, const ds_lapack_t* lapack, ds_s
     Mat Gxp(b, b);
     for (int i = 0; i < b; ++i) Gxp(i, i) = lam[i];
     int ncl = 0, npc = 0, k0 = 0, since_refresh = 0, it = 0;
+    // the fused residual needs the operands the neighbour-union kernel takes (one descriptor per operand block) and replaces
+    // the fresh K X' of kx_fresh - without kx_fresh K X' comes out of the recurrence and is there anyway
+    const bool fused_res = p->res_work && p->kx_fresh && 3 * p->nv * std::max(lds, ldr) * 4 < (int64_t)0x7f000000 &&
+                           p->res_work_bytes >= ds_union_residual_workspace_bytes(p->level.ngroups, b);
     double worst = std::numeric_limits<double>::infinity();
     for (it = 0; it <= p->maxit; ++it) {
         int na = b - ncl;
         float* X = c.S + ny;
         float* Xa = X + ncl;
-        if ((rc = c.apply_M(Xa, lds, p->MX, ldr, na)) != DS_OK) return rc;
         double* lam_pin = g_ring.back + 2048;  // (the previous iteration's copy completed before its last synchronise)
         std::memcpy(lam_pin, lam.data() + ncl, sizeof(double) * na);
         if ((rc = c.hip(hipMemcpyAsync(p->lam_dev, lam_pin, sizeof(double) * na, hipMemcpyHostToDevice, c.st),
                         "ds_lobpcg_iterate: Ritz values to device")) != DS_OK)
             return rc;
-        if ((rc = ds_residual(c.KS + k0, ldks, p->R, ldr, p->MX, ldr, Xa, lds, p->lam_dev, n, na, p->nrm, p->nrm + 1024,
-                              stream)) != DS_OK)
-            return rc;
+        if (fused_res) {  // R = K X - (M X) diag(lam) and the norms in one walk of the unions; K X, M X never reach memory
+            const ds_level_t& L = p->level;
+            if ((rc = ds_union_residual(L.level_tag, L.utab, L.ctab, L.ngroups, L.cap_blocks, L.gent, L.kgrp, p->mgrp, L.nnzb,
+                                        L.nv, Xa, lds, p->lam_dev, p->R, ldr, na, p->res_work, p->res_work_bytes, p->nrm,
+                                        p->nrm + 1024, stream)) != DS_OK)
+                return rc;
+        } else {
+            if ((rc = c.apply_M(Xa, lds, p->MX, ldr, na)) != DS_OK) return rc;
+            if ((rc = ds_residual(c.KS + k0, ldks, p->R, ldr, p->MX, ldr, Xa, lds, p->lam_dev, n, na, p->nrm, p->nrm + 1024,
+                                  stream)) != DS_OK)
+                return rc;
+        }
         double* nrm = g_ring.back;
         if ((rc = c.hip(hipMemcpyAsync(nrm, p->nrm, sizeof(double) * 2048, hipMemcpyDeviceToHost, c.st),
                         "ds_lobpcg_iterate: residual norms to host")) != DS_OK)
@@ -540,7 +552,8 @@ extern "C" int ds_lobpcg_iterate(ds_lobpcg_t* p, const ds_lapack_t* lapack, ds_s
             }
         }
         // K X' fresh: one b-column product instead of the 3b -> 2b column update of K [X P W] (K P' is never needed)
-        if (p->kx_fresh && (rc = c.apply_K(c.S2 + ny + ncl, lds, c.KS2, ldks, na)) != DS_OK) return rc;
+        // (with the fused residual the next iteration forms K X' inside its residual kernel and nobody else reads it)
+        if (p->kx_fresh && !fused_res && (rc = c.apply_K(c.S2 + ny + ncl, lds, c.KS2, ldks, na)) != DS_OK) return rc;
         std::swap(c.S, c.S2);
         std::swap(c.KS, c.KS2);
         k0 = 0;

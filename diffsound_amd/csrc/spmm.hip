@@ -178,6 +178,11 @@ struct ChebEpilogue {
     // last term of a polynomial run on compact scratch blocks can then land in a column range of a wider buffer
     const float* wprev = nullptr;
     int64_t ldp = 0;
+    // neighbour-union kernel, epilogue 4 (fused residual R = K X - (M X) diag(lam)): node-scalar mass values in group order,
+    // the Ritz values (device, fp64, one per column) and the per-group partial column norms (ngroups x 2 x ncols floats)
+    const float* mvals = nullptr;
+    const double* lam = nullptr;
+    float* nwork = nullptr;
 };
 
 template <int KIND, int RS, int LPN_CT, int EPI>
@@ -793,6 +798,53 @@ extern "C" int ds_spmm_union(int epilogue, int level_tag, const int32_t* utab, c
 #undef DS_U
 }
 
+
+// The eigensolver's residual in ONE walk of the unions (spmm_union.inc, epilogue 4): R = K X - (M_s (x) I3) X diag(lam) and
+// the column norms ||R_j||^2, ||X_j||^2, with neither K X nor M X written to memory.
+extern "C" int64_t ds_union_residual_workspace_bytes(int64_t ngroups, int ncols) {
+    return ngroups * 2 * (int64_t)ncols * 4 + (int64_t)UN_NORM_BLOCKS * 2 * ncols * 8;
+}
+
+extern "C" int ds_union_residual(int level_tag, const int32_t* utab, const int32_t* ctab, int64_t ngroups, int cap_blocks,
+                                 const int32_t* gent, const float* kgrp, const float* mgrp, int64_t nnzb, int64_t nv,
+                                 const float* X, int64_t ldx, const double* lam, float* R, int64_t ldr, int ncols, void* work,
+                                 int64_t work_bytes, double* rn2, double* xn2, ds_stream_t stream) {
+    DS_REQUIRE(ctab && gent && kgrp && mgrp && X && lam && R && work && rn2 && xn2, "ds_union_residual: null pointer");
+    DS_REQUIRE(level_tag == 0 || level_tag == 1, "ds_union_residual: level_tag must be 0 (fine) or 1 (corner-node level)");
+    DS_REQUIRE(nv > 0 && ngroups == (nv + 3) / 4 && nnzb > 0 && ncols > 0 && ncols % 4 == 0 && ncols <= 84,
+               "ds_union_residual: ncols must be a multiple of 4 <= 84 and ngroups = ceil(nv / 4)");
+    DS_REQUIRE(cap_blocks > 0 && cap_blocks <= UN_CAPB, "ds_union_residual: a chunk of %d blocks exceeds the LDS image", cap_blocks);
+    DS_REQUIRE(ldx >= ncols && ldr >= ncols, "ds_union_residual: leading dimension smaller than ncols");
+    DS_REQUIRE(X != R, "ds_union_residual: X and R must be different buffers");
+    DS_REQUIRE(ldx * 12 < (int64_t)PIPE_OOB && ldr * 12 < (int64_t)PIPE_OOB && nnzb * 36 < ((int64_t)1 << 32),
+               "ds_union_residual: operand beyond the descriptor range");
+    const uintptr_t al = reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(R) | (uintptr_t)(ldx * 4) | (uintptr_t)(ldr * 4) |
+                         reinterpret_cast<uintptr_t>(kgrp) | reinterpret_cast<uintptr_t>(ctab) | reinterpret_cast<uintptr_t>(work);
+    DS_REQUIRE((al & 15) == 0, "ds_union_residual: rows, kgrp, ctab and the workspace must be 16-byte aligned");
+    DS_REQUIRE(work_bytes >= ds_union_residual_workspace_bytes(ngroups, ncols), "ds_union_residual: workspace of %lld bytes needed",
+               (long long)ds_union_residual_workspace_bytes(ngroups, ncols));
+    hipStream_t st = ds::as_stream(stream);
+    ChebEpilogue epi{nullptr, 0, nullptr, 0.f, 0.f, 0};
+    epi.mvals = mgrp, epi.lam = lam, epi.nwork = static_cast<float*>(work);
+    const int lpn = ncols / 4;
+    int rc;
+#define DS_UR(L, V) rc = launch_union<L, 4, false, true, V>(utab, ctab, ngroups, cap_blocks, gent, kgrp, nnzb, nv, X, ldx, R, ldr, lpn, st, epi)
+    if (lpn == 20) {
+        if (level_tag == 1) DS_UR(20, 1);
+        else DS_UR(20, 0);
+    } else {
+        if (level_tag == 1) DS_UR(0, 1);
+        else DS_UR(0, 0);
+    }
+#undef DS_UR
+    if (rc != DS_OK) return rc;
+    double* partial = reinterpret_cast<double*>(static_cast<char*>(work) + ngroups * 2 * (int64_t)ncols * 4);
+    union_norm_partial_kernel<<<UN_NORM_BLOCKS, 256, 0, st>>>(static_cast<const float*>(work), (unsigned)ngroups, 2 * ncols, partial);
+    DS_LAUNCH_CHECK("union_norm_partial_kernel");
+    union_norm_final_kernel<<<1, 256, 0, st>>>(partial, ncols, rn2, xn2);
+    DS_LAUNCH_CHECK("union_norm_final_kernel");
+    return DS_OK;
+}
 
 // bf16-block form of the two preconditioner epilogues (the V-cycle's iterates are stored in bf16, arithmetic in fp32):
 // X, R0, W_prev bf16; Y bf16, or fp32 when y_f32 (the last term of a cycle, written into the solver's basis buffer).

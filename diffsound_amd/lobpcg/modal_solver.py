@@ -66,6 +66,10 @@ class SolverConfig:
     # [K X' | K P'] = K [X P W] [Z1 Zp] (a 3b -> 2b column mix, 0.37 ms): K P is then never formed - the Gram blocks among X
     # and P come from the small Ritz algebra and only the residual needs K X - and K X' carries no recurrence error
     kx_fresh: bool = True
+    # ... and then K X' and M X' feed nothing but the residual: ops that offer ``residual_fused`` form R = K X' - (M X') diag(lam)
+    # and its column norms in ONE walk of the neighbour unions - neither product is written, X' is gathered once instead of
+    # twice, and the separate residual pass over three blocks is gone (needs kx_fresh)
+    fused_residual: bool = True
     # storage of the preconditioner's internal blocks (V-cycle iterates, residuals, corner-level vectors): "bf16" halves
     # the bytes of every fused term - the cycle is bound by them - and leaves the outer iteration counts unchanged
     # (fp32 arithmetic in registers; the cycle's input R and output W stay fp32); "fp32" keeps everything in fp32
@@ -600,10 +604,15 @@ class ModalSolver:
             na = b - ncl
             X = S[:, ny:ny + b]
             Xa = X[:, ncl:]
-            ops.apply_M(Xa, MX[:, :na])
-            # R <- K X - M X lam on the active columns (K X_active sits at column k0 = 0 of KS here: the Ritz step
-            # has just rewritten it), with ||R_j||^2 and ||X_j||^2 in fp64
-            rn2, xn2 = ops.residual(R[:, :na], MX[:, :na], Xa, lam[ncl:], src=KS[:, k0:k0 + na])
+            fused = (cfg.fused_residual and cfg.kx_fresh and hasattr(ops, "residual_fused")
+                     and ops.residual_fused_ok(Xa, R[:, :na]))
+            if fused:
+                rn2, xn2 = ops.residual_fused(Xa, lam[ncl:], R[:, :na])
+            else:
+                ops.apply_M(Xa, MX[:, :na])
+                # R <- K X - M X lam on the active columns (K X_active sits at column k0 = 0 of KS here: the Ritz step
+                # has just rewritten it), with ||R_j||^2 and ||X_j||^2 in fp64
+                rn2, xn2 = ops.residual(R[:, :na], MX[:, :na], Xa, lam[ncl:], src=KS[:, k0:k0 + na])
             rel[ncl:] = torch.sqrt(rn2 / xn2) / (A_norm + lam[ncl:].abs() * B_norm)
             relk = rel[:k]
             conv = (relk < tol).to(torch.int32)
@@ -682,7 +691,7 @@ class ModalSolver:
                 if not cfg.kx_fresh:
                     ops.mix(KSa, Z1, KS2[:, :na])  # K X_new
                     ops.mix(KSa, Zp, KS2[:, na:2 * na])  # K P_new
-            if cfg.kx_fresh:
+            if cfg.kx_fresh and not fused:
                 ops.apply_K(S2[:, ny + ncl:ny + b], KS2[:, :na])  # K X_new, fresh (K P_new is never needed)
             S, S2 = S2, S
             KS, KS2 = KS2, KS

@@ -516,6 +516,11 @@ class _HipBlockOps:
             self._gram_ws = torch.empty((need,), dtype=torch.uint8, device=dev)
         d.gbuf, d.cbuf, d.nrm, d.lam_dev = gbuf.data_ptr(), cbuf.data_ptr(), self._nrm.data_ptr(), lam_dev.data_ptr()
         d.gram_work, d.gram_work_bytes = self._gram_ws.data_ptr(), self._gram_ws.numel()
+        if getattr(cfg, "fused_residual", False) and getattr(cfg, "kx_fresh", False):
+            rws = self._residual_ws(b)
+            d.res_work, d.res_work_bytes = rws.data_ptr(), rws.numel()
+        else:
+            d.res_work, d.res_work_bytes = None, 0
         lam_h = (ctypes.c_double * b)(*lam.detach().double().cpu().tolist())
         rerr_h = (ctypes.c_double * b)()
         hist_h = (ctypes.c_double * (cfg.maxit + 1))()
@@ -604,6 +609,34 @@ class _HipBlockOps:
         W.copy_(tmp)
 
     # ------------------------------------------------------------------ fused elementwise
+    def _residual_ws(self, ncols):
+        u = self.sys.groups["union"]
+        need = self._L.ds_union_residual_workspace_bytes(u["ngroups"], ncols)
+        ws = self._tmp.get("residual_ws")
+        if ws is None or ws.numel() < need:
+            ws = self._tmp["residual_ws"] = torch.empty((need,), dtype=torch.uint8, device=self.device)
+        return ws
+
+    def residual_fused_ok(self, X, R):
+        return (self.m_kind == 1 and self.mgrp is not None and self._union_ok(X, R)
+                and 3 * self.nv * max(X.stride(0), R.stride(0)) * 4 < 0x7F000000)
+
+    def residual_fused(self, X, lam, R):
+        """R <- K X - (M X) diag(lam) and (||R_j||^2, ||X_j||^2) in ONE walk of the neighbour unions (ds_union_residual): K X
+        and M X are never written.  R equals what apply_K + apply_M + residual give bit for bit."""
+        b = X.shape[1]
+        lam64 = lam.to(torch.float64).contiguous()
+        pp = _hip.ptr
+        g, u = self.sys.groups, self.sys.groups["union"]
+        ws = self._residual_ws(b)
+        _hip.check(self._L.ds_union_residual(self._level_tag, None if u.get("single") else pp(u["utab"]), pp(u["ctab"]), u["ngroups"],
+                                             u["capb"], pp(g["gent"]), pp(self.kgrp), pp(self.mgrp), self.kgrp.shape[0], self.nv,
+                                             pp(X), _ld(X), pp(lam64), pp(R), _ld(R), b, pp(ws), ws.numel(), pp(self._nrm[0]),
+                                             pp(self._nrm[1]), _hip.stream_ptr()), "ds_union_residual")
+        self.counts["apply_K_cols"] += b
+        self.counts["apply_M_cols"] += b
+        return self._nrm[0, :b].clone(), self._nrm[1, :b].clone()
+
     def residual(self, R, MX, X, lam, src=None):
         """R <- src - MX diag(lam) (src = K X; None: R holds it already), returns (||R_j||^2, ||X_j||^2) in fp64."""
         b = R.shape[1]

@@ -222,6 +222,18 @@ int ds_spmm_union(int epilogue, int level_tag, const int32_t* utab, const int32_
                   const int32_t* gent, const float* kgrp, int64_t nnzb, int64_t nv, const float* X, int64_t ldx,
                   float* Y, int64_t ldy, const float* R0, int64_t ldr, const float* dinv, int ncols, float c1, float c2,
                   int first, const float* Wprev, int64_t ldp, ds_stream_t stream);
+/* The eigensolver's residual in ONE walk of the neighbour unions (ABI 26): R <- K X - (M_s (x) I3) X diag(lam) on a block of
+ * <= 84 columns, and rn2[j] = ||R_j||^2, xn2[j] = ||X_j||^2 (fp64) - what ds_spmm_union (epilogue 0), ds_spmm_union
+ * (epilogue 3) and ds_residual compute in three launches and five passes over (n x ncols) blocks (reference:
+ * update_residual / update_converged_count, src/lobpcg/_lobpcg.py:301-333).  kgrp / mgrp: the transposed 3x3 blocks and the
+ * node-scalar mass values in group order, as for ds_spmm_union; lam: ncols Ritz values on the device (fp64, rounded to fp32 as
+ * ds_residual does).  R equals the three-launch result bit for bit; the norms are summed over the groups in a fixed order (no
+ * atomics: reproducible, which ds_residual's are not).  work: ds_union_residual_workspace_bytes(ngroups, ncols) bytes. */
+int64_t ds_union_residual_workspace_bytes(int64_t ngroups, int ncols);
+int ds_union_residual(int level_tag, const int32_t* utab, const int32_t* ctab, int64_t ngroups, int cap_blocks,
+                      const int32_t* gent, const float* kgrp, const float* mgrp, int64_t nnzb, int64_t nv, const float* X,
+                      int64_t ldx, const double* lam, float* R, int64_t ldr, int ncols, void* work, int64_t work_bytes,
+                      double* rn2, double* xn2, ds_stream_t stream);
 /* ------------------------------------------------------------------------------------------------
  * Two-level V-cycle preconditioner in one call (host-side driver, csrc/vcycle.cpp): issues on `stream` the launch
  * sequence  W1 = S R ; W2 = W1 + P C P^T (R - K W1) ; W = W2 + S (R - K W2)  out of ds_cheb_init, ds_spmm_union and
@@ -385,6 +397,9 @@ typedef struct {
     float* cbuf;              /* device, 8 x (ny + 3 b) x 2 b floats: update coefficients (a ring of 8 slots) */
     double* nrm;              /* device, 2 x 1024 doubles */
     double* lam_dev;          /* device, b doubles */
+    void* res_work;           /* not NULL (and kx_fresh != 0): the residual of every iteration by ds_union_residual - K X' and
+                                 M X' of the new Ritz block are then never written; ds_union_residual_workspace_bytes bytes */
+    int64_t res_work_bytes;
     void* gram_work;
     int64_t gram_work_bytes;
     double* lam;              /* host, b: in / out */

@@ -550,6 +550,51 @@ def test_mfma32_entry_point_refuses_what_it_does_not_serve(dev):
     torch.cuda.synchronize()
 
 
+@pytest.mark.parametrize("mesh,order,ncols", [(6, 2, 80), (6, 2, 72), (6, 2, 40), (10, 2, 80), (3, 2, 8), (12, 1, 80), (5, 1, 24), (2, 1, 4)])
+def test_fused_residual_equals_the_three_launches_bit_for_bit(dev, mesh, order, ncols):
+    """ds_union_residual (R = K X - (M X) diag(lam) and the column norms in ONE walk of the neighbour unions; K X and M X
+    never written) against what it replaces - ds_spmm_union epilogue 0, epilogue 3, ds_residual: R must be IDENTICAL (per
+    output the same sums in the same order, one fused multiply-add), the norms agree to fp32 partial-sum accuracy and are
+    reproducible to the last bit (fixed-order reduction, no atomics).  Operands are column ranges of wider buffers, as the
+    solver passes them."""
+    from diffsound_amd import meshgen
+    from diffsound_amd.diffelastic.mesh import TetMesh
+    from diffsound_amd.modal_ops import HipModalOps, TetSystem
+
+    v, t = meshgen.kuhn_box(mesh)
+    tm = TetMesh(torch.from_numpy(v).to(dev), torch.from_numpy(t).long().to(dev)).to_high_order(order)
+    sysd = TetSystem(tm.vertices, tm.tets, order, 2700.0)
+    ops = HipModalOps(sysd, 2e10, 3e10, two_level=False)
+    g = torch.Generator(device=dev).manual_seed(mesh * 100 + ncols)
+    big = torch.full((sysd.n, 256), float("nan"), device=dev)
+    X = big[:, 8:8 + ncols]
+    X.copy_(torch.randn((sysd.n, ncols), generator=g, device=dev))
+    lam = (torch.rand(ncols, generator=g, device=dev, dtype=torch.float64) + 0.5) * 1e9
+    assert ops.residual_fused_ok(X, torch.empty((sysd.n, ncols), device=dev))
+    # the three launches
+    KX, MX = torch.empty((sysd.n, ncols), device=dev), torch.empty((sysd.n, ncols), device=dev)
+    ops._union(0, X, KX)
+    ops._union(3, X, MX)
+    R0 = torch.empty((sysd.n, ncols), device=dev)
+    rn0, xn0 = ops.residual(R0, MX, X, lam, src=KX)
+    # one launch, into a column range of a wider buffer
+    wide = torch.full((sysd.n, ncols + 8), float("nan"), device=dev)
+    R1 = wide[:, 4:4 + ncols]
+    rn1, xn1 = ops.residual_fused(X, lam, R1)
+    assert bool(torch.isnan(wide[:, :4]).all()) and bool(torch.isnan(wide[:, 4 + ncols:]).all())
+    assert torch.equal(R1, R0)
+    assert float(((rn1 - rn0) / rn0).abs().max()) < 2e-6 and float(((xn1 - xn0) / xn0).abs().max()) < 2e-6
+    R2 = torch.empty((sysd.n, ncols), device=dev)
+    rn2, xn2 = ops.residual_fused(X, lam, R2)
+    assert torch.equal(R2, R0) and torch.equal(rn2, rn1) and torch.equal(xn2, xn1)  # reproducible to the last bit
+    L, p = __import__("diffsound_amd")._hip.lib(), __import__("diffsound_amd")._hip.ptr
+    u, gr = sysd.groups["union"], sysd.groups
+    ws = torch.empty(8, dtype=torch.uint8, device=dev)  # too small a workspace is refused before any launch
+    assert L.ds_union_residual(0, None if u["single"] else p(u["utab"]), p(u["ctab"]), u["ngroups"], u["capb"], p(gr["gent"]), p(ops.kgrp),
+                               p(ops.mgrp), ops.kgrp.shape[0], sysd.nv, p(X), X.stride(0), p(lam), p(R2), ncols, ncols, p(ws), 8,
+                               p(ops._nrm[0]), p(ops._nrm[1]), __import__("diffsound_amd")._hip.stream_ptr()) != 0
+
+
 def test_mfma_entry_point_refuses_what_it_does_not_serve(dev):
     """ds_spmm_union16m validates on the host before any launch: group size, table limits, aliasing, alignment."""
     from diffsound_amd import _hip, meshgen

@@ -165,3 +165,31 @@ def test_native_iteration_driver_matches_python_loop(dev, mesh, order, k, block,
     assert float(a.rerr.max()) < 1e-5 and float(b_.rerr.max()) < 1e-5
     assert float((a.eigenvalues / b_.eigenvalues - 1).abs().max()) < 1e-6
     assert len(a.history) == a.iterations + 1 and a.history[-1][1] < 1e-5
+
+
+@pytest.mark.parametrize("native", [True, False])
+def test_fresh_products_and_fused_residual_change_nothing_but_rounding(dev, native):
+    """The three forms of the iteration's K X' / residual step - (a) K X' by the update of K [X P W] (round 3), (b) K X' by one
+    fresh product (kx_fresh), (c) residual and norms in one walk of the unions (fused_residual, the default) - are the same
+    mathematics: the same iteration counts (within one) and eigenvalues to the solver's accuracy; (b) and (c) form the SAME
+    residual bit for bit, so they agree far more closely than that."""
+    from diffsound_amd import meshgen
+    from diffsound_amd.lobpcg.modal_solver import ModalSolver, SolverConfig
+    from diffsound_amd.modal_ops import HipModalOps, TetSystem
+
+    v, t = meshgen.kuhn_box(8)
+    v, t = fem.to_high_order(torch.from_numpy(v), torch.from_numpy(t).long(), 2)
+    sysd = TetSystem(v.to(dev), t.to(dev), 2, MAT[0])
+    lam, mu = fem.lame(MAT[1], MAT[2])
+    res = {}
+    for name, kw in (("recurrence", dict(kx_fresh=False, fused_residual=False)), ("fresh", dict(kx_fresh=True, fused_residual=False)),
+                     ("fused", dict(kx_fresh=True, fused_residual=True))):
+        ops = HipModalOps(sysd, lam, mu)  # fresh operators: no state carried from one form to the next
+        cfg = SolverConfig(block=40, lmax_cap=10.0, tol=1e-5, nested_tol=1e-2, native=native, **kw)
+        res[name] = ModalSolver(ops, cfg).solve(32)
+        assert float(res[name].rerr.max()) < 1e-5
+    for name in ("fresh", "fused"):
+        assert abs(res[name].iterations - res["recurrence"].iterations) <= 1
+        assert float((res[name].eigenvalues / res["recurrence"].eigenvalues - 1).abs().max()) < 1e-6
+    assert res["fused"].iterations == res["fresh"].iterations
+    assert float((res["fused"].eigenvalues / res["fresh"].eigenvalues - 1).abs().max()) < 1e-9
