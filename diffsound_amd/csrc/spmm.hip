@@ -479,6 +479,12 @@ __global__ void __launch_bounds__(256)
 // launches of spmm_f64_node_kernel are bound by exactly those gathers (3.2 GB out of L2 per 64-column product at the
 // benchmark size: 0.63 + 0.63 + 0.22 ms); per output the arithmetic and its order are theirs, so the results are
 // bit-identical.
+// Round 4: the row's fp64 coefficients (9 + 9 + 1 doubles per block) no longer come through seven dependent-address global
+// loads per block and lane (the kernel was bound by vector-memory ISSUE: 33 M wave-loads for 4.1 M blocks) but are staged per
+// chunk of the row in LDS with coalesced 8-byte loads and read back as broadcasts; the neighbour ids of the chunk sit in one
+// register (a coalesced load) and come back with v_readlane, so a panel's address is scalar arithmetic.  The sums and their
+// order are unchanged: results bit-identical to the three separate launches, as before.
+constexpr int PL_CHUNK = 32;  // blocks of a row staged per pass
 __global__ void __launch_bounds__(256)
     spmm_f64_polish_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx,
                            const double* __restrict__ va, const double* __restrict__ vb, const double* __restrict__ vm,
@@ -486,6 +492,7 @@ __global__ void __launch_bounds__(256)
                            double* __restrict__ Yb, double* __restrict__ Ym, int64_t ldy, int lpn, unsigned nblk) {
     using d2 = __attribute__((ext_vector_type(2))) double;
     using xv4 = __attribute__((ext_vector_type(4))) float;
+    __shared__ double s_a[4][PL_CHUNK * 9], s_b[4][PL_CHUNK * 9], s_m[4][PL_CHUNK];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t node = (int64_t)ds::xcd_remap(blockIdx.x, nblk) * 4 + wave;
@@ -495,6 +502,9 @@ __global__ void __launch_bounds__(256)
     const int ga = active ? g : 0;
     const int kb = __builtin_amdgcn_readfirstlane(rowptr[node]), ke = __builtin_amdgcn_readfirstlane(rowptr[node + 1]);
     const float* xb = X + (int64_t)ga * ldx + cl * 4;
+    double* sa = s_a[wave];
+    double* sb = s_b[wave];
+    double* sm = s_m[wave];
     double aa[3][4], ab[3][4], am[4];
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
@@ -502,23 +512,39 @@ __global__ void __launch_bounds__(256)
 #pragma unroll
         for (int r = 0; r < 3; ++r) aa[r][v] = ab[r][v] = 0.0;
     }
+    for (int kc = kb; kc < ke; kc += PL_CHUNK) {
+        const int cnt = min(PL_CHUNK, ke - kc);  // wave-uniform
+        const int colreg = lane < cnt ? colidx[kc + lane] : 0;
+        const double* pa = va + (int64_t)kc * 9;
+        const double* pb = vb + (int64_t)kc * 9;
+        for (int t = lane; t < cnt * 9; t += 64) sa[t] = pa[t], sb[t] = pb[t];
+        if (lane < cnt) sm[lane] = vm[kc + lane];
+        // same-wave LDS write -> read (rows differ in length: no workgroup barrier)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll 4
-    for (int k = kb; k < ke; ++k) {
-        const int64_t col = colidx[k];
-        const xv4 x = *reinterpret_cast<const xv4*>(xb + col * 3 * ldx);
-        const double* pa = va + (int64_t)k * 9 + ga;  // column g of the blocks
-        const double* pb = vb + (int64_t)k * 9 + ga;
-        const double a0 = pa[0], a1 = pa[3], a2 = pa[6], b0 = pb[0], b1 = pb[3], b2 = pb[6], m = vm[k];
+        for (int u = 0; u < cnt; ++u) {
+            const int64_t col = __builtin_amdgcn_readlane(colreg, u);
+            const xv4 x = *reinterpret_cast<const xv4*>(xb + col * 3 * ldx);
+            const double* ca = sa + u * 9 + ga;  // column g of the blocks
+            const double* cb = sb + u * 9 + ga;
+            const double a0 = ca[0], a1 = ca[3], a2 = ca[6], b0 = cb[0], b1 = cb[3], b2 = cb[6], m = sm[u];
 #pragma unroll
-        for (int v = 0; v < 4; ++v) {
-            const double xv = (double)x[v];
-            aa[0][v] = fma(a0, xv, aa[0][v]);
-            aa[1][v] = fma(a1, xv, aa[1][v]);
-            aa[2][v] = fma(a2, xv, aa[2][v]);
-            ab[0][v] = fma(b0, xv, ab[0][v]);
-            ab[1][v] = fma(b1, xv, ab[1][v]);
-            ab[2][v] = fma(b2, xv, ab[2][v]);
-            am[v] = fma(m, xv, am[v]);
+            for (int v = 0; v < 4; ++v) {
+                const double xv = (double)x[v];
+                aa[0][v] = fma(a0, xv, aa[0][v]);
+                aa[1][v] = fma(a1, xv, aa[1][v]);
+                aa[2][v] = fma(a2, xv, aa[2][v]);
+                ab[0][v] = fma(b0, xv, ab[0][v]);
+                ab[1][v] = fma(b1, xv, ab[1][v]);
+                ab[2][v] = fma(b2, xv, ab[2][v]);
+                am[v] = fma(m, xv, am[v]);
+            }
+        }
+        if (kc + PL_CHUNK < ke) {  // the slabs are rewritten by the next pass
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
         }
     }
     // lane (g, cl) ends with output row g: its own share plus the shares of the two other groups (as the node kernel)
