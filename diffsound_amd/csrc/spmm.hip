@@ -523,7 +523,6 @@ __global__ void __launch_bounds__(256)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll 4
         for (int u = 0; u < cnt; ++u) {
             const int64_t col = __builtin_amdgcn_readlane(colreg, u);
             const xv4 x = *reinterpret_cast<const xv4*>(xb + col * 3 * ldx);
@@ -867,7 +866,7 @@ extern "C" int ds_union_residual(int level_tag, const int32_t* utab, const int32
     double* partial = reinterpret_cast<double*>(static_cast<char*>(work) + ngroups * 2 * (int64_t)ncols * 4);
     union_norm_partial_kernel<<<UN_NORM_BLOCKS, 256, 0, st>>>(static_cast<const float*>(work), (unsigned)ngroups, 2 * ncols, partial);
     DS_LAUNCH_CHECK("union_norm_partial_kernel");
-    union_norm_final_kernel<<<1, 256, 0, st>>>(partial, ncols, rn2, xn2);
+    union_norm_final_kernel<<<(unsigned)(2 * ncols), 256, 0, st>>>(partial, ncols, rn2, xn2);
     DS_LAUNCH_CHECK("union_norm_final_kernel");
     return DS_OK;
 }
