@@ -1,95 +1,107 @@
 #!/usr/bin/env python3
-"""Regenerate profiles/README.md from the committed round-3 evidence (bench JSON, rocprofv3 kernel-stat summaries, PMC)."""
-import csv, json, os
+"""profiles/README.md for round 4 from the files under profiles/ (python tools/make_profiles_readme.py)."""
+import csv
+import json
+import os
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-P = lambda f: os.path.join(ROOT, "profiles", f)
+P = lambda *a: os.path.join(ROOT, "profiles", *a)
 
 
-def table(f, n=16):
-    rows = list(csv.reader(open(P(f))))
-    out = ["| kernel | calls | total ms | avg us | % |", "|---|---|---|---|---|"]
-    for r in rows[1:n + 1]:
-        name = r[0].replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", "")
-        if name.startswith("Cijk"):
-            name = "rocBLAS `Cijk_…` (set-up, outside the timed region)"
-        elif name.startswith("void at::native"):
-            name = "torch elementwise / reduce kernel"
-        else:
-            name = "`" + name.split("(")[0].replace("void ", "") + "`"
-        out.append(f"| {name} | {r[1]} | {r[2]} | {r[3]} | {r[6]} |")
-    t = rows[-1]
-    out.append(f"| all kernels | {t[1]} | {t[2]} | | 100 |")
+def table(name, top):
+    rows = list(csv.DictReader(open(P(name))))[:top]
+    out = ["| kernel | calls | total ms | avg us | min | max | % |", "|---|---|---|---|---|---|---|"]
+    for r in rows:
+        k = r["kernel"].replace("(anonymous namespace)::", "").replace("void ", "")
+        k = k.split("(")[0]
+        out.append(f"| `{k}` | {r['calls']} | {float(r['total_ms']):.1f} | {float(r['avg_us']):.1f} | {float(r['min_us']):.1f} | "
+                   f"{float(r['max_us']):.1f} | {float(r['percent']):.1f} |")
     return "\n".join(out)
 
 
-d = json.load(open(P("r03_bench_n1.json")))
-r = d["roofline"]
-pmc = json.load(open(P("spmm_pmc_bytes_per_launch.json")))
-gm = json.load(open(P("r03_gram_mix_pmc.json")))
-util = {k: v["SQ_VALU_MFMA_BUSY_CYCLES"]["mean"] / (v["GRBM_GUI_ACTIVE"]["mean"] / 8 * 1024) for k, v in gm.items()}
-cb = d["cpu_baseline"]
-c5 = json.load(open(P("r03_c5_bench_noprof.json")))
-am = d.get("amortised") or {}
-lines = f'''# profiles/ — round 3 evidence (MI355X, gfx950, ROCm 7.2); round 1 under `r01/`, round 2 as `r02_*`
+def kernel_row(name, key):
+    for r in csv.DictReader(open(P(name))):
+        if key in r["kernel"]:
+            return r
+    return None
 
-All runs: `bench.py` defaults = workload C3 (Kuhn box 26³ = 105 456 tets, ord-2, n = 446 631, nnz = 37.2 M, 64 modes,
-block 80, two-level preconditioner on bf16 blocks with both levels' terms on the matrix cores, nested start to 3e-3,
-tolerance 1e-5), 8 hypotheses per step, 8 in flight per GPU, cold-start eigensolve and numeric assembly in every pass.
-Collected by `tools/collect_profiles.sh r03` on the GPU box (regenerate this file with `python tools/make_profiles_readme.py`).
+
+d = json.load(open(P("r04_bench_n1.json")))
+r = d["roofline"]
+kw = r["lobpcg_spmm"]
+cb = d["cpu_baseline"]
+pmc = json.load(open(P("spmm_pmc_bytes_per_launch.json")))
+l1 = "r04_bench_lanes1_kernel_stats.csv"
+st = kernel_row(l1, "stream_triad_kernel")
+stream_l1 = 3 * (1 << 28) * 4 / (float(st["avg_us"]) * 1e-6) / 1e9
+fine = kernel_row(l1, "spmm_union_mfma_kernel<8, 5, 1, false, 16, 0>")
+kx = kernel_row(l1, "spmm_union_kernel<20, 0, 140, false, false, true, 0>")
+res = kernel_row(l1, "spmm_union_kernel<20, 4, 140, false, false, true, 0>")
+fb, kb = r["algorithmic_bytes_per_launch"], kw["algorithmic_bytes_per_launch"]
+
+
+def frac(nbytes, row):
+    g = nbytes / (float(row["avg_us"]) * 1e-6) / 1e9
+    return f"{row['calls']} launches, avg {float(row['avg_us']):.1f} us (min {float(row['min_us']):.1f}, max {float(row['max_us']):.1f}) -> {g:.0f} GB/s = {100 * g / 8000:.1f} % of 8 TB/s, {100 * g / stream_l1:.1f} % of that run's STREAM triad ({stream_l1:.0f} GB/s)"
+
+
+lines = f'''# profiles/ — round 4 evidence (MI355X, gfx950, ROCm 7.2); round 3 as `r03_*`, round 2 as `r02_*`, round 1 under `r01/`
+
+All runs: `bench.py` defaults = workload C3 (Kuhn box 26³ = 105 456 tets, ord-2, n = 446 631, nnz = 37.2 M, 64 modes, block 80,
+two-level preconditioner on bf16 blocks with both levels' terms on the matrix cores, nested start to 3e-3, tolerance 1e-5),
+8 hypotheses per step, 8 in flight per GPU, cold-start eigensolve and numeric assembly in every pass.
+Collected by `tools/collect_profiles.sh r04 <part>` on the GPU box (this file: `python tools/make_profiles_readme.py`).
 
 | file | what |
 |---|---|
-| `r03_bench_n1.json` | the JSON line of `python bench.py` (N = 1, {d["steps"]} steps, {d["warmup"]} warm-up, CPU baseline included): **{d["value"]:.1f} passes/s**; amortised variant (eigendecomposition every 15 passes) {am.get("value", float("nan")):.0f} passes/s |
-| `r03_bench_kernel_stats.csv` | `rocprofv3 --kernel-trace --stats` of `python bench.py --no-cpu-baseline --steps 8` (8 hypothesis lanes overlap: durations stretched by sharing) |
-| `r03_bench_lanes1_kernel_stats.csv` | the same with `--lanes 1 --hyp-per-gpu 2 --steps 4`: one hypothesis at a time, every kernel alone on the device — the table to read kernel durations from |
-| `r03_gpu_busy.txt`, `r03_concurrency_profile.txt` | device-busy fraction of the timed window (`tools/gpu_busy.py`) and the concurrency profile (`tools/gpu_timeline.py`: kernels in flight, busy share per stream, idle time by gap size, which kernels border the short gaps) |
-| `r03_spmm_pmc_fp32.json`, `r03_spmm_pmc_bf16.json`, `r03_spmm_pmc_mfma.json`, `spmm_pmc_bytes_per_launch.json` | HBM-side traffic of the fused Chebyshev-term SpMM (fine level, 80 columns) from separate `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes; bytes = (2·FETCH + WRITE)·1024 (gfx950 correction of `guides/MI355X_MICROARCH.md`): VALU kernel on fp32 blocks {pmc["cells26_cols80_fp32"]["bytes"] / 1e6:.0f} MB (743.1 MB algorithmic), on bf16 blocks {pmc["cells26_cols80_bf16"]["bytes"] / 1e6:.0f} MB (457.3 MB algorithmic), **MFMA kernel (production) {pmc["cells26_cols80_mfma"]["bytes"] / 1e6:.0f} MB ({r["algorithmic_bytes_per_launch"] / 1e6:.1f} MB algorithmic, {pmc["cells26_cols80_mfma"]["bytes"] / r["algorithmic_bytes_per_launch"]:.2f} ×)**; every record carries the hash of the SpMM sources it was measured on (`bench.py` reports a record with another hash as stale: `traffic: null`) |
-| `r03_mfma_interference_matrix.txt` | the gfx950 finding from the victim's side (`tools/mfma_interference.py`, `tests/probes/mfma_probe.hip`): register-only MFMA spins (x32 / x16 bf16, fp32, plain FMA) beside register-only chains of `v_pk_fma_f32` / `v_fma_f32` and beside the production kernels, every launch compared bit for bit with its solo result - taken with the packed-FMA build of round 2 as the production victim (120 of 120 launches changed beside the double-rate form) |
-| `r03_no_packed_fp32_ab.txt` | A/B of the build without packed FP32 (shipped) against the packed build: kernel timings, benchmark, bit-identical loss, and the same matrix with 0 of 120 for every production kernel |
-| `r03_mfma_batch_sizes.txt` | the fused term at C3 with LDS batches of 32 / 16 / 8 entries (2 / 3 / 4 waves per SIMD): 171 / 145 / 144 us |
-| `r03_union_knockout.txt`, `r03_union_prefetch_ab.txt` | knock-out builds of the neighbour-union kernel (`tools/exp_knockout.sh`, `-DDS_KO=bits`): K X 248 us whole, 201 without FMAs, 221 without coefficient reads, 174 without gathers, 92 with none of the three, 78 skeleton - the parts add up (a wave's chain, no saturated unit); the A/B of what followed (coefficients one block ahead, 84 VGPRs): K W 231 -> 220 us in the bench |
-| `r03_gather_probe.txt` | `tools/gather_probe.hip` on the real C3 union tables: the panels of every group pulled into registers with no arithmetic. Mode 7 (added late in the round) maps workgroups to groups as the library does (each XCD a contiguous range): **94 us = 24 TB/s** for the 4-node fp32 unions, 82 / 86 us for 8- / 16-node unions, against 220 / 180 / 146 us with workgroups dealt round-robin over the XCDs (modes 0-6, which the round first read as the bound of K W); tail: the outer-product MFMA experiment |
-| `r03_gram_knockout.txt`, `r03_mix_knockout.txt` | knock-out builds of the Gram and `mix` kernels (`-DDS_KOG`, `-DDS_KOM`): Gram 240x80 0.225-0.234 ms whole, MFMAs alone 0.168, operand loads alone 0.208 (B through LDS measured: -4.5 %, not adopted); `mix` 240->80 0.207 whole / 0.194 MFMAs alone / 0.160 loads alone, 240->160 0.370 / 0.337 / 0.222: `mix` runs at the rate its MFMA loop issues (88-102 TF/s; the instruction alone sustains 134-138 TF/s at 2.3-2.4 GHz, `tools/mfma_rate_probe.hip`) |
-| `r03_cpu_memsafe_8_container.json`, `r03_cpu_memsafe_12_container.json`, `r03_cpu_memsafe_16_container.json` | BASELINE.md section 3 (i)/(ii): the memory-safe CPU restatement (`tools/cpu_baseline_memsafe.py`) on the build container's 8 cores: 23.5 s / 181.5 s / 1 025 s per pass at 3 072 / 10 368 / 24 576 tets; ARPACK's shift-invert 11.7 / 100 / 776 s (n^2.5): about 7 hours at the benchmark mesh, which is why (i) is not measured |
-| `r03_cached_pass_profile.txt` | `tools/prof_cached_pass.py`: host profile of the pass between eigendecompositions as torch operations (0.83 ms: autograd engine 0.43, ~45 element-wise launches) and its time as one native call (`ds_readout_pass`): 0.11 ms |
-| `r03_bench_step_barrier.json` | the same run with `--step-barrier` (all lanes join after every step: the schedule up to the middle of round 3), same call as `r03_bench_n1.json`: 42.8 against 44.9 passes/s |
-| `r03_lane_tail.txt` | `tools/lane_tail.py`: when each of the 8 hypothesis lanes finishes inside a step joined at its end (90 ... 195 ms of 195: 14-15 % of the lane time is tail) and when each hypothesis' last step ends without the join (10 %: the hypotheses themselves cost differently; 8 hardware queues instead of 4 change nothing) |
-| `r03_lanes_sweep.txt`, `r03_exp_knobs.txt`, `r03_exp_nested_tol.txt` | throughput against lanes, block width, smoother / corner-level degree, nested-start tolerance (the re-tuning behind this round's defaults) |
-| `r03_host_time_one_lane.txt`, `r03_device_eigh_probe.txt` | host time of one solve by cause (`DS_EXP_TIMING=1`); the dense Rayleigh-Ritz steps through rocSOLVER on the device against one host core |
-| `r03_symbolic_phase_timing.txt` | `tools/time_lift.py`: ord-2 lifting and the symbolic phase per topology at C3 |
-| `r03_gram_mix.txt`, `r03_gram_mix_pmc.json` | Gram / `mix` timings at the solver's shapes and their MFMA counters: utilisation = busy cycles ÷ (GRBM_GUI_ACTIVE / 8 XCDs × 1024 SIMDs) = ''' + ", ".join(f"{k.split('(')[0]} {100 * v:.0f} %" for k, v in util.items()) + f''' |
-| `r03_c5_bench_noprof.json`, `r03_c5_bench.json`, `r03_c5_kernel_stats.csv` | **configs[4]** (`bench.py --workload c5`, plain and under `rocprofv3 --kernel-trace --stats`): 998 250 tets, n = 4.1 M, 128 modes - SpMM bandwidth of every product form against the in-run STREAM triad, fp32 solve {c5["solve"]["fp32_iteration_plus_fp64_polish"]["seconds"]:.1f} s, with the fp64 refinement to 1e-10 **{c5["solve"]["with_fp64_refinement"]["seconds"]:.1f} s** ({c5["solve"]["with_fp64_refinement"]["fp64_steps"]} fp64 steps; second solve of the process, figures of the plain run) |
+| `r04_bench_n1.json` | the JSON line of `python bench.py` (N = 1, 10 steps, 2 warm-up, CPU baseline at two sizes included): **{d["value"]:.1f} passes/s**; amortised variant {d["amortised"]["value"]:.0f} passes/s |
+| `r04_bench_kernel_stats.csv`, `r04_gpu_busy.txt` | `rocprofv3 --kernel-trace --stats` of `python bench.py --no-cpu-baseline --steps 8` (8 lanes overlap: durations stretched by sharing) and the device-busy fraction of its timed window |
+| `r04_bench_lanes1_kernel_stats.csv` | the same with `--lanes 1 --hyp-per-gpu 2 --steps 4`: one hypothesis at a time, every kernel alone on the device — **the table to read kernel durations from; fine- and corner-node-level launches carry different symbols (the last template argument: 0 fine, 1 corner-node level)** |
+| `spmm_pmc_bytes_per_launch.json`, `r04_spmm_pmc_{{fp32,bf16,mfma,kx}}.json` | HBM-side traffic per launch from separate `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes; bytes = (2·FETCH + WRITE)·1024 (gfx950 correction of `guides/MI355X_MICROARCH.md`); every record carries the hash of the SpMM sources and of `modal_ops.py` (the ordering and the union tables) it was measured on — `bench.py` reports a record with another hash as stale (`traffic: null`) |
+| `r04_node_order_ab.txt` | A/B on one box of the node ORDERING: Morton curve over raw coordinates (round 3) against bricks aligned to the mesh's node planes — 45.5 → 48.0 passes/s, K·W 210 → 198 µs, bf16 term 2 500 → 3 100 GB/s |
+| `r04_union_cap_ab.txt` | chunk cap of the neighbour-union tables 116 → 140 blocks (every group one chunk): K·X 215 → 204 µs |
+| `r04_kx_fresh_ab.txt` | K·X′ by one fresh product instead of the update of K·[X P W]: 48.3 → 49.6 passes/s |
+| `r04_basis_row_pitch_ab.txt`, `r04_mb_kx_strided.txt`, `r04_mb_kx_layout.txt` | the solver's basis buffers with rows 1 KiB apart (256-column pitch instead of 248): K·X / M·X against operand layouts, interleaved and warmed up — compact blocks 177 / 137 µs, ranges of a 248-column buffer 193 / 165, of a 256-column buffer 182 / 152; +1–2 % passes/s |
+| `r04_fused_residual_ab.txt`, `r04_mb_fused_residual.txt` | the residual of every iteration in ONE walk of the unions (`ds_union_residual`): 459 µs (K·X′ + M·X′ + residual) → 280 µs (239 after the norm reduction was parallelised); 49.3 → 51.8 passes/s |
+| `r04_mfma32_knockout.txt`, `r04_m32_diag.txt`, `r04_mb_kx.txt`, `r04_mb_kx_raw_morton.txt`, `r04_mb_kx_plane_order.txt` | **the fp32 matrix-core form of the eigensolver's own products (`ds_spmm_union32m`): built, parity-green, slower** — K·X 263–277 µs against the VALU kernel's 205–235 on the same boxes; knock-out builds (no MFMAs 189, no gathers 249, no A-fragment chain 222, none 110); per-wave `s_memtime` stamps of a diagnostic build (`tools/m32_diag.py`): where a wave's cycles go in that kernel and in the bf16 term, the in-kernel clock (2.0–2.1 GHz), wave slots occupied |
+| `r04_corner_batch_ab.txt`, `r04_mb_corner.txt` | the corner-node level's bf16 term with batches of 16 and of 32 entries at its real size (2 461 groups): 18.2 against 23.5 µs — both levels run 16 |
+| `r04_union_waves_per_workgroup_ab.txt` | the VALU union kernel with 4 / 2 / 1 waves per workgroup: 208 / 213 / 215 µs (4 stays) |
+| `r04_lanes_sweep.txt` | 6 / 8 / 12 / 16 hypothesis lanes: 47.9 / 49.2 / 49.7 / 49.0 passes/s (the device, not the host, is the bound) |
+| `r04_gram_mix.txt`, `r04_gram_mix_pmc.json` | Gram / `mix` timings at the solver's shapes and their MFMA counters |
+| `r04_symbolic_phase_timing.txt` | ord-2 lifting and the symbolic phase per topology at C3 |
+| `r04_c5_bench.json`, `r04_c5_kernel_stats.csv` | **configs[4]** (`bench.py --workload c5` under `rocprofv3 --kernel-trace --stats`): 998 250 tets, n = 4.1 M, 128 modes |
 
 ## A note on the profiled runs
 
-One of about ten `rocprofv3 --kernel-trace --stats -- python3 bench.py ...` runs of this round ended in a host SIGSEGV inside the HIP
-runtime's launch path under the profiler's hooks (a hypothesis lane's thread, first seconds of the run; `ds_spmm_union16m` happened to be
-the caller). Two immediate reruns of the same command on fresh boxes were clean, no unprofiled run or test has ever shown it, and the
-stack ends in runtime / profiler frames, not in this library: recorded here as a profiler-side flake of concurrent launches from eight
-threads, not investigated further.
+About one in ten `rocprofv3 --kernel-trace --stats -- python3 bench.py ...` runs with 8 lanes ends in a host SIGSEGV inside the HIP
+runtime's launch path under the profiler's hooks (first seconds of the run; it happened once in round 3 and once in round 4, each
+time an immediate rerun was clean; no unprofiled run or test has ever shown it). `collect_profiles.sh` gives that step a second try.
 
-## Roofline figures of `r03_bench_n1.json`
+## Roofline figures of `r04_bench_n1.json` (HIP events inside `bench.py`) and of the kernel table
 
-* dominant kernel `{r["kernel"]}`: {r["algorithmic_bytes_per_launch"] / 1e6:.1f} MB algorithmic per launch, {r["avg_launch_ms"]:.3f} ms alone on the device
-  → **{r["achieved"]:.0f} GB/s = {100 * r["frac"]:.1f} % of 8 TB/s, {100 * r["frac_of_stream"]:.1f} % of the STREAM triad measured in the same run ({r["stream_triad"]:.0f} GB/s)**; PMC traffic {r["traffic"]} B ({r["traffic_note"]});
+* dominant kernel `{r["kernel"]}`: {fb / 1e6:.1f} MB algorithmic per launch (SURVEY.md §8(d), BSR-3 count), {r["avg_launch_ms"]:.4f} ms alone on the device (30 back-to-back launches right after the timed region)
+  → **{r["achieved"]:.0f} GB/s = {100 * r["frac"]:.1f} % of 8 TB/s, {100 * r["frac_of_stream"]:.1f} % of the STREAM triad measured in the same run ({r["stream_triad"]:.0f} GB/s)**; PMC traffic {pmc["cells26_cols80_mfma"]["bytes"] / 1e6:.1f} MB = {pmc["cells26_cols80_mfma"]["bytes"] / fb:.2f} × algorithmic;
+  from `{l1}` alone: {frac(fb, fine)};
   in situ (8 lanes sharing the chip): fine {r["in_situ"]["levels"]["fine"]["avg_launch_ms"]:.3f} ms, corner-node {r["in_situ"]["levels"]["corner_node"]["avg_launch_ms"]:.3f} ms per launch;
-* the eigensolver's K·W: {r.get("lobpcg_spmm", {}).get("achieved", float("nan")):.0f} GB/s = {100 * r.get("lobpcg_spmm", {}).get("frac_of_stream", float("nan")):.0f} % of STREAM ({r.get("lobpcg_spmm", {}).get("avg_launch_ms", float("nan")):.3f} ms for 451.9 MB, fine level, alone on the device);
-* CPU baseline: {cb["sample"]} on {cb["cores"]} threads of {cb["cpu_model"]} ({cb["host_hardware_threads"]} hardware threads on the host); stages of the median pass {cb["stage_seconds"]}.
+* the eigensolver's K·W (`{kw["kernel"][:60]}…`): {kb / 1e6:.1f} MB in {kw["avg_launch_ms"]:.4f} ms on the iteration's own operands ({kw["avg_launch_ms_on_compact_blocks"]:.4f} ms on compact blocks) = {kw["achieved"]:.0f} GB/s = **{100 * kw["frac_of_stream"]:.1f} % of STREAM** in the bench's post-run state; PMC traffic {pmc["cells26_cols80_kx"]["bytes"] / 1e6:.1f} MB = {pmc["cells26_cols80_kx"]["bytes"] / kb:.2f} × algorithmic;
+  from `{l1}` alone: {frac(kb, kx)};
+  in a fresh process, interleaved and warmed up (`r04_mb_kx_layout.txt`): 177 µs on compact blocks (42 %), 182–186 µs on the solver's operands (40–41 %);
+* the fused residual (`spmm_union_kernel<20,4,…,0>`, K·X′ and M·X′ of one block in one walk): {frac(kb + 4136393 * 4.0, res)} (bytes: K·X's plus the mass scalars; the block R replaces Y);
+* CPU baseline: {cb["sample"]} on {cb["cores"]} threads of {cb["cpu_model"]} ({cb["host_hardware_threads"]} hardware threads on the host); measured exponent {cb["measured_exponent"]["value"]:.2f}; extrapolated with it to the benchmark mesh {cb["extrapolated_to_benchmark_mesh_measured_exponent"]["seconds_per_pass"]:.0f} s per pass.
 
-## One hypothesis at a time (`r03_bench_lanes1_kernel_stats.csv`; 15 passes incl. the target render and one warm-up step)
+## One hypothesis at a time (`{l1}`; 15 passes incl. the target render and one warm-up step)
 
-{table("r03_bench_lanes1_kernel_stats.csv", 22)}
+{table(l1, 26)}
 
-`spmm_union_mfma_kernel<8, NT, EPI, OUT32, BATCH>`: the bf16 terms of both levels on the matrix cores (8 nodes per
-wavefront, NT 16-column tiles: 5 = the full 80-column block, fewer after locking; EPI 1 fused Chebyshev term, 2 residual
-handed to the corner-node level; OUT32 = the term that leaves the V-cycle; BATCH 16 on the fine level, 32 on levels smaller
-than the device's wave slots - the name covers the fine level's ~145 us launches and the corner-node level's ~18 us ones).
-`spmm_union_kernel<20|0, EPI, 116, BIG, BF, OUT32>`: the VALU kernel - LPN 20 = full 80-column blocks, 0 = the narrower
-blocks after locking; EPI 0 K·W, 3 mass product.
+`spmm_union_mfma_kernel<8, NT, EPI, OUT32, 16, LVL>`: the bf16 terms on the matrix cores (8 nodes per wavefront, NT 16-column
+tiles: 5 = the full 80-column block, fewer after locking; EPI 1 fused Chebyshev term, 2 residual handed to the corner-node level;
+OUT32 = the term that leaves the V-cycle; LVL 0 fine level, 1 corner-node level).
+`spmm_union_kernel<20|0, EPI, 140, BIG, BF, OUT32, LVL>`: the VALU kernel — LPN 20 = full 80-column blocks, 0 = the narrower blocks
+after locking; EPI 0 K·W, 3 mass product (M·W of the orthonormalisation), 4 the fused residual.
 
-## Default run, 8 lanes (`r03_bench_kernel_stats.csv`)
+## Default run, 8 lanes (`r04_bench_kernel_stats.csv`)
 
-{table("r03_bench_kernel_stats.csv", 16)}
+{table("r04_bench_kernel_stats.csv", 16)}
 '''
 open(P("README.md"), "w").write(lines)
 print("wrote profiles/README.md")
