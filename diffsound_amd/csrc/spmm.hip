@@ -404,6 +404,10 @@ int launch_fast(const int32_t* rowptr, const int32_t* colidx, const void* vals, 
 // merged at the end.  The generic kernel above gives a lane 2 columns of one node and makes it load all 9 values
 // of every block itself: 12 dependent-address loads per block and lane, 1.17 ms per 64-column product on the
 // benchmark mesh; this one issues 4.
+// (round 4: the row's fp64 coefficients are staged per chunk in LDS with coalesced loads and the neighbour ids come back with
+// v_readlane, as in spmm_f64_polish_kernel below - three dependent-address global loads per block and lane fewer; same sums in
+// the same order)
+constexpr int F64_CHUNK = 32;  // blocks of a row staged per pass
 template <int KIND, typename TX>
 __global__ void __launch_bounds__(256)
     spmm_f64_node_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx,
@@ -411,6 +415,7 @@ __global__ void __launch_bounds__(256)
                          double* __restrict__ Y, int64_t ldy, int lpn, unsigned nblk) {
     using d2 = __attribute__((ext_vector_type(2))) double;
     using xv4 = __attribute__((ext_vector_type(4))) TX;  // 16 bytes of an f32 row, 32 bytes of an f64 row
+    __shared__ double s_v[4][F64_CHUNK * (KIND == 0 ? 9 : 1)];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t node = (int64_t)ds::xcd_remap(blockIdx.x, nblk) * 4 + wave;
@@ -420,29 +425,47 @@ __global__ void __launch_bounds__(256)
     const int ga = active ? g : 0;
     const int kb = __builtin_amdgcn_readfirstlane(rowptr[node]), ke = __builtin_amdgcn_readfirstlane(rowptr[node + 1]);
     const TX* xb = X + (int64_t)ga * ldx + cl * 4;
+    double* sv = s_v[wave];
     double acc[3][4];
 #pragma unroll
     for (int r = 0; r < 3; ++r)
 #pragma unroll
         for (int v = 0; v < 4; ++v) acc[r][v] = 0.0;
+    if (KIND == 1) {  // node scalars: index and value of a block are wave-uniform loads (the scalar path): nothing to stage
 #pragma unroll 4
-    for (int k = kb; k < ke; ++k) {
-        const int64_t col = colidx[k];
-        const xv4 x = *reinterpret_cast<const xv4*>(xb + col * 3 * ldx);
-        if (KIND == 0) {
-            const double* a = vals + (int64_t)k * 9 + ga;  // column g of the block
-            const double a0 = a[0], a1 = a[3], a2 = a[6];
-#pragma unroll
-            for (int v = 0; v < 4; ++v) {
-                const double xv = (double)x[v];
-                acc[0][v] = fma(a0, xv, acc[0][v]);
-                acc[1][v] = fma(a1, xv, acc[1][v]);
-                acc[2][v] = fma(a2, xv, acc[2][v]);
-            }
-        } else {
+        for (int k = kb; k < ke; ++k) {
+            const int64_t col = colidx[k];
+            const xv4 x = *reinterpret_cast<const xv4*>(xb + col * 3 * ldx);
             const double m = vals[k];
 #pragma unroll
             for (int v = 0; v < 4; ++v) acc[0][v] = fma(m, (double)x[v], acc[0][v]);  // m I3: row g feeds row g only
+        }
+    } else {
+        for (int kc = kb; kc < ke; kc += F64_CHUNK) {
+            const int cnt = min(F64_CHUNK, ke - kc);  // wave-uniform
+            const int colreg = lane < cnt ? colidx[kc + lane] : 0;
+            const double* pv = vals + (int64_t)kc * 9;
+            for (int t = lane; t < cnt * 9; t += 64) sv[t] = pv[t];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            for (int u = 0; u < cnt; ++u) {
+                const int64_t col = __builtin_amdgcn_readlane(colreg, u);
+                const xv4 x = *reinterpret_cast<const xv4*>(xb + col * 3 * ldx);
+                const double* a = sv + u * 9 + ga;  // column g of the block
+                const double a0 = a[0], a1 = a[3], a2 = a[6];
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const double xv = (double)x[v];
+                    acc[0][v] = fma(a0, xv, acc[0][v]);
+                    acc[1][v] = fma(a1, xv, acc[1][v]);
+                    acc[2][v] = fma(a2, xv, acc[2][v]);
+                }
+            }
+            if (kc + F64_CHUNK < ke) {  // the slab is rewritten by the next pass
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
         }
     }
     double out[4];
