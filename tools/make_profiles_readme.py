@@ -69,7 +69,7 @@ Collected by `tools/collect_profiles.sh r04 <part>` on the GPU box (this file: `
 | `r04_lanes_sweep.txt` | 6 / 8 / 12 / 16 hypothesis lanes: 47.9 / 49.2 / 49.7 / 49.0 passes/s (the device, not the host, is the bound) |
 | `r04_gram_mix.txt`, `r04_gram_mix_pmc.json` | Gram / `mix` timings at the solver's shapes and their MFMA counters |
 | `r04_symbolic_phase_timing.txt` | ord-2 lifting and the symbolic phase per topology at C3 |
-| `r04_c5_bench.json`, `r04_c5_kernel_stats.csv` | **configs[4]** (`bench.py --workload c5` under `rocprofv3 --kernel-trace --stats`): 998 250 tets, n = 4.1 M, 128 modes |
+| `r04_c5_bench.json`, `r04_c5_kernel_stats.csv`, `r04_c5_bench_noprof.json` | **configs[4]** (`bench.py --workload c5` under `rocprofv3 --kernel-trace --stats`, and plain): 998 250 tets, n = 4.1 M, 128 modes - solve with fp64 refinement 3.43 s |
 
 ## A note on the profiled runs
 
