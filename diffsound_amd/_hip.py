@@ -13,7 +13,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DS_EXP_LIB") or os.path.join(_HERE, "csrc", "libdiffsound_hip.so")  # (DS_EXP_LIB: A/B builds, experiments)
-ABI_VERSION = 26  # DS_ABI_VERSION of include/diffsound_hip.h
+ABI_VERSION = 27  # DS_ABI_VERSION of include/diffsound_hip.h
 
 c_i32p = ctypes.POINTER(ctypes.c_int32)
 _P = ctypes.c_void_p
@@ -63,6 +63,7 @@ _SIGNATURES = {
     "ds_union_residual_workspace_bytes": (_I64, [_I64, _I]),
     "ds_union_residual": (_I, [_I, _P, _P, _I64, _I, _P, _P, _P, _I64, _I64, _P, _I64, _P, _P, _I64, _I, _P, _I64, _P, _P, _P]),
     "ds_mix": (_I, [_P, _I64, _I, _P, _I, _P, _I64, _I64, _F, _F, _P]),
+    "ds_mix64": (_I, [_I, _P, _P, _I64, _I, _P, _I64, _I64, _D, _D, _P]),
     "ds_osc_bank_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _D, _P, _P]),
     "ds_osc_bank_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _D, _P, _P, _P, _P, _P]),
     "ds_readout_pass": (_I, [_P, _P, _P, _P, _I, _D, _D, _D, _D, _D, _D, _D, _D, _P, _I, _I, _D, _P, _I, _P, _P, _P, _P, _P, _P]),
@@ -76,6 +77,11 @@ _SIGNATURES = {
     "ds_spec_loss": (_I, [_I, _P, _P, _I, _I, _I, _F, _F, _I, _P, _P, _P]),
     "ds_stft_power_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _F, _P, _P, _P]),
 }
+
+class Mix64Block(ctypes.Structure):
+    """ds_mix64_block_t of include/diffsound_hip.h."""
+    _fields_ = [("a", _P), ("lda", _I64), ("p", ctypes.c_int32), ("c_row", ctypes.c_int32)]
+
 
 class LevelDesc(ctypes.Structure):
     """ds_level_t of include/diffsound_hip.h."""

@@ -723,8 +723,8 @@ class ModalSolver:
         RAYLEIGH-RITZ BY RECURRENCE, as in the fp32 iteration: only the NEW columns meet the vectors - the Gram blocks
         S^T K W and S^T M W (8 tall-skinny products per step instead of 22) - while the blocks among Y, X and P follow
         from the last step's eigenvector matrix by (3b + 6)-dimensional algebra; every ``refine_refresh``-th step
-        recomputes all blocks from the vectors.  The n x b updates accumulate in place (``addmm``): no temporaries of
-        the size of a block."""
+        recomputes all blocks from the vectors.  The n x b updates are ``ops.mix64`` (ds_mix64, fp64 MFMA) over the LIST
+        of blocks of S: one pass per result, no temporaries of the size of a block."""
         ops, cfg = self.ops, self.cfg
         dev = ops.device
         X = res.block_vectors.double()
@@ -768,7 +768,7 @@ class ModalSolver:
         # K-diagonal / M-orthonormal - which every later step's X is by construction
         GA, GB = ops.gram(X, KX), ops.gram(X, MX)
         lam, C = _small(gen_eigh, dev, GA, GB)
-        X, KX, MX = X @ C, KX @ C, MX @ C
+        X, KX, MX = ops.mix64([X], C), ops.mix64([KX], C), ops.mix64([MX], C)
         P = KP = MP = None
         G0A = G0B = None  # Gram blocks among [Y | X | P] of the current basis (fp64, m0 x m0), by recurrence
         refresh = max(1, int(getattr(cfg, "refine_refresh", 8)))
@@ -850,26 +850,24 @@ class ModalSolver:
             Zs = Z[:, ny:ny + b].contiguous()  # the six lowest pairs are the rigid modes
             lam = E_[ny:ny + b].contiguous()
             xo = ny  # row offset of X in S
-            Cx = Zs[xo:xo + b].contiguous()
-            # update directions: everything of the new X that is not the old X, accumulated in place
+            # update directions: everything of the new X that is not the old X.  Their scale (unit M-norm) comes from the
+            # small algebra (Pn = S Zr), so the coefficients of the scaled directions in S are known before any n-sized
+            # work, and every result is ONE pass over the blocks of S (ds_mix64: each block read once, the result
+            # written once, no n x b temporaries)
             Zr = Zs.clone()
             Zr[xo:xo + b] = 0.0
+            pn2 = ((Zr.transpose(0, 1) @ GB) * Zr.transpose(0, 1)).sum(1)[idx].clamp(min=1e-300)
+            sc = torch.rsqrt(pn2)
+            Tp = (Zr[:, idx] * sc[None, :]).contiguous()
+            xi = 1 if ny else 0  # position of X in the head
             news = []
             for which in range(3):  # the vectors, their K-products, their M-products
                 parts = [h[which] for h in head] + [(W, KW, MW)[which]]
-                Pn = None
-                for i_, blk in enumerate(parts):
-                    if blk is head[1 if ny else 0][which]:
-                        continue  # (the old X: it enters through Cx below)
-                    c = Zs[offs[i_]:offs[i_ + 1]]
-                    Pn = torch.mm(blk, c) if Pn is None else Pn.addmm_(blk, c)
-                news.append(Pn)
-            Pn, KPn, MPn = news
-            X, KX, MX = torch.addmm(Pn, X, Cx), torch.addmm(KPn, KX, Cx), torch.addmm(MPn, MX, Cx)
-            # directions of the active pairs only, unit M-norm (from the small algebra: Pn = S Zr)
-            pn2 = ((Zr.transpose(0, 1) @ GB) * Zr.transpose(0, 1)).sum(1)[idx].clamp(min=1e-300)
-            sc = torch.rsqrt(pn2)
-            P, KP, MP = Pn[:, idx] * sc[None, :], KPn[:, idx] * sc[None, :], MPn[:, idx] * sc[None, :]
+                Xn = ops.mix64(parts, Zs)
+                Pd = ops.mix64([(blk, offs[i_]) for i_, blk in enumerate(parts) if i_ != xi], Tp)  # (X's rows of Tp are zero)
+                news.append((Xn, Pd))
+            (X, P), (KX, KP), (MX, MP) = news
+            del news
             # Gram blocks among [Y | X_new | P_new] for the next step: T^T G T with T the coefficients of that basis in S
             T = torch.zeros((m, ny + b + idx.numel()), **f64)
             if ny:
@@ -877,7 +875,7 @@ class ModalSolver:
             T[:, ny:ny + b] = Zs
             T[:, ny + b:] = Zr[:, idx] * sc[None, :]
             G0A, G0B = _sym(T.transpose(0, 1) @ GA @ T), _sym(T.transpose(0, 1) @ GB @ T)
-            del W, KW, MW, Pn, KPn, MPn, news
+            del W, KW, MW
         if hasattr(ops, "combined_k64"):
             ops.combined_k64(False)
         U = X[:, :k].contiguous()

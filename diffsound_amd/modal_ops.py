@@ -317,7 +317,7 @@ class _HipBlockOps:
         self.gram_exact = False
         self._tmp = {}
         self._nrm = torch.empty((2, 1024), dtype=torch.float64, device=device)
-        self.counts = dict(apply_K_cols=0, apply_M_cols=0, gram=0, mix=0)
+        self.counts = dict(apply_K_cols=0, apply_M_cols=0, gram=0, mix=0, mix64=0)
 
     # ------------------------------------------------------------------ sparse products
     def _spmm(self, kind, vals, X, out):
@@ -599,6 +599,43 @@ class _HipBlockOps:
         _hip.check(self._L.ds_mix(pp(A), _ld(A), p, pp(C32), q, pp(out), _ld(out), self.n, float(alpha),
                                   float(beta), _hip.stream_ptr()), "ds_mix")
         self.counts["mix"] += 1
+
+    def mix64(self, blocks, C, out=None, alpha=1.0, beta=0.0):
+        """out <- alpha * [blocks[0] | blocks[1] | ...] C + beta * out in fp64 (ds_mix64): the basis is a LIST of (n x p_i)
+        fp64 blocks - never concatenated - and C their stacked (sum p_i) x q coefficients; every block is read once and
+        the result written once.  ``None`` entries of ``blocks`` are (block, rows of C) pairs to skip: pass
+        ``(block, first_row)`` tuples to address C explicitly."""
+        C = C.contiguous()
+        if C.dtype != torch.float64:
+            raise ValueError("mix64: fp64 coefficients")
+        q = C.shape[1]
+        items, row = [], 0
+        for blk in blocks:
+            if isinstance(blk, tuple):
+                blk, row = blk
+            if blk.dtype != torch.float64 or blk.shape[0] != self.n or blk.stride(1) != 1:
+                raise ValueError("mix64: blocks are (n x p) fp64 with unit column stride")
+            items.append((blk, row))
+            row += blk.shape[1]
+        if max(r + b.shape[1] for b, r in items) > C.shape[0]:
+            raise ValueError("mix64: the blocks need more coefficient rows than C has")
+        if out is None:
+            out = torch.empty((self.n, q), dtype=torch.float64, device=self.device)
+            if beta != 0.0:
+                raise ValueError("mix64: beta != 0 needs an out")
+        if out.dtype != torch.float64 or out.shape != (self.n, q) or out.stride(1) != 1:
+            raise ValueError("mix64: out is (n x q) fp64 with unit column stride")
+        pp = _hip.ptr
+        nmax = 4  # DS_MIX64_MAX_BLOCKS
+        for i0 in range(0, len(items), nmax):
+            part = items[i0:i0 + nmax]
+            arr = (_hip.Mix64Block * len(part))()
+            for d, (blk, r) in zip(arr, part):
+                d.a, d.lda, d.p, d.c_row = pp(blk), _ld(blk), blk.shape[1], r
+            _hip.check(self._L.ds_mix64(len(part), ctypes.addressof(arr), pp(C), _ld(C), q, pp(out), _ld(out), self.n,
+                                        float(alpha), float(beta if i0 == 0 else 1.0), _hip.stream_ptr()), "ds_mix64")
+        self.counts["mix64"] += 1
+        return out
 
     def mix_inplace(self, W, T):
         if T.shape[1] <= 160:  # ds_mix reads a row tile completely before writing it

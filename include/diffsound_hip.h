@@ -40,7 +40,7 @@ enum { DS_OK = 0, DS_ERR_ARG = 1, DS_ERR_HIP = 2, DS_ERR_NOMEM = 3 };
 /* Thread-local text of the last error returned on this thread ("" if none). */
 const char* ds_last_error(void);
 /* Library ABI version (bumped on any signature change); ds_abi_version() returns the value the library was built with. */
-#define DS_ABI_VERSION 26
+#define DS_ABI_VERSION 27
 int ds_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------------
@@ -416,6 +416,21 @@ int ds_lobpcg_iterate(ds_lobpcg_t* p, const ds_lapack_t* lapack, ds_stream_t str
  * written.  (reference: X <- S Z etc., _lobpcg.py:463-466) */
 int ds_mix(const float* A, int64_t lda, int p, const float* C, int q, float* Out, int64_t ldo,
            int64_t n, float alpha, float beta, ds_stream_t stream);
+
+/* Out <- alpha * sum_b A_b C[c_row_b : c_row_b + p_b, :q] + beta * Out, all fp64: the dense n x b updates of the fp64
+ * refinement over a basis given as a LIST of blocks (the rigid modes, X, P, W: separate arrays of different widths) and
+ * one stacked coefficient matrix C (row-major device, leading dimension ldc) - every block is read once, the result
+ * written once.  Out must not overlap any block.  (reference: X <- S Z, src/lobpcg/_lobpcg.py:457-477, there as
+ * torch.matmul on the concatenated basis) */
+#define DS_MIX64_MAX_BLOCKS 4
+typedef struct {
+    const double* a;  /* device, n x p, row-major */
+    int64_t lda;
+    int32_t p;
+    int32_t c_row;    /* first row of this block's coefficients in C */
+} ds_mix64_block_t;
+int ds_mix64(int nblocks, const ds_mix64_block_t* blocks, const double* C, int64_t ldc, int q, double* Out,
+             int64_t ldo, int64_t n, double alpha, double beta, ds_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Geometry backward of the modal read-out (reference: autograd through get_vals -> K, M -> vertices,

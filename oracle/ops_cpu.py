@@ -134,6 +134,21 @@ class CpuModalOps:
     def mix_inplace(self, W, T):
         W.copy_(W @ T.to(self.dtype))
 
+    def mix64(self, blocks, C, out=None, alpha=1.0, beta=0.0):
+        """alpha * [blocks] C + beta * out in fp64; an entry (block, row) names the block's first row of C."""
+        acc, row = None, 0
+        for blk in blocks:
+            if isinstance(blk, tuple):
+                blk, row = blk
+            t = blk @ C[row:row + blk.shape[1]]
+            acc = t if acc is None else acc + t
+            row += blk.shape[1]
+        acc = alpha * acc
+        if out is None:
+            return acc
+        out.copy_(acc + beta * out if beta != 0.0 else acc)
+        return out
+
     # -- fused elementwise ---------------------------------------------------------------
     def residual(self, R, MX, X, lam, src=None):
         if src is not None:

@@ -186,6 +186,37 @@ def test_mix(case, dev, p, q):
         assert torch.equal(Ad[:, :p - q].cpu(), A[:, :p - q])
 
 
+@pytest.mark.parametrize("widths,q", [((6, 40, 24, 24), 40), ((136,), 136), ((6, 136, 52, 52), 136), ((80, 12), 200), ((7, 5, 3), 9)])
+def test_mix64_over_a_list_of_blocks_equals_the_fp64_product_of_the_concatenated_basis(case, dev, widths, q):
+    """ds_mix64 (the fp64 refinement's dense updates; reference: X <- S Z, src/lobpcg/_lobpcg.py:457-477 on the
+    concatenated basis): blocks of different widths, one of them a column range of a wider array, widths that are not
+    multiples of 4 (scalar operand loads), more columns than one launch holds, beta != 0, and a block skipped by
+    addressing C explicitly."""
+    h = case["hops"]
+    g = torch.Generator().manual_seed(sum(widths) + q)
+    blocks = [torch.randn((h.n, w), generator=g, dtype=torch.float64) for w in widths]
+    C = torch.randn((sum(widths), q), generator=g, dtype=torch.float64)
+    S = torch.cat(blocks, 1)
+    ref = S @ C
+    wide = torch.full((h.n, widths[0] + 10), float("nan"), dtype=torch.float64)
+    wide[:, :widths[0]] = blocks[0]
+    dblocks = [wide.to(dev)[:, :widths[0]]] + [b.to(dev) for b in blocks[1:]]
+    out = h.mix64(dblocks, C.to(dev))
+    assert rel(out.cpu().numpy(), ref.numpy()) < 1e-14
+    O = torch.randn((h.n, q), generator=g, dtype=torch.float64)
+    out = O.to(dev).clone()
+    h.mix64(dblocks, C.to(dev), out=out, alpha=-0.5, beta=2.0)
+    assert rel(out.cpu().numpy(), (2.0 * O - 0.5 * ref).numpy()) < 1e-14
+    if len(widths) > 2:  # without the second block: the others keep their rows of C
+        offs = np.concatenate([[0], np.cumsum(widths)])
+        out = h.mix64([(b, int(offs[i])) for i, b in enumerate(dblocks) if i != 1], C.to(dev))
+        C0 = C.clone()
+        C0[offs[1]:offs[2]] = 0.0
+        assert rel(out.cpu().numpy(), (S @ C0).numpy()) < 1e-14
+    with pytest.raises(RuntimeError, match="overlaps"):
+        h.mix64([dblocks[-1]], C.to(dev)[:widths[-1], :widths[-1]].contiguous(), out=dblocks[-1])
+
+
 def test_residual_and_cheb(case, dev):
     h, c = case["hops"], case["cops"]
     b = 40
