@@ -63,6 +63,7 @@ _SIGNATURES = {
     "ds_union_residual_workspace_bytes": (_I64, [_I64, _I]),
     "ds_union_residual": (_I, [_I, _P, _P, _I64, _I, _P, _P, _P, _I64, _I64, _P, _I64, _P, _P, _I64, _I, _P, _I64, _P, _P, _P]),
     "ds_mix": (_I, [_P, _I64, _I, _P, _I, _P, _I64, _I64, _F, _F, _P]),
+    "ds_gram64_blocks": (_I, [_I, _P, _I, _P, _I64, _I, _P, _P, _I64, _P]),
     "ds_mix64": (_I, [_I, _P, _P, _I64, _I, _P, _I64, _I64, _D, _D, _P]),
     "ds_osc_bank_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _D, _P, _P]),
     "ds_osc_bank_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _D, _P, _P, _P, _P, _P]),
@@ -78,9 +79,9 @@ _SIGNATURES = {
     "ds_stft_power_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _F, _P, _P, _P]),
 }
 
-class Mix64Block(ctypes.Structure):
-    """ds_mix64_block_t of include/diffsound_hip.h."""
-    _fields_ = [("a", _P), ("lda", _I64), ("p", ctypes.c_int32), ("c_row", ctypes.c_int32)]
+class Block64(ctypes.Structure):
+    """ds_block64_t of include/diffsound_hip.h."""
+    _fields_ = [("a", _P), ("lda", _I64), ("p", ctypes.c_int32), ("offset", ctypes.c_int32)]
 
 
 class LevelDesc(ctypes.Structure):

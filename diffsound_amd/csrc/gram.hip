@@ -33,120 +33,107 @@ constexpr int WT = 16 * TI;    // wave tile edge (48)
 constexpr int KS = 4;          // MFMA k-steps (of 4 rows) per pipelined batch
 constexpr int RB = 4 * KS;     // rows per batch (16)
 
-template <typename TA, typename TB>
-struct Batch {
-    TA a[KS][TI];
-    TB b[KS][TJ];
-};
-
-// which of the wave tile's 3x3 MFMA tiles exist (wave-uniform): a < na, b < nb, and on a diagonal wave tile of
-// a symmetric product only a <= b (the reduction mirrors the rest)
-struct Active {
-    int na, nb, diag;
-    __device__ __forceinline__ bool operator()(int a, int b) const { return a < na && b < nb && (!diag || a <= b); }
-};
-
-template <typename TA, typename TB>
-__device__ __forceinline__ void load_batch(Batch<TA, TB>& t, const TA* __restrict__ A, int64_t lda,
-                                           const TB* __restrict__ B, int64_t ldb, int64_t r0, int64_t r_end, int lr,
-                                           int acol, int bcol, const bool (&ia)[TI], const bool (&jb)[TJ],
-                                           const Active act) {
+// One wave tile with its shape as template arguments: NA x NB MFMA tiles, DIAG = a diagonal wave tile of a symmetric
+// product (tiles a > b are mirrors: the fp64 MFMA pipe is the bound of this kernel, idle tiles cost as much as useful
+// ones).  Every lane's three columns of A and of B come as (pointer to the lane's first row, row stride) pairs - a plain
+// (n x p) operand and a LIST of blocks (ds_gram64_blocks) look the same from here.  With the shape known at compile time
+// the row loop has no branch, and no load is predicated (the compiler turns a select behind a load into a branch around
+// it with a vmcnt(0) behind it), so the compiler's wait counts are exact: the loads of batch t + 1 fly under the MFMAs of
+// batch t.  (The first version of this kernel kept the tile counts in registers: every MFMA sat behind a branch and a
+// full wait, and it ran at 40 % of what this one does.)  Full 16-row batches need no mask; the one ragged batch at the
+// end of the rows reads clamped rows and zeroes A's values there.
+template <typename TA, typename TB, int NA, int NB, bool DIAG>
+__device__ __forceinline__ void gram_tile(const TA* const (&pa)[TI], const TB* const (&pb)[TJ], const int64_t (&sa)[TI],
+                                          const int64_t (&sb)[TJ], int64_t nrows, int lr, int lc, int i0, int j0, int p,
+                                          int q, double* __restrict__ w) {
+    d4 acc[NA][NB];
 #pragma unroll
-    for (int s = 0; s < KS; ++s) {
-        const int64_t r = r0 + 4 * s + lr;
-        const bool rv = r < r_end;
-        const TA* ap = A + r * lda + acol;
-        const TB* bp = B + r * ldb + bcol;
+    for (int a = 0; a < NA; ++a)
 #pragma unroll
-        for (int a = 0; a < TI; ++a)
-            if (a < act.na) t.a[s][a] = (rv && ia[a]) ? ap[a * 16] : (TA)0;
+        for (int b = 0; b < NB; ++b) acc[a][b] = d4{0.0, 0.0, 0.0, 0.0};
+    // (global address space, spelled out: behind a pointer selection the compiler no longer knows it and emits flat
+    // loads, whose completion it can only wait for with vmcnt(0))
+    using gpa = const __attribute__((address_space(1))) TA*;
+    using gpb = const __attribute__((address_space(1))) TB*;
+    gpa qa[NA];
+    gpb qb[NB];
 #pragma unroll
-        for (int b = 0; b < TJ; ++b)
-            if (b < act.nb) t.b[s][b] = (rv && jb[b]) ? bp[b * 16] : (TB)0;
-    }
-}
-
-template <typename TA, typename TB>
-__device__ __forceinline__ void mfma_batch(const Batch<TA, TB>& t, d4 (&acc)[TI][TJ], const Active act) {
+    for (int a = 0; a < NA; ++a) qa[a] = (gpa)pa[a];
 #pragma unroll
-    for (int s = 0; s < KS; ++s)
+    for (int b = 0; b < NB; ++b) qb[b] = (gpb)pb[b];
+    struct Rows {
+        TA a[KS][NA];
+        TB b[KS][NB];
+    };
+    // a full batch (16 existing rows) at the pointers, which then move on by `adv` batches (0 at the end of the rows:
+    // the prefetch behind the last batch re-reads it)
+    auto load_full = [&](Rows& t, int adv) {
 #pragma unroll
-        for (int a = 0; a < TI; ++a)
+        for (int s = 0; s < KS; ++s) {
 #pragma unroll
-            for (int b = 0; b < TJ; ++b)
-                if (act(a, b))
-                    acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)t.a[s][a], (double)t.b[s][b], acc[a][b], 0, 0, 0);
-}
-
-// One wave per (48 x 48) wave tile of the NEEDED part of G: all tiles for a general product, the block-upper
-// triangle for a symmetric one; ragged edges and the diagonal tiles skip the MFMA tiles that are out of range
-// or mirrored (the fp64 MFMA pipe is the bound of this kernel, idle tiles cost as much as useful ones).
-// blockIdx.x: groups of 4 consecutive wave tiles (they share row batches through L1/L2); blockIdx.y: row split.
-template <typename TA, typename TB>
-__global__ void __launch_bounds__(256)
-    gram_partial_kernel(const TA* __restrict__ A, int64_t lda, int p, const TB* __restrict__ B, int64_t ldb, int q,
-                        int64_t n, int64_t rows_per_split, int ntj, int ntiles, int symmetric,
-                        double* __restrict__ ws) {
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int wt = blockIdx.x * 4 + wave;
-    if (wt >= ntiles) return;  // wave-uniform; the kernel has no workgroup barrier
-    int ti, tj;
-    if (symmetric) {  // row-major walk of the upper triangle
-        int rem = wt;
-        ti = 0;
-        while (rem >= ntj - ti) {
-            rem -= ntj - ti;
-            ++ti;
+            for (int a = 0; a < NA; ++a) t.a[s][a] = qa[a][4 * s * sa[a]];
+#pragma unroll
+            for (int b = 0; b < NB; ++b) t.b[s][b] = qb[b][4 * s * sb[b]];
         }
-        tj = ti + rem;
-    } else {
-        ti = wt / ntj;
-        tj = wt - ti * ntj;
+#pragma unroll
+        for (int a = 0; a < NA; ++a) qa[a] += adv * RB * sa[a];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) qb[b] += adv * RB * sb[b];
+    };
+    auto mfma = [&](const Rows& t) {
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+#pragma unroll
+            for (int a = 0; a < NA; ++a)
+#pragma unroll
+                for (int b = 0; b < NB; ++b)
+                    if (!DIAG || a <= b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)t.a[s][a], (double)t.b[s][b], acc[a][b], 0, 0, 0);
+    };
+    const int64_t nfull = nrows / RB;
+    Rows t0, t1;
+    if (nfull > 0) {
+        load_full(t0, nfull > 1 ? 1 : 0);
+        __builtin_amdgcn_sched_barrier(0);
+        for (int64_t k = 0; k < nfull; k += 2) {
+            load_full(t1, k + 2 < nfull ? 1 : 0);  // batch k + 1 (or, behind the last batch, that one again: unused)
+            __builtin_amdgcn_sched_barrier(0);
+            mfma(t0);
+            __builtin_amdgcn_sched_barrier(0);
+            load_full(t0, k + 3 < nfull ? 1 : 0);  // batch k + 2
+            __builtin_amdgcn_sched_barrier(0);
+            if (k + 1 < nfull) mfma(t1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // the pointers stand on the last full batch: move behind it
+#pragma unroll
+        for (int a = 0; a < NA; ++a) qa[a] += RB * sa[a];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) qb[b] += RB * sb[b];
     }
-    const int i0 = ti * WT, j0 = tj * WT;
-    Active act;
-    act.na = min(TI, (p - i0 + 15) >> 4);
-    act.nb = min(TJ, (q - j0 + 15) >> 4);
-    act.diag = symmetric && ti == tj;
-    const int64_t r_begin = (int64_t)blockIdx.y * rows_per_split;
-    const int64_t r_end = min(n, r_begin + rows_per_split);
-    const int lc = lane & 15, lr = lane >> 4;
-
-    d4 acc[TI][TJ];
+    if (nfull * RB < nrows) {  // the ragged batch: rows past the end read the last existing row, A is zero there
+        const int64_t left = nrows - nfull * RB;
 #pragma unroll
-    for (int a = 0; a < TI; ++a)
+        for (int s = 0; s < KS; ++s) {
+            const int64_t rr = 4 * s + lr;  // row of the batch
+            const int64_t back = rr < left ? 0 : rr - (left - 1);
 #pragma unroll
-        for (int b = 0; b < TJ; ++b) acc[a][b] = d4{0.0, 0.0, 0.0, 0.0};
-
-    bool ia[TI], jb[TJ];
+            for (int a = 0; a < NA; ++a) {
+                const TA v = qa[a][(4 * s - back) * sa[a]];
+                t0.a[s][a] = rr < left ? v : (TA)0;
+            }
 #pragma unroll
-    for (int a = 0; a < TI; ++a) ia[a] = (i0 + a * 16 + lc) < p;
-#pragma unroll
-    for (int b = 0; b < TJ; ++b) jb[b] = (j0 + b * 16 + lc) < q;
-
-    Batch<TA, TB> cur, nxt;
-#pragma unroll
-    for (int s = 0; s < KS; ++s) {
-#pragma unroll
-        for (int a = 0; a < TI; ++a) cur.a[s][a] = nxt.a[s][a] = (TA)0;
-#pragma unroll
-        for (int b = 0; b < TJ; ++b) cur.b[s][b] = nxt.b[s][b] = (TB)0;
+            for (int b = 0; b < NB; ++b) t0.b[s][b] = qb[b][(4 * s - back) * sb[b]];
+        }
+        mfma(t0);
     }
-    load_batch(cur, A, lda, B, ldb, r_begin, r_end, lr, i0 + lc, j0 + lc, ia, jb, act);
-    for (int64_t r0 = r_begin; r0 < r_end; r0 += RB) {
-        const int64_t rn = r0 + RB;
-        if (rn < r_end) load_batch(nxt, A, lda, B, ldb, rn, r_end, lr, i0 + lc, j0 + lc, ia, jb, act);
-        mfma_batch(cur, acc, act);
-        cur = nxt;
-    }
-    // partial tile -> workspace (every element of the computed MFMA tiles is written by exactly one lane)
-    double* w = ws + (int64_t)blockIdx.y * p * q;
+    // partial tile -> workspace (every element of the computed MFMA tiles is written by exactly one lane);
+    // fp64 C/D map: lane (lc, lr) holds rows lr + 4 g, column lc of each tile
 #pragma unroll
-    for (int a = 0; a < TI; ++a)
+    for (int a = 0; a < NA; ++a)
 #pragma unroll
-        for (int b = 0; b < TJ; ++b)
-            if (act(a, b)) {
+        for (int b = 0; b < NB; ++b)
+            if (!DIAG || a <= b) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int row = i0 + a * 16 + lr + 4 * g;
@@ -154,6 +141,85 @@ __global__ void __launch_bounds__(256)
                     if (row < p && col < q) w[(int64_t)row * q + col] = acc[a][b][g];
                 }
             }
+}
+
+// the tile shape of a wave, from run-time counts to template arguments (wave-uniform)
+#define DS_GRAM_DISPATCH(TA_, TB_, na_, nb_, diag_, ...)                                    \
+    do {                                                                                    \
+        if (diag_) {                                                                        \
+            if ((na_) == 3) gram_tile<TA_, TB_, 3, 3, true>(__VA_ARGS__);                    \
+            else if ((na_) == 2) gram_tile<TA_, TB_, 2, 2, true>(__VA_ARGS__);               \
+            else gram_tile<TA_, TB_, 1, 1, true>(__VA_ARGS__);                               \
+        } else {                                                                            \
+            switch ((na_) * 4 + (nb_)) {                                                    \
+                case 3 * 4 + 3: gram_tile<TA_, TB_, 3, 3, false>(__VA_ARGS__); break;        \
+                case 3 * 4 + 2: gram_tile<TA_, TB_, 3, 2, false>(__VA_ARGS__); break;        \
+                case 3 * 4 + 1: gram_tile<TA_, TB_, 3, 1, false>(__VA_ARGS__); break;        \
+                case 2 * 4 + 3: gram_tile<TA_, TB_, 2, 3, false>(__VA_ARGS__); break;        \
+                case 2 * 4 + 2: gram_tile<TA_, TB_, 2, 2, false>(__VA_ARGS__); break;        \
+                case 2 * 4 + 1: gram_tile<TA_, TB_, 2, 1, false>(__VA_ARGS__); break;        \
+                case 1 * 4 + 3: gram_tile<TA_, TB_, 1, 3, false>(__VA_ARGS__); break;        \
+                case 1 * 4 + 2: gram_tile<TA_, TB_, 1, 2, false>(__VA_ARGS__); break;        \
+                default: gram_tile<TA_, TB_, 1, 1, false>(__VA_ARGS__); break;               \
+            }                                                                               \
+        }                                                                                   \
+    } while (0)
+
+// which (48 x 48) wave tile of the NEEDED part of G a wave owns: all tiles for a general product, the block-upper
+// triangle (row-major) for a symmetric one.  1-D grid, split-major: the groups of one row split are consecutive
+// logical workgroups of ONE XCD and fetch the rows they share into one L2.
+struct WaveTile {
+    int split, ti, tj;
+    bool any;
+};
+__device__ __forceinline__ WaveTile wave_tile(int groups, int ntj, int ntiles, int symmetric) {
+    WaveTile t;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const unsigned logical = ds::xcd_remap(blockIdx.x, gridDim.x);
+    t.split = (int)(logical / (unsigned)groups);
+    const int wt = (int)(logical - (unsigned)t.split * groups) * 4 + wave;
+    t.any = wt < ntiles;
+    if (symmetric) {
+        int rem = wt;
+        t.ti = 0;
+        while (t.any && rem >= ntj - t.ti) {
+            rem -= ntj - t.ti;
+            ++t.ti;
+        }
+        t.tj = t.ti + rem;
+    } else {
+        t.ti = wt / ntj;
+        t.tj = wt - t.ti * ntj;
+    }
+    return t;
+}
+
+// One wave per (48 x 48) wave tile; workgroups of 4 consecutive wave tiles of one row split (they share its rows
+// through L1/L2).
+template <typename TA, typename TB>
+__global__ void __launch_bounds__(256)
+    gram_partial_kernel(const TA* __restrict__ A, int64_t lda, int p, const TB* __restrict__ B, int64_t ldb, int q,
+                        int64_t n, int64_t rows_per_split, int ntj, int ntiles, int groups, int symmetric,
+                        double* __restrict__ ws) {
+    const WaveTile t = wave_tile(groups, ntj, ntiles, symmetric);
+    if (!t.any) return;  // wave-uniform; the kernel has no workgroup barrier
+    const int lane = threadIdx.x & 63;
+    const int i0 = t.ti * WT, j0 = t.tj * WT;
+    const int na = min(TI, (p - i0 + 15) >> 4), nb = min(TJ, (q - j0 + 15) >> 4);
+    const bool diag = symmetric && t.ti == t.tj;
+    const int64_t r_begin = (int64_t)t.split * rows_per_split;
+    const int64_t nrows = min(n, r_begin + rows_per_split) - r_begin;
+    const int lc = lane & 15, lr = lane >> 4;
+    // a lane past p or q reads the last column: its products land in elements that are never stored
+    const TA* pa[TI];
+    const TB* pb[TJ];
+    int64_t sa[TI], sb[TJ];
+#pragma unroll
+    for (int a = 0; a < TI; ++a) pa[a] = A + (r_begin + lr) * lda + min(i0 + a * 16 + lc, p - 1), sa[a] = lda;
+#pragma unroll
+    for (int b = 0; b < TJ; ++b) pb[b] = B + (r_begin + lr) * ldb + min(j0 + b * 16 + lc, q - 1), sb[b] = ldb;
+    double* w = ws + (int64_t)t.split * p * q;
+    DS_GRAM_DISPATCH(TA, TB, na, nb, diag, pa, pb, sa, sb, nrows, lr, lc, i0, j0, p, q, w);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -411,6 +477,56 @@ __global__ void __launch_bounds__(256)
     if (threadIdx.x < 16 && idx < pq) G[idx] = (part[0][e] + part[1][e]) + (part[2][e] + part[3][e]);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Both operands as LISTS of fp64 blocks (ds_gram64_blocks): every lane's three columns of A and of B are resolved to
+// (pointer, row stride) once - a wave tile may straddle blocks.  The blocks tile [0, P) and [0, Q) (the entry point
+// checks); a lane past P or Q reads the last column.
+struct GramBlocksArgs {
+    ds_block64_t a[DS_MIX64_MAX_BLOCKS], b[DS_MIX64_MAX_BLOCKS];
+    int na, nb;
+};
+
+__device__ __forceinline__ void resolve_column(const ds_block64_t* blk, int nblk, int col, const double*& ptr, int64_t& ld) {
+    ptr = blk[nblk - 1].a + (blk[nblk - 1].p - 1);  // past the last block: its last column
+    ld = blk[nblk - 1].lda;
+    for (int k = 0; k < nblk; ++k) {
+        const int c = col - blk[k].offset;
+        if (c >= 0 && c < blk[k].p) {
+            ptr = blk[k].a + c;
+            ld = blk[k].lda;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256)
+    gram_blocks_kernel(const GramBlocksArgs args, int p, int q, int64_t n, int64_t rows_per_split, int ntj, int ntiles,
+                       int groups, int symmetric, double* __restrict__ ws) {
+    const WaveTile t = wave_tile(groups, ntj, ntiles, symmetric);
+    if (!t.any) return;  // wave-uniform; the kernel has no workgroup barrier
+    const int lane = threadIdx.x & 63;
+    const int i0 = t.ti * WT, j0 = t.tj * WT;
+    const int na = min(TI, (p - i0 + 15) >> 4), nb = min(TJ, (q - j0 + 15) >> 4);
+    const bool diag = symmetric && t.ti == t.tj;
+    const int64_t r_begin = (int64_t)t.split * rows_per_split;
+    const int64_t nrows = min(n, r_begin + rows_per_split) - r_begin;
+    const int lc = lane & 15, lr = lane >> 4;
+    const double* pa[TI];
+    const double* pb[TJ];
+    int64_t sa[TI], sb[TJ];
+#pragma unroll
+    for (int a = 0; a < TI; ++a) {
+        resolve_column(args.a, args.na, i0 + a * 16 + lc, pa[a], sa[a]);
+        pa[a] += (r_begin + lr) * sa[a];
+    }
+#pragma unroll
+    for (int b = 0; b < TJ; ++b) {
+        resolve_column(args.b, args.nb, j0 + b * 16 + lc, pb[b], sb[b]);
+        pb[b] += (r_begin + lr) * sb[b];
+    }
+    double* w = ws + (int64_t)t.split * p * q;
+    DS_GRAM_DISPATCH(double, double, na, nb, diag, pa, pb, sa, sb, nrows, lr, lc, i0, j0, p, q, w);
+}
+
 struct Plan {
     int tiw, tjw;  // MFMA tiles per wave tile (fast kernel: 3 x 3 symmetric, 2 x 5 otherwise; fp64 kernel 3 x 3)
     int ntj, ntiles, groups, nsplit;
@@ -427,7 +543,7 @@ int resident_workgroups(K kernel) {
     return per_cu * cus;
 }
 
-Plan make_plan(int64_t n, int p, int q, int symmetric, bool fast) {
+Plan make_plan(int64_t n, int p, int q, int symmetric, bool fast, int64_t resident = 0) {
     Plan pl;
     pl.tiw = (fast && !symmetric) ? 2 : TI;
     pl.tjw = (fast && !symmetric) ? 5 : TJ;
@@ -438,9 +554,8 @@ Plan make_plan(int64_t n, int p, int q, int symmetric, bool fast) {
     // The grid is sized to fill the chip an integer number of times: the fp64 kernel holds 152 VGPRs = 3 workgroups
     // per CU, 768 on the chip, and a 1026-workgroup grid ran one full round and a second one at a third of the
     // occupancy, i.e. in the time of two.
-    static const int64_t res64 = resident_workgroups(gram_partial_kernel<float, float>);
     static const int64_t res32 = resident_workgroups(gram32_partial_kernel);
-    const int64_t target = fast ? res32 : res64;
+    const int64_t target = resident > 0 ? resident : (fast ? res32 : 512);
     int64_t nsplit = std::max<int64_t>(1, target / pl.groups);
     nsplit = std::min<int64_t>(nsplit, ds::ceil_div(n, 512));   // at least 512 rows per split
     nsplit = std::max<int64_t>(nsplit, 1);
@@ -455,9 +570,12 @@ Plan make_plan(int64_t n, int p, int q, int symmetric, bool fast) {
 
 extern "C" int64_t ds_gram_workspace_bytes(int64_t n, int p, int q) {
     if (n <= 0 || p <= 0 || q <= 0) return 0;
+    // (the row splits follow from how many workgroups of the kernel taken are resident - at most 4 per CU, 1024)
     int ns = 1;
-    for (int sym = 0; sym <= (p == q ? 1 : 0); ++sym)
-        for (int fast = 0; fast <= 1; ++fast) ns = std::max(ns, make_plan(n, p, q, sym, fast != 0).nsplit);
+    for (int sym = 0; sym <= (p == q ? 1 : 0); ++sym) {
+        ns = std::max(ns, make_plan(n, p, q, sym, true).nsplit);
+        ns = std::max(ns, make_plan(n, p, q, sym, false, 1024).nsplit);
+    }
     return (int64_t)ns * p * q * (int64_t)sizeof(double);
 }
 
@@ -473,34 +591,76 @@ extern "C" int ds_gram(const void* A, int a_dtype, int64_t lda, int p, const voi
     const int symmetric = (flags & DS_GRAM_SYMMETRIC) ? 1 : 0;
     DS_REQUIRE(!symmetric || p == q, "ds_gram: symmetric needs p == q");
     const bool fast = a_dtype == DS_F32 && b_dtype == DS_F32 && !(flags & DS_GRAM_EXACT);
-    const Plan pl = make_plan(n, p, q, symmetric, fast);
+    static const int64_t res_ff = resident_workgroups(gram_partial_kernel<float, float>),
+                         res_fd = resident_workgroups(gram_partial_kernel<float, double>),
+                         res_dd = resident_workgroups(gram_partial_kernel<double, double>);
+    const Plan pl = make_plan(n, p, q, symmetric, fast, fast ? 0 : (b_dtype == DS_F32 ? res_ff : (a_dtype == DS_F32 ? res_fd : res_dd)));
     DS_REQUIRE(work_bytes >= (int64_t)pl.nsplit * p * q * (int64_t)sizeof(double),
                "ds_gram: workspace too small (%lld bytes given)", (long long)work_bytes);
     // the fast kernel addresses a row split with 32-bit byte offsets (prefetched batches overshoot it by up to 5 batches)
     DS_REQUIRE(!fast || (pl.rows_per_split + 6 * RB) * std::max(lda, ldb) * 4 < (int64_t)1 << 31,
                "ds_gram: row split of %lld rows too large for 32-bit offsets", (long long)pl.rows_per_split);
     hipStream_t st = ds::as_stream(stream);
-    dim3 grid((unsigned)pl.groups, (unsigned)pl.nsplit);
+    const unsigned grid = (unsigned)(pl.groups * pl.nsplit);
     double* ws = static_cast<double*>(work);
     const float* Af = static_cast<const float*>(A);
     if (fast)
-        gram32_partial_kernel<<<(unsigned)(pl.groups * pl.nsplit), 256, 0, st>>>(
-            Af, lda, p, static_cast<const float*>(B), ldb, q, n, pl.rows_per_split, pl.tiw, pl.tjw, pl.ntj, pl.ntiles,
-            pl.groups,
-            symmetric, ws);
+        gram32_partial_kernel<<<grid, 256, 0, st>>>(Af, lda, p, static_cast<const float*>(B), ldb, q, n, pl.rows_per_split, pl.tiw,
+                                                    pl.tjw, pl.ntj, pl.ntiles, pl.groups, symmetric, ws);
     else if (b_dtype == DS_F32)
         gram_partial_kernel<float, float><<<grid, 256, 0, st>>>(Af, lda, p, static_cast<const float*>(B), ldb, q, n,
-                                                                pl.rows_per_split, pl.ntj, pl.ntiles, symmetric, ws);
+                                                                pl.rows_per_split, pl.ntj, pl.ntiles, pl.groups, symmetric, ws);
     else if (a_dtype == DS_F32)
         gram_partial_kernel<float, double><<<grid, 256, 0, st>>>(Af, lda, p, static_cast<const double*>(B), ldb, q, n,
-                                                                 pl.rows_per_split, pl.ntj, pl.ntiles, symmetric, ws);
+                                                                 pl.rows_per_split, pl.ntj, pl.ntiles, pl.groups, symmetric, ws);
     else
         gram_partial_kernel<double, double><<<grid, 256, 0, st>>>(static_cast<const double*>(A), lda, p,
-                                                                  static_cast<const double*>(B), ldb, q, n,
-                                                                  pl.rows_per_split, pl.ntj, pl.ntiles, symmetric, ws);
+                                                                  static_cast<const double*>(B), ldb, q, n, pl.rows_per_split,
+                                                                  pl.ntj, pl.ntiles, pl.groups, symmetric, ws);
     DS_LAUNCH_CHECK("gram_partial_kernel");
     const int64_t pq = (int64_t)p * q;
     gram_reduce_kernel<<<(unsigned)ds::ceil_div(pq, 16), 256, 0, st>>>(ws, pl.nsplit, p, q, symmetric, fast ? 1 : 0, G);
+    DS_LAUNCH_CHECK("gram_reduce_kernel");
+    return DS_OK;
+}
+
+extern "C" int ds_gram64_blocks(int na, const ds_block64_t* A, int nb, const ds_block64_t* B, int64_t n, int flags, double* G,
+                                void* work, int64_t work_bytes, ds_stream_t stream) {
+    DS_REQUIRE(A && B && G && work, "ds_gram64_blocks: null pointer");
+    DS_REQUIRE(na >= 1 && na <= DS_MIX64_MAX_BLOCKS && nb >= 1 && nb <= DS_MIX64_MAX_BLOCKS,
+               "ds_gram64_blocks: %d x %d blocks (1..%d per side)", na, nb, DS_MIX64_MAX_BLOCKS);
+    DS_REQUIRE(n > 0, "ds_gram64_blocks: empty problem");
+    DS_REQUIRE((flags & ~DS_GRAM_SYMMETRIC) == 0, "ds_gram64_blocks: unknown flag bits %d", flags);
+    GramBlocksArgs args;
+    args.na = na, args.nb = nb;
+    int p = 0, q = 0;
+    for (int k = 0; k < na; ++k) {
+        DS_REQUIRE(A[k].a && A[k].p > 0 && A[k].lda >= A[k].p, "ds_gram64_blocks: block %d of A", k);
+        DS_REQUIRE(A[k].offset == p, "ds_gram64_blocks: the blocks of A tile the rows of G in order (block %d at %d, expected %d)",
+                   k, A[k].offset, p);
+        args.a[k] = A[k];
+        p += A[k].p;
+    }
+    for (int k = 0; k < nb; ++k) {
+        DS_REQUIRE(B[k].a && B[k].p > 0 && B[k].lda >= B[k].p, "ds_gram64_blocks: block %d of B", k);
+        DS_REQUIRE(B[k].offset == q, "ds_gram64_blocks: the blocks of B tile the columns of G in order (block %d at %d, expected %d)",
+                   k, B[k].offset, q);
+        args.b[k] = B[k];
+        q += B[k].p;
+    }
+    const int symmetric = (flags & DS_GRAM_SYMMETRIC) ? 1 : 0;
+    DS_REQUIRE(!symmetric || p == q, "ds_gram64_blocks: symmetric needs P == Q");
+    static const int64_t resident = resident_workgroups(gram_blocks_kernel);
+    const Plan pl = make_plan(n, p, q, symmetric, false, resident);
+    DS_REQUIRE(work_bytes >= (int64_t)pl.nsplit * p * q * (int64_t)sizeof(double),
+               "ds_gram64_blocks: workspace too small (%lld bytes given)", (long long)work_bytes);
+    hipStream_t st = ds::as_stream(stream);
+    double* ws = static_cast<double*>(work);
+    gram_blocks_kernel<<<(unsigned)(pl.groups * pl.nsplit), 256, 0, st>>>(args, p, q, n, pl.rows_per_split, pl.ntj, pl.ntiles,
+                                                                         pl.groups, symmetric, ws);
+    DS_LAUNCH_CHECK("gram_blocks_kernel");
+    const int64_t pq = (int64_t)p * q;
+    gram_reduce_kernel<<<(unsigned)ds::ceil_div(pq, 16), 256, 0, st>>>(ws, pl.nsplit, p, q, symmetric, 0, G);
     DS_LAUNCH_CHECK("gram_reduce_kernel");
     return DS_OK;
 }

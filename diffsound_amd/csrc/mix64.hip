@@ -24,7 +24,7 @@ using d2 = __attribute__((ext_vector_type(2))) double;
 constexpr int RT64 = 2;  // 16-row tiles per wave
 
 struct Mix64Args {
-    ds_mix64_block_t blk[DS_MIX64_MAX_BLOCKS];
+    ds_block64_t blk[DS_MIX64_MAX_BLOCKS];
     int nblk;
 };
 
@@ -62,7 +62,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
         const double* __restrict__ A = args.blk[b].a;
         const int64_t lda = args.blk[b].lda;
         const int p = args.blk[b].p;
-        const double* __restrict__ Cb = C + (int64_t)args.blk[b].c_row * ldc;
+        const double* __restrict__ Cb = C + (int64_t)args.blk[b].offset * ldc;
         const bool vec = ((reinterpret_cast<uintptr_t>(A) | (uintptr_t)(lda * 8)) & 15) == 0 && (p & 3) == 0;  // wave-uniform
         const int nstep = (p + 15) >> 4;
         // the four values A[row][16 step + 4 lq + s] of the lane's rows
@@ -166,7 +166,7 @@ int launch_mix64(const Mix64Args& args, const double* C, int64_t ldc, int q, dou
 
 }  // namespace
 
-extern "C" int ds_mix64(int nblocks, const ds_mix64_block_t* blocks, const double* C, int64_t ldc, int q, double* Out,
+extern "C" int ds_mix64(int nblocks, const ds_block64_t* blocks, const double* C, int64_t ldc, int q, double* Out,
                         int64_t ldo, int64_t n, double alpha, double beta, ds_stream_t stream) {
     DS_REQUIRE(blocks && C && Out, "ds_mix64: null pointer");
     DS_REQUIRE(nblocks >= 1 && nblocks <= DS_MIX64_MAX_BLOCKS, "ds_mix64: %d blocks (1..%d)", nblocks, DS_MIX64_MAX_BLOCKS);
@@ -177,8 +177,8 @@ extern "C" int ds_mix64(int nblocks, const ds_mix64_block_t* blocks, const doubl
     const char* o0 = reinterpret_cast<const char*>(Out);
     const char* o1 = o0 + ((n - 1) * ldo + q) * 8;
     for (int b = 0; b < nblocks; ++b) {
-        const ds_mix64_block_t& k = blocks[b];
-        DS_REQUIRE(k.a && k.p > 0 && k.lda >= k.p && k.c_row >= 0, "ds_mix64: block %d: bad pointer, width or offset", b);
+        const ds_block64_t& k = blocks[b];
+        DS_REQUIRE(k.a && k.p > 0 && k.lda >= k.p && k.offset >= 0, "ds_mix64: block %d: bad pointer, width or offset", b);
         // (other waves read the rows a wave writes only if Out and a block share memory)
         const char* a0 = reinterpret_cast<const char*>(k.a);
         const char* a1 = a0 + ((n - 1) * k.lda + k.p) * 8;

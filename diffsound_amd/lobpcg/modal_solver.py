@@ -721,7 +721,7 @@ class ModalSolver:
         generalised (3b + 6)-dimensional pencil (S^T K S, S^T M S) - the rigid modes come out as its six ~zero
         eigenvalues and are dropped - and X, P and their products with K and M for the next step by linearity.
         RAYLEIGH-RITZ BY RECURRENCE, as in the fp32 iteration: only the NEW columns meet the vectors - the Gram blocks
-        S^T K W and S^T M W (8 tall-skinny products per step instead of 22) - while the blocks among Y, X and P follow
+        S^T K W and S^T M W (ONE pass over the rows of S, K W and M W per step: ds_gram64_blocks) - while the blocks among Y, X and P follow
         from the last step's eigenvector matrix by (3b + 6)-dimensional algebra; every ``refine_refresh``-th step
         recomputes all blocks from the vectors.  The n x b updates are ``ops.mix64`` (ds_mix64, fp64 MFMA) over the LIST
         of blocks of S: one pass per result, no temporaries of the size of a block."""
@@ -750,19 +750,8 @@ class ModalSolver:
             return E_, (Li.transpose(0, 1) @ Zt).contiguous()
 
         def full_grams(blocks, kblocks, mblocks):
-            offs = [0]
-            for blk in blocks:
-                offs.append(offs[-1] + blk.shape[1])
-            m = offs[-1]
-            GA, GB = torch.zeros((m, m), **f64), torch.zeros((m, m), **f64)
-            for i_, Si in enumerate(blocks):
-                for j_ in range(i_, len(blocks)):
-                    for Gm, blks in ((GB, mblocks), (GA, kblocks)):
-                        G = ops.gram(Si, blks[j_])
-                        Gm[offs[i_]:offs[i_ + 1], offs[j_]:offs[j_ + 1]] = G
-                        if j_ > i_:
-                            Gm[offs[j_]:offs[j_ + 1], offs[i_]:offs[i_ + 1]] = G.transpose(0, 1)
-            return GA, GB
+            # all pairs of blocks of S = [Y | X | P | W] against K S and M S: one pass over the rows each
+            return ops.gram_blocks(blocks, kblocks, symmetric=True), ops.gram_blocks(blocks, mblocks, symmetric=True)
 
         # Rayleigh-Ritz on the fp32 block alone: the pairs whose residual is tested first, and an X that is
         # K-diagonal / M-orthonormal - which every later step's X is by construction
@@ -826,15 +815,13 @@ class ModalSolver:
             if since >= refresh or G0A is None or G0A.shape[0] != m0:
                 GA, GB = full_grams(blocks, [h[1] for h in head] + [KW], [h[2] for h in head] + [MW])
                 since = 1
-            else:  # only the new columns meet the vectors
+            else:  # only the new columns meet the vectors: S^T [K W | M W] in one pass over the rows
                 GA, GB = torch.zeros((m, m), **f64), torch.zeros((m, m), **f64)
                 GA[:m0, :m0], GB[:m0, :m0] = G0A, G0B
-                for i_, blk in enumerate(blocks):
-                    for Gm, Wp in ((GA, KW), (GB, MW)):
-                        G = ops.gram(blk, Wp)
-                        Gm[offs[i_]:offs[i_ + 1], m0:] = G
-                        if i_ < len(blocks) - 1:
-                            Gm[m0:, offs[i_]:offs[i_ + 1]] = G.transpose(0, 1)
+                Gw = ops.gram_blocks(blocks, [KW, MW])
+                for Gm, G in ((GA, Gw[:, :na]), (GB, Gw[:, na:])):
+                    Gm[:, m0:] = G
+                    Gm[m0:, :m0] = G[:m0].transpose(0, 1)
                 since += 1
             GA, GB = _sym(GA), _sym(GB)
             use_p = P is not None

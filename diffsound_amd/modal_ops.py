@@ -583,6 +583,29 @@ class _HipBlockOps:
         self.counts["gram"] += 1
         return G
 
+    def gram_blocks(self, A_blocks, B_blocks, symmetric=False):
+        """G = [A_0 | A_1 | ...]^T [B_0 | B_1 | ...] in fp64 (ds_gram64_blocks) for bases held as LISTS of (n x p) fp64
+        blocks: one pass over the rows for all pairs of blocks.  ``symmetric``: B = K A with a symmetric K and the same
+        widths on both sides - only the tiles on and above the diagonal are computed.  At most 4 blocks per side."""
+        def table(blocks):
+            arr, off = (_hip.Block64 * len(blocks))(), 0
+            for d, blk in zip(arr, blocks):
+                if blk.dtype != torch.float64 or blk.shape[0] != self.n or blk.stride(1) != 1:
+                    raise ValueError("gram_blocks: blocks are (n x p) fp64 with unit column stride")
+                d.a, d.lda, d.p, d.offset = _hip.ptr(blk), _ld(blk), blk.shape[1], off
+                off += blk.shape[1]
+            return arr, off
+        (ta, p), (tb, q) = table(A_blocks), table(B_blocks)
+        need = self._L.ds_gram_workspace_bytes(self.n, p, q)
+        if self._gram_ws is None or self._gram_ws.numel() < need:
+            self._gram_ws = torch.empty((need,), dtype=torch.uint8, device=self.device)
+        G = torch.empty((p, q), dtype=torch.float64, device=self.device)
+        _hip.check(self._L.ds_gram64_blocks(len(A_blocks), ctypes.addressof(ta), len(B_blocks), ctypes.addressof(tb), self.n,
+                                            int(bool(symmetric)), _hip.ptr(G), _hip.ptr(self._gram_ws), self._gram_ws.numel(),
+                                            _hip.stream_ptr()), "ds_gram64_blocks")
+        self.counts["gram"] += 1
+        return G
+
     def _scratch(self, key, shape, dtype):
         t = self._tmp.get(key)
         if t is None or t.shape != tuple(shape) or t.dtype != dtype:
@@ -629,9 +652,9 @@ class _HipBlockOps:
         nmax = 4  # DS_MIX64_MAX_BLOCKS
         for i0 in range(0, len(items), nmax):
             part = items[i0:i0 + nmax]
-            arr = (_hip.Mix64Block * len(part))()
+            arr = (_hip.Block64 * len(part))()
             for d, (blk, r) in zip(arr, part):
-                d.a, d.lda, d.p, d.c_row = pp(blk), _ld(blk), blk.shape[1], r
+                d.a, d.lda, d.p, d.offset = pp(blk), _ld(blk), blk.shape[1], r
             _hip.check(self._L.ds_mix64(len(part), ctypes.addressof(arr), pp(C), _ld(C), q, pp(out), _ld(out), self.n,
                                         float(alpha), float(beta if i0 == 0 else 1.0), _hip.stream_ptr()), "ds_mix64")
         self.counts["mix64"] += 1

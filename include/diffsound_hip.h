@@ -417,19 +417,34 @@ int ds_lobpcg_iterate(ds_lobpcg_t* p, const ds_lapack_t* lapack, ds_stream_t str
 int ds_mix(const float* A, int64_t lda, int p, const float* C, int q, float* Out, int64_t ldo,
            int64_t n, float alpha, float beta, ds_stream_t stream);
 
-/* Out <- alpha * sum_b A_b C[c_row_b : c_row_b + p_b, :q] + beta * Out, all fp64: the dense n x b updates of the fp64
- * refinement over a basis given as a LIST of blocks (the rigid modes, X, P, W: separate arrays of different widths) and
- * one stacked coefficient matrix C (row-major device, leading dimension ldc) - every block is read once, the result
- * written once.  Out must not overlap any block.  (reference: X <- S Z, src/lobpcg/_lobpcg.py:457-477, there as
- * torch.matmul on the concatenated basis) */
+/* A basis held as a list of fp64 blocks (ds_gram64_blocks, ds_mix64). */
 #define DS_MIX64_MAX_BLOCKS 4
 typedef struct {
     const double* a;  /* device, n x p, row-major */
     int64_t lda;
     int32_t p;
-    int32_t c_row;    /* first row of this block's coefficients in C */
-} ds_mix64_block_t;
-int ds_mix64(int nblocks, const ds_mix64_block_t* blocks, const double* C, int64_t ldc, int q, double* Out,
+    int32_t offset;   /* ds_mix64: first row of this block's coefficients in C; ds_gram64_blocks: the block's first row
+                         (a block of A) or column (a block of B) of G */
+} ds_block64_t;
+
+/* G[oa_i + r][ob_j + c] = (A_i^T B_j)[r][c] for every pair of a block of A and a block of B (fp64 operands, fp64 MFMA,
+ * fixed-order reduction over the row splits): the Gram blocks of a basis held as a LIST of arrays, [S]^T [K W | M W] of the
+ * fp64 refinement in ONE pass over the rows instead of one ds_gram call per pair of blocks.  G is dense row-major,
+ * P = sum p_i rows by Q = sum q_j columns: the blocks tile G in the order given (offset_k = the sum of the widths
+ * before block k; checked).
+ * flags: DS_GRAM_SYMMETRIC - G is symmetric (B = K A with symmetric K, same offsets on both sides): only the tiles on
+ * and above the diagonal are computed, the rest mirrored.  At most DS_MIX64_MAX_BLOCKS blocks per side.
+ * work: ds_gram_workspace_bytes(n, P, Q) bytes.  (reference: the Gram products of _lobpcg.py:516-525 on the concatenated
+ * basis) */
+int ds_gram64_blocks(int na, const ds_block64_t* A, int nb, const ds_block64_t* B, int64_t n, int flags, double* G,
+                     void* work, int64_t work_bytes, ds_stream_t stream);
+
+/* Out <- alpha * sum_b A_b C[offset_b : offset_b + p_b, :q] + beta * Out, all fp64: the dense n x b updates of the fp64
+ * refinement over a basis given as a LIST of blocks (the rigid modes, X, P, W: separate arrays of different widths) and
+ * one stacked coefficient matrix C (row-major device, leading dimension ldc) - every block is read once, the result
+ * written once.  Out must not overlap any block.  (reference: X <- S Z, src/lobpcg/_lobpcg.py:457-477, there as
+ * torch.matmul on the concatenated basis) */
+int ds_mix64(int nblocks, const ds_block64_t* blocks, const double* C, int64_t ldc, int q, double* Out,
              int64_t ldo, int64_t n, double alpha, double beta, ds_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------

@@ -124,6 +124,9 @@ class CpuModalOps:
         self.counts["gram"] += 1
         return A.double().transpose(0, 1) @ B.double()
 
+    def gram_blocks(self, A_blocks, B_blocks, symmetric=False):
+        return torch.cat(list(A_blocks), 1).double().transpose(0, 1) @ torch.cat(list(B_blocks), 1).double()
+
     def mix(self, A, C, out, alpha=1.0, beta=0.0):
         self.counts["mix"] += 1
         r = (A @ C.to(self.dtype)) * alpha

@@ -217,6 +217,32 @@ def test_mix64_over_a_list_of_blocks_equals_the_fp64_product_of_the_concatenated
         h.mix64([dblocks[-1]], C.to(dev)[:widths[-1], :widths[-1]].contiguous(), out=dblocks[-1])
 
 
+@pytest.mark.parametrize("wa,wb", [((6, 40, 24, 24), (24, 24)), ((136,), (52, 52)), ((6, 136, 52, 52), (6, 136, 52, 52)), ((7, 50), (3,))])
+def test_gram64_over_lists_of_blocks_equals_the_fp64_gram_of_the_concatenated_bases(case, dev, wa, wb):
+    """ds_gram64_blocks (S^T [K W | M W] of the fp64 refinement in one pass; reference: the Gram products of
+    src/lobpcg/_lobpcg.py:516-525 on the concatenated basis): wave tiles that straddle blocks, a block that is a column range
+    of a wider array, and the symmetric mode (upper tiles computed, the rest mirrored)."""
+    h = case["hops"]
+    g = torch.Generator().manual_seed(sum(wa) + 3 * sum(wb))
+    A = [torch.randn((h.n, w), generator=g, dtype=torch.float64) for w in wa]
+    B = [torch.randn((h.n, w), generator=g, dtype=torch.float64) for w in wb]
+    wide = torch.full((h.n, wa[0] + 10), float("nan"), dtype=torch.float64)
+    wide[:, 4:4 + wa[0]] = A[0]
+    dA = [wide.to(dev)[:, 4:4 + wa[0]]] + [a.to(dev) for a in A[1:]]
+    dB = [b.to(dev) for b in B]
+    ref = torch.cat(A, 1).T @ torch.cat(B, 1)
+    scale = np.sqrt(np.outer((torch.cat(A, 1) ** 2).sum(0).numpy(), (torch.cat(B, 1) ** 2).sum(0).numpy()))
+    G = h.gram_blocks(dA, dB).cpu()
+    assert (np.abs(G.numpy() - ref.numpy()) / scale).max() < 1e-14
+    if wa == wb:  # symmetric mode: B = Md A with the (symmetric) mass matrix of the mesh
+        Md = case["cops"].Md
+        KA = [torch.from_numpy(np.asarray(Md @ a.numpy())) for a in A]
+        refs = torch.cat(A, 1).T @ torch.cat(KA, 1)
+        Gs = h.gram_blocks(dA, [k.to(dev) for k in KA], symmetric=True).cpu()
+        assert rel(Gs.numpy(), refs.numpy()) < 1e-13
+        assert rel(Gs.numpy(), Gs.numpy().T) < 1e-13
+
+
 def test_residual_and_cheb(case, dev):
     h, c = case["hops"], case["cops"]
     b = 40

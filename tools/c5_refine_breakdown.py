@@ -46,7 +46,7 @@ def wrap(obj, name, label=None):
     setattr(obj, name, g)
 
 
-for nm in ("mix64", "gram", "apply_K64", "apply_M64", "apply_K"):
+for nm in ("mix64", "gram", "gram_blocks", "apply_K64", "apply_M64", "apply_K"):
     wrap(ops, nm)
 wrap(ms, "_small", "host Rayleigh-Ritz (_small)")
 nest = dict(nested_tol=3e-3, nested_maxit=8, nested_cheb_degree=22, nested_cheb_ratio=350.0)  # bench.py's defaults

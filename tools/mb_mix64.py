@@ -28,9 +28,9 @@ offs = [0, 6, 6 + b, 6 + b + na]
 
 
 def mix64(items, C, out):
-    arr = (_hip.Mix64Block * len(items))()
+    arr = (_hip.Block64 * len(items))()
     for d, (blk, r) in zip(arr, items):
-        d.a, d.lda, d.p, d.c_row = blk.data_ptr(), blk.stride(0), blk.shape[1], r
+        d.a, d.lda, d.p, d.offset = blk.data_ptr(), blk.stride(0), blk.shape[1], r
     _hip.check(L.ds_mix64(len(items), ctypes.addressof(arr), C.data_ptr(), C.stride(0), C.shape[1], out.data_ptr(), out.stride(0),
                           n, 1.0, 0.0, _hip.stream_ptr()), "ds_mix64")
 
