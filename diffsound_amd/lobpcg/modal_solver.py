@@ -799,10 +799,9 @@ class ModalSolver:
             del R32, W32, R
             KW, MW = torch.empty_like(W), torch.empty_like(W)
             ops.apply_M64(W, MW)
-            wn = torch.rsqrt((W * MW).sum(0).clamp(min=1e-300))  # unit M-norm columns: a well scaled pencil
-            W *= wn[None, :]
-            MW *= wn[None, :]
             ops.apply_K64(W, KW)
+            # (unit M-norm columns of W - a well scaled pencil - without touching the vectors: the scale wn comes off the
+            # diagonal of W^T M W below, goes into the small matrices there and into the coefficients of the update)
             # pencil on S = [Y | X | P | W]  (P: the previous step's update directions - the locally optimal 3-term
             # recurrence; without it the pairs next to the guard vectors crawl); should the Gram matrix of S be
             # numerically singular (P and W nearly dependent close to convergence), the step is repeated without P
@@ -814,12 +813,19 @@ class ModalSolver:
             m, m0, na = offs[-1], offs[-2], W.shape[1]
             if since >= refresh or G0A is None or G0A.shape[0] != m0:
                 GA, GB = full_grams(blocks, [h[1] for h in head] + [KW], [h[2] for h in head] + [MW])
+                wn = torch.rsqrt(torch.diagonal(GB)[m0:].clamp(min=1e-300))
+                for Gm in (GA, GB):
+                    Gm[:, m0:] *= wn[None, :]
+                    Gm[m0:, :] *= wn[:, None]
                 since = 1
             else:  # only the new columns meet the vectors: S^T [K W | M W] in one pass over the rows
                 GA, GB = torch.zeros((m, m), **f64), torch.zeros((m, m), **f64)
                 GA[:m0, :m0], GB[:m0, :m0] = G0A, G0B
                 Gw = ops.gram_blocks(blocks, [KW, MW])
+                wn = torch.rsqrt(torch.diagonal(Gw[m0:, na:]).clamp(min=1e-300))
                 for Gm, G in ((GA, Gw[:, :na]), (GB, Gw[:, na:])):
+                    G = G * wn[None, :]
+                    G[m0:] *= wn[:, None]
                     Gm[:, m0:] = G
                     Gm[m0:, :m0] = G[:m0].transpose(0, 1)
                 since += 1
@@ -847,11 +853,14 @@ class ModalSolver:
             sc = torch.rsqrt(pn2)
             Tp = (Zr[:, idx] * sc[None, :]).contiguous()
             xi = 1 if ny else 0  # position of X in the head
+            Zu, Tu = Zs.clone(), Tp.clone()  # the same coefficients for the W held in memory (not scaled)
+            Zu[m0:] *= wn[:, None]
+            Tu[m0:] *= wn[:, None]
             news = []
             for which in range(3):  # the vectors, their K-products, their M-products
                 parts = [h[which] for h in head] + [(W, KW, MW)[which]]
-                Xn = ops.mix64(parts, Zs)
-                Pd = ops.mix64([(blk, offs[i_]) for i_, blk in enumerate(parts) if i_ != xi], Tp)  # (X's rows of Tp are zero)
+                Xn = ops.mix64(parts, Zu)
+                Pd = ops.mix64([(blk, offs[i_]) for i_, blk in enumerate(parts) if i_ != xi], Tu)  # (X's rows of Tu are zero)
                 news.append((Xn, Pd))
             (X, P), (KX, KP), (MX, MP) = news
             del news

@@ -19,6 +19,7 @@ from diffsound_amd.modal_ops import HipModalOps, TetSystem  # noqa: E402
 cells = int(sys.argv[1]) if len(sys.argv) > 1 else 55
 modes = int(sys.argv[2]) if len(sys.argv) > 2 else 128
 block = int(sys.argv[3]) if len(sys.argv) > 3 else 136
+sweeps = int(sys.argv[4]) if len(sys.argv) > 4 else 2
 dev = torch.device("cuda", 0)
 v, t = meshgen.kuhn_box(cells)
 mesh = TetMesh(torch.from_numpy(v).to(dev), torch.from_numpy(t).long().to(dev)).to_high_order(2)
@@ -51,7 +52,7 @@ for nm in ("mix64", "gram", "gram_blocks", "apply_K64", "apply_M64", "apply_K"):
 wrap(ms, "_small", "host Rayleigh-Ritz (_small)")
 nest = dict(nested_tol=3e-3, nested_maxit=8, nested_cheb_degree=22, nested_cheb_ratio=350.0)  # bench.py's defaults
 for rep in range(2):
-    solver = ms.ModalSolver(ops, ms.SolverConfig(block=block, lmax_cap=10.0, refine_tol=1e-10, **nest))
+    solver = ms.ModalSolver(ops, ms.SolverConfig(block=block, lmax_cap=10.0, refine_tol=1e-10, refine_sweeps=sweeps, **nest))
     wrap(solver, "precond_apply", "preconditioner (fp32 V-cycle)")
     orig = solver.refine64
 
@@ -71,7 +72,7 @@ for rep in range(2):
     r64 = solver.solve(modes)
     torch.cuda.synchronize()
     tot = time.perf_counter() - t0
-print(f"cells {cells}: n = {sysd.n}, {modes} modes, block {block}; solve {tot:.3f} s, {r64.refine_iterations} fp64 steps, "
+print(f"cells {cells}: n = {sysd.n}, {modes} modes, block {block}, {sweeps} preconditioner sweeps per step; solve {tot:.3f} s, {r64.refine_iterations} fp64 steps, "
       f"worst backward error {float(r64.rerr.max()):.2e} (second solve; timers synchronise, so the parts add up to more than an "
       "unsynchronised run)")
 total = acc.pop("refine64 total")
