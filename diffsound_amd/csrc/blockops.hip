@@ -232,7 +232,7 @@ struct alignas(4) FloatPack {
 
 template <int JT>
 __global__ void __launch_bounds__(64 * MIX_NW)
-    mix_lds_kernel(const float* A, int64_t lda, int p, const float* __restrict__ C, int q, float* Out, int64_t ldo,
+    mix_lds_kernel(const float* A, int64_t lda, int p, const float* __restrict__ C, int ldc, int q, float* Out, int64_t ldo,
                    int64_t n, float alpha, float beta) {
     extern __shared__ __attribute__((aligned(16))) float s_c[];  // [p16 / 4][JT * 16][4], rows >= p and columns >= q zero
     constexpr int W = JT * 16;
@@ -246,7 +246,7 @@ __global__ void __launch_bounds__(64 * MIX_NW)
             const int t = t0 + u * NTHR;
             const int kq = t / (W * 4), rem = t - kq * (W * 4), pos = rem >> 2;
             const int r = kq * 4 + (rem & 3), c = (pos & 15) * JT + (pos >> 4);
-            v[u] = (t < p16 * W && r < p && c < q) ? C[r * q + c] : 0.f;
+            v[u] = (t < p16 * W && r < p && c < q) ? C[r * ldc + c] : 0.f;
         }
 #pragma unroll
         for (int u = 0; u < STG; ++u)
@@ -350,7 +350,7 @@ __global__ void __launch_bounds__(64 * MIX_NW)
 }
 
 template <int JT>
-int launch_mix_lds(const float* A, int64_t lda, int p, const float* C, int q, float* Out, int64_t ldo, int64_t n,
+int launch_mix_lds(const float* A, int64_t lda, int p, const float* C, int ldc, int q, float* Out, int64_t ldo, int64_t n,
                    float alpha, float beta, hipStream_t st) {
     const int p16 = (p + 15) & ~15;
     const size_t lds = (size_t)p16 * JT * 16 * sizeof(float);
@@ -365,7 +365,7 @@ int launch_mix_lds(const float* A, int64_t lda, int p, const float* C, int q, fl
     const int64_t ntile = ds::ceil_div(n, RT * 16);
     // persistent: 2 workgroups per CU while two coefficient images fit its LDS, else 1
     const unsigned grid = (unsigned)std::min<int64_t>(ds::ceil_div(ntile, MIX_NW), 2 * lds <= 160 * 1024 ? 512 : 256);
-    mix_lds_kernel<JT><<<grid, 64 * MIX_NW, lds, st>>>(A, lda, p, C, q, Out, ldo, n, alpha, beta);
+    mix_lds_kernel<JT><<<grid, 64 * MIX_NW, lds, st>>>(A, lda, p, C, ldc, q, Out, ldo, n, alpha, beta);
     DS_LAUNCH_CHECK("mix_lds_kernel");
     return DS_OK;
 }
@@ -445,20 +445,38 @@ extern "C" int ds_mix(const float* A, int64_t lda, int p, const float* C, int q,
     int rc = DS_OK;
     // LDS-staged path: the coefficient image ((p rounded to 16) x (q rounded to 16) floats) has to fit the CU's 160 KB;
     // up to 80 columns two workgroups share a CU, wider results (the fused [X' P'] = [X P W] [Z1 Zp] update) take it whole
-    const int jt = (q + 15) / 16;
-    const size_t image = (size_t)((p + 15) & ~15) * jt * 16 * sizeof(float);
-    if (veca && q <= 160 && p <= 256 && n >= 4096 && image <= 160 * 1024) {
-        switch (jt) {
-            case 1: return launch_mix_lds<1>(A, lda, p, C, q, Out, ldo, n, alpha, beta, st);
-            case 2: return launch_mix_lds<2>(A, lda, p, C, q, Out, ldo, n, alpha, beta, st);
-            case 3: return launch_mix_lds<3>(A, lda, p, C, q, Out, ldo, n, alpha, beta, st);
-            case 4: return launch_mix_lds<4>(A, lda, p, C, q, Out, ldo, n, alpha, beta, st);
-            case 5: return launch_mix_lds<5>(A, lda, p, C, q, Out, ldo, n, alpha, beta, st);
-            case 6: return launch_mix_lds<6>(A, lda, p, C, q, Out, ldo, n, alpha, beta, st);
-            case 7: return launch_mix_lds<7>(A, lda, p, C, q, Out, ldo, n, alpha, beta, st);
-            case 8: return launch_mix_lds<8>(A, lda, p, C, q, Out, ldo, n, alpha, beta, st);
-            case 9: return launch_mix_lds<9>(A, lda, p, C, q, Out, ldo, n, alpha, beta, st);
-            default: return launch_mix_lds<10>(A, lda, p, C, q, Out, ldo, n, alpha, beta, st);
+    auto lds_path = [&](const float* A_, int p_, const float* C_, int q_, float* O_, float beta_) {
+        switch ((q_ + 15) / 16) {
+            case 1: return launch_mix_lds<1>(A_, lda, p_, C_, q, q_, O_, ldo, n, alpha, beta_, st);
+            case 2: return launch_mix_lds<2>(A_, lda, p_, C_, q, q_, O_, ldo, n, alpha, beta_, st);
+            case 3: return launch_mix_lds<3>(A_, lda, p_, C_, q, q_, O_, ldo, n, alpha, beta_, st);
+            case 4: return launch_mix_lds<4>(A_, lda, p_, C_, q, q_, O_, ldo, n, alpha, beta_, st);
+            case 5: return launch_mix_lds<5>(A_, lda, p_, C_, q, q_, O_, ldo, n, alpha, beta_, st);
+            case 6: return launch_mix_lds<6>(A_, lda, p_, C_, q, q_, O_, ldo, n, alpha, beta_, st);
+            case 7: return launch_mix_lds<7>(A_, lda, p_, C_, q, q_, O_, ldo, n, alpha, beta_, st);
+            case 8: return launch_mix_lds<8>(A_, lda, p_, C_, q, q_, O_, ldo, n, alpha, beta_, st);
+            case 9: return launch_mix_lds<9>(A_, lda, p_, C_, q, q_, O_, ldo, n, alpha, beta_, st);
+            default: return launch_mix_lds<10>(A_, lda, p_, C_, q, q_, O_, ldo, n, alpha, beta_, st);
+        }
+    };
+    const size_t image = (size_t)((p + 15) & ~15) * ((q + 15) / 16) * 16 * sizeof(float);
+    if (veca && q <= 160 && p <= 256 && n >= 4096 && image <= 160 * 1024) return lds_path(A, p, C, q, Out, beta);
+    // A deeper basis or a wider result (configs[4]: [X' P'] = [X P W] Z with a 136-column block is 408 -> 272 columns)
+    // in slices of at most 160 columns whose coefficient image fits the LDS, the slices of the basis accumulated into
+    // Out - unless Out overlaps A (a later slice would read what an earlier one wrote)
+    {
+        const char* a0 = reinterpret_cast<const char*>(A);
+        const char* a1 = a0 + ((n - 1) * lda + p) * 4;
+        const char* o0 = reinterpret_cast<const char*>(Out);
+        const char* o1 = o0 + ((n - 1) * ldo + q) * 4;
+        if (veca && n >= 4096 && (o1 <= a0 || a1 <= o0) && (((uintptr_t)Out | (uintptr_t)(ldo * 4)) & 3) == 0) {
+            for (int j0 = 0; j0 < q && rc == DS_OK; j0 += 160) {
+                const int qc = std::min(160, q - j0);
+                const int slice = std::min(256, (int)(160 * 1024 / (((qc + 15) / 16) * 16 * sizeof(float))) & ~15);
+                for (int k0 = 0; k0 < p && rc == DS_OK; k0 += slice)
+                    rc = lds_path(A + k0, std::min(slice, p - k0), C + (int64_t)k0 * q + j0, qc, Out + j0, k0 == 0 ? beta : 1.f);
+            }
+            return rc;
         }
     }
     // column chunks of at most 10 MFMA tiles (160 columns) so the accumulators stay in registers

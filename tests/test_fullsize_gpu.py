@@ -86,6 +86,28 @@ def test_c3_gram_folded_fp32_accuracy(c3, dev, p, q, sym):
     assert np.array_equal(ops.gram(A, B, symmetric=sym).cpu().numpy(), G)  # deterministic
 
 
+@pytest.mark.parametrize("p,q", [(240, 80), (240, 160), (408, 136), (408, 272), (264, 200)])
+def test_c3_mix_lds_staged_paths_match_fp64(c3, dev, p, q):
+    """ds_mix at the benchmark's row count, where the LDS-staged kernel runs (the small meshes of test_hip_kernels take the
+    generic one): one launch up to 256 x 160, and the sliced form (slices of the basis accumulated into the result, column
+    chunks of 160) for configs[4]'s deeper bases; accumulate mode; a result inside a wider array."""
+    ops = c3["ops"]
+    g = torch.Generator().manual_seed(p + q)
+    A = torch.randn((ops.n, p + 8), generator=g).to(dev)[:, 4:4 + p]
+    C = torch.randn((p, q), generator=g, dtype=torch.float64).to(dev)
+    ref = A.double() @ C
+    wide = torch.full((ops.n, q + 16), float("nan"), device=dev)
+    out = wide[:, 8:8 + q]
+    ops.mix(A, C, out)
+    scale = float(ref.abs().max())
+    assert float((out.double() - ref).abs().max()) / scale < 2e-6
+    assert bool(torch.isnan(wide[:, :8]).all()) and bool(torch.isnan(wide[:, 8 + q:]).all())
+    O = torch.randn((ops.n, q), generator=g).to(dev)
+    out = O.clone()
+    ops.mix(A, C, out, alpha=-1.0, beta=1.0)
+    assert float((out.double() - (O.double() - ref)).abs().max()) / scale < 2e-6
+
+
 @pytest.mark.parametrize("ncols", [80, 72])
 def test_c3_union_spmm_matches_wave_per_node(c3, dev, ncols):
     """The production SpMM of the eigensolver (ds_spmm_union: one wavefront per 4 nodes, five waves per SIMD) against
