@@ -66,6 +66,7 @@ Collected by `tools/collect_profiles.sh r04 <part>` on the GPU box (this file: `
 | `r04_mfma32_knockout.txt`, `r04_m32_diag.txt`, `r04_mb_kx.txt`, `r04_mb_kx_raw_morton.txt`, `r04_mb_kx_plane_order.txt` | **the fp32 matrix-core form of the eigensolver's own products (`ds_spmm_union32m`): built, parity-green, slower** — K·X 263–277 µs against the VALU kernel's 205–235 on the same boxes; knock-out builds (no MFMAs 189, no gathers 249, no A-fragment chain 222, none 110); per-wave `s_memtime` stamps of a diagnostic build (`tools/m32_diag.py`): where a wave's cycles go in that kernel and in the bf16 term, the in-kernel clock (2.0–2.1 GHz), wave slots occupied |
 | `r04_corner_batch_ab.txt`, `r04_mb_corner.txt` | the corner-node level's bf16 term with batches of 16 and of 32 entries at its real size (2 461 groups): 18.2 against 23.5 µs — both levels run 16 |
 | `r04_union_waves_per_workgroup_ab.txt` | the VALU union kernel with 4 / 2 / 1 waves per workgroup: 208 / 213 / 215 µs (4 stays) |
+| `r04_hw_queues.txt`, `r04_block_sweep.txt`, `r04_lane_memory.txt` | hardware queues 2 / 4 (default) / 8 / 16: no gain; eigensolver block 72 / 76 / 80: 48.8 / 49.2 / 53.2 passes/s (80 stays); what one hypothesis lane holds in HBM, by tensor |
 | `r04_lanes_sweep.txt` | 6 / 8 / 12 / 16 hypothesis lanes: 47.9 / 49.2 / 49.7 / 49.0 passes/s (the device, not the host, is the bound) |
 | `r04_gram_mix.txt`, `r04_gram_mix_pmc.json` | Gram / `mix` timings at the solver's shapes and their MFMA counters |
 | `r04_symbolic_phase_timing.txt` | ord-2 lifting and the symbolic phase per topology at C3 |
