@@ -12,7 +12,7 @@
 # Copy what is to be judged into profiles/.
 # A gpurun call is capped at 20 minutes: tools/collect_profiles.sh <tag> <part>, part = 1 (bench line + kernel tables + busy
 # fraction), 2 (PMC passes, microbenchmarks, diagnostics), 3 (configs[4]) or all.
-set -e
+set -e -o pipefail  # (a failing tool must not leave its traceback behind as evidence)
 tag=${1:-rXX}
 part=${2:-all}
 export TMPDIR=/tmp
