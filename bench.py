@@ -115,6 +115,10 @@ def parse():
                     help="c3 = the headline benchmark (BASELINE.json configs[2]); c5 = configs[4], the 1M-tet / 128-mode / fp64 "
                          "stress (one rank): SpMM bandwidth of every product form at that size and the fp32 + fp64-refined "
                          "solve - its own JSON line, not the headline metric")
+    ap.add_argument("--no-solo", action="store_true",
+                    help="skip the roofline object's kernel-alone measurements (hundreds of launches of the fused term, K W and "
+                         "the STREAM triad after the timed region): for a rocprofv3 kernel table that should hold nothing but "
+                         "the passes' own launches (tools/collect_profiles.sh, the one-lane table)")
     ap.add_argument("--amortised-cycle", type=int, default=15,
                     help="also time the amortised variant the reference trains with (eigendecomposition every this many "
                          "passes, material_sync_train.py:135-141: EIGEN_DECOMPOSE_CYCLE = 15); 0 = skip")
@@ -619,7 +623,7 @@ def main():
 
     sysd = pipe.system
     roof = None
-    if nrec:
+    if nrec and not a.no_solo:
         ms_all = np.array(pms[:nrec], dtype=np.float64)
         nv_a, nz_a = np.array(pnv[:nrec], dtype=np.float64), np.array(pnz[:nrec], dtype=np.float64)
         nc_a = np.array(pnc[:nrec], dtype=np.float64)
@@ -651,15 +655,27 @@ def main():
         Wk = torch.randn((sysd.n, a.block), device=dev).to(vdt)
         Wp, R0 = torch.randn((sysd.n, a.block), device=dev).to(vdt), torch.randn((sysd.n, a.block), device=dev).to(vdt)
         term = (lambda: ops0.cheb_spmm16(Wk, Wp, R0, 0.3, 0.7, False)) if bf else (lambda: ops0._cheb_spmm_launch(Wk, Wp, R0, 0.3, 0.7, False))
-        for _ in range(3):
-            term()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(30):
-            term()
-        e1.record()
-        torch.cuda.synchronize()
-        solo_ms = e0.elapsed_time(e1) / 30
+
+        def alone(fn):
+            """Average launch duration of ``fn`` alone on the device by HIP events: (the first 30 back-to-back launches after
+            3 untimed ones, 100 launches after 200 more).  The first figure carries a transient - right after the synchronising
+            end of the timed region successive 30-launch averages of K W fall from 0.201 to 0.181 ms over the first ~100
+            launches and stay there (DS_BENCH_KW_SERIES=40 prints the series) - the second is the steady state the roofline
+            fractions are quoted on; both are in the line."""
+            out = []
+            for warm, reps in ((3, 30), (200, 100)):
+                for _ in range(warm):
+                    fn()
+                e0.record()
+                for _ in range(reps):
+                    fn()
+                e1.record()
+                torch.cuda.synchronize()
+                out.append(e0.elapsed_time(e1) / reps)
+            return out
+
+        solo_ms_first, solo_ms = alone(term)
         fine_bytes = ops0.cheb_term_bytes(a.block, elem_bytes=2 if bf else 4)
         solo = fine_bytes / (solo_ms * 1e-3) / 1e9
         del Wk, Wp, R0
@@ -670,19 +686,12 @@ def main():
         Sb, KSb = torch.randn((sysd.n, pitch), device=dev), torch.empty((sysd.n, pitch), device=dev)
         Xk, Yk = Sb[:, ny_ + 2 * a.block:ny_ + 3 * a.block], KSb[:, 2 * a.block:3 * a.block]
 
-        def time_kx(x_, y_):
-            for _ in range(3):
-                ops0.apply_K(x_, y_)
-            e0.record()
-            for _ in range(30):
-                ops0.apply_K(x_, y_)
-            e1.record()
-            torch.cuda.synchronize()
-            return e0.elapsed_time(e1) / 30
-
-        kw_ms = time_kx(Xk, Yk)
+        kw_ms_first, kw_ms = alone(lambda: ops0.apply_K(Xk, Yk))
+        if int(os.environ.get("DS_BENCH_KW_SERIES", "0")) > 0:
+            series = [alone(lambda: ops0.apply_K(Xk, Yk))[0] for _ in range(int(os.environ["DS_BENCH_KW_SERIES"]))]
+            print("K W, successive 30-launch averages (ms):", " ".join(f"{x:.4f}" for x in [kw_ms_first] + series), file=sys.stderr)
         Xc, Yc = torch.randn((sysd.n, a.block), device=dev), torch.empty((sysd.n, a.block), device=dev)
-        kw_ms_compact = time_kx(Xc, Yc)
+        kw_ms_compact = alone(lambda: ops0.apply_K(Xc, Yc))[1]
         del Sb, KSb, Xc, Yc
         kw_bytes = sysd.nnzb * 40 + (sysd.nv + 1) * 4 + 2 * sysd.n * a.block * 4
         del Xk, Yk
@@ -691,14 +700,9 @@ def main():
         ta, tb, tc = (torch.empty(ne, device=dev) for _ in range(3))
         tb.fill_(1.0), tc.fill_(2.0)
         L = _hip.lib()
-        for _ in range(3):
-            _hip.check(L.ds_stream_triad(ta.data_ptr(), tb.data_ptr(), tc.data_ptr(), ne, 0.5, _hip.stream_ptr()), "ds_stream_triad")
-        e0.record()
-        for _ in range(20):
-            _hip.check(L.ds_stream_triad(ta.data_ptr(), tb.data_ptr(), tc.data_ptr(), ne, 0.5, _hip.stream_ptr()), "ds_stream_triad")
-        e1.record()
-        torch.cuda.synchronize()
-        stream_gbs = 3.0 * ne * 4 / (e0.elapsed_time(e1) / 20 * 1e-3) / 1e9
+        triad_first, triad_ms = alone(lambda: _hip.check(L.ds_stream_triad(ta.data_ptr(), tb.data_ptr(), tc.data_ptr(), ne, 0.5,
+                                                                           _hip.stream_ptr()), "ds_stream_triad"))
+        stream_gbs = 3.0 * ne * 4 / (triad_ms * 1e-3) / 1e9
         del ta, tb, tc
         # PMC bytes of one such launch: a figure measured in its own rocprofv3 --pmc passes (tools/collect_profiles.sh)
         # and valid ONLY for the kernel sources it was measured on - another source hash means stale, reported as null
@@ -734,16 +738,21 @@ def main():
                            (f"spmm_union_kernel<{a.block // 4},1,...,{'bf16' if bf else 'fp32'} blocks>: W' = W + c1(W - W_prev) + "
                             f"c2 T(R0 - K W) on a {a.block}-column block, fine level (fp32 K blocks, "
                             f"{'bf16' if bf else 'fp32'} iterates, fp32 arithmetic)")),
-                "algorithmic_bytes_per_launch": fine_bytes, "avg_launch_ms": solo_ms,
+                "algorithmic_bytes_per_launch": fine_bytes, "avg_launch_ms": solo_ms, "avg_launch_ms_first_30": solo_ms_first,
+                "stream_triad_first_30": 3.0 * ne * 4 / (triad_first * 1e-3) / 1e9,
                 "how": ("'achieved' = algorithmic bytes of ONE fine-level fused-term launch / its HIP-event time with the "
                         "kernel alone on the device, on the compact blocks the V-cycle runs it on, right after the timed "
-                        "region (30 back-to-back launches); 'stream_triad' = ds_stream_triad on 3 x 1 GiB arrays, same "
-                        "device, same run; 'traffic' = PMC bytes of one such launch (profiles/)"),
+                        "region: 100 back-to-back launches after 230 untimed ones - the steady state; the first 30 launches "
+                        "after the synchronising end of the timed region run 5-10 % longer (a transient of ~100 launches, "
+                        "'avg_launch_ms_first_30'; rounds 1-3 quoted that figure); 'stream_triad' = ds_stream_triad on 3 x 1 GiB "
+                        "arrays, same device, same run, timed the same way; 'traffic' = PMC bytes of one such launch "
+                        "(profiles/)"),
                 "lobpcg_spmm": {"kernel": (f"spmm_union_kernel<{a.block // 4},0,140,...,0>: Y = K X on a {a.block}-column fp32 block (K W of the "
                                            f"iteration), on the iteration's own operands: W = columns {ny_ + 2 * a.block}..{ny_ + 3 * a.block} of the "
                                            f"[Y | X | P | W] basis buffer, K W = columns {2 * a.block}..{3 * a.block} of the K [X P W] buffer, rows "
-                                           f"{pitch * 4} bytes apart; alone on the device, 30 back-to-back launches, HIP events"),
-                                "algorithmic_bytes_per_launch": kw_bytes, "avg_launch_ms": kw_ms,
+                                           f"{pitch * 4} bytes apart; alone on the device, 100 back-to-back launches after 230 untimed "
+                                           "ones, HIP events"),
+                                "algorithmic_bytes_per_launch": kw_bytes, "avg_launch_ms": kw_ms, "avg_launch_ms_first_30": kw_ms_first,
                                 "avg_launch_ms_on_compact_blocks": kw_ms_compact,
                                 "achieved": kw_bytes / (kw_ms * 1e-3) / 1e9, "frac": kw_bytes / (kw_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                 "frac_of_stream": kw_bytes / (kw_ms * 1e-3) / 1e9 / stream_gbs, "traffic": kw_traffic},

@@ -32,9 +32,11 @@ kw = r["lobpcg_spmm"]
 cb = d["cpu_baseline"]
 pmc = json.load(open(P("spmm_pmc_bytes_per_launch.json")))
 l1 = "r04_bench_lanes1_kernel_stats.csv"
-st = kernel_row(l1, "stream_triad_kernel")
-stream_l1 = 3 * (1 << 28) * 4 / (float(st["avg_us"]) * 1e-6) / 1e9
+stream_l1 = d["roofline"]["stream_triad"]  # (the one-lane table holds the passes' own launches only: no triad in it)
+solo = "r04_bench_solo_kernel_stats.csv"
 fine = kernel_row(l1, "spmm_union_mfma_kernel<8, 5, 1, false, 16, 0>")
+fine_solo = kernel_row(solo, "spmm_union_mfma_kernel<8, 5, 1, false, 16, 0>")
+kx_solo = kernel_row(solo, "spmm_union_kernel<20, 0, 140, false, false, true, 0>")
 kx = kernel_row(l1, "spmm_union_kernel<20, 0, 140, false, false, true, 0>")
 res = kernel_row(l1, "spmm_union_kernel<20, 4, 140, false, false, true, 0>")
 fb, kb = r["algorithmic_bytes_per_launch"], kw["algorithmic_bytes_per_launch"]
@@ -55,8 +57,9 @@ Collected by `tools/collect_profiles.sh r04 <part>` on the GPU box (this file: `
 | file | what |
 |---|---|
 | `r04_bench_n1.json` | the JSON line of `python bench.py` (N = 1, 10 steps, 2 warm-up, CPU baseline at two sizes included): **{d["value"]:.1f} passes/s**; amortised variant {d["amortised"]["value"]:.0f} passes/s |
-| `r04_bench_kernel_stats.csv`, `r04_gpu_busy.txt` | `rocprofv3 --kernel-trace --stats` of `python bench.py --no-cpu-baseline --steps 8` (8 lanes overlap: durations stretched by sharing) and the device-busy fraction of its timed window |
-| `r04_bench_lanes1_kernel_stats.csv` | the same with `--lanes 1 --hyp-per-gpu 2 --steps 4`: one hypothesis at a time, every kernel alone on the device — **the table to read kernel durations from; fine- and corner-node-level launches carry different symbols (the last template argument: 0 fine, 1 corner-node level)** |
+| `r04_bench_kernel_stats.csv`, `r04_gpu_busy.txt` | `rocprofv3 --kernel-trace --stats` of `python bench.py --no-cpu-baseline --no-solo --amortised-cycle 1 --steps 8` (the passes' own launches only; 8 lanes overlap: durations stretched by sharing) and the device-busy fraction inside its timed steps (55 % .. 95 % of the run) |
+| `r04_bench_lanes1_kernel_stats.csv` | the same with `--lanes 1 --hyp-per-gpu 2 --steps 4`: one hypothesis at a time, every kernel alone on the device but between the other kernels of a pass — **the table to read in-pass kernel durations from; fine- and corner-node-level launches carry different symbols (the last template argument: 0 fine, 1 corner-node level)** |
+| `r04_bench_solo_kernel_stats.csv`, `r04_solo_timing_transient.txt` | the bench line's kernel-ALONE figures under the profiler (`python bench.py --no-cpu-baseline --lanes 1 --hyp-per-gpu 1 --steps 1 --warmup 1 --amortised-cycle 1`: nearly all launches of the fused term, K W and the triad in this table are the 330 back-to-back ones of `roofline.avg_launch_ms`), and why those are steady-state figures since this round: successive 30-launch averages after the timed region fall from 0.201 to 0.181 ms over ~100 launches |
 | `spmm_pmc_bytes_per_launch.json`, `r04_spmm_pmc_{{fp32,bf16,mfma,kx}}.json` | HBM-side traffic per launch from separate `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes; bytes = (2·FETCH + WRITE)·1024 (gfx950 correction of `guides/MI355X_MICROARCH.md`); every record carries the hash of the SpMM sources and of `modal_ops.py` (the ordering and the union tables) it was measured on — `bench.py` reports a record with another hash as stale (`traffic: null`) |
 | `r04_node_order_ab.txt` | A/B on one box of the node ORDERING: Morton curve over raw coordinates (round 3) against bricks aligned to the mesh's node planes — 45.5 → 48.0 passes/s, K·W 210 → 198 µs, bf16 term 2 500 → 3 100 GB/s |
 | `r04_union_cap_ab.txt` | chunk cap of the neighbour-union tables 116 → 140 blocks (every group one chunk): K·X 215 → 204 µs |
@@ -82,17 +85,17 @@ time an immediate rerun was clean; no unprofiled run or test has ever shown it).
 
 ## Roofline figures of `r04_bench_n1.json` (HIP events inside `bench.py`) and of the kernel table
 
-* dominant kernel `{r["kernel"]}`: {fb / 1e6:.1f} MB algorithmic per launch (SURVEY.md §8(d), BSR-3 count), {r["avg_launch_ms"]:.4f} ms alone on the device (30 back-to-back launches right after the timed region)
-  → **{r["achieved"]:.0f} GB/s = {100 * r["frac"]:.1f} % of 8 TB/s, {100 * r["frac_of_stream"]:.1f} % of the STREAM triad measured in the same run ({r["stream_triad"]:.0f} GB/s)**; PMC traffic {pmc["cells26_cols80_mfma"]["bytes"] / 1e6:.1f} MB = {pmc["cells26_cols80_mfma"]["bytes"] / fb:.2f} × algorithmic;
-  from `{l1}` alone: {frac(fb, fine)};
+* dominant kernel `{r["kernel"]}`: {fb / 1e6:.1f} MB algorithmic per launch (SURVEY.md §8(d), BSR-3 count), {r["avg_launch_ms"]:.4f} ms alone on the device in steady state (100 back-to-back launches after 230 untimed ones, right after the timed region; the first 30 of them: {r["avg_launch_ms_first_30"]:.4f} ms)
+  → **{r["achieved"]:.0f} GB/s = {100 * r["frac"]:.1f} % of 8 TB/s, {100 * r["frac_of_stream"]:.1f} % of the STREAM triad measured in the same run ({r["stream_triad"]:.0f} GB/s)**; the same under rocprofv3 (`{solo}`): {frac(fb, fine_solo)}; PMC traffic {pmc["cells26_cols80_mfma"]["bytes"] / 1e6:.1f} MB = {pmc["cells26_cols80_mfma"]["bytes"] / fb:.2f} × algorithmic;
+  inside a pass, from `{l1}` alone: {frac(fb, fine)};
   in situ (8 lanes sharing the chip): fine {r["in_situ"]["levels"]["fine"]["avg_launch_ms"]:.3f} ms, corner-node {r["in_situ"]["levels"]["corner_node"]["avg_launch_ms"]:.3f} ms per launch;
-* the eigensolver's K·W (`{kw["kernel"][:60]}…`): {kb / 1e6:.1f} MB in {kw["avg_launch_ms"]:.4f} ms on the iteration's own operands ({kw["avg_launch_ms_on_compact_blocks"]:.4f} ms on compact blocks) = {kw["achieved"]:.0f} GB/s = **{100 * kw["frac_of_stream"]:.1f} % of STREAM** in the bench's post-run state; PMC traffic {pmc["cells26_cols80_kx"]["bytes"] / 1e6:.1f} MB = {pmc["cells26_cols80_kx"]["bytes"] / kb:.2f} × algorithmic;
-  from `{l1}` alone: {frac(kb, kx)};
+* the eigensolver's K·W (`{kw["kernel"][:60]}…`): {kb / 1e6:.1f} MB in {kw["avg_launch_ms"]:.4f} ms on the iteration's own operands alone in steady state ({kw["avg_launch_ms_on_compact_blocks"]:.4f} ms on compact blocks; first 30 launches {kw["avg_launch_ms_first_30"]:.4f} ms) = {kw["achieved"]:.0f} GB/s = **{100 * kw["frac_of_stream"]:.1f} % of STREAM**; under rocprofv3 (`{solo}`, strided and compact operands together): {frac(kb, kx_solo)}; PMC traffic {pmc["cells26_cols80_kx"]["bytes"] / 1e6:.1f} MB = {pmc["cells26_cols80_kx"]["bytes"] / kb:.2f} × algorithmic;
+  inside a pass, from `{l1}` alone: {frac(kb, kx)};
   in a fresh process, interleaved and warmed up (`r04_mb_kx_layout.txt`): 177 µs on compact blocks (42 %), 182–186 µs on the solver's operands (40–41 %);
 * the fused residual (`spmm_union_kernel<20,4,…,0>`, K·X′ and M·X′ of one block in one walk): {frac(kb + 4136393 * 4.0, res)} (bytes: K·X's plus the mass scalars; the block R replaces Y);
 * CPU baseline: {cb["sample"]} on {cb["cores"]} threads of {cb["cpu_model"]} ({cb["host_hardware_threads"]} hardware threads on the host); measured exponent {cb["measured_exponent"]["value"]:.2f}; extrapolated with it to the benchmark mesh {cb["extrapolated_to_benchmark_mesh_measured_exponent"]["seconds_per_pass"]:.0f} s per pass.
 
-## One hypothesis at a time (`{l1}`; 15 passes incl. the target render and one warm-up step)
+## One hypothesis at a time (`{l1}`; 15 passes incl. the target render, one warm-up step and the 4 full passes of the amortised variant; the passes' own launches only)
 
 {table(l1, 26)}
 
