@@ -465,10 +465,14 @@ extern "C" int ds_lobpcg_iterate(ds_lobpcg_t* p, const ds_lapack_t* lapack, ds_s
         if (nconv >= k || it == p->maxit) break;
         // hard locking: converged leading columns leave the Ritz problem, the residual block and the preconditioner
         const int new_ncl = p->lock ? (nconv / 4) * 4 : 0;
+        float* Ract = p->R;  // the residual columns of the pairs that stay active
         if (new_ncl > ncl) {
             const int shift = new_ncl - ncl;
-            if ((rc = c.copy_cols(p->MW, ldr, p->R + shift, ldr, na - shift)) != DS_OK) return rc;
-            if ((rc = c.copy_cols(p->R, ldr, p->MW, ldr, na - shift)) != DS_OK) return rc;
+            // the newly locked columns leave the residual block by a pointer offset (a multiple of 4 columns: 16-byte aligned)
+            // and enter the OTHER basis buffer once, here - from then on both buffers hold them (they used to be copied in
+            // front of the active ones in every later iteration, and the residual block was shifted through a scratch block)
+            Ract = p->R + shift;
+            if ((rc = c.copy_cols(c.S2 + ny + ncl, lds, c.S + ny + ncl, lds, shift)) != DS_OK) return rc;
             Mat G2(Gxp.r - shift, Gxp.c - shift);
             for (int i = 0; i < G2.r; ++i)
                 for (int j = 0; j < G2.c; ++j) G2(i, j) = Gxp(i + shift, j + shift);
@@ -479,7 +483,7 @@ extern "C" int ds_lobpcg_iterate(ds_lobpcg_t* p, const ds_lapack_t* lapack, ds_s
         }
         const int w0 = ny + b + npc;
         float* W = c.S + w0;
-        if ((rc = c.precond(p->R, na, W, lds)) != DS_OK) return rc;
+        if ((rc = c.precond(Ract, na, W, lds)) != DS_OK) return rc;
         if ((rc = c.orthonormalize(w0, na)) != DS_OK) return rc;
         const int sz = na + npc + na, nxp = na + npc;
         float* Sa = c.S + ny + ncl;
@@ -539,7 +543,6 @@ extern "C" int ds_lobpcg_iterate(ds_lobpcg_t* p, const ds_lapack_t* lapack, ds_s
         Gxp = gemm(*lapack, ZZ, true, gemm(*lapack, G, false, ZZ, false), false);
         symmetrize(Gxp);
         for (int j = 0; j < na; ++j) lam[ncl + j] = E[j];
-        if (ncl && (rc = c.copy_cols(c.S2 + ny, lds, c.S + ny, lds, ncl)) != DS_OK) return rc;
         if (2 * na <= 160) {
             if ((rc = c.mix(Sa, lds, sz, ZZ, c.S2 + ny + ncl, lds)) != DS_OK) return rc;
             if (!p->kx_fresh && (rc = c.mix(KSa, ldks, sz, ZZ, c.KS2, ldks)) != DS_OK) return rc;
