@@ -408,6 +408,7 @@ int launch_fast(const int32_t* rowptr, const int32_t* colidx, const void* vals, 
 // v_readlane, as in spmm_f64_polish_kernel below - three dependent-address global loads per block and lane fewer; same sums in
 // the same order)
 constexpr int F64_CHUNK = 32;  // blocks of a row staged per pass
+constexpr int F64_WIN = 8;     // neighbour panels in flight per wave
 template <int KIND, typename TX>
 __global__ void __launch_bounds__(256)
     spmm_f64_node_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx,
@@ -443,23 +444,43 @@ __global__ void __launch_bounds__(256)
     } else {
         for (int kc = kb; kc < ke; kc += F64_CHUNK) {
             const int cnt = min(F64_CHUNK, ke - kc);  // wave-uniform
-            const int colreg = lane < cnt ? colidx[kc + lane] : 0;
+            const int colreg = colidx[kc + min(lane, cnt - 1)];
             const double* pv = vals + (int64_t)kc * 9;
-            for (int t = lane; t < cnt * 9; t += 64) sv[t] = pv[t];
+            // (all the chunk's coefficient loads in flight at once, clamped instead of predicated: a loop of one load per
+            // trip met every load with a full wait)
+            constexpr int NSL = (F64_CHUNK * 9 + 63) / 64;
+            double stg[NSL];
+#pragma unroll
+            for (int i = 0; i < NSL; ++i) stg[i] = pv[min(lane + 64 * i, cnt * 9 - 1)];
+#pragma unroll
+            for (int i = 0; i < NSL; ++i)
+                if (lane + 64 * i < cnt * 9) sv[lane + 64 * i] = stg[i];
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            for (int u = 0; u < cnt; ++u) {
-                const int64_t col = __builtin_amdgcn_readlane(colreg, u);
-                const xv4 x = *reinterpret_cast<const xv4*>(xb + col * 3 * ldx);
-                const double* a = sv + u * 9 + ga;  // column g of the block
-                const double a0 = a[0], a1 = a[3], a2 = a[6];
+            // The gathers of F64_WIN neighbour panels are in flight before the first of them is used (the loop used to
+            // issue one and wait for it: every block of a row paid a full L2 round trip).  Slots past the chunk's last
+            // block re-read it and are skipped; the sums and their order are unchanged.
+            for (int u0 = 0; u0 < cnt; u0 += F64_WIN) {
+                xv4 xs[F64_WIN];
 #pragma unroll
-                for (int v = 0; v < 4; ++v) {
-                    const double xv = (double)x[v];
-                    acc[0][v] = fma(a0, xv, acc[0][v]);
-                    acc[1][v] = fma(a1, xv, acc[1][v]);
-                    acc[2][v] = fma(a2, xv, acc[2][v]);
+                for (int j = 0; j < F64_WIN; ++j) {
+                    const int64_t col = __builtin_amdgcn_readlane(colreg, min(u0 + j, cnt - 1));
+                    xs[j] = *reinterpret_cast<const xv4*>(xb + col * 3 * ldx);
+                }
+#pragma unroll
+                for (int j = 0; j < F64_WIN; ++j) {
+                    if (u0 + j < cnt) {  // wave-uniform
+                        const double* a = sv + (u0 + j) * 9 + ga;  // column g of the block
+                        const double a0 = a[0], a1 = a[3], a2 = a[6];
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) {
+                            const double xv = (double)xs[j][v];
+                            acc[0][v] = fma(a0, xv, acc[0][v]);
+                            acc[1][v] = fma(a1, xv, acc[1][v]);
+                            acc[2][v] = fma(a2, xv, acc[2][v]);
+                        }
+                    }
                 }
             }
             if (kc + F64_CHUNK < ke) {  // the slab is rewritten by the next pass
@@ -508,6 +529,7 @@ __global__ void __launch_bounds__(256)
 // register (a coalesced load) and come back with v_readlane, so a panel's address is scalar arithmetic.  The sums and their
 // order are unchanged: results bit-identical to the three separate launches, as before.
 constexpr int PL_CHUNK = 32;  // blocks of a row staged per pass
+constexpr int PL_WIN = 4;     // panels per gather window (two windows: 8 in flight)
 __global__ void __launch_bounds__(256)
     spmm_f64_polish_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx,
                            const double* __restrict__ va, const double* __restrict__ vb, const double* __restrict__ vm,
@@ -537,32 +559,65 @@ __global__ void __launch_bounds__(256)
     }
     for (int kc = kb; kc < ke; kc += PL_CHUNK) {
         const int cnt = min(PL_CHUNK, ke - kc);  // wave-uniform
-        const int colreg = lane < cnt ? colidx[kc + lane] : 0;
+        const int colreg = colidx[kc + min(lane, cnt - 1)];
         const double* pa = va + (int64_t)kc * 9;
         const double* pb = vb + (int64_t)kc * 9;
-        for (int t = lane; t < cnt * 9; t += 64) sa[t] = pa[t], sb[t] = pb[t];
-        if (lane < cnt) sm[lane] = vm[kc + lane];
+        {  // all the chunk's coefficient loads in flight at once (clamped, not predicated)
+            constexpr int NSL = (PL_CHUNK * 9 + 63) / 64;
+            double ra[NSL], rb[NSL];
+#pragma unroll
+            for (int i = 0; i < NSL; ++i) {
+                const int t = min(lane + 64 * i, cnt * 9 - 1);
+                ra[i] = pa[t], rb[i] = pb[t];
+            }
+            const double rm = vm[kc + min(lane, cnt - 1)];
+#pragma unroll
+            for (int i = 0; i < NSL; ++i)
+                if (lane + 64 * i < cnt * 9) sa[lane + 64 * i] = ra[i], sb[lane + 64 * i] = rb[i];
+            if (lane < cnt) sm[lane] = rm;
+        }
         // same-wave LDS write -> read (rows differ in length: no workgroup barrier)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        for (int u = 0; u < cnt; ++u) {
-            const int64_t col = __builtin_amdgcn_readlane(colreg, u);
-            const xv4 x = *reinterpret_cast<const xv4*>(xb + col * 3 * ldx);
-            const double* ca = sa + u * 9 + ga;  // column g of the blocks
-            const double* cb = sb + u * 9 + ga;
-            const double a0 = ca[0], a1 = ca[3], a2 = ca[6], b0 = cb[0], b1 = cb[3], b2 = cb[6], m = sm[u];
+        // Two windows of PL_WIN panel gathers: the next window is requested before the current one is used (see
+        // spmm_f64_node_kernel); same sums, same order
+        auto issue = [&](xv4 (&xs)[PL_WIN], int u0) {
 #pragma unroll
-            for (int v = 0; v < 4; ++v) {
-                const double xv = (double)x[v];
-                aa[0][v] = fma(a0, xv, aa[0][v]);
-                aa[1][v] = fma(a1, xv, aa[1][v]);
-                aa[2][v] = fma(a2, xv, aa[2][v]);
-                ab[0][v] = fma(b0, xv, ab[0][v]);
-                ab[1][v] = fma(b1, xv, ab[1][v]);
-                ab[2][v] = fma(b2, xv, ab[2][v]);
-                am[v] = fma(m, xv, am[v]);
+            for (int j = 0; j < PL_WIN; ++j) {
+                const int64_t col = __builtin_amdgcn_readlane(colreg, min(u0 + j, cnt - 1));
+                xs[j] = *reinterpret_cast<const xv4*>(xb + col * 3 * ldx);
             }
+        };
+        auto consume = [&](const xv4 (&xs)[PL_WIN], int u0) {
+#pragma unroll
+            for (int j = 0; j < PL_WIN; ++j) {
+                if (u0 + j < cnt) {  // wave-uniform
+                    const int u = u0 + j;
+                    const double* ca = sa + u * 9 + ga;  // column g of the blocks
+                    const double* cb = sb + u * 9 + ga;
+                    const double a0 = ca[0], a1 = ca[3], a2 = ca[6], b0 = cb[0], b1 = cb[3], b2 = cb[6], m = sm[u];
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        const double xv = (double)xs[j][v];
+                        aa[0][v] = fma(a0, xv, aa[0][v]);
+                        aa[1][v] = fma(a1, xv, aa[1][v]);
+                        aa[2][v] = fma(a2, xv, aa[2][v]);
+                        ab[0][v] = fma(b0, xv, ab[0][v]);
+                        ab[1][v] = fma(b1, xv, ab[1][v]);
+                        ab[2][v] = fma(b2, xv, ab[2][v]);
+                        am[v] = fma(m, xv, am[v]);
+                    }
+                }
+            }
+        };
+        xv4 x0[PL_WIN], x1[PL_WIN];
+        issue(x0, 0);
+        for (int u0 = 0; u0 < cnt; u0 += 2 * PL_WIN) {
+            issue(x1, u0 + PL_WIN);  // (a window past the chunk re-reads its last panel and is skipped)
+            consume(x0, u0);
+            issue(x0, u0 + 2 * PL_WIN);
+            consume(x1, u0 + PL_WIN);
         }
         if (kc + PL_CHUNK < ke) {  // the slabs are rewritten by the next pass
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
