@@ -73,9 +73,9 @@ Collected by `tools/collect_profiles.sh r04 <part>` on the GPU box (this file: `
 | `r04_lanes_sweep.txt` | 6 / 8 / 12 / 16 hypothesis lanes: 47.9 / 49.2 / 49.7 / 49.0 passes/s (the device, not the host, is the bound) |
 | `r04_gram_mix.txt`, `r04_gram_mix_pmc.json` | Gram / `mix` timings at the solver's shapes and their MFMA counters |
 | `r04_symbolic_phase_timing.txt` | ord-2 lifting and the symbolic phase per topology at C3 |
-| `r04_c5_bench.json`, `r04_c5_kernel_stats.csv`, `r04_c5_bench_noprof.json` | **configs[4]** (`bench.py --workload c5` under `rocprofv3 --kernel-trace --stats`, and plain): 998 250 tets, n = 4.1 M, 128 modes - solve with fp64 refinement 2.93 s in both (2.6-2.9 s over the round's runs; round 3: 3.6-3.9); the SpMM forms alone in steady state |
+| `r04_c5_bench.json`, `r04_c5_kernel_stats.csv`, `r04_c5_bench_noprof.json` | **configs[4]** (`bench.py --workload c5` under `rocprofv3 --kernel-trace --stats`, and plain): 998 250 tets, n = 4.1 M, 128 modes - solve with fp64 refinement 2.63 s / 2.93 s (2.6-2.9 s over the round's runs; round 3: 3.6-3.9); the SpMM forms alone in steady state |
 | `r04_mb_mix64.txt`, `r04_mb_gram64.txt`, `r04_c5_refine_breakdown.txt`, `r04_c5_refine_sweeps.txt` | configs[4]'s fp64 refinement: `ds_mix64` (fp64 MFMA over the list of blocks of the basis) 7.9 ms against 18.0 ms for the `torch.mm`/`addmm` chain; `ds_gram64_blocks` 8.8 ms against 17.1 (11.6 after the fp64 Gram kernels got exact wait counts) for eight `ds_gram` calls; where the 1.65 s of 16 steps go; 1 / 2 / 3 preconditioner sweeps per step |
-| `r04_mb_polish.txt` | the read-out's fp64 products at C3: `ds_spmm_f64_polish` 0.86 ms, with the 80 x 240 exact Gram 1.29 ms |
+| `r04_mb_polish.txt` | the read-out's fp64 products at C3: `ds_spmm_f64_polish` 0.65 ms (0.86 before its gather loop kept eight panels in flight), with the 80 x 240 exact Gram 1.10 ms |
 
 ## A note on the profiled runs
 
