@@ -460,6 +460,13 @@ __global__ void __launch_bounds__(256)
         }
         const double* src = ws + (int64_t)i * q + j;
         int k = sub;
+        for (; k + 112 < nsplit; k += 128) {  // eight loads in flight (two per trip met a full wait each: 8 trips of latency)
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = src[(int64_t)(k + 16 * u) * pq];
+#pragma unroll
+            for (int u = 0; u < 8; u += 2) s0 += v[u], s1 += v[u + 1];
+        }
         for (; k + 16 < nsplit; k += 32) {
             s0 += src[(int64_t)k * pq];
             s1 += src[(int64_t)(k + 16) * pq];

@@ -74,7 +74,20 @@ __global__ void __launch_bounds__(256)
     const int c0 = (c - r * lpn) * 4;
     f4 acc = {0.f, 0.f, 0.f, 0.f};
     const int kb = rowptr[node], ke = rowptr[node + 1];
-    for (int k = kb; k < ke; ++k) acc += w[k] * load_piece<false>(X, 3 * (int64_t)colidx[k] + r, ldx, c0);
+    // four independent gathers in flight (a restriction row has 30-60 entries and the plain loop met every gather - an
+    // index load and the panel load that depends on it - with a full wait); the sum keeps its order
+    int k = kb;
+    for (; k + 4 <= ke; k += 4) {
+        const int64_t j0 = colidx[k], j1 = colidx[k + 1], j2 = colidx[k + 2], j3 = colidx[k + 3];
+        const float w0 = w[k], w1 = w[k + 1], w2 = w[k + 2], w3 = w[k + 3];
+        const f4 x0 = load_piece<false>(X, 3 * j0 + r, ldx, c0), x1 = load_piece<false>(X, 3 * j1 + r, ldx, c0);
+        const f4 x2 = load_piece<false>(X, 3 * j2 + r, ldx, c0), x3 = load_piece<false>(X, 3 * j3 + r, ldx, c0);
+        acc += w0 * x0;
+        acc += w1 * x1;
+        acc += w2 * x2;
+        acc += w3 * x3;
+    }
+    for (; k < ke; ++k) acc += w[k] * load_piece<false>(X, 3 * (int64_t)colidx[k] + r, ldx, c0);
     if (beta != 0.f) acc += beta * load_piece<false>(Y, 3 * node + r, ldy, c0);
     store_piece(Y, 3 * node + r, ldy, c0, acc);
 }

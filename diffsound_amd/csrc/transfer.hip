@@ -26,7 +26,19 @@ __global__ void __launch_bounds__(256)
     const int c0 = (c - r * lpn) * 4;
     f4 acc = {0.f, 0.f, 0.f, 0.f};
     const int kb = rowptr[node], ke = rowptr[node + 1];
-    for (int k = kb; k < ke; ++k) {
+    // four independent gathers in flight (see scalar_csr16_kernel); the sum keeps its order
+    int k = kb;
+    for (; k + 4 <= ke; k += 4) {
+        const int64_t j0 = colidx[k], j1 = colidx[k + 1], j2 = colidx[k + 2], j3 = colidx[k + 3];
+        const float w0 = w[k], w1 = w[k + 1], w2 = w[k + 2], w3 = w[k + 3];
+        const f4 x0 = *reinterpret_cast<const f4*>(X + (3 * j0 + r) * ldx + c0), x1 = *reinterpret_cast<const f4*>(X + (3 * j1 + r) * ldx + c0);
+        const f4 x2 = *reinterpret_cast<const f4*>(X + (3 * j2 + r) * ldx + c0), x3 = *reinterpret_cast<const f4*>(X + (3 * j3 + r) * ldx + c0);
+        acc += w0 * x0;
+        acc += w1 * x1;
+        acc += w2 * x2;
+        acc += w3 * x3;
+    }
+    for (; k < ke; ++k) {
         const int64_t j = colidx[k];
         acc += w[k] * *reinterpret_cast<const f4*>(X + (3 * j + r) * ldx + c0);
     }

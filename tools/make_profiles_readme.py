@@ -75,6 +75,7 @@ Collected by `tools/collect_profiles.sh r04 <part>` on the GPU box (this file: `
 | `r04_symbolic_phase_timing.txt` | ord-2 lifting and the symbolic phase per topology at C3 |
 | `r04_c5_bench.json`, `r04_c5_kernel_stats.csv`, `r04_c5_bench_noprof.json` | **configs[4]** (`bench.py --workload c5` under `rocprofv3 --kernel-trace --stats`, and plain): 998 250 tets, n = 4.1 M, 128 modes - solve with fp64 refinement 2.63 s / 2.93 s (2.6-2.9 s over the round's runs; round 3: 3.6-3.9); the SpMM forms alone in steady state |
 | `r04_mb_mix64.txt`, `r04_mb_gram64.txt`, `r04_c5_refine_breakdown.txt`, `r04_c5_refine_sweeps.txt` | configs[4]'s fp64 refinement: `ds_mix64` (fp64 MFMA over the list of blocks of the basis) 7.9 ms against 18.0 ms for the `torch.mm`/`addmm` chain; `ds_gram64_blocks` 8.8 ms against 17.1 (11.6 after the fp64 Gram kernels got exact wait counts) for eight `ds_gram` calls; where the 1.65 s of 16 steps go; 1 / 2 / 3 preconditioner sweeps per step |
+| `r04_gather_loops_ab.txt` | gather loops that issued one load per trip and waited for it (found by an ISA scan of all kernels): restriction 32.8 -> 22.4 us with four gathers in flight; the numeric assembly does not gain from it (write-bound) |
 | `r04_mb_polish.txt` | the read-out's fp64 products at C3: `ds_spmm_f64_polish` 0.65 ms (0.86 before its gather loop kept eight panels in flight), with the 80 x 240 exact Gram 1.10 ms |
 
 ## A note on the profiled runs
