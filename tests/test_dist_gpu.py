@@ -116,6 +116,33 @@ def test_two_ranks_rccl(ndev, one_rank):
     assert abs(two["loss_sum_last_step"] / one_rank["loss_sum_last_step"] - 1) < 1e-6
 
 
+def test_rccl_collectives_of_the_n_gt_1_path_run_with_one_rank(ndev):
+    """RCCL itself on this box: the collectives bench.py's N > 1 branch makes - barrier on the rank's own device, the
+    all-reduce of the scalar loss, the all-gather of the rank statistics - through the same functions, backend "nccl", in a
+    process group of ONE rank (all a one-device box allows: two ranks need two devices).  Child process, so that the test
+    runner itself never owns a process group."""
+    code = (
+        "import os, torch, torch.distributed as dist\n"
+        "from diffsound_amd.pipeline import all_reduce_loss, gather_rank_stats\n"
+        "torch.cuda.set_device(0)\n"
+        "dist.init_process_group('nccl', rank=0, world_size=1)\n"
+        "dev = torch.device('cuda', 0)\n"
+        "dist.barrier(device_ids=[0])\n"
+        "s = all_reduce_loss(1.25, dev)\n"
+        "g = gather_rank_stats([1.0, 2.0, 3.5], dev)\n"
+        "dist.barrier(device_ids=[0])\n"
+        "torch.cuda.synchronize()\n"
+        "print('RCCL', dist.get_backend(), s, g)\n"
+        "dist.destroy_process_group()\n")
+    env = dict(os.environ)
+    env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29641", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    assert "RCCL nccl 1.25 [[1.0, 2.0, 3.5]]" in out.stdout, out.stdout[-2000:]
+
+
 def test_more_gpus_than_devices_is_an_error(ndev):
     env = dict(os.environ)
     env.pop("WORLD_SIZE", None)
