@@ -29,6 +29,8 @@ import torch  # noqa: E402
 
 MAT = (2700.0, 5e10, 0.25, 6.0, 1e-7)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md); the STREAM triad below is MEASURED in the run
+MFMA_F32_PEAK_TFS = 157.3  # v_mfma_f32_16x16x4_f32: 256 flop / cycle / CU x 256 CUs x 2.4 GHz (the same guide); fp32 Gram / update kernels
+PROF_KINDS = {0: "term", 1: "kx", 2: "mx", 3: "resid", 4: "gram", 5: "mix", 6: "km"}  # DS_PROF_* of include/diffsound_hip.h
 
 
 # (the node ordering and the union tables decide the traffic as much as the kernels do: modal_ops.py is part of the key)
@@ -42,6 +44,20 @@ def spmm_source_hash():
 
     h = hashlib.sha256()
     for name in SPMM_SOURCES:
+        with open(os.path.join(ROOT, "diffsound_amd", "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+DENSE_SOURCES = ("gram.hip", "blockops.hip", "ds_common.h")
+
+
+def dense_source_hash():
+    """The same key for the Gram / update kernels' counter record (profiles/gram_mix_mfma_util.json)."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for name in DENSE_SOURCES:
         with open(os.path.join(ROOT, "diffsound_amd", "csrc", name), "rb") as f:
             h.update(f.read())
     return h.hexdigest()[:16]
@@ -83,6 +99,9 @@ def parse():
                     help="recompute K [X P W] and the whole Gram matrix every this many iterations (-1 = solver default)")
     ap.add_argument("--kx-fresh", type=int, default=-1,
                     help="1: K X' of every new Ritz block by one product (solver default), 0: by the update of K [X P W]")
+    ap.add_argument("--raw-rr", type=int, default=-1,
+                    help="1: Rayleigh-Ritz on the raw basis (solver default: [K W | M W] in one walk, one Gram, one update per "
+                         "iteration), 0: the explicit sequence M W, Gram, update of W, K W, Gram, update")
     ap.add_argument("--fused-residual", type=int, default=-1,
                     help="1: the residual of every iteration in one walk of the unions (solver default), 0: K X', M X', residual")
     ap.add_argument("--tol", type=float, default=1e-5,
@@ -157,6 +176,8 @@ def solver_config(a=None, **over):
         cfg.kx_fresh = bool(a.kx_fresh)
     if getattr(a, "fused_residual", -1) >= 0:
         cfg.fused_residual = bool(a.fused_residual)
+    if getattr(a, "raw_rr", -1) >= 0:
+        cfg.raw_rr = bool(a.raw_rr)
     cfg.tol = a.tol
     cfg.power_iters = a.power_iters
     if a.warm_power_iters > 0:
@@ -456,6 +477,89 @@ def main_c5(a):
         "hbm_in_use_gib": (total_b - free_b) / 2 ** 30}))
 
 
+def in_pass_profile(pipe, hyps, dev, block, passes=2):
+    """``roofline.in_pass``: complete passes run ONE AT A TIME on one stream with every SpMM form, Gram and update launch of
+    the pass bracketed by HIP events inside the library (ds_profile_stream / ds_profile_kinds) - each kernel alone on the device,
+    but BETWEEN the other kernels of a pass, which is where the caches are in the state a real pass leaves them in (a back-to-back
+    series of one kernel on the same operands keeps part of them in the 256 MB Infinity Cache: that is ``avg_launch_ms``).
+    Returns the records as arrays (kind, ms, a, b, c, flags)."""
+    import ctypes
+
+    from diffsound_amd import _hip
+
+    L = _hip.lib()
+    if pipe._lanes:
+        lane, stream = pipe._lanes[0], pipe._lanes[0].stream
+    else:
+        lane, stream = None, torch.cuda.Stream(device=dev)
+    cap = 6000 * passes
+    torch.cuda.synchronize()
+    with torch.cuda.stream(stream):
+        pipe.run_pass(*hyps[0], _lane=lane)  # (untimed: the stream's first pass after the lanes' concurrent run)
+        stream.synchronize()
+        _hip.check(L.ds_profile_kinds(0x7F), "ds_profile_kinds")
+        _hip.check(L.ds_profile_stream(stream.cuda_stream, cap), "ds_profile_stream")
+        t0 = time.time()
+        for i in range(passes):
+            pipe.run_pass(*hyps[(i + 1) % len(hyps)], _lane=lane)
+        stream.synchronize()
+        secs = (time.time() - t0) / passes
+    ms = (ctypes.c_float * cap)()
+    a_, b_ = (ctypes.c_int64 * cap)(), (ctypes.c_int64 * cap)()
+    c_, f_ = (ctypes.c_int32 * cap)(), (ctypes.c_int32 * cap)()
+    n = int(L.ds_profile_collect(ms, a_, b_, c_, f_, cap))
+    _hip.check(L.ds_profile_kinds(0), "ds_profile_kinds")
+    fl = np.array(f_[:n], dtype=np.int64)
+    return {"kind": fl >> 16, "ms": np.array(ms[:n], dtype=np.float64), "a": np.array(a_[:n], dtype=np.float64),
+            "b": np.array(b_[:n], dtype=np.float64), "c": np.array(c_[:n], dtype=np.int64), "flags": fl & 0xFFFF,
+            "passes": passes, "seconds_per_pass": secs}
+
+
+def summarize_in_pass(rec, sysd, block, stream_gbs, mf_levels):
+    """Per kernel family of a pass: launches at the full block width on the fine level, average duration, algorithmic bytes
+     or flops, and the fractions of the HBM roofline / the in-run STREAM triad / the fp32 matrix-core peak."""
+    nv, nnzb, n = sysd.nv, sysd.nnzb, sysd.n
+    out = {}
+    kind, ms, a, b, c, fl = (rec[k] for k in ("kind", "ms", "a", "b", "c", "flags"))
+
+    def hbm(name, sel, nbytes, what):
+        if sel.any():
+            t = float(ms[sel].mean())
+            gbs = nbytes / (t * 1e-3) / 1e9
+            out[name] = {"what": what, "launches": int(sel.sum()), "avg_launch_ms": t, "min_launch_ms": float(ms[sel].min()),
+                         "algorithmic_bytes_per_launch": float(nbytes), "achieved": gbs, "unit": "GB/s",
+                         "frac": gbs / HBM_PEAK_GBS, "frac_of_stream": gbs / stream_gbs if stream_gbs else None}
+
+    fine = a == nv
+    full = c == block
+    eb = (fl >> 8).astype(np.float64)
+    sel = (kind == 0) & fine & full & ((fl & 1) == 0) & (eb == 2)
+    vb = 2.0 if nv in mf_levels else 4.0
+    hbm("fused_term_bf16", sel, nnzb * (9 * vb + 4) + (nv + 1) * 4 + nv * 36 + 4 * n * block * 2,
+        "the dominant kernel (fused bf16 Chebyshev term, fine level), 4 vector streams")
+    hbm("lobpcg_kw", (kind == 1) & fine & full, nnzb * 40 + (nv + 1) * 4 + 2 * n * block * 4, "Y = K W of the iteration (fp32)")
+    hbm("lobpcg_mw", (kind == 2) & fine & full, nnzb * 8 + (nv + 1) * 4 + 2 * n * block * 4, "Y = M_s W of the orthonormalisation (fp32)")
+    hbm("fused_residual", (kind == 3) & fine & full, nnzb * 44 + (nv + 1) * 4 + 2 * n * block * 4,
+        "R = K X - (M X) diag(lam) in one walk: K's and M's values, X gathered, R written")
+    hbm("lobpcg_kw_mw", (kind == 6) & fine & full, nnzb * 44 + (nv + 1) * 4 + 3 * n * block * 4,
+        "[K W | M W] of the raw preconditioned residuals in one walk (round 5): K's and M's values, W gathered, two blocks written")
+    rr = {}
+    for kd, nm in ((4, "gram"), (5, "mix")):
+        m = (kind == kd) & (b == n)
+        for p_, q_ in sorted({(int(x), int(y)) for x, y in zip(a[m], c[m])}, key=lambda t: -t[0] * t[1])[:4]:
+            sel = m & (a == p_) & (c == q_)
+            if sel.sum() < 2:
+                continue
+            t = float(ms[sel].mean())
+            flops, nbytes = 2.0 * n * p_ * q_, n * (p_ + q_) * 4.0
+            rr[f"{nm}_{p_}x{q_}"] = {"launches": int(sel.sum()), "avg_ms": t, "min_ms": float(ms[sel].min()),
+                                      "tflops": flops / (t * 1e-3) / 1e12, "frac_of_mfma_f32_peak": flops / (t * 1e-3) / 1e12 / MFMA_F32_PEAK_TFS,
+                                      "gbs": nbytes / (t * 1e-3) / 1e9, "frac_of_hbm_peak": nbytes / (t * 1e-3) / 1e9 / HBM_PEAK_GBS}
+    by_kind = {PROF_KINDS[k]: {"launches": int((kind == k).sum()), "total_ms_per_pass": float(ms[kind == k].sum() / rec["passes"])}
+               for k in sorted(PROF_KINDS) if (kind == k).any()}
+    return out, rr, by_kind
+
+
 def main():
     a = parse()
     if a.workload == "c5":
@@ -647,6 +751,10 @@ def main():
                      if o is not None and o._mfma is not None and o.kc is not None}
         vb_a = np.where((eb_a == 2) & np.isin(nv_a.astype(np.int64), sorted(mf_levels)), 2.0, 4.0)
         by_all = nz_a * (9 * vb_a + 4) + (nv_a + 1) * 4 + nv_a * 36 + (4 - fi_a) * 3 * nv_a * nc_a * eb_a
+        kd_a = fl_a >> 16  # kind of the record (DS_PROF_*): the timed region records the fused term only
+        assert (kd_a == 0).all()
+        fl_a = fl_a & 0xFFFF
+        fi_a, eb_a = (fl_a & 1).astype(np.float64), (fl_a >> 8).astype(np.float64)
         full = nc_a == a.block  # full-width blocks (after locking the narrower ones run another instantiation)
         ms, nbytes = ms_all[full], by_all[full]
         achieved = float(nbytes.sum() / (ms.sum() * 1e-3) / 1e9)
@@ -657,6 +765,8 @@ def main():
                          "achieved": float(nbytes[m].sum() / (ms[m].sum() * 1e-3) / 1e9)}
                   for name, m in (("fine", fine), ("corner_node", ~fine)) if m.any()}
         all_widths = {"launches": int(nrec), "achieved": float(by_all.sum() / (ms_all.sum() * 1e-3) / 1e9)}
+        # ---- complete passes one at a time with every SpMM / Gram / update launch timed in place (roofline.in_pass)
+        inpass_rec = in_pass_profile(pipe, hyps, dev, a.block, passes=2)
         # the same kernel alone on the device (fine level, 80 columns): what one launch achieves when it does not
         # share the chip with the other hypothesis lanes' kernels
         ops0 = lane_ops[0]
@@ -692,7 +802,8 @@ def main():
         # the eigensolver's own stiffness product K W (fp32 blocks, the "LOBPCG SpMM" of the north star), alone as well - ON THE
         # OPERANDS THE ITERATION GIVES IT: W = the last b columns of the solver's [Y | X | P | W] basis buffer, K W = the last b
         # columns of its K [X P W] buffer (both with rows 1 KiB apart, lobpcg/modal_solver.py), and beside it on compact blocks
-        ny_, pitch = 8, -(-(8 + 3 * a.block) // 256) * 256
+        ny_ = 16 if a.block % 16 == 0 else 8  # (the solver pads the rigid block to 16 columns: modal_solver.py)
+        pitch = -(-(ny_ + 3 * a.block) // 256) * 256
         Sb, KSb = torch.randn((sysd.n, pitch), device=dev), torch.empty((sysd.n, pitch), device=dev)
         Xk, Yk = Sb[:, ny_ + 2 * a.block:ny_ + 3 * a.block], KSb[:, 2 * a.block:3 * a.block]
 
@@ -714,6 +825,52 @@ def main():
                                                                            _hip.stream_ptr()), "ds_stream_triad"))
         stream_gbs = 3.0 * ne * 4 / (triad_ms * 1e-3) / 1e9
         del ta, tb, tc
+        # ---- the Rayleigh-Ritz kernels alone on the device, at the iteration's shapes and on its operand layout (north star:
+        #      "MFMA utilisation on the Rayleigh-Ritz reported against gfx950 peaks"): [Y X P W]^T (M W) of the orthonormalisation,
+        #      [X P W]^T (K W) of the Ritz step, the in-place update W <- [Y X P W] C and [X' P'] = [X P W] [Z1 Zp]
+        b_ = a.block
+        Sb = torch.randn((sysd.n, pitch), device=dev)
+        S2b = torch.empty((sysd.n, pitch), device=dev)
+        KSb = torch.randn((sysd.n, pitch), device=dev)
+        MWb = torch.randn((sysd.n, b_), device=dev)
+        rr_solo = {}
+
+        def rr_record(name, p_, q_, fn, what):
+            first_, t = alone(fn)
+            flops, nbytes = 2.0 * sysd.n * p_ * q_, sysd.n * (p_ + q_) * 4.0
+            rr_solo[name] = {"what": what, "avg_ms": t, "avg_ms_first_30": first_, "tflops": flops / (t * 1e-3) / 1e12,
+                             "frac_of_mfma_f32_peak": flops / (t * 1e-3) / 1e12 / MFMA_F32_PEAK_TFS,
+                             "gbs": nbytes / (t * 1e-3) / 1e9, "frac_of_hbm_peak": nbytes / (t * 1e-3) / 1e9 / HBM_PEAK_GBS}
+
+        pw = ny_ + 3 * b_
+        rr_record(f"gram_{pw}x{b_}", pw, b_, lambda: ops0.gram(Sb[:, :pw], MWb), "[Y X P W]^T (M W): gram32_partial_kernel + gram_reduce_kernel")
+        rr_record(f"gram_{3 * b_}x{b_}", 3 * b_, b_, lambda: ops0.gram(Sb[:, ny_:pw], KSb[:, 2 * b_:3 * b_]),
+                  "[X P W]^T (K W): the Ritz step's Gram block")
+        Cw = torch.randn((pw, b_), device=dev) / pw
+        rr_record(f"mix_{pw}x{b_}", pw, b_, lambda: ops0.mix(Sb[:, :pw], Cw, Sb[:, pw - b_:pw]), "W <- [Y X P W] C in place: mix_lds_kernel<5>")
+        Cz = torch.randn((3 * b_, 2 * b_), device=dev) / pw
+        rr_record(f"mix_{3 * b_}x{2 * b_}", 3 * b_, 2 * b_, lambda: ops0.mix(Sb[:, ny_:pw], Cz, S2b[:, ny_:ny_ + 2 * b_]),
+                  "[X' P'] = [X P W] [Z1 Zp]: mix_lds_kernel<10>")
+        rr_record(f"gram_{pw}x{2 * b_}", pw, 2 * b_, lambda: ops0.gram(Sb[:, :pw], KSb[:, :2 * b_]),
+                  "[Y X P W]^T [K W | M W]: the ONE Gram launch of an iteration on the raw basis (round 5)")
+        Cr = torch.randn((pw, 2 * b_), device=dev) / pw
+        rr_record(f"mix_{pw}x{2 * b_}", pw, 2 * b_, lambda: ops0.mix(Sb[:, :pw], Cr, S2b[:, ny_:ny_ + 2 * b_]),
+                  "[X' P'] = [Y X P W] Z_raw: the ONE update of an iteration on the raw basis (round 5)")
+        del Sb, S2b, KSb, MWb, Cw, Cz, Cr
+        # MFMA pipe utilisation of those kernels from the rocprofv3 --pmc passes of tools/collect_profiles.sh (a counter pass cannot
+        # run inside this process): SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 4 SIMDs x CUs), valid for the kernel sources it names
+        rr_pmc, rr_pmc_note = None, "no counter record under profiles/ (tools/collect_profiles.sh part 2 writes profiles/gram_mix_mfma_util.json)"
+        try:
+            rec = json.load(open(os.path.join(ROOT, "profiles", "gram_mix_mfma_util.json")))
+            if rec.get("dense_source_sha16") == dense_source_hash():
+                rr_pmc, rr_pmc_note = rec["kernels"], f"counter passes of {rec.get('measured', '?')} on these kernel sources"
+            else:
+                rr_pmc_note = f"stale: measured on kernel sources {rec.get('dense_source_sha16')}, this run's are {dense_source_hash()}"
+        except (OSError, ValueError, KeyError):
+            pass
+        mf_lv = {int(o.nv) for o in (lane_ops[0], getattr(lane_ops[0], "coarse", None))
+                 if o is not None and o._mfma is not None and o.kc is not None}
+        inpass, rr_inpass, inpass_kinds = summarize_in_pass(inpass_rec, sysd, a.block, stream_gbs, mf_lv)
         # PMC bytes of one such launch: a figure measured in its own rocprofv3 --pmc passes (tools/collect_profiles.sh)
         # and valid ONLY for the kernel sources it was measured on - another source hash means stale, reported as null
         traffic, traffic_note = None, "no PMC figure under profiles/ for this shape"
@@ -766,6 +923,17 @@ def main():
                                 "avg_launch_ms_on_compact_blocks": kw_ms_compact,
                                 "achieved": kw_bytes / (kw_ms * 1e-3) / 1e9, "frac": kw_bytes / (kw_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                 "frac_of_stream": kw_bytes / (kw_ms * 1e-3) / 1e9 / stream_gbs, "traffic": kw_traffic},
+                "in_pass": {"how": ("complete passes one at a time on one stream (one hypothesis lane), every launch of these kernels "
+                                    "bracketed by HIP events inside the library: alone on the device but BETWEEN the other kernels of a "
+                                    "pass - the figure to hold against the roofline of a real pass; 'avg_launch_ms' above is the kernel's "
+                                    "own steady state in a back-to-back series"),
+                            "passes": inpass_rec["passes"], "seconds_per_pass_one_at_a_time": inpass_rec["seconds_per_pass"],
+                            "kernels": inpass, "event_time_per_pass_ms_by_kind": inpass_kinds},
+                "rayleigh_ritz": {"peak": MFMA_F32_PEAK_TFS, "unit": "TFLOP/s", "peak_what": "v_mfma_f32_16x16x4_f32, dense, 256 CUs x 2.4 GHz",
+                                  "alone": rr_solo, "in_pass": rr_inpass, "mfma_busy": rr_pmc, "mfma_busy_note": rr_pmc_note,
+                                  "how": ("Gram G = A^T B (fp32 MFMA folded into fp64) and update Out = A C at the iteration's shapes and "
+                                          "operand layout; 'alone' = 100 back-to-back launches after 230 untimed ones, 'in_pass' = the "
+                                          "launches of the one-at-a-time passes; flops = 2 n p q, bytes = n (p + q) 4")},
                 "in_situ": {"achieved": achieved, "frac": achieved / HBM_PEAK_GBS,
                             "algorithmic_bytes_per_launch": float(nbytes.mean()), "avg_launch_ms": float(ms.mean()),
                             "launches_timed": int(len(ms)), "levels": levels, "all_block_widths": all_widths,

@@ -13,7 +13,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DS_EXP_LIB") or os.path.join(_HERE, "csrc", "libdiffsound_hip.so")  # (DS_EXP_LIB: A/B builds, experiments)
-ABI_VERSION = 27  # DS_ABI_VERSION of include/diffsound_hip.h
+ABI_VERSION = 28  # DS_ABI_VERSION of include/diffsound_hip.h
 
 c_i32p = ctypes.POINTER(ctypes.c_int32)
 _P = ctypes.c_void_p
@@ -61,6 +61,7 @@ _SIGNATURES = {
     "ds_spmm_union": (_I, [_I, _I, _P, _P, _I64, _I, _P, _P, _I64, _I64, _P, _I64, _P, _I64, _P, _I64, _P, _I, _F, _F, _I, _P,
                           _I64, _P]),
     "ds_union_residual_workspace_bytes": (_I64, [_I64, _I]),
+    "ds_spmm_union_km": (_I, [_I, _P, _P, _I64, _I, _P, _P, _P, _I64, _I64, _P, _I64, _P, _I64, _P, _I64, _I, _P]),
     "ds_union_residual": (_I, [_I, _P, _P, _I64, _I, _P, _P, _P, _I64, _I64, _P, _I64, _P, _P, _I64, _I, _P, _I64, _P, _P, _P]),
     "ds_mix": (_I, [_P, _I64, _I, _P, _I, _P, _I64, _I64, _F, _F, _P]),
     "ds_gram64_blocks": (_I, [_I, _P, _I, _P, _I64, _I, _P, _P, _I64, _P]),
@@ -74,6 +75,7 @@ _SIGNATURES = {
     "ds_stream_triad": (_I, [_P, _P, _P, _I64, _F, _P]),
     "ds_profile_stream": (_I, [_P, _I64]),
     "ds_profile_collect": (_I64, [_P, _P, _P, _P, _P, _I64]),
+    "ds_profile_kinds": (_I, [ctypes.c_uint]),
     "ds_stft_power": (_I, [_P, _I, _I, _I, _I, _P, _P, _P, _P]),
     "ds_spec_loss": (_I, [_I, _P, _P, _I, _I, _I, _F, _F, _I, _P, _P, _P]),
     "ds_stft_power_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _F, _P, _P, _P]),
@@ -113,7 +115,7 @@ class LobpcgDesc(ctypes.Structure):
     """ds_lobpcg_t of include/diffsound_hip.h."""
     _i32 = ctypes.c_int32
     _fields_ = [("n", _I64), ("nv", _I64), ("b", _i32), ("k", _i32), ("ny", _i32), ("maxit", _i32), ("lock", _i32),
-                ("ortho_passes", _i32), ("rr_refresh", _i32), ("gram_exact", _i32), ("kx_fresh", _i32), ("reserved0", _i32),
+                ("ortho_passes", _i32), ("rr_refresh", _i32), ("gram_exact", _i32), ("kx_fresh", _i32), ("raw_rr", _i32),
                 ("tol", _D), ("ortho_tol", _D),
                 ("A_norm", _D), ("B_norm", _D), ("S", _P), ("S2", _P), ("KS", _P), ("KS2", _P), ("R", _P), ("MX", _P),
                 ("MW", _P), ("lds", _I64), ("ldks", _I64), ("ldr", _I64), ("level", LevelDesc), ("mgrp", _P),

@@ -443,6 +443,7 @@ extern "C" int ds_mix(const float* A, int64_t lda, int p, const float* C, int q,
     hipStream_t st = ds::as_stream(stream);
     const bool veca = aligned16(A, lda) && (p % 4 == 0);
     int rc = DS_OK;
+    ds::ProfScope prof(stream, DS_PROF_MIX, p, n, q, 0);
     // LDS-staged path: the coefficient image ((p rounded to 16) x (q rounded to 16) floats) has to fit the CU's 160 KB;
     // up to 80 columns two workgroups share a CU, wider results (the fused [X' P'] = [X P W] [Z1 Zp] update) take it whole
     auto lds_path = [&](const float* A_, int p_, const float* C_, int q_, float* O_, float beta_) {

@@ -31,6 +31,18 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nblk) {
     return base + idx;
 }
 
+// Launch timing hook (include/diffsound_hip.h: ds_profile_stream / ds_profile_kinds / ds_profile_collect).  A scope brackets
+// the launches issued inside it with HIP events when `stream` is the registered one and `kind` is enabled - else it does
+// nothing (one relaxed load).  Kinds: DS_PROF_* of the public header; (a, b, c, d) = the launch's shape as that header lists.
+struct ProfScope {
+    ProfScope(ds_stream_t stream, int kind, int64_t a, int64_t b, int c, int d);
+    ~ProfScope();
+    ProfScope(const ProfScope&) = delete;
+    ProfScope& operator=(const ProfScope&) = delete;
+    void* rec_ = nullptr;
+    hipStream_t st_ = nullptr;
+};
+
 }  // namespace ds
 
 #define DS_REQUIRE(cond, ...)            \

@@ -577,11 +577,16 @@ Plan make_plan(int64_t n, int p, int q, int symmetric, bool fast, int64_t reside
 
 extern "C" int64_t ds_gram_workspace_bytes(int64_t n, int p, int q) {
     if (n <= 0 || p <= 0 || q <= 0) return 0;
-    // (the row splits follow from how many workgroups of the kernel taken are resident - at most 4 per CU, 1024)
+    // (the row splits follow from how many workgroups of the kernel taken are resident: the SAME occupancy queries the launch
+    // paths use, the largest over the kernels - a register-allocation change that lets a fifth workgroup share a CU must not
+    // turn into "workspace too small")
+    static const int64_t resident = std::max(
+        std::max(resident_workgroups(gram_partial_kernel<float, float>), resident_workgroups(gram_partial_kernel<float, double>)),
+        std::max(resident_workgroups(gram_partial_kernel<double, double>), resident_workgroups(gram_blocks_kernel)));
     int ns = 1;
     for (int sym = 0; sym <= (p == q ? 1 : 0); ++sym) {
         ns = std::max(ns, make_plan(n, p, q, sym, true).nsplit);
-        ns = std::max(ns, make_plan(n, p, q, sym, false, 1024).nsplit);
+        ns = std::max(ns, make_plan(n, p, q, sym, false, resident).nsplit);
     }
     return (int64_t)ns * p * q * (int64_t)sizeof(double);
 }
@@ -611,6 +616,7 @@ extern "C" int ds_gram(const void* A, int a_dtype, int64_t lda, int p, const voi
     const unsigned grid = (unsigned)(pl.groups * pl.nsplit);
     double* ws = static_cast<double*>(work);
     const float* Af = static_cast<const float*>(A);
+    ds::ProfScope prof(stream, DS_PROF_GRAM, p, n, q, symmetric | (fast ? 2 : 0));  // (partial products + reduction)
     if (fast)
         gram32_partial_kernel<<<grid, 256, 0, st>>>(Af, lda, p, static_cast<const float*>(B), ldb, q, n, pl.rows_per_split, pl.tiw,
                                                     pl.tjw, pl.ntj, pl.ntiles, pl.groups, symmetric, ws);

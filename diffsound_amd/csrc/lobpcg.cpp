@@ -300,6 +300,13 @@ struct Ctx {
                              nullptr, 0, nullptr, ncols, 0.f, 0.f, 0, nullptr, 0, stream);
     }
 
+    // K X -> KX and M X -> MX of one block in one walk of the unions
+    int apply_KM(const float* X, int64_t ldx, float* KX, int64_t ldk, float* MX, int64_t ldm, int ncols) {
+        const ds_level_t& L = p->level;
+        return ds_spmm_union_km(L.level_tag, L.utab, L.ctab, L.ngroups, L.cap_blocks, L.gent, L.kgrp, p->mgrp, L.nnzb, L.nv, X, ldx,
+                                KX, ldk, MX, ldm, ncols, stream);
+    }
+
     int copy_cols(float* dst, int64_t ldd, const float* src, int64_t lds_, int ncols) {
         if (ncols <= 0) return DS_OK;
         return hip(hipMemcpy2DAsync(dst, (size_t)ldd * 4, src, (size_t)lds_ * 4, (size_t)ncols * 4, (size_t)p->n,
@@ -427,6 +434,8 @@ extern "C" int ds_lobpcg_iterate(ds_lobpcg_t* p, const ds_lapack_t* lapack, ds_s
     // the fresh K X' of kx_fresh - without kx_fresh K X' comes out of the recurrence and is there anyway
     const bool fused_res = p->res_work && p->kx_fresh && 3 * p->nv * std::max(lds, ldr) * 4 < (int64_t)0x7f000000 &&
                            p->res_work_bytes >= ds_union_residual_workspace_bytes(p->level.ngroups, b);
+    // Rayleigh-Ritz on the raw basis: K X' must not be needed from K [X P W] (kx_fresh) and comes from the fused residual
+    const bool raw = p->raw_rr && fused_res && !p->gram_exact;
     double worst = std::numeric_limits<double>::infinity();
     for (it = 0; it <= p->maxit; ++it) {
         int na = b - ncl;
@@ -484,13 +493,72 @@ extern "C" int ds_lobpcg_iterate(ds_lobpcg_t* p, const ds_lapack_t* lapack, ds_s
         const int w0 = ny + b + npc;
         float* W = c.S + w0;
         if ((rc = c.precond(Ract, na, W, lds)) != DS_OK) return rc;
-        if ((rc = c.orthonormalize(w0, na)) != DS_OK) return rc;
         const int sz = na + npc + na, nxp = na + npc;
         float* Sa = c.S + ny + ncl;
         float* KSa = c.KS + k0;
         const bool full = p->rr_refresh <= 0 || since_refresh >= p->rr_refresh;
         Mat G(sz, sz);
-        if (full) {
+        // ---- Rayleigh-Ritz on the RAW basis (round 5, p->raw_rr): W stays as the preconditioner left it.  K W and M W come out of
+        // one walk of the unions, [Y X P W]^T [K W | M W] out of ONE Gram launch; [Y X P] is M-orthonormal, so C = V^T M W and
+        // G0 = W^T M W give the projected Cholesky-QR transform W_o = [V W] [-C T; T] in coefficients only, and every block of
+        // S_a^T K S_a for S_a = [X_a P W_o] follows from the Gram rows and the recurrence's [X_a P]^T K [X_a P] (K Y = 0;
+        // X_l^T K X_l = diag(lam_l), X_l^T K [X_a P] = 0 for the locked - converged - columns).  The Ritz coefficients go back
+        // to the raw basis, Z_raw = Q Z, and ONE update [X' P'] = [Y X P W] Z_raw writes the new basis: the explicit
+        // orthonormalisation's product M W, its Gram and its in-place update of W are gone (an iteration was
+        // M W, Gram, update, K W, Gram, update; it is [K W | M W], Gram, update).  An iteration whose W is too ill-conditioned for a
+        // single sweep (eps x amplification >= ortho_tol, or a breakdown of the factorisation) takes the explicit route below.
+        Mat Qraw;  // (w0 + na) x sz: the active orthonormal basis in coordinates of the raw one; empty = explicit route
+        if (raw && !full) {
+            const int pr = w0 + na;
+            if ((rc = c.apply_KM(W, lds, c.KS, ldks, c.KS + na, ldks, na)) != DS_OK) return rc;
+            Mat GG;
+            if ((rc = c.gram(c.S, lds, pr, c.KS, ldks, 2 * na, false, GG)) != DS_OK) return rc;
+            Mat C(w0, na), G0(na, na);
+            for (int i = 0; i < w0; ++i)
+                for (int j = 0; j < na; ++j) C(i, j) = GG(i, na + j);
+            for (int i = 0; i < na; ++i)
+                for (int j = 0; j < na; ++j) G0(i, j) = GG(w0 + i, na + j);
+            symmetrize(G0);
+            const Mat CtC = gemm(*lapack, C, true, C, false);
+            Mat Gp(na, na);
+            bool ok = true;
+            for (int i = 0; i < na; ++i)
+                for (int j = 0; j < na; ++j) Gp(i, j) = G0(i, j) - CtC(i, j);
+            for (int i = 0; i < na; ++i)
+                if (Gp(i, i) <= 1e-9 * std::fabs(G0(i, i))) ok = false;
+            Mat Lc, T;
+            double amp = 0.0;
+            if (ok && all_finite(Gp) && cholesky(Gp, Lc)) {
+                std::vector<double> rem(na);
+                for (int i = 0; i < na; ++i) rem[i] = CtC(i, i);
+                ok = orthonormalizer_q(*lapack, Gp, &rem, T, amp) && std::isfinite(amp) && !(p->ortho_tol > 0.0 && 6e-8 * amp >= p->ortho_tol);
+            } else {
+                ok = false;
+            }
+            if (ok) {
+                const Mat CT = gemm(*lapack, C, false, T, false);
+                Mat GKraw(pr, pr);  // [Y X P W]^T K [Y X P W]: known blocks among Y, X, P; measured columns of W
+                for (int i = 0; i < ncl; ++i) GKraw(ny + i, ny + i) = lam[i];
+                for (int i = 0; i < nxp; ++i)
+                    for (int j = 0; j < nxp; ++j) GKraw(ny + ncl + i, ny + ncl + j) = Gxp(i, j);
+                for (int i = 0; i < w0; ++i)
+                    for (int j = 0; j < na; ++j) GKraw(i, w0 + j) = GKraw(w0 + j, i) = GG(i, j);
+                for (int i = 0; i < na; ++i)
+                    for (int j = 0; j < na; ++j) GKraw(w0 + i, w0 + j) = 0.5 * (GG(w0 + i, j) + GG(w0 + j, i));
+                Qraw = Mat(pr, sz);
+                for (int i = 0; i < nxp; ++i) Qraw(ny + ncl + i, i) = 1.0;
+                for (int i = 0; i < w0; ++i)
+                    for (int j = 0; j < na; ++j) Qraw(i, nxp + j) = -CT(i, j);
+                for (int i = 0; i < na; ++i)
+                    for (int j = 0; j < na; ++j) Qraw(w0 + i, nxp + j) = T(i, j);
+                G = gemm(*lapack, Qraw, true, gemm(*lapack, GKraw, false, Qraw, false), false);
+                ++since_refresh;
+            }
+        }
+        if (Qraw.r == 0 && (rc = c.orthonormalize(w0, na)) != DS_OK) return rc;
+        if (Qraw.r != 0) {
+            // (G is complete)
+        } else if (full) {
             if ((rc = c.apply_K(Sa, lds, KSa, ldks, sz)) != DS_OK) return rc;
             if ((rc = c.gram(Sa, lds, sz, KSa, ldks, sz, true, G)) != DS_OK) return rc;
             since_refresh = 0;
@@ -543,7 +611,19 @@ extern "C" int ds_lobpcg_iterate(ds_lobpcg_t* p, const ds_lapack_t* lapack, ds_s
         Gxp = gemm(*lapack, ZZ, true, gemm(*lapack, G, false, ZZ, false), false);
         symmetrize(Gxp);
         for (int j = 0; j < na; ++j) lam[ncl + j] = E[j];
-        if (2 * na <= 160) {
+        if (Qraw.r != 0) {  // the new basis straight from the raw one: [X' P'] = [Y X P W] (Q [Z1 Zp])
+            const Mat Zr = gemm(*lapack, Qraw, false, ZZ, false);
+            const int pr = w0 + na;
+            if (2 * na <= 160) {
+                if ((rc = c.mix(c.S, lds, pr, Zr, c.S2 + ny + ncl, lds)) != DS_OK) return rc;
+            } else {
+                Mat Za(pr, na), Zb(pr, na);
+                for (int i = 0; i < pr; ++i)
+                    for (int j = 0; j < na; ++j) Za(i, j) = Zr(i, j), Zb(i, j) = Zr(i, na + j);
+                if ((rc = c.mix(c.S, lds, pr, Za, c.S2 + ny + ncl, lds)) != DS_OK) return rc;
+                if ((rc = c.mix(c.S, lds, pr, Zb, c.S2 + ny + b, lds)) != DS_OK) return rc;
+            }
+        } else if (2 * na <= 160) {
             if ((rc = c.mix(Sa, lds, sz, ZZ, c.S2 + ny + ncl, lds)) != DS_OK) return rc;
             if (!p->kx_fresh && (rc = c.mix(KSa, ldks, sz, ZZ, c.KS2, ldks)) != DS_OK) return rc;
         } else {

@@ -185,6 +185,14 @@ extern "C" int ds_mix64(int nblocks, const ds_block64_t* blocks, const double* C
         DS_REQUIRE(o1 <= a0 || a1 <= o0, "ds_mix64: Out overlaps block %d", b);
         args.blk[b] = k;
     }
+    {   // every wave reads C while other waves write Out: the two must not share memory (rows of C used: up to the
+        // last block's offset + width)
+        int crow = 0;
+        for (int b = 0; b < nblocks; ++b) crow = std::max(crow, blocks[b].offset + blocks[b].p);
+        const char* c0 = reinterpret_cast<const char*>(C);
+        const char* c1 = c0 + ((int64_t)(crow - 1) * ldc + q) * 8;
+        DS_REQUIRE(o1 <= c0 || c1 <= o0, "ds_mix64: Out overlaps the coefficient matrix C");
+    }
     hipStream_t st = ds::as_stream(stream);
     // column chunks of at most 9 MFMA tiles (144 columns): the accumulators of a chunk stay in registers
     constexpr int CH = 16 * 9;

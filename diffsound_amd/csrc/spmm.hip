@@ -777,39 +777,55 @@ extern "C" int ds_spmm_residual(const int32_t* rowptr, const int32_t* colidx, co
 
 
 // ------------------------------------------------------------------------------------------------
-// Launch timing hook (bench.py's live roofline figure): while a stream is registered with ds_profile_stream, every
-// fused Chebyshev-term launch (epilogue 1) on it is bracketed by HIP events; ds_profile_collect returns the durations
-// with the shape of each launch.  One registered stream at a time; a relaxed flag keeps the cost off every other launch.
+// Launch timing hook (bench.py's live roofline figures): while a stream is registered with ds_profile_stream, every launch
+// of an ENABLED kind (ds_profile_kinds; default: the fused Chebyshev term only) on it is bracketed by HIP events;
+// ds_profile_collect returns the durations with the shape of each launch.  One registered stream at a time; a relaxed flag
+// keeps the cost off every other launch.
 namespace {
 struct TermRecord {
     hipEvent_t e0, e1;
     int64_t nv, nnzb;
-    int ncols, first;  // first | element bytes of the vector blocks << 8
+    int ncols, first;  // first | element bytes of the vector blocks << 8 | kind << 16
 };
 std::atomic<void*> g_prof_stream{nullptr};
+std::atomic<unsigned> g_prof_kinds{1u};
 std::mutex g_prof_mutex;
 std::vector<TermRecord> g_prof_records;
 size_t g_prof_cap = 0;
 }  // namespace
 
-// run `launch` bracketed by events when `stream` is the registered one; returns false when it did not run it
-template <typename F>
-bool profiled_launch(ds_stream_t stream, hipStream_t st, int64_t nv, int64_t nnzb, int ncols, int first, int ebytes,
-                     F&& launch, int& rc) {
-    if (g_prof_stream.load(std::memory_order_relaxed) != stream || stream == nullptr) return false;
+ds::ProfScope::ProfScope(ds_stream_t stream, int kind, int64_t a, int64_t b, int c, int d) {
+    if (stream == nullptr || g_prof_stream.load(std::memory_order_relaxed) != stream) return;
+    if (!((g_prof_kinds.load(std::memory_order_relaxed) >> kind) & 1u)) return;
     std::lock_guard<std::mutex> lock(g_prof_mutex);
-    if (g_prof_records.size() >= g_prof_cap) return false;
-    TermRecord r{nullptr, nullptr, nv, nnzb, ncols, first | (ebytes << 8)};
-    if (hipEventCreate(&r.e0) != hipSuccess) return false;
-    if (hipEventCreate(&r.e1) != hipSuccess) {
-        (void)hipEventDestroy(r.e0);
-        return false;
+    if (g_prof_records.size() >= g_prof_cap) return;
+    auto* r = new TermRecord{nullptr, nullptr, a, b, c, (d & 0xffff) | (kind << 16)};
+    if (hipEventCreate(&r->e0) != hipSuccess) {
+        delete r;
+        return;
     }
-    (void)hipEventRecord(r.e0, st);
-    rc = launch();
-    (void)hipEventRecord(r.e1, st);
-    g_prof_records.push_back(r);
-    return true;
+    if (hipEventCreate(&r->e1) != hipSuccess) {
+        (void)hipEventDestroy(r->e0);
+        delete r;
+        return;
+    }
+    st_ = ds::as_stream(stream);
+    (void)hipEventRecord(r->e0, st_);
+    rec_ = r;
+}
+
+ds::ProfScope::~ProfScope() {
+    if (!rec_) return;
+    auto* r = static_cast<TermRecord*>(rec_);
+    (void)hipEventRecord(r->e1, st_);
+    std::lock_guard<std::mutex> lock(g_prof_mutex);
+    g_prof_records.push_back(*r);
+    delete r;
+}
+
+extern "C" int ds_profile_kinds(unsigned mask) {
+    g_prof_kinds.store(mask ? mask : 1u);
+    return DS_OK;
 }
 
 extern "C" int ds_profile_stream(ds_stream_t stream, int64_t capacity) {
@@ -876,14 +892,9 @@ extern "C" int ds_spmm_union(int epilogue, int level_tag, const int32_t* utab, c
         epi.wprev = Wprev, epi.ldp = ldp;
     }
     const int lpn = ncols / 4;
-    if (epilogue == 1) {
-        int rc = DS_OK;
-        if (profiled_launch(stream, st, nv, nnzb, ncols, first, 4, [&] {
-                return lpn == 20 ? launch_union<20, 1>(utab, ctab, ngroups, cap_blocks, gent, kgrp, nnzb, nv, X, ldx, Y, ldy, lpn, st, epi)
-                                 : launch_union<0, 1>(utab, ctab, ngroups, cap_blocks, gent, kgrp, nnzb, nv, X, ldx, Y, ldy, lpn, st, epi);
-            }, rc))
-            return rc;
-    }
+    // (kinds of the timing hook: the fused term, Y = K X, Y = M_s X; the residual epilogue 2 is not recorded)
+    const int pkind = epilogue == 1 ? DS_PROF_TERM : (epilogue == 0 ? DS_PROF_KX : (epilogue == 3 ? DS_PROF_MX : -1));
+    ds::ProfScope prof(pkind < 0 ? nullptr : stream, pkind < 0 ? 0 : pkind, nv, nnzb, ncols, (first ? 1 : 0) | (4 << 8));
 #define DS_U(L, E) return launch_union<L, E>(utab, ctab, ngroups, cap_blocks, gent, kgrp, nnzb, nv, X, ldx, Y, ldy, lpn, st, epi)
 #define DS_UL(L, E) do { if (level_tag == 1) return launch_union<L, E, false, true, 1>(utab, ctab, ngroups, cap_blocks, gent, kgrp, nnzb, nv, X, ldx, Y, ldy, lpn, st, epi); \
                          return launch_union<L, E, false, true, 0>(utab, ctab, ngroups, cap_blocks, gent, kgrp, nnzb, nv, X, ldx, Y, ldy, lpn, st, epi); } while (0)
@@ -931,6 +942,8 @@ extern "C" int ds_union_residual(int level_tag, const int32_t* utab, const int32
     epi.mvals = mgrp, epi.lam = lam, epi.nwork = static_cast<float*>(work);
     const int lpn = ncols / 4;
     int rc;
+    {
+    ds::ProfScope prof(stream, DS_PROF_RESID, nv, nnzb, ncols, 4 << 8);  // (the walk of the unions; the two norm reductions follow)
 #define DS_UR(L, V) rc = launch_union<L, 4, false, true, V>(utab, ctab, ngroups, cap_blocks, gent, kgrp, nnzb, nv, X, ldx, R, ldr, lpn, st, epi)
     if (lpn == 20) {
         if (level_tag == 1) DS_UR(20, 1);
@@ -940,6 +953,7 @@ extern "C" int ds_union_residual(int level_tag, const int32_t* utab, const int32
         else DS_UR(0, 0);
     }
 #undef DS_UR
+    }
     if (rc != DS_OK) return rc;
     double* partial = reinterpret_cast<double*>(static_cast<char*>(work) + ngroups * 2 * (int64_t)ncols * 4);
     union_norm_partial_kernel<<<UN_NORM_BLOCKS, 256, 0, st>>>(static_cast<const float*>(work), (unsigned)ngroups, 2 * ncols, partial);
@@ -947,6 +961,39 @@ extern "C" int ds_union_residual(int level_tag, const int32_t* utab, const int32
     union_norm_final_kernel<<<(unsigned)(2 * ncols), 256, 0, st>>>(partial, ncols, rn2, xn2);
     DS_LAUNCH_CHECK("union_norm_final_kernel");
     return DS_OK;
+}
+
+// Y = K X and Y2 = (M_s (x) I3) X of ONE block in one walk of the unions (spmm_union.inc, epilogue 5): the eigensolver's
+// products of the raw preconditioned residuals W (round 5: Rayleigh-Ritz on the raw basis, csrc/lobpcg.cpp).
+extern "C" int ds_spmm_union_km(int level_tag, const int32_t* utab, const int32_t* ctab, int64_t ngroups, int cap_blocks,
+                                const int32_t* gent, const float* kgrp, const float* mgrp, int64_t nnzb, int64_t nv,
+                                const float* X, int64_t ldx, float* KX, int64_t ldk, float* MX, int64_t ldm, int ncols,
+                                ds_stream_t stream) {
+    DS_REQUIRE(ctab && gent && kgrp && mgrp && X && KX && MX, "ds_spmm_union_km: null pointer");
+    DS_REQUIRE(level_tag == 0 || level_tag == 1, "ds_spmm_union_km: level_tag must be 0 (fine) or 1 (corner-node level)");
+    DS_REQUIRE(nv > 0 && ngroups == (nv + 3) / 4 && nnzb > 0 && ncols > 0 && ncols % 4 == 0 && ncols <= 84,
+               "ds_spmm_union_km: ncols must be a multiple of 4 <= 84 and ngroups = ceil(nv / 4)");
+    DS_REQUIRE(cap_blocks > 0 && cap_blocks <= UN_CAPB, "ds_spmm_union_km: a chunk of %d blocks exceeds the LDS image", cap_blocks);
+    DS_REQUIRE(ldx >= ncols && ldk >= ncols && ldm >= ncols, "ds_spmm_union_km: leading dimension smaller than ncols");
+    DS_REQUIRE(X != KX && X != MX && KX != MX, "ds_spmm_union_km: X, KX and MX must be different buffers");
+    DS_REQUIRE(ldx * 12 < (int64_t)PIPE_OOB && nnzb * 36 < ((int64_t)1 << 32), "ds_spmm_union_km: operand beyond the descriptor range");
+    const uintptr_t al = reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(KX) | reinterpret_cast<uintptr_t>(MX) |
+                         (uintptr_t)(ldx * 4) | (uintptr_t)(ldk * 4) | (uintptr_t)(ldm * 4) | reinterpret_cast<uintptr_t>(kgrp) |
+                         reinterpret_cast<uintptr_t>(ctab);
+    DS_REQUIRE((al & 15) == 0, "ds_spmm_union_km: rows, kgrp and ctab must be 16-byte aligned");
+    hipStream_t st = ds::as_stream(stream);
+    ChebEpilogue epi{nullptr, ldm, nullptr, 0.f, 0.f, 0};
+    epi.mvals = mgrp, epi.nwork = MX;
+    const int lpn = ncols / 4;
+    ds::ProfScope prof(stream, DS_PROF_KM, nv, nnzb, ncols, 4 << 8);
+#define DS_UKM(L, V) return launch_union<L, 5, false, true, V>(utab, ctab, ngroups, cap_blocks, gent, kgrp, nnzb, nv, X, ldx, KX, ldk, lpn, st, epi)
+    if (lpn == 20) {
+        if (level_tag == 1) DS_UKM(20, 1);
+        DS_UKM(20, 0);
+    }
+    if (level_tag == 1) DS_UKM(0, 1);
+    DS_UKM(0, 0);
+#undef DS_UKM
 }
 
 // bf16-block form of the two preconditioner epilogues (the V-cycle's iterates are stored in bf16, arithmetic in fp32):
@@ -985,14 +1032,8 @@ extern "C" int ds_spmm_union16(int epilogue, const int32_t* utab, const int32_t*
     const float* Xf = static_cast<const float*>(X);
     float* Yf = static_cast<float*>(Y);
     const int lpn = ncols / 4;
-    if (epilogue == 1 && !y_f32) {  // (the bf16-in / bf16-out term: the launch the benchmark's roofline figure is about)
-        int rc = DS_OK;
-        if (profiled_launch(stream, st, nv, nnzb, ncols, first, 2, [&] {
-                return lpn == 20 ? launch_union<20, 1, true, false>(utab, ctab, ngroups, cap_blocks, gent, kgrp, nnzb, nv, Xf, ldx, Yf, ldy, lpn, st, epi)
-                                 : launch_union<0, 1, true, false>(utab, ctab, ngroups, cap_blocks, gent, kgrp, nnzb, nv, Xf, ldx, Yf, ldy, lpn, st, epi);
-            }, rc))
-            return rc;
-    }
+    // (the bf16-in / bf16-out term: the launch the benchmark's roofline figure is about)
+    ds::ProfScope prof((epilogue == 1 && !y_f32) ? stream : nullptr, DS_PROF_TERM, nv, nnzb, ncols, (first ? 1 : 0) | (2 << 8));
 #define DS_U16(L, E, O) return launch_union<L, E, true, O>(utab, ctab, ngroups, cap_blocks, gent, kgrp, nnzb, nv, Xf, ldx, Yf, ldy, lpn, st, epi)
     if (lpn == 20) {
         if (epilogue == 2) DS_U16(20, 2, false);
@@ -1097,10 +1138,7 @@ extern "C" int ds_spmm_union16m(int epilogue, int group_nodes, int level_tag, co
     };
 #undef DS_MF_GO
 #undef DS_MF_GOC
-    if (epilogue == 1 && !y_f32) {
-        int rc = DS_OK;
-        if (profiled_launch(stream, st, nv, nnzb, ncols, first, 2, go, rc)) return rc;
-    }
+    ds::ProfScope prof((epilogue == 1 && !y_f32) ? stream : nullptr, DS_PROF_TERM, nv, nnzb, ncols, (first ? 1 : 0) | (2 << 8));
     return go();
 }
 

@@ -70,6 +70,13 @@ class SolverConfig:
     # and its column norms in ONE walk of the neighbour unions - neither product is written, X' is gathered once instead of
     # twice, and the separate residual pass over three blocks is gone (needs kx_fresh)
     fused_residual: bool = True
+    # Round 5 - Rayleigh-Ritz on the RAW basis [Y X P W] (needs fused_residual): W stays as the preconditioner left it; K W and
+    # M W come out of ONE walk of the unions (ops.apply_KM), [Y X P W]^T [K W | M W] out of ONE Gram launch; [Y X P] is
+    # M-orthonormal, so the projected Cholesky-QR transform of W is known in coefficients only, every block of the Ritz matrix
+    # follows from those Gram rows and the recurrence's [X P]^T K [X P], and ONE update [X' P'] = [Y X P W] Z_raw writes the new
+    # basis.  Per iteration: [K W | M W], Gram, update - instead of M W, Gram, update of W, K W, Gram, update.  An iteration whose
+    # W is too ill-conditioned for a single sweep (eps x amplification >= ortho_tol) takes the explicit route.
+    raw_rr: bool = True
     # storage of the preconditioner's internal blocks (V-cycle iterates, residuals, corner-level vectors): "bf16" halves
     # the bytes of every fused term - the cycle is bound by them - and leaves the outer iteration counts unchanged
     # (fp32 arithmetic in registers; the cycle's input R and output W stay fp32); "fp32" keeps everything in fp32
@@ -169,32 +176,30 @@ def _orthonormal_columns(Tm):
 class _one_thread:
     """LAPACK on <= 3b x 3b matrices is fastest single-threaded (measured on the MI355X host: 240 x 240
     fp64 eigh 2.5 ms with 1 thread, no faster with 2-8, 150 ms with the default 128 threads; rocSOLVER's
-    launch-bound syevd takes 5.7 ms).  Re-entrant across the worker threads of concurrent solves.
-    ``torch.set_num_threads`` is PER CALLING THREAD for what matters here (omp_set_num_threads and
-    mkl_set_num_threads_local): every thread that enters lowers ITS OWN count; the last one that leaves restores the
-    saved value (for itself and as torch's process-wide default).  Until round 4 only the first thread to enter lowered
-    a count - its own - and the other hypothesis lanes ran their small LAPACK steps on however many threads they happened
-    to have: slow, and the reason two identical 8-lane runs could differ in the last bits of a gradient
-    (tests/test_fullsize_gpu.py::test_c3_eight_lanes_are_bit_identical_from_run_to_run)."""
+    launch-bound syevd takes 5.7 ms).  ``torch.set_num_threads`` is PER CALLING THREAD for what matters here
+    (omp_set_num_threads and mkl_set_num_threads_local), so every thread that enters lowers ITS OWN count and restores ITS
+    OWN previous value when it leaves (a ``threading.local``; re-entrant).  Until round 4 only the first thread to enter
+    lowered a count - the reason two identical 8-lane runs could differ in the last bits of a gradient
+    (tests/test_fullsize_gpu.py::test_c3_eight_lanes_are_bit_identical_from_run_to_run); round 4's fix saved ONE value
+    for all threads, so a lane that re-entered at depth 0 could save "1" and the last thread to leave then made 1 the
+    process-wide default for every later CPU op."""
 
-    _lock = threading.Lock()
-    _depth = 0
-    _saved = 1
+    _tls = threading.local()
 
     def __enter__(self):
-        cls = _one_thread
-        with cls._lock:
-            if cls._depth == 0:
-                cls._saved = torch.get_num_threads()
-            cls._depth += 1
-        torch.set_num_threads(1)
+        st = _one_thread._tls
+        depth = getattr(st, "depth", 0)
+        if depth == 0:
+            st.saved = torch.get_num_threads()
+            if st.saved != 1:
+                torch.set_num_threads(1)
+        st.depth = depth + 1
 
     def __exit__(self, *a):
-        cls = _one_thread
-        with cls._lock:
-            cls._depth -= 1
-            if cls._depth == 0:
-                torch.set_num_threads(cls._saved)
+        st = _one_thread._tls
+        st.depth -= 1
+        if st.depth == 0 and st.saved != 1:
+            torch.set_num_threads(st.saved)
 
 
 def _small(fn, dev, *mats):
@@ -207,6 +212,41 @@ def _small(fn, dev, *mats):
     if isinstance(out, tuple):
         return tuple(o.to(dev, non_blocking=True) if torch.is_tensor(o) else o for o in out)
     return out.to(dev, non_blocking=True)
+
+
+def _raw_basis_transform(GG, Gxp, lam_locked, ny, ncl, nxp, na, ortho_tol, eps):
+    """Round 5, Rayleigh-Ritz on the raw basis (host, fp64; the same steps as csrc/lobpcg.cpp).  GG = [Y X P W]^T [K W | M W]
+    ((w0 + na) x 2 na, w0 = ny + ncl + nxp columns of the M-orthonormal V = [Y | X_locked | X_active P]).  Returns (G, Q):
+    G = S_a^T K S_a for S_a = [X_a P W_o] (W_o = the M-orthonormalised projection of W) and Q = S_a in coordinates of the raw
+    basis - or None when a single sweep would not be enough for this W."""
+    w0 = ny + ncl + nxp
+    pr = w0 + na
+    GK, GM = GG[:, :na], GG[:, na:]
+    C = GM[:w0]
+    G0 = _sym(GM[w0:])
+    CtC = C.transpose(0, 1) @ C
+    Gp = G0 - CtC
+    if bool((Gp.diagonal() <= 1e-9 * G0.diagonal().abs()).any()) or not bool(torch.isfinite(Gp).all()):
+        return None
+    L, info = torch.linalg.cholesky_ex(Gp)
+    if int(info) != 0:
+        return None
+    T, amp = _orthonormalizer_q(torch.cat([Gp, CtC.diagonal()[None, :]], 0))
+    if not (amp < float("inf")) or (ortho_tol > 0.0 and eps * amp >= ortho_tol):
+        return None
+    CT = C @ T
+    GKraw = torch.zeros((pr, pr), dtype=GG.dtype)
+    if ncl:
+        GKraw[ny:ny + ncl, ny:ny + ncl] = torch.diag(lam_locked)
+    GKraw[ny + ncl:w0, ny + ncl:w0] = Gxp
+    GKraw[:w0, w0:] = GK[:w0]
+    GKraw[w0:, :w0] = GK[:w0].transpose(0, 1)
+    GKraw[w0:, w0:] = _sym(GK[w0:])
+    Q = torch.zeros((pr, nxp + na), dtype=GG.dtype)
+    Q[ny + ncl:w0, :nxp] = torch.eye(nxp, dtype=GG.dtype)
+    Q[:w0, nxp:] = -CT
+    Q[w0:, nxp:] = T
+    return Q.transpose(0, 1) @ GKraw @ Q, Q
 
 
 def _rr_step(GA, na):
@@ -530,6 +570,13 @@ class ModalSolver:
         # projection against [Y, X, P] is ONE Gram + ONE update launch; the active basis S[:, ny:] is what
         # the stiffness SpMM and the Rayleigh-Ritz Gram see.
         ny = 0 if Y is None else Y.shape[1]
+        # Round 5: on the device the rigid block takes 16 columns (its 6 vectors + zero columns) instead of 8, so that X, P and W
+        # - 80-column blocks in the benchmark - start at byte offsets 64, 384 and 704 of a 1 KiB row: every 320-byte row piece
+        # the neighbour-union products gather is then five whole 64-byte sectors (with 8 columns in front they started 32 bytes
+        # into a sector and touched six: K W drew 1.31 x its algorithmic bytes from memory on these operands against 1.17 x
+        # on compact blocks, profiles/r04_spmm_pmc_kx.json).  The zero columns cost the Gram / update kernels 3 % more columns.
+        if ny and ny % 16 and dev.type == "cuda" and dt == torch.float32 and b % 16 == 0:
+            ny = -(-ny // 16) * 16
 
         def wide(cols):
             """(n x cols) block inside a buffer whose rows are a multiple of 1 KiB apart (fp32 on the device): every 3-row
@@ -542,8 +589,10 @@ class ModalSolver:
         S = wide(ny + 3 * b)
         S2 = wide(ny + 3 * b)
         if ny:
-            S[:, :ny].copy_(Y)
-            S2[:, :ny].copy_(Y)
+            for buf in (S, S2):
+                buf[:, :Y.shape[1]].copy_(Y)
+                if ny > Y.shape[1]:
+                    buf[:, Y.shape[1]:ny].zero_()
         KS = wide(3 * b)
         R = torch.empty((n, b), dtype=dt, device=dev)
         MX = torch.empty((n, b), dtype=dt, device=dev)
@@ -639,12 +688,29 @@ class ModalSolver:
             w0 = ny + b + npc
             W = S[:, w0:w0 + na]
             self.precond_apply(R[:, :na], W)
-            self._orthonormalize(W, S[:, :w0], MW[:, :na], VW=S[:, :w0 + na])
             sz = na + npc + na
             Sa = S[:, ny + ncl:ny + ncl + sz]
             KSa = KS[:, k0:k0 + sz]
             full = cfg.rr_refresh <= 0 or since_refresh >= cfg.rr_refresh
-            if full:
+            rawQ = None  # Rayleigh-Ritz on the raw basis (SolverConfig.raw_rr): (G, Q) of _raw_basis_transform
+            if (cfg.raw_rr and fused and not full and hasattr(ops, "apply_KM") and not getattr(ops, "gram_exact", False)
+                    and ops.apply_KM_ok(W, KS[:, :na], KS[:, na:2 * na])):
+                ops.apply_KM(W, KS[:, :na], KS[:, na:2 * na])
+                GG = ops.gram(S[:, :w0 + na], KS[:, :2 * na])
+                eps_ = 6e-8 if ops.dtype == torch.float32 else 1.1e-16
+                lam_l = lam[:ncl].detach().to(torch.float64).cpu()
+                if dev.type == "cuda":
+                    with _one_thread():
+                        rawQ = _raw_basis_transform(GG.cpu(), Gxp, lam_l, ny, ncl, na + npc, na, cfg.ortho_tol, eps_)
+                else:
+                    rawQ = _raw_basis_transform(GG, Gxp, lam_l, ny, ncl, na + npc, na, cfg.ortho_tol, eps_)
+                if rawQ is not None:
+                    since_refresh += 1
+            if rawQ is None:
+                self._orthonormalize(W, S[:, :w0], MW[:, :na], VW=S[:, :w0 + na])
+            if rawQ is not None:
+                GA = rawQ[0]
+            elif full:
                 ops.apply_K(Sa, KSa)
                 GA = ops.gram(Sa, KSa, symmetric=True)
                 since_refresh = 0
@@ -654,7 +720,7 @@ class ModalSolver:
                 GA = ops.gram(Sa, KSa[:, na + npc:])  # (sz x na) = [X P W]^T K W
                 since_refresh += 1
 
-            def ritz(GA_, Gxp_=Gxp, full_=full, na_=na, nxp=na + npc):
+            def ritz(GA_, Gxp_=Gxp, full_=full or rawQ is not None, na_=na, nxp=na + npc):
                 if full_:
                     G = _sym(GA_)
                 else:
@@ -671,12 +737,18 @@ class ModalSolver:
                 host = GA.cpu()
                 with _one_thread():
                     Ea, ZZ, Gxp = ritz(host)
+                    if rawQ is not None:
+                        ZZ = (rawQ[1] @ ZZ).contiguous()  # coefficients of [X' P'] in the raw basis [Y X P W]
                 Ea, ZZ = Ea.to(dev, non_blocking=True), ZZ.to(dev, non_blocking=True)
             else:
                 Ea, ZZ, Gxp = ritz(GA)
+                if rawQ is not None:
+                    ZZ = (rawQ[1] @ ZZ).contiguous()
             lam[ncl:] = Ea
             if ncl:
                 S2[:, ny:ny + ncl].copy_(S[:, ny:ny + ncl])
+            if rawQ is not None:
+                Sa = S[:, :w0 + na]  # the update reads the whole raw basis
             # X_new | P_new (and K X_new | K P_new) are adjacent column ranges: ONE update [X' P'] = [X P W] [Z1 Zp]
             # per product reads the 240-column operand once instead of twice (the LDS-staged mix kernel holds the
             # 240 x 160 coefficient image; with the first, register-only kernel one wide launch was slower than two)

@@ -493,6 +493,7 @@ class _HipBlockOps:
         d.maxit, d.lock, d.ortho_passes, d.rr_refresh = cfg.maxit, int(cfg.lock), cfg.ortho_passes, cfg.rr_refresh
         d.gram_exact = int(bool(self.gram_exact))
         d.kx_fresh = int(bool(getattr(cfg, "kx_fresh", False)))
+        d.raw_rr = int(bool(getattr(cfg, "raw_rr", False)))
         d.tol, d.ortho_tol, d.A_norm, d.B_norm = float(tol), float(cfg.ortho_tol), A_norm, B_norm
         d.S, d.S2, d.KS, d.KS2 = S.data_ptr(), S2.data_ptr(), KS.data_ptr(), KS2.data_ptr()
         d.R, d.MX, d.MW = R.data_ptr(), MX.data_ptr(), MW.data_ptr()
@@ -555,6 +556,21 @@ class _HipBlockOps:
         else:
             self._spmm(0, self.k32, X, out)
         self.counts["apply_K_cols"] += X.shape[1]
+
+    def apply_KM_ok(self, X, KX, MX):
+        return self.m_kind == 1 and self.mgrp is not None and self._union_ok(X, KX, MX)
+
+    def apply_KM(self, X, KX, MX):
+        """KX <- K X and MX <- M X in ONE walk of the neighbour unions (ds_spmm_union_km): X is gathered once; each product
+        equals what apply_K / apply_M give bit for bit."""
+        pp = _hip.ptr
+        g, u = self.sys.groups, self.sys.groups["union"]
+        _hip.check(self._L.ds_spmm_union_km(self._level_tag, None if u.get("single") else pp(u["utab"]), pp(u["ctab"]), u["ngroups"],
+                                            u["capb"], pp(g["gent"]), pp(self.kgrp), pp(self.mgrp), self.kgrp.shape[0], self.nv,
+                                            pp(X), _ld(X), pp(KX), _ld(KX), pp(MX), _ld(MX), X.shape[1], _hip.stream_ptr()),
+                   "ds_spmm_union_km")
+        self.counts["apply_K_cols"] += X.shape[1]
+        self.counts["apply_M_cols"] += X.shape[1]
 
     def apply_M(self, X, out):
         if self.m_kind == 1 and self.m4 is not None and self._union32_ok(X, out):
@@ -626,8 +642,9 @@ class _HipBlockOps:
     def mix64(self, blocks, C, out=None, alpha=1.0, beta=0.0):
         """out <- alpha * [blocks[0] | blocks[1] | ...] C + beta * out in fp64 (ds_mix64): the basis is a LIST of (n x p_i)
         fp64 blocks - never concatenated - and C their stacked (sum p_i) x q coefficients; every block is read once and
-        the result written once.  ``None`` entries of ``blocks`` are (block, rows of C) pairs to skip: pass
-        ``(block, first_row)`` tuples to address C explicitly."""
+        the result written once.  An entry of ``blocks`` is a block - its coefficients are the rows of C that follow the
+        previous entry's - or a ``(block, first_row)`` tuple that addresses its rows of C explicitly (rows of C no entry
+        names are skipped).  ``out`` must not share memory with a block or with C."""
         C = C.contiguous()
         if C.dtype != torch.float64:
             raise ValueError("mix64: fp64 coefficients")

@@ -40,7 +40,7 @@ enum { DS_OK = 0, DS_ERR_ARG = 1, DS_ERR_HIP = 2, DS_ERR_NOMEM = 3 };
 /* Thread-local text of the last error returned on this thread ("" if none). */
 const char* ds_last_error(void);
 /* Library ABI version (bumped on any signature change); ds_abi_version() returns the value the library was built with. */
-#define DS_ABI_VERSION 27
+#define DS_ABI_VERSION 28
 int ds_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------------
@@ -234,6 +234,13 @@ int ds_union_residual(int level_tag, const int32_t* utab, const int32_t* ctab, i
                       const int32_t* gent, const float* kgrp, const float* mgrp, int64_t nnzb, int64_t nv, const float* X,
                       int64_t ldx, const double* lam, float* R, int64_t ldr, int ncols, void* work, int64_t work_bytes,
                       double* rn2, double* xn2, ds_stream_t stream);
+/* Y = K X and Y2 = (M_s (x) I3) X of ONE block (<= 84 columns) in one walk of the neighbour unions (ABI 28; epilogue 5 of the
+ * kernel): X is gathered once instead of twice; each product is formed exactly as ds_spmm_union's epilogues 0 and 3 form it
+ * (bit-identical results).  The eigensolver's K W and M W of the raw preconditioned residuals (ds_lobpcg_t.raw_rr).
+ * (reference: the two torch.sparse.mm of _lobpcg.py:441-459 on the same block) */
+int ds_spmm_union_km(int level_tag, const int32_t* utab, const int32_t* ctab, int64_t ngroups, int cap_blocks,
+                     const int32_t* gent, const float* kgrp, const float* mgrp, int64_t nnzb, int64_t nv, const float* X,
+                     int64_t ldx, float* KX, int64_t ldk, float* MX, int64_t ldm, int ncols, ds_stream_t stream);
 /* ------------------------------------------------------------------------------------------------
  * Two-level V-cycle preconditioner in one call (host-side driver, csrc/vcycle.cpp): issues on `stream` the launch
  * sequence  W1 = S R ; W2 = W1 + P C P^T (R - K W1) ; W = W2 + S (R - K W2)  out of ds_cheb_init, ds_spmm_union and
@@ -378,7 +385,11 @@ typedef struct {
     int32_t kx_fresh;         /* != 0: K X' of the new Ritz block by ONE product K X' (b columns) instead of the update
                                  [K X' | K P'] = K [X P W] [Z1 Zp] (3b -> 2b columns) - K P is then never formed: the Gram
                                  blocks among X and P come from the small Ritz algebra, only the residual needs K X */
-    int32_t reserved0;
+    int32_t raw_rr;           /* != 0 (needs kx_fresh and res_work): Rayleigh-Ritz on the RAW basis [Y X P W], W = the preconditioned
+                                 residuals as they come - K W and M W in one walk (ds_spmm_union_km), ONE Gram launch
+                                 [Y X P W]^T [K W | M W], the orthonormalisation of W against [Y X P] folded into the small dense
+                                 algebra and into the coefficients of ONE update [X' P'] = [Y X P W] Z; an iteration whose W is
+                                 too ill-conditioned for that (eps x amplification >= ortho_tol) takes the explicit route */
     double tol, ortho_tol, A_norm, B_norm;
     float *S, *S2;            /* (n x (ny + 3 b)), leading dimension lds */
     float *KS, *KS2;          /* (n x 3 b), leading dimension ldks */
@@ -534,6 +545,22 @@ int ds_stft_power_bwd(const float* gP, const float* re, const float* im, int B, 
  * blocks << 8 (4: fp32 term, 2: bf16 term of ds_spmm_union16) of each launch - the algorithmic bytes follow from those.
  * One stream at a time. */
 int ds_profile_stream(ds_stream_t stream, int64_t capacity);
+/* Which launches the hook records (bit k = kind k; 0 restores the default, the fused term only).  The kind of a record
+ * comes back in bits 16.. of ds_profile_collect's `first` word; its shape in (nv, nnzb, ncols):
+ *   DS_PROF_TERM   fused Chebyshev term (ds_spmm_union / 16 / 16m epilogue 1)   nv, nnzb, ncols
+ *   DS_PROF_KX     Y = K X   (ds_spmm_union epilogue 0)                        nv, nnzb, ncols
+ *   DS_PROF_MX     Y = M_s X (ds_spmm_union epilogue 3)                        nv, nnzb, ncols
+ *   DS_PROF_RESID  the walk of ds_union_residual (without its two reductions)  nv, nnzb, ncols
+ *   DS_PROF_GRAM   ds_gram (partial products + reduction)                      p, n, q ; first = symmetric | fast << 1
+ *   DS_PROF_MIX    ds_mix                                                      p, n, q */
+#define DS_PROF_TERM 0
+#define DS_PROF_KX 1
+#define DS_PROF_MX 2
+#define DS_PROF_RESID 3
+#define DS_PROF_GRAM 4
+#define DS_PROF_MIX 5
+#define DS_PROF_KM 6 /* ds_spmm_union_km: nv, nnzb, ncols */
+int ds_profile_kinds(unsigned mask);
 int64_t ds_profile_collect(float* ms, int64_t* nv, int64_t* nnzb, int32_t* ncols, int32_t* first, int64_t cap);
 
 /* ------------------------------------------------------------------------------------------------

@@ -134,8 +134,13 @@ def test_rccl_collectives_of_the_n_gt_1_path_run_with_one_rank(ndev):
         "torch.cuda.synchronize()\n"
         "print('RCCL', dist.get_backend(), s, g)\n"
         "dist.destroy_process_group()\n")
+    import socket
+
+    with socket.socket() as sk:  # a free port of this box, not a fixed one (a lingering socket of an aborted run must not
+        sk.bind(("127.0.0.1", 0))  # read as an RCCL failure)
+        port = sk.getsockname()[1]
     env = dict(os.environ)
-    env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29641", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
         env.pop(k, None)
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)

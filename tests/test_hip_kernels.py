@@ -652,6 +652,46 @@ def test_fused_residual_equals_the_three_launches_bit_for_bit(dev, mesh, order, 
                                p(ops._nrm[0]), p(ops._nrm[1]), __import__("diffsound_amd")._hip.stream_ptr()) != 0
 
 
+@pytest.mark.parametrize("mesh,order,ncols", [(6, 2, 80), (6, 2, 72), (10, 2, 80), (3, 2, 8), (12, 1, 80), (5, 1, 24), (2, 1, 4)])
+def test_union_km_equals_the_two_products_bit_for_bit(dev, mesh, order, ncols):
+    """ds_spmm_union_km (Y = K X and Y2 = M X of one block in ONE walk of the neighbour unions, round 5) against the two
+    launches it replaces: both results IDENTICAL, written into column ranges of a wider buffer as the solver passes them,
+    nothing outside those ranges touched; bad arguments refused before any launch."""
+    from diffsound_amd import _hip, meshgen
+    from diffsound_amd.diffelastic.mesh import TetMesh
+    from diffsound_amd.modal_ops import HipModalOps, TetSystem
+
+    v, t = meshgen.kuhn_box(mesh)
+    tm = TetMesh(torch.from_numpy(v).to(dev), torch.from_numpy(t).long().to(dev)).to_high_order(order)
+    sysd = TetSystem(tm.vertices, tm.tets, order, 2700.0)
+    ops = HipModalOps(sysd, 2e10, 3e10, two_level=False)
+    g = torch.Generator(device=dev).manual_seed(mesh * 100 + ncols)
+    big = torch.full((sysd.n, 256), float("nan"), device=dev)
+    X = big[:, 16:16 + ncols]
+    X.copy_(torch.randn((sysd.n, ncols), generator=g, device=dev))
+    KX, MX = torch.empty((sysd.n, ncols), device=dev), torch.empty((sysd.n, ncols), device=dev)
+    ops._union(0, X, KX)
+    ops._union(3, X, MX)
+    wide = torch.full((sysd.n, 2 * ncols + 8), float("nan"), device=dev)
+    K1, M1 = wide[:, 4:4 + ncols], wide[:, 4 + ncols:4 + 2 * ncols]
+    assert ops.apply_KM_ok(X, K1, M1)
+    ops.apply_KM(X, K1, M1)
+    assert bool(torch.isnan(wide[:, :4]).all()) and bool(torch.isnan(wide[:, 4 + 2 * ncols:]).all())
+    assert torch.equal(K1, KX) and torch.equal(M1, MX)
+    L, p = _hip.lib(), _hip.ptr
+    u, gr = sysd.groups["union"], sysd.groups
+
+    def call(x=X, kx=K1, mx=M1, nc=ncols, tag=0):
+        return L.ds_spmm_union_km(tag, None if u["single"] else p(u["utab"]), p(u["ctab"]), u["ngroups"], u["capb"], p(gr["gent"]),
+                                  p(ops.kgrp), p(ops.mgrp), ops.kgrp.shape[0], sysd.nv, p(x), x.stride(0), p(kx), kx.stride(0),
+                                  p(mx), mx.stride(0), nc, _hip.stream_ptr())
+
+    assert call() == 0
+    for bad in (dict(kx=X), dict(mx=K1), dict(nc=88), dict(nc=ncols + 2), dict(tag=2), dict(x=big[:, 1:1 + ncols])):
+        assert call(**bad) != 0, bad
+    torch.cuda.synchronize()
+
+
 def test_mfma_entry_point_refuses_what_it_does_not_serve(dev):
     """ds_spmm_union16m validates on the host before any launch: group size, table limits, aliasing, alignment."""
     from diffsound_amd import _hip, meshgen

@@ -193,3 +193,36 @@ def test_fresh_products_and_fused_residual_change_nothing_but_rounding(dev, nati
         assert float((res[name].eigenvalues / res["recurrence"].eigenvalues - 1).abs().max()) < 1e-6
     assert res["fused"].iterations == res["fresh"].iterations
     assert float((res["fused"].eigenvalues / res["fresh"].eigenvalues - 1).abs().max()) < 1e-9
+
+
+@pytest.mark.parametrize("native", [True, False])
+@pytest.mark.parametrize("mesh,order,k,block,nested", [(8, 2, 32, 40, 1e-2), (8, 2, 64, 80, 3e-3), (10, 1, 20, 28, 0.0)])
+def test_rayleigh_ritz_on_the_raw_basis_changes_nothing_but_rounding(dev, native, mesh, order, k, block, nested):
+    """Round 5: SolverConfig.raw_rr - K W and M W of the raw preconditioned residuals in one walk, ONE Gram launch, the
+    orthonormalisation of W folded into the small dense algebra and ONE update from the raw basis - is the same mathematics
+    as the explicit sequence (M W, Gram, update of W, K W, Gram, update): the same iteration counts (within one), eigenvalues
+    to the solver's accuracy, and against ARPACK to the stated tolerance; per iteration it must really issue fewer products."""
+    from diffsound_amd import meshgen
+    from diffsound_amd.lobpcg.modal_solver import ModalSolver, SolverConfig
+    from diffsound_amd.modal_ops import HipModalOps, TetSystem
+
+    v, t = meshgen.kuhn_box(mesh)
+    v, t = fem.to_high_order(torch.from_numpy(v), torch.from_numpy(t).long(), order)
+    sysd = TetSystem(v.to(dev), t.to(dev), order, MAT[0])
+    lam, mu = fem.lame(MAT[1], MAT[2])
+    res, counts = {}, {}
+    for raw in (False, True):
+        ops = HipModalOps(sysd, lam, mu)
+        cfg = SolverConfig(block=block, lmax_cap=float({1: 4, 2: 10}[order]), tol=1e-5, nested_tol=nested, native=native, raw_rr=raw)
+        res[raw] = ModalSolver(ops, cfg).solve(k)
+        counts[raw] = dict(ops.counts)
+        assert float(res[raw].rerr.max()) < 1e-5
+    assert abs(res[True].iterations - res[False].iterations) <= 1
+    assert float((res[True].eigenvalues / res[False].eigenvalues - 1).abs().max()) < 1e-6
+    if not native:  # (the Python loop counts its launches: two Gram products and two updates per iteration became one each)
+        assert counts[True]["gram"] < counts[False]["gram"] and counts[True]["mix"] < counts[False]["mix"]
+    d = fem.OracleDeform(v, t, order)
+    K = fem.assemble_stiffness(d, lam, mu)
+    M3, _ = fem.assemble_mass(v, t, order, MAT[0])
+    ev = modal.eigsh_shift_invert(K, M3, k)[0]
+    assert float(np.abs(res[True].eigenvalues.cpu().numpy() / ev - 1).max()) < EIG_TOL

@@ -10,11 +10,13 @@
 #   <tag>_c5_bench.json / _c5_kernel_stats.csv   bench.py --workload c5 (configs[4]) under rocprofv3 --kernel-trace --stats
 #   <tag>_mb_kx.txt / _mb_corner.txt / _m32_diag.txt   the eigensolver's own products alone, the corner-node level, per-wave cycles
 # Copy what is to be judged into profiles/.
-# A gpurun call is capped at 20 minutes: tools/collect_profiles.sh <tag> <part>, part = 1 (bench line + kernel tables + busy
-# fraction), 2 (PMC passes, microbenchmarks, diagnostics), 3 (configs[4]) or all.
+# A gpurun call is capped at 20 minutes: tools/collect_profiles.sh <tag> <part>, part = 1 (the bench line), 1b (rocprofv3 kernel
+# tables of the 8-lane / one-lane / kernel-alone runs + busy fraction), 2 (PMC passes, microbenchmarks, diagnostics),
+# 3 (configs[4]) or all.
 set -e -o pipefail  # (a failing tool must not leave its traceback behind as evidence)
 tag=${1:-rXX}
 part=${2:-all}
+case "$part" in 1|1b|2|3|all) ;; *) echo "collect_profiles.sh: unknown part '$part' (1, 1b, 2, 3 or all)" >&2; exit 2;; esac
 export TMPDIR=/tmp
 out=gpurun_out
 mkdir -p $out

@@ -28,6 +28,21 @@ torch.set_num_threads(nthreads)
 stages, clock = {}, [time.time()]
 
 
+def _heartbeat():
+    # (the shift-invert stage is minutes of silence: a GPU-box call with nothing new on stderr for 7 minutes is taken to be hung)
+    import threading
+
+    def beat():
+        while True:
+            time.sleep(60)
+            print(f"... {time.time() - clock[0]:.0f} s into the current stage", file=sys.stderr, flush=True)
+
+    threading.Thread(target=beat, daemon=True).start()
+
+
+_heartbeat()
+
+
 def lap(name):
     now = time.time()
     stages[name] = round(now - clock[0], 2)
