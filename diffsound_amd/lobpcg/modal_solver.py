@@ -964,24 +964,30 @@ class ModalSolver:
     def _polish(self, X, k, it, rerr, history):
         ops = self.ops
         GK, coef, GM = ops.polish_products(X)  # fp64 (b x b) Gram matrices of the terms of K, and of M
-        GA = _sym(sum(c * G for c, G in zip(coef, GK)))
-        GB = _sym(GM)
+        coef = [float(c) for c in coef]
 
-        def gen_eigh(GA_, GB_):
+        def small(GM_, *GK_):
+            # everything (b x b) on the host, fp64, one LAPACK thread: the generalised Ritz problem and the quadratic forms
+            # u^T K_i u, u^T M u of the wanted pairs.  (Until round 5 the quadratic forms were torch matmuls on the device: eight
+            # more tiny launches per pass, and rocBLAS is free to sum a split-K product with atomics - the one place of a pass whose
+            # last bits were not tied down; tests/test_fullsize_gpu.py compares two 8-lane runs bit for bit.)
+            GA_ = _sym(sum(c * G for c, G in zip(coef, GK_)))
+            GB_ = _sym(GM_)
             L = torch.linalg.cholesky(GB_)
             Li = torch.linalg.solve_triangular(L, torch.eye(L.shape[0], dtype=L.dtype), upper=False)
             E_, Zt = torch.linalg.eigh(_sym(Li @ GA_ @ Li.transpose(0, 1)))
-            return E_, Li.transpose(0, 1) @ Zt  # generalized eigenvectors, C^T GB C = I
+            C_ = (Li.transpose(0, 1) @ Zt).contiguous()  # generalized eigenvectors, C^T GB C = I
+            Ck_ = C_[:, :k].contiguous()
+            quad = lambda G: ((Ck_.transpose(0, 1) @ _sym(G)) * Ck_.transpose(0, 1)).sum(1)
+            qs = torch.stack([quad(G) for G in GK_] + [quad(GB_)])
+            return E_[:k].clone(), C_, Ck_, qs
 
-        E, C = _small(gen_eigh, ops.device, GA, GB)
-        Ck = C[:, :k].contiguous()
+        E, C, Ck, qs = _small(small, ops.device, GM, *GK)
         U = torch.empty((ops.n, k), dtype=ops.dtype, device=ops.device)
         ops.mix(X, Ck, U)
-        quad = lambda G: ((Ck.transpose(0, 1) @ _sym(G)) * Ck.transpose(0, 1)).sum(1)
-        a = quad(GK[0])
-        bq = quad(GK[1]) if len(GK) > 1 else None
-        m = quad(GB)
+        a = qs[0]
+        bq = qs[1] if len(GK) > 1 else None
+        m = qs[-1]
         Xb = torch.empty_like(X)
-        ops.mix(X, C.contiguous(), Xb)
-        return ModalResult(E[:k].clone(), U, a, bq, m, iterations=it, rerr=rerr, history=history,
-                           block_vectors=Xb)
+        ops.mix(X, C, Xb)
+        return ModalResult(E, U, a, bq, m, iterations=it, rerr=rerr, history=history, block_vectors=Xb)

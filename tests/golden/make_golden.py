@@ -381,13 +381,32 @@ def lobpcg_trajectory():
     print("g6 done")
 
 
+def mesh_file_fixture():
+    """G8 (round 5): one small Gmsh 2.2 binary file of the reference's data directory - data/mesh/shape/oloid.msh, 179 KB, DATA
+    the reference ships (not source) - copied next to the fixtures, with what the REFERENCE's own loader
+    (TetMesh.import_from_file, src/diffelastic/mesh.py:181-199: reader, float cast, remove_duplicate_vertices) makes of it.
+    The product's byte-format reader / writer is checked against both (tests/test_host_logic.py)."""
+    import shutil
+
+    src = os.path.join(_ref_harness.REFERENCE_ROOT, "data/mesh/shape/oloid.msh")
+    shutil.copyfile(src, os.path.join(HERE, "oloid.msh"))
+    os.chmod(os.path.join(HERE, "oloid.msh"), 0o644)
+    pts, tets = _ref_harness.read_gmsh22_binary(src)
+    m = TetMesh().import_from_file(src)
+    np.savez_compressed(os.path.join(HERE, "g8_oloid_import.npz"), raw_points=pts, raw_tets=tets.astype(np.int64),
+                        vertices=m.vertices.numpy(), tets=m.tets.numpy().astype(np.int64), order=m.order)
+    print("g8 done", m.vertices.shape, m.tets.shape)
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="")
     ap.add_argument("--skip-ord2-bowl", action="store_true")
     a = ap.parse_args()
-    todo = a.only.split(",") if a.only else ["g1", "g2", "g3o1", "g3o2", "g4", "g5", "g6", "g7"]
+    todo = a.only.split(",") if a.only else ["g1", "g2", "g3o1", "g3o2", "g4", "g5", "g6", "g7", "g8"]
     torch.set_num_threads(8)
+    if "g8" in todo:
+        mesh_file_fixture()
     if "g1" in todo:
         constants()
     if "g2" in todo:

@@ -108,6 +108,37 @@ def test_gmsh_reader_on_reference_style_file(golden):
     assert np.array_equal(pts.astype(np.float32), m["verts"]) and np.array_equal(tets, m["tets"])
 
 
+def test_gmsh_reader_and_writer_against_a_file_the_reference_ships(golden, tmp_path):
+    """Byte-format pin: tests/golden/oloid.msh is data/mesh/shape/oloid.msh of the reference (Gmsh 2.2
+    binary as fTetWild wrote it; copied by make_golden.py).  (1) read_gmsh22 returns the file's nodes and tetrahedra bit for
+    bit; (2) TetMesh.import_from_file gives exactly what the REFERENCE's loader gave (src/diffelastic/mesh.py:181-199:
+    float cast + remove_duplicate_vertices - lexicographic node order, lowest-index representative); (3) write_gmsh22 of what
+    was read reproduces the file's $MeshFormat / $Nodes / $Elements sections byte for byte - up to the newline this writer (as
+    Gmsh itself and meshio) puts behind each binary section (before $EndMeshFormat / $EndNodes / $EndElements), which fTetWild omits; the file's trailing $ElementData
+    section (a per-element colour the reference never reads) is not mesh data."""
+    import os
+
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "oloid.msh")
+    g = golden("g8_oloid_import.npz")
+    pts, tets = dmesh.read_gmsh22(path)
+    assert pts.dtype == np.float64 and np.array_equal(pts, g["raw_points"]) and np.array_equal(tets, g["raw_tets"])
+    # (import_from_file itself puts the mesh on the HIP device - tests/test_parity_gpu.py runs it there; here its steps on
+    # host tensors: float cast, then the duplicate merge)
+    m = dmesh.TetMesh(torch.from_numpy(pts).float(), torch.from_numpy(tets[:, :4]).long())
+    m.remove_duplicate_vertices()
+    assert int(g["order"]) == 1 and m.vertices.dtype == torch.float32
+    assert np.array_equal(m.vertices.numpy(), g["vertices"]) and np.array_equal(m.tets.numpy(), g["tets"])
+    out = str(tmp_path / "oloid_out.msh")
+    dmesh.write_gmsh22(out, pts, tets)
+    a, b = open(path, "rb").read(), open(out, "rb").read()
+    a = a[:a.index(b"$EndElements\n") + len(b"$EndElements\n")]
+    for tag in (b"$EndMeshFormat", b"$EndNodes", b"$EndElements"):  # (the newline behind a binary section, see above)
+        b = b.replace(b"\n" + tag, tag)
+    assert b == a
+    p2, t2 = dmesh.read_gmsh22(out)
+    assert np.array_equal(p2, pts) and np.array_equal(t2, tets)
+
+
 def test_shard_hypotheses_partitions():
     for num, world in ((64, 8), (7, 2), (3, 4)):
         parts = [shard_hypotheses(num, r, world) for r in range(world)]
