@@ -61,6 +61,7 @@ _SIGNATURES = {
     "ds_spmm_union": (_I, [_I, _I, _P, _P, _I64, _I, _P, _P, _I64, _I64, _P, _I64, _P, _I64, _P, _I64, _P, _I, _F, _F, _I, _P,
                           _I64, _P]),
     "ds_union_residual_workspace_bytes": (_I64, [_I64, _I]),
+    "ds_spmm_union_narrow": (_I, [_I, _I, _P, _P, _I64, _P, _P, _I64, _I64, _P, _I64, _P, _I64, _I, _P]),
     "ds_spmm_union_km": (_I, [_I, _P, _P, _I64, _I, _P, _P, _P, _I64, _I64, _P, _I64, _P, _I64, _P, _I64, _I, _P]),
     "ds_union_residual": (_I, [_I, _P, _P, _I64, _I, _P, _P, _P, _I64, _I64, _P, _I64, _P, _P, _I64, _I, _P, _I64, _P, _P, _P]),
     "ds_mix": (_I, [_P, _I64, _I, _P, _I, _P, _I64, _I64, _F, _F, _P]),

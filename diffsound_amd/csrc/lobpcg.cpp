@@ -61,6 +61,7 @@ Mat gemm(const ds_lapack_t& la, const Mat& A, bool ta, const Mat& B, bool tb) {
     const int m = ta ? A.c : A.r, k = ta ? A.r : A.c, n = tb ? B.r : B.c;
     Mat C(m, n);
     if (m == 0 || n == 0 || k == 0) return C;
+    struct T_ { double t0 = now_s(); ~T_() { g_tm.dense += now_s() - t0; } } t_;
     char opb = tb ? 'T' : 'N', opa = ta ? 'T' : 'N';
     int mm = n, nn = m, kk = k, ldb = B.c, lda = A.c, ldc = n;
     double one = 1.0, zero = 0.0;
@@ -545,13 +546,22 @@ extern "C" int ds_lobpcg_iterate(ds_lobpcg_t* p, const ds_lapack_t* lapack, ds_s
                     for (int j = 0; j < na; ++j) GKraw(i, w0 + j) = GKraw(w0 + j, i) = GG(i, j);
                 for (int i = 0; i < na; ++i)
                     for (int j = 0; j < na; ++j) GKraw(w0 + i, w0 + j) = 0.5 * (GG(w0 + i, j) + GG(w0 + j, i));
-                Qraw = Mat(pr, sz);
-                for (int i = 0; i < nxp; ++i) Qraw(ny + ncl + i, i) = 1.0;
+                // Q = [E | Qw]: E picks the rows of [X_a P] (unit columns), Qw = [-C T; T] are W_o's coordinates.  G = Q^T GKraw Q
+                // block by block - the unit columns cost nothing: a third of the flops of the two full products (one lane alone is
+                // bound by this host algebra, not by the kernels)
+                Qraw = Mat(pr, na);  // Qw only; the unit part is implicit
                 for (int i = 0; i < w0; ++i)
-                    for (int j = 0; j < na; ++j) Qraw(i, nxp + j) = -CT(i, j);
+                    for (int j = 0; j < na; ++j) Qraw(i, j) = -CT(i, j);
                 for (int i = 0; i < na; ++i)
-                    for (int j = 0; j < na; ++j) Qraw(w0 + i, nxp + j) = T(i, j);
-                G = gemm(*lapack, Qraw, true, gemm(*lapack, GKraw, false, Qraw, false), false);
+                    for (int j = 0; j < na; ++j) Qraw(w0 + i, j) = T(i, j);
+                const Mat H = gemm(*lapack, GKraw, false, Qraw, false);    // (pr x na) = GKraw Qw
+                const Mat Gww = gemm(*lapack, Qraw, true, H, false);       // (na x na) = Qw^T GKraw Qw
+                for (int i = 0; i < nxp; ++i)
+                    for (int j = 0; j < nxp; ++j) G(i, j) = Gxp(i, j);
+                for (int i = 0; i < nxp; ++i)
+                    for (int j = 0; j < na; ++j) G(i, nxp + j) = G(nxp + j, i) = H(ny + ncl + i, j);
+                for (int i = 0; i < na; ++i)
+                    for (int j = 0; j < na; ++j) G(nxp + i, nxp + j) = Gww(i, j);
                 ++since_refresh;
             }
         }
@@ -608,11 +618,28 @@ extern "C" int ds_lobpcg_iterate(ds_lobpcg_t* p, const ds_lapack_t* lapack, ds_s
                 ZZ(i, j) = Z1(i, j);
                 ZZ(i, na + j) = Zp(i, j);
             }
-        Gxp = gemm(*lapack, ZZ, true, gemm(*lapack, G, false, ZZ, false), false);
+        // [X' P']^T K [X' P'] = ZZ^T G ZZ of the new basis.  The columns of Z1 are eigenvectors of G (Z1^T G Z1 = diag(E) to the
+        // rounding of dsyevd), so only the products with Zp are formed: half the flops of the two full products
+        {
+            const Mat GZp = gemm(*lapack, G, false, Zp, false);
+            const Mat Gxz = gemm(*lapack, Z1, true, GZp, false), Gpp = gemm(*lapack, Zp, true, GZp, false);
+            Gxp = Mat(2 * na, 2 * na);
+            for (int i = 0; i < na; ++i) Gxp(i, i) = E[i];
+            for (int i = 0; i < na; ++i)
+                for (int j = 0; j < na; ++j) {
+                    Gxp(i, na + j) = Gxp(na + j, i) = Gxz(i, j);
+                    Gxp(na + i, na + j) = Gpp(i, j);
+                }
+        }
         symmetrize(Gxp);
         for (int j = 0; j < na; ++j) lam[ncl + j] = E[j];
-        if (Qraw.r != 0) {  // the new basis straight from the raw one: [X' P'] = [Y X P W] (Q [Z1 Zp])
-            const Mat Zr = gemm(*lapack, Qraw, false, ZZ, false);
+        if (Qraw.r != 0) {  // the new basis straight from the raw one: [X' P'] = [Y X P W] (Q [Z1 Zp]), Q = [E | Qw]
+            Mat Zbot(na, 2 * na);
+            for (int i = 0; i < na; ++i)
+                for (int j = 0; j < 2 * na; ++j) Zbot(i, j) = ZZ(nxp + i, j);
+            Mat Zr = gemm(*lapack, Qraw, false, Zbot, false);  // Qw Z_w ...
+            for (int i = 0; i < nxp; ++i)                       // ... + E Z_xp
+                for (int j = 0; j < 2 * na; ++j) Zr(ny + ncl + i, j) += ZZ(i, j);
             const int pr = w0 + na;
             if (2 * na <= 160) {
                 if ((rc = c.mix(c.S, lds, pr, Zr, c.S2 + ny + ncl, lds)) != DS_OK) return rc;
@@ -644,9 +671,9 @@ extern "C" int ds_lobpcg_iterate(ds_lobpcg_t* p, const ds_lapack_t* lapack, ds_s
     }
     if (getenv("DS_EXP_TIMING")) {
         g_tm.total = now_s() - t_begin;
-        fprintf(stderr, "lobpcg n=%lld b=%d: %d iterations, host total %.2f ms: waiting for the stream %.2f ms (%d syncs), dsyevd %.2f ms (%d calls), rest (launch calls, Cholesky, gemm, copies) %.2f ms\n",
-                (long long)p->n, b, it, g_tm.total * 1e3, g_tm.sync * 1e3, g_tm.nsync, g_tm.eigh * 1e3, g_tm.neigh,
-                (g_tm.total - g_tm.sync - g_tm.eigh) * 1e3);
+        fprintf(stderr, "lobpcg n=%lld b=%d: %d iterations, host total %.2f ms: waiting for the stream %.2f ms (%d syncs), dsyevd %.2f ms (%d calls), dgemm %.2f ms, rest (launch calls, Cholesky, copies) %.2f ms\n",
+                (long long)p->n, b, it, g_tm.total * 1e3, g_tm.sync * 1e3, g_tm.nsync, g_tm.eigh * 1e3, g_tm.neigh, g_tm.dense * 1e3,
+                (g_tm.total - g_tm.sync - g_tm.eigh - g_tm.dense) * 1e3);
     }
     p->iterations = it;
     p->result_in_s2 = (c.S == p->S) ? 0 : 1;

@@ -377,6 +377,7 @@ int launch_wn(const int32_t* rowptr, const int32_t* colidx, const void* vals, co
 #include "spmm_union.inc"
 #include "spmm_mfma.inc"
 #include "spmm_mfma32.inc"
+#include "spmm_narrow.inc"
 
 template <int KIND>
 int launch_fast(const int32_t* rowptr, const int32_t* colidx, const void* vals, const void* vals_t, int64_t nv,
@@ -912,6 +913,37 @@ extern "C" int ds_spmm_union(int epilogue, int level_tag, const int32_t* utab, c
 #undef DS_U
 }
 
+
+// Narrow blocks (<= 16 columns): the lanes dealt over the union's entries (spmm_narrow.inc)
+extern "C" int ds_spmm_union_narrow(int kind, int level_tag, const int32_t* utab, const int32_t* ctab, int64_t ngroups,
+                                    const int32_t* gent, const float* vals, int64_t nnzb, int64_t nv, const float* X, int64_t ldx,
+                                    float* Y, int64_t ldy, int ncols, ds_stream_t stream) {
+    DS_REQUIRE(ctab && gent && vals && X && Y, "ds_spmm_union_narrow: null pointer");
+    DS_REQUIRE(kind == 0 || kind == 3, "ds_spmm_union_narrow: kind must be 0 (3x3 blocks) or 3 (node-scalar values)");
+    DS_REQUIRE(level_tag == 0 || level_tag == 1, "ds_spmm_union_narrow: level_tag must be 0 (fine) or 1 (corner-node level)");
+    DS_REQUIRE(nv > 0 && ngroups == (nv + 3) / 4 && nnzb > 0 && ncols > 0 && ncols % 4 == 0 && ncols <= 16,
+               "ds_spmm_union_narrow: ncols must be a multiple of 4 <= 16 and ngroups = ceil(nv / 4)");
+    DS_REQUIRE(ldx >= ncols && ldy >= ncols, "ds_spmm_union_narrow: leading dimension smaller than ncols");
+    DS_REQUIRE(X != Y, "ds_spmm_union_narrow: X and Y must be different buffers");
+    const uintptr_t al = reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(Y) | (uintptr_t)(ldx * 4) | (uintptr_t)(ldy * 4) |
+                         reinterpret_cast<uintptr_t>(ctab);
+    DS_REQUIRE((al & 15) == 0, "ds_spmm_union_narrow: rows and ctab must be 16-byte aligned");
+    hipStream_t st = ds::as_stream(stream);
+    const unsigned nwg = (unsigned)ds::ceil_div(ngroups, 4);
+    ds::ProfScope prof(stream, kind == 0 ? DS_PROF_KX : DS_PROF_MX, nv, nnzb, ncols, 4 << 8);
+#define DS_UN(S, V) spmm_union_narrow_kernel<S, V><<<nwg, 256, 0, st>>>(reinterpret_cast<const int2*>(utab), reinterpret_cast<const int4*>(ctab), \
+                                                                       (unsigned)ngroups, gent, vals, nv, X, ldx, Y, ldy, ncols, nwg)
+    if (kind == 0) {
+        if (level_tag == 1) DS_UN(false, 1);
+        else DS_UN(false, 0);
+    } else {
+        if (level_tag == 1) DS_UN(true, 1);
+        else DS_UN(true, 0);
+    }
+#undef DS_UN
+    DS_LAUNCH_CHECK("spmm_union_narrow_kernel");
+    return DS_OK;
+}
 
 // The eigensolver's residual in ONE walk of the unions (spmm_union.inc, epilogue 4): R = K X - (M_s (x) I3) X diag(lam) and
 // the column norms ||R_j||^2, ||X_j||^2, with neither K X nor M X written to memory.

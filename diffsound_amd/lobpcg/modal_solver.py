@@ -173,16 +173,42 @@ def _orthonormal_columns(Tm):
     return Q
 
 
+def _thread_local_setters():
+    """(mkl_set_num_threads_local, omp_set_num_threads, omp_get_max_threads) of the libraries torch's CPU kernels run on, or None.
+    All three act on the CALLING THREAD only - unlike ``torch.set_num_threads``, which also stores a process-wide default and
+    re-creates torch's pthreadpool with the new thread count on every call."""
+    global _TLS_SETTERS
+    if _TLS_SETTERS is False:
+        _TLS_SETTERS = None
+        try:
+            import ctypes
+
+            lib = ctypes.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "libtorch_cpu.so"))
+            # (the C interface: the lower-case mkl_set_num_threads_local is the Fortran one and takes a pointer)
+            mkl, oset, oget = lib.MKL_Set_Num_Threads_Local, lib.omp_set_num_threads, lib.omp_get_max_threads
+            mkl.restype, mkl.argtypes = ctypes.c_int, [ctypes.c_int]
+            oset.restype, oset.argtypes = None, [ctypes.c_int]
+            oget.restype, oget.argtypes = ctypes.c_int, []
+            _TLS_SETTERS = (mkl, oset, oget)
+        except (OSError, AttributeError):
+            pass
+    return _TLS_SETTERS
+
+
+_TLS_SETTERS = False
+
+
 class _one_thread:
     """LAPACK on <= 3b x 3b matrices is fastest single-threaded (measured on the MI355X host: 240 x 240
     fp64 eigh 2.5 ms with 1 thread, no faster with 2-8, 150 ms with the default 128 threads; rocSOLVER's
-    launch-bound syevd takes 5.7 ms).  ``torch.set_num_threads`` is PER CALLING THREAD for what matters here
-    (omp_set_num_threads and mkl_set_num_threads_local), so every thread that enters lowers ITS OWN count and restores ITS
-    OWN previous value when it leaves (a ``threading.local``; re-entrant).  Until round 4 only the first thread to enter
-    lowered a count - the reason two identical 8-lane runs could differ in the last bits of a gradient
-    (tests/test_fullsize_gpu.py::test_c3_eight_lanes_are_bit_identical_from_run_to_run); round 4's fix saved ONE value
-    for all threads, so a lane that re-entered at depth 0 could save "1" and the last thread to leave then made 1 the
-    process-wide default for every later CPU op."""
+    launch-bound syevd takes 5.7 ms).  Every thread that enters lowers ITS OWN MKL / OpenMP thread count
+    (``mkl_set_num_threads_local``, ``omp_set_num_threads``: per-thread settings) and restores its own previous values when it
+    leaves; re-entrant; nothing process-wide is touched.
+    History: until round 4 only the first thread to enter lowered a count - the reason two identical 8-lane runs could differ in
+    the last bits of a gradient (tests/test_fullsize_gpu.py::test_c3_eight_lanes_are_bit_identical_from_run_to_run).  Round 4
+    saved ONE value for all threads and restored it from the last thread to leave, which could leave 1 as the process-wide
+    default - and, as a side effect, kept the hypothesis lanes' threads at one thread for good; the lanes now
+    pin themselves (``pin_thread_to_one_core`` from the lane pool's initializer), this guard only brackets the dense steps."""
 
     _tls = threading.local()
 
@@ -190,16 +216,41 @@ class _one_thread:
         st = _one_thread._tls
         depth = getattr(st, "depth", 0)
         if depth == 0:
-            st.saved = torch.get_num_threads()
-            if st.saved != 1:
-                torch.set_num_threads(1)
+            fns = _thread_local_setters()
+            if fns is not None:
+                mkl, oset, oget = fns
+                torch.get_num_threads()  # (a thread's first torch call sizes its OpenMP team from MKL's count: before we lower it)
+                st.saved = (mkl(1), oget())  # (MKL_Set_Num_Threads_Local returns the previous local value; 0 = unset)
+                oset(1)
+            else:  # another BLAS behind torch: its own (heavier) switch, and only when there is something to lower
+                st.saved = torch.get_num_threads()
+                if st.saved != 1:
+                    torch.set_num_threads(1)
         st.depth = depth + 1
 
     def __exit__(self, *a):
         st = _one_thread._tls
         st.depth -= 1
-        if st.depth == 0 and st.saved != 1:
-            torch.set_num_threads(st.saved)
+        if st.depth == 0:
+            fns = _thread_local_setters()
+            if fns is not None:
+                fns[0](st.saved[0])
+                fns[1](st.saved[1])
+            elif st.saved != 1:
+                torch.set_num_threads(st.saved)
+
+
+def pin_thread_to_one_core():
+    """For a private worker thread (a hypothesis lane): one MKL / OpenMP thread for its whole life, thread-local settings only.
+    A lane issues launches and solves <= 3b x 3b dense problems; left at the host's full thread count (256 hardware threads on
+    the GPU box) any OpenMP region it enters would spin up a team of that size next to the other lanes' teams."""
+    fns = _thread_local_setters()
+    if fns is not None:
+        torch.get_num_threads()  # (sizes the thread's team first, see _one_thread)
+        fns[0](1)
+        fns[1](1)
+    else:
+        torch.set_num_threads(1)
 
 
 def _small(fn, dev, *mats):

@@ -548,9 +548,22 @@ class _HipBlockOps:
                                          0 if Wprev is None else _ld(Wprev), _hip.stream_ptr()),
                    "ds_spmm_union")
 
+    def _narrow(self, kind, X, Y):
+        """<= 16 columns: the kernel that deals a wave's lanes over the union's entries (ds_spmm_union_narrow)."""
+        pp = _hip.ptr
+        g, u = self.sys.groups, self.sys.groups["union"]
+        vals = self.mgrp if kind == 3 else self.kgrp
+        _hip.check(self._L.ds_spmm_union_narrow(kind, self._level_tag, None if u.get("single") else pp(u["utab"]), pp(u["ctab"]),
+                                                u["ngroups"], pp(g["gent"]), pp(vals), vals.shape[0], self.nv, pp(X), _ld(X), pp(Y),
+                                                _ld(Y), X.shape[1], _hip.stream_ptr()), "ds_spmm_union_narrow")
+
     def apply_K(self, X, out):
         if self._union32_ok(X, out):
             self._union32(0, X, out)
+        elif X.shape[1] <= 16 and self._level_tag == 0 and self._union_ok(X, out):
+            # (fine level only: 131 -> 115 us on 8 columns at C3; the corner-node level's production launch is as short as a wave's
+            # life either way, and the node-scalar product M X is faster on the production kernel: profiles/r05_mb_narrow.txt)
+            self._narrow(0, X, out)
         elif self._union_ok(X, out):
             self._union(0, X, out)
         else:

@@ -43,6 +43,11 @@ class DirectLinear(nn.Module):
         return E * nu / ((1 + nu) * (1 - 2 * nu)), E / (2 * (1 + nu))
 
 
+import os as _os
+
+_PASS_TIMING = bool(_os.environ.get("DS_EXP_TIMING"))
+
+
 def shard_hypotheses(num, rank, world):
     """Indices of the hypotheses owned by ``rank`` (round-robin; embarrassingly parallel)."""
     return list(range(rank, num, world))
@@ -95,6 +100,18 @@ class ModalPipeline:
         model = DirectLinear(youngs, poisson, self.mat)
         lam, mu = model.lame()
         holder = self if _lane is None else _lane
+        timing = _PASS_TIMING  # (DS_EXP_TIMING=1: where the host time of one pass goes, with a device synchronisation per stage)
+        if timing:
+            import sys
+            import time
+
+            stamps = []
+
+            def lap(name):
+                torch.cuda.current_stream(self.device).synchronize()
+                stamps.append((name, time.time()))
+
+            lap("start")
         if assemble:
             holder.system.assemble()
         lam_f, mu_f = float(lam.detach()), float(mu.detach())
@@ -102,8 +119,20 @@ class ModalPipeline:
             holder.ops = HipModalOps(holder.system, lam_f, mu_f)
         else:
             holder.ops.set_material(lam_f, mu_f)
-        res = ModalSolver(holder.ops, self.cfg).solve(self.modes, X0=warm)
-        return self._readout(holder, model, res, backward)
+        if timing:
+            lap("assemble + set_material")
+        solver = ModalSolver(holder.ops, self.cfg)
+        if timing:
+            lap("preconditioner set-up (power iterations)")
+        res = solver.solve(self.modes, X0=warm)
+        if timing:
+            lap("solve (nested start + iteration + polish)")
+        out = self._readout(holder, model, res, backward)
+        if timing:
+            lap("read-out + render + loss + backward")
+            print("pass: " + ", ".join(f"{n} {1e3 * (t - stamps[i][1]):.2f} ms" for i, (n, t) in enumerate(stamps[1:])) +
+                  f", total {1e3 * (stamps[-1][1] - stamps[0][1]):.2f} ms", file=sys.stderr, flush=True)
+        return out
 
     def run_cached_pass(self, res, youngs, poisson, backward=True, _lane=None):
         """A pass BETWEEN eigendecompositions (reference experiments/material_sync_train.py:135-141 with
@@ -232,7 +261,10 @@ def _lane_pool(pipe, lanes):
 
         if pool is not None:
             pool.shutdown(wait=True)
-        pool = pipe._lane_pool = ThreadPoolExecutor(max_workers=lanes, thread_name_prefix="ds-lane")
+        from .lobpcg.modal_solver import pin_thread_to_one_core
+
+        pool = pipe._lane_pool = ThreadPoolExecutor(max_workers=lanes, thread_name_prefix="ds-lane",
+                                                    initializer=pin_thread_to_one_core)
     return pool
 
 

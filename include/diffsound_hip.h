@@ -234,6 +234,14 @@ int ds_union_residual(int level_tag, const int32_t* utab, const int32_t* ctab, i
                       const int32_t* gent, const float* kgrp, const float* mgrp, int64_t nnzb, int64_t nv, const float* X,
                       int64_t ldx, const double* lam, float* R, int64_t ldr, int ncols, void* work, int64_t work_bytes,
                       double* rn2, double* xn2, ds_stream_t stream);
+/* Narrow blocks (ABI 28): Y = K X (kind 0, vals = kgrp) or Y = (M_s (x) I3) X (kind 3, vals = mgrp) on <= 16 columns with the
+ * lanes of a wave dealt over the union's ENTRIES instead of over the columns (ds_spmm_union keeps 6 of 64 lanes busy on an
+ * 8-column block and takes as long as on 80 columns): the block power iteration of the Chebyshev interval and the operator-norm
+ * estimates of the eigensolver.  Same tables as ds_spmm_union; sums in another order: equal to it to fp32 rounding, not bit for
+ * bit.  (reference: the operator-norm estimates of src/lobpcg/_lobpcg.py:280-285) */
+int ds_spmm_union_narrow(int kind, int level_tag, const int32_t* utab, const int32_t* ctab, int64_t ngroups, const int32_t* gent,
+                         const float* vals, int64_t nnzb, int64_t nv, const float* X, int64_t ldx, float* Y, int64_t ldy,
+                         int ncols, ds_stream_t stream);
 /* Y = K X and Y2 = (M_s (x) I3) X of ONE block (<= 84 columns) in one walk of the neighbour unions (ABI 28; epilogue 5 of the
  * kernel): X is gathered once instead of twice; each product is formed exactly as ds_spmm_union's epilogues 0 and 3 form it
  * (bit-identical results).  The eigensolver's K W and M W of the raw preconditioned residuals (ds_lobpcg_t.raw_rr).

@@ -692,6 +692,51 @@ def test_union_km_equals_the_two_products_bit_for_bit(dev, mesh, order, ncols):
     torch.cuda.synchronize()
 
 
+@pytest.mark.parametrize("mesh,order,ncols", [(6, 2, 8), (6, 2, 16), (6, 2, 12), (6, 2, 4), (10, 2, 8), (3, 2, 8), (12, 1, 8), (5, 1, 16), (2, 1, 4)])
+def test_narrow_union_kernel_matches_the_production_kernel(dev, mesh, order, ncols):
+    """ds_spmm_union_narrow (<= 16 columns, a wave's lanes dealt over the union's entries; round 5) against ds_spmm_union on the
+    same block: K X and M X equal to fp32 summation-order rounding (1e-6 of the row's |K| |x| scale), written into a column
+    range of a wider buffer with nothing outside it touched; apply_K / apply_M take it for such blocks; bad arguments refused."""
+    from diffsound_amd import _hip, meshgen
+    from diffsound_amd.diffelastic.mesh import TetMesh
+    from diffsound_amd.modal_ops import HipModalOps, TetSystem
+
+    v, t = meshgen.kuhn_box(mesh)
+    tm = TetMesh(torch.from_numpy(v).to(dev), torch.from_numpy(t).long().to(dev)).to_high_order(order)
+    sysd = TetSystem(tm.vertices, tm.tets, order, 2700.0)
+    ops = HipModalOps(sysd, 2e10, 3e10, two_level=False)
+    g = torch.Generator(device=dev).manual_seed(mesh * 100 + ncols)
+    big = torch.full((sysd.n, 64), float("nan"), device=dev)
+    X = big[:, 16:16 + ncols]
+    X.copy_(torch.randn((sysd.n, ncols), generator=g, device=dev))
+    for kind in (0, 3):
+        ref = torch.empty((sysd.n, ncols), device=dev)
+        ops._union(kind, X, ref)
+        wide = torch.full((sysd.n, ncols + 8), float("nan"), device=dev)
+        Y = wide[:, 4:4 + ncols]
+        ops._narrow(kind, X, Y)
+        assert bool(torch.isnan(wide[:, :4]).all()) and bool(torch.isnan(wide[:, 4 + ncols:]).all())
+        scale = float(ref.abs().max())
+        assert float((Y - ref).abs().max()) < 2e-6 * scale, (kind, float((Y - ref).abs().max()), scale)
+        if kind == 0:  # the fine level's K X of a narrow block is routed here (M X stays on the production kernel: faster)
+            out = torch.empty((sysd.n, ncols), device=dev)
+            ops.apply_K(X, out)
+            assert torch.equal(out, Y)
+    L, p = _hip.lib(), _hip.ptr
+    u, gr = sysd.groups["union"], sysd.groups
+    Yc = torch.empty((sysd.n, ncols), device=dev)
+
+    def call(kind=0, x=X, y=Yc, nc=ncols, tag=0):
+        vals = ops.mgrp if kind == 3 else ops.kgrp
+        return L.ds_spmm_union_narrow(kind, tag, None if u["single"] else p(u["utab"]), p(u["ctab"]), u["ngroups"], p(gr["gent"]),
+                                      p(vals), vals.shape[0], sysd.nv, p(x), x.stride(0), p(y), y.stride(0), nc, _hip.stream_ptr())
+
+    assert call() == 0
+    for bad in (dict(kind=1), dict(y=X), dict(nc=20), dict(nc=ncols + 2), dict(tag=2), dict(x=big[:, 1:1 + ncols])):
+        assert call(**bad) != 0, bad
+    torch.cuda.synchronize()
+
+
 def test_mfma_entry_point_refuses_what_it_does_not_serve(dev):
     """ds_spmm_union16m validates on the host before any launch: group size, table limits, aliasing, alignment."""
     from diffsound_amd import _hip, meshgen
