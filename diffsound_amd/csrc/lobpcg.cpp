@@ -201,6 +201,20 @@ bool orthonormal_columns(const ds_lapack_t& la, const Mat& Tm, Mat& Q) {
     return true;
 }
 
+// column ranges of at most 84 columns (multiples of 4, as equal as possible) that tile a c-column block: what one launch of
+// the neighbour-union kernels takes (the same rule as _HipBlockOps.col_slices of the Python binding)
+template <typename F>
+int for_col_slices(int c, F&& fn) {
+    if (c <= 84) return fn(0, c);
+    const int k = (c + 83) / 84;
+    const int w = (((c + k - 1) / k) + 3) / 4 * 4;
+    for (int c0 = 0; c0 < c; c0 += w) {
+        const int rc = fn(c0, std::min(c, c0 + w));
+        if (rc != DS_OK) return rc;
+    }
+    return DS_OK;
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int COEF_SLOTS = 8;
 
@@ -274,16 +288,20 @@ struct Ctx {
         return ds_mix(A, lda, pc, dv, C.c, Out, ldo, p->n, alpha, beta, stream);
     }
 
+    // (blocks wider than one launch of the neighbour-union kernels takes - configs[4]'s 136-column block, the periodic refresh
+    // K [X P W] - go in column slices through the same kernels: round 5; until then they fell to the wave-per-node kernels)
     int apply_K(const float* X, int64_t ldx, float* Y, int64_t ldy, int ncols) {
         const ds_level_t& L = p->level;
         if (ncols <= 84 && ncols % 4 == 0 && L.m32_gptr && L.m32_k && 3 * L.nv * ldx * 4 < (int64_t)0x7f000000)
             return ds_spmm_union32m(0, L.level_tag, L.m32_gptr, L.m32_gcol, L.m32_gmeta, L.m32_gbase, L.m32_k, L.nnzb * 36 + 16,
                                     L.nnzb, (L.nv + 3) / 4, L.m32_max_entries, L.m32_max_batch_blocks, L.nv, X, ldx, Y, ldy,
                                     ncols, stream);
-        if (ncols <= 84 && ncols % 4 == 0)
-            return ds_spmm_union(0, L.level_tag, L.utab, L.ctab, L.ngroups, L.cap_blocks, L.gent, L.kgrp, L.nnzb, L.nv, X, ldx, Y, ldy,
-                                 nullptr, 0, nullptr, ncols, 0.f, 0.f, 0, nullptr, 0, stream);
-        for (int c0 = 0; c0 < ncols; c0 += 256) {  // wide blocks (the periodic full refresh): wave-per-node kernels
+        if (ncols % 4 == 0)
+            return for_col_slices(ncols, [&](int c0, int c1) {
+                return ds_spmm_union(0, L.level_tag, L.utab, L.ctab, L.ngroups, L.cap_blocks, L.gent, L.kgrp, L.nnzb, L.nv, X + c0, ldx,
+                                     Y + c0, ldy, nullptr, 0, nullptr, c1 - c0, 0.f, 0.f, 0, nullptr, 0, stream);
+            });
+        for (int c0 = 0; c0 < ncols; c0 += 256) {  // odd widths: wave-per-node kernels
             const int c1 = std::min(ncols, c0 + 256);
             int rc = ds_spmm_bsr3(0, p->rowptr, p->colidx, p->k32, p->k32t, p->nv, X + c0, ldx, Y + c0, ldy, c1 - c0, stream);
             if (rc != DS_OK) return rc;
@@ -293,19 +311,33 @@ struct Ctx {
 
     int apply_M(const float* X, int64_t ldx, float* Y, int64_t ldy, int ncols) {
         const ds_level_t& L = p->level;
-        if (L.m32_gptr && L.m32_m && 3 * L.nv * ldx * 4 < (int64_t)0x7f000000)
+        if (ncols <= 84 && L.m32_gptr && L.m32_m && 3 * L.nv * ldx * 4 < (int64_t)0x7f000000)
             return ds_spmm_union32m(3, L.level_tag, L.m32_gptr, L.m32_gcol, L.m32_gmeta, L.m32_gbase, L.m32_m, L.nnzb * 4 + 16,
                                     L.nnzb, (L.nv + 3) / 4, L.m32_max_entries, L.m32_max_batch_blocks, L.nv, X, ldx, Y, ldy,
                                     ncols, stream);
-        return ds_spmm_union(3, L.level_tag, L.utab, L.ctab, L.ngroups, L.cap_blocks, L.gent, p->mgrp, L.nnzb, L.nv, X, ldx, Y, ldy,
-                             nullptr, 0, nullptr, ncols, 0.f, 0.f, 0, nullptr, 0, stream);
+        return for_col_slices(ncols, [&](int c0, int c1) {
+            return ds_spmm_union(3, L.level_tag, L.utab, L.ctab, L.ngroups, L.cap_blocks, L.gent, p->mgrp, L.nnzb, L.nv, X + c0, ldx,
+                                 Y + c0, ldy, nullptr, 0, nullptr, c1 - c0, 0.f, 0.f, 0, nullptr, 0, stream);
+        });
     }
 
     // K X -> KX and M X -> MX of one block in one walk of the unions
     int apply_KM(const float* X, int64_t ldx, float* KX, int64_t ldk, float* MX, int64_t ldm, int ncols) {
         const ds_level_t& L = p->level;
-        return ds_spmm_union_km(L.level_tag, L.utab, L.ctab, L.ngroups, L.cap_blocks, L.gent, L.kgrp, p->mgrp, L.nnzb, L.nv, X, ldx,
-                                KX, ldk, MX, ldm, ncols, stream);
+        return for_col_slices(ncols, [&](int c0, int c1) {
+            return ds_spmm_union_km(L.level_tag, L.utab, L.ctab, L.ngroups, L.cap_blocks, L.gent, L.kgrp, p->mgrp, L.nnzb, L.nv,
+                                    X + c0, ldx, KX + c0, ldk, MX + c0, ldm, c1 - c0, stream);
+        });
+    }
+
+    // R = K X - (M X) diag(lam) and the column norms (nrm, nrm + 1024) in one walk of the unions per column slice
+    int residual_fused(const float* X, int64_t ldx, float* R, int64_t ldr_, int ncols) {
+        const ds_level_t& L = p->level;
+        return for_col_slices(ncols, [&](int c0, int c1) {
+            return ds_union_residual(L.level_tag, L.utab, L.ctab, L.ngroups, L.cap_blocks, L.gent, L.kgrp, p->mgrp, L.nnzb, L.nv,
+                                     X + c0, ldx, p->lam_dev + c0, R + c0, ldr_, c1 - c0, p->res_work, p->res_work_bytes, p->nrm + c0,
+                                     p->nrm + 1024 + c0, stream);
+        });
     }
 
     int copy_cols(float* dst, int64_t ldd, const float* src, int64_t lds_, int ncols) {
@@ -315,15 +347,19 @@ struct Ctx {
                    "ds_lobpcg_iterate: column copy");
     }
 
-    // W <- B R  (two-level V-cycle, or the one-level Chebyshev polynomial W = p(T K) T R)
+    // W <- B R  (two-level V-cycle, or the one-level Chebyshev polynomial W = p(T K) T R); columns are independent: blocks wider
+    // than the fused kernels take go in slices that share the scratch blocks (stream order)
     int precond(float* R, int na, float* W, int64_t ldw) {
-        if (p->twolevel) {
-            ds_twolevel_t d = *p->twolevel;
-            d.R = R, d.ldr = p->ldr, d.W = W, d.ldw = ldw, d.ncols = na;
-            return ds_twolevel_apply(&d, stream);
-        }
-        if (p->pr16) return ds_chebyshev_apply16(&p->level, R, p->ldr, W, ldw, p->pa, p->pb, p->pr16, p->ldp, na, stream);
-        return ds_chebyshev_apply(&p->level, R, p->ldr, W, ldw, p->pa, p->pb, p->ldp, na, stream);
+        return for_col_slices(na, [&](int c0, int c1) {
+            if (p->twolevel) {
+                ds_twolevel_t d = *p->twolevel;
+                d.R = R + c0, d.ldr = p->ldr, d.W = W + c0, d.ldw = ldw, d.ncols = c1 - c0;
+                return ds_twolevel_apply(&d, stream);
+            }
+            if (p->pr16)
+                return ds_chebyshev_apply16(&p->level, R + c0, p->ldr, W + c0, ldw, p->pa, p->pb, p->pr16, p->ldp, c1 - c0, stream);
+            return ds_chebyshev_apply(&p->level, R + c0, p->ldr, W + c0, ldw, p->pa, p->pb, p->ldp, c1 - c0, stream);
+        });
     }
 
     PinnedRing* ring = &g_ring;
@@ -407,14 +443,12 @@ extern "C" int ds_lobpcg_iterate(ds_lobpcg_t* p, const ds_lapack_t* lapack, ds_s
     DS_REQUIRE(p->S && p->S2 && p->KS && p->KS2 && p->R && p->MX && p->MW && p->lam && p->rerr && p->gbuf && p->cbuf &&
                    p->nrm && p->lam_dev && p->gram_work && p->mgrp,
                "ds_lobpcg_iterate: null buffer");
-    DS_REQUIRE(p->b > 0 && p->b <= 84 && p->b % 4 == 0 && p->k > 0 && p->k <= p->b && (p->ny == 0 || p->ny % 4 == 0),
-               "ds_lobpcg_iterate: block width must be a multiple of 4 <= 84 (got %d)", p->b);
+    DS_REQUIRE(p->b > 0 && p->b <= 168 && p->b % 4 == 0 && p->k > 0 && p->k <= p->b && (p->ny == 0 || p->ny % 4 == 0),
+               "ds_lobpcg_iterate: block width must be a multiple of 4 <= 168 (got %d)", p->b);
     DS_REQUIRE(p->n == 3 * p->nv && p->n >= 3 * p->b + p->ny, "ds_lobpcg_iterate: bad problem size");
     DS_REQUIRE(p->twolevel || (p->pa && p->pb), "ds_lobpcg_iterate: no preconditioner scratch");
-    // the periodic full refresh multiplies K by [X P W] (up to 3 b columns): wider than 84 it goes through ds_spmm_bsr3,
-    // which needs the plain BSR arrays - asked for here, not at the 8th iteration
-    DS_REQUIRE(3 * p->b <= 84 || (p->rowptr && p->colidx && p->k32 && p->k32t),
-               "ds_lobpcg_iterate: rowptr / colidx / k32 / k32t are needed for the full refresh of a block wider than 28");
+    // (the periodic full refresh multiplies K by [X P W], up to 3 b columns, in column slices through the union kernels: the
+    // plain BSR arrays are no longer needed for it - every width the loop forms is a multiple of 4)
     Ctx c{p, ds::as_stream(stream), stream, *lapack, p->S, p->S2, p->KS, p->KS2};
     const int b = p->b, k = p->k, ny = p->ny;
     {   // cbuf holds COEF_SLOTS slots of (ny + 3 b) x 2 b floats
@@ -433,8 +467,8 @@ extern "C" int ds_lobpcg_iterate(ds_lobpcg_t* p, const ds_lapack_t* lapack, ds_s
     int ncl = 0, npc = 0, k0 = 0, since_refresh = 0, it = 0;
     // the fused residual needs the operands the neighbour-union kernel takes (one descriptor per operand block) and replaces
     // the fresh K X' of kx_fresh - without kx_fresh K X' comes out of the recurrence and is there anyway
-    const bool fused_res = p->res_work && p->kx_fresh && 3 * p->nv * std::max(lds, ldr) * 4 < (int64_t)0x7f000000 &&
-                           p->res_work_bytes >= ds_union_residual_workspace_bytes(p->level.ngroups, b);
+    const bool fused_res = p->res_work && p->kx_fresh &&
+                           p->res_work_bytes >= ds_union_residual_workspace_bytes(p->level.ngroups, std::min(b, 84));
     // Rayleigh-Ritz on the raw basis: K X' must not be needed from K [X P W] (kx_fresh) and comes from the fused residual
     const bool raw = p->raw_rr && fused_res && !p->gram_exact;
     double worst = std::numeric_limits<double>::infinity();
@@ -448,11 +482,7 @@ extern "C" int ds_lobpcg_iterate(ds_lobpcg_t* p, const ds_lapack_t* lapack, ds_s
                         "ds_lobpcg_iterate: Ritz values to device")) != DS_OK)
             return rc;
         if (fused_res) {  // R = K X - (M X) diag(lam) and the norms in one walk of the unions; K X, M X never reach memory
-            const ds_level_t& L = p->level;
-            if ((rc = ds_union_residual(L.level_tag, L.utab, L.ctab, L.ngroups, L.cap_blocks, L.gent, L.kgrp, p->mgrp, L.nnzb,
-                                        L.nv, Xa, lds, p->lam_dev, p->R, ldr, na, p->res_work, p->res_work_bytes, p->nrm,
-                                        p->nrm + 1024, stream)) != DS_OK)
-                return rc;
+            if ((rc = c.residual_fused(Xa, lds, p->R, ldr, na)) != DS_OK) return rc;
         } else {
             if ((rc = c.apply_M(Xa, lds, p->MX, ldr, na)) != DS_OK) return rc;
             if ((rc = ds_residual(c.KS + k0, ldks, p->R, ldr, p->MX, ldr, Xa, lds, p->lam_dev, n, na, p->nrm, p->nrm + 1024,

@@ -333,9 +333,19 @@ class _HipBlockOps:
             _hip.check(self._L.ds_spmm_bsr3(kind, p(self.rowptr), p(self.colidx), p(vals), p(vt), self.nv, p(xs),
                                             _ld(xs), p(os_), _ld(os_), c1 - c0, _hip.stream_ptr()), "ds_spmm_bsr3")
 
-    def _union_ok(self, X, *others):
+    @staticmethod
+    def col_slices(c):
+        """Column ranges of at most 84 columns (multiples of 4, as equal as possible) that tile a c-column block: what the
+        neighbour-union kernels take per launch.  136 -> (0, 68), (68, 136); 240 -> three of 80."""
+        if c <= 84:
+            return [(0, c)]
+        k = -(-c // 84)
+        w = -(-(-(-c // k)) // 4) * 4
+        return [(c0, min(c, c0 + w)) for c0 in range(0, c, w)]
+
+    def _union_ok(self, X, *others, wide=False):
         g = getattr(getattr(self, "sys", None), "groups", None)
-        if g is None or g.get("union") is None or self.kgrp is None or X.shape[1] > 84 or X.shape[1] % 4:
+        if g is None or g.get("union") is None or self.kgrp is None or (X.shape[1] > 84 and not wide) or X.shape[1] % 4:
             return False
         # every operand is read / written 16 bytes at a time (blocks of 2 GB and more take the kernel's per-panel
         # descriptor variant; the dinv table and the value array stay under one descriptor: nv * 36, nnzb * 36 < 4 GB)
@@ -448,7 +458,7 @@ class _HipBlockOps:
 
         g = getattr(getattr(self, "sys", None), "groups", None)
         if (g is None or g.get("union") is None or self.kgrp is None or self.mgrp is None or self.m_kind != 1
-                or b > 84 or b % 4 or ny % 4 or not self._union_ok(R, MX, MW, S[:, ny:ny + b], KS[:, :b])):
+                or b > 168 or b % 4 or ny % 4 or not self._union_ok(R, MX, MW, S[:, ny:ny + b], KS[:, :b], wide=True)):
             return None
         dev = self.device
         d = _hip.LobpcgDesc()
@@ -510,8 +520,9 @@ class _HipBlockOps:
         key = (self.n, b, ny)
         need = self._native_ws.get(key)
         if need is None:  # the split count depends on the shape: take the largest need over every shape the driver forms
+            # (q: the active width na, 2 na for [K W | M W] of the Ritz step on the raw basis, p itself for the full refresh)
             need = max(self._L.ds_gram_workspace_bytes(self.n, p_, q_)
-                       for p_ in range(4, m + 1, 4) for q_ in sorted(set(range(4, b + 1, 4)) | {p_}) if q_ <= 3 * b)
+                       for p_ in range(4, m + 1, 4) for q_ in sorted(set(range(4, 2 * b + 1, 4)) | {p_}) if q_ <= 3 * b)
             self._native_ws[key] = need
         if self._gram_ws is None or self._gram_ws.numel() < need:
             self._gram_ws = torch.empty((need,), dtype=torch.uint8, device=dev)
@@ -566,22 +577,29 @@ class _HipBlockOps:
             self._narrow(0, X, out)
         elif self._union_ok(X, out):
             self._union(0, X, out)
+        elif self._union_ok(X, out, wide=True):
+            # wider than one launch takes (configs[4]'s 136-column block, the periodic refresh K [X P W]): column slices through the
+            # same kernel - the wave-per-node kernel this used to fall to runs at 21 % of STREAM on the 1M-tet mesh, the slices at ~40 %
+            for c0, c1 in self.col_slices(X.shape[1]):
+                self._union(0, X[:, c0:c1], out[:, c0:c1])
         else:
             self._spmm(0, self.k32, X, out)
         self.counts["apply_K_cols"] += X.shape[1]
 
     def apply_KM_ok(self, X, KX, MX):
-        return self.m_kind == 1 and self.mgrp is not None and self._union_ok(X, KX, MX)
+        return self.m_kind == 1 and self.mgrp is not None and self._union_ok(X, KX, MX, wide=True)
 
     def apply_KM(self, X, KX, MX):
         """KX <- K X and MX <- M X in ONE walk of the neighbour unions (ds_spmm_union_km): X is gathered once; each product
         equals what apply_K / apply_M give bit for bit."""
         pp = _hip.ptr
         g, u = self.sys.groups, self.sys.groups["union"]
-        _hip.check(self._L.ds_spmm_union_km(self._level_tag, None if u.get("single") else pp(u["utab"]), pp(u["ctab"]), u["ngroups"],
-                                            u["capb"], pp(g["gent"]), pp(self.kgrp), pp(self.mgrp), self.kgrp.shape[0], self.nv,
-                                            pp(X), _ld(X), pp(KX), _ld(KX), pp(MX), _ld(MX), X.shape[1], _hip.stream_ptr()),
-                   "ds_spmm_union_km")
+        for c0, c1 in self.col_slices(X.shape[1]):
+            xs, ks, ms = X[:, c0:c1], KX[:, c0:c1], MX[:, c0:c1]
+            _hip.check(self._L.ds_spmm_union_km(self._level_tag, None if u.get("single") else pp(u["utab"]), pp(u["ctab"]), u["ngroups"],
+                                                u["capb"], pp(g["gent"]), pp(self.kgrp), pp(self.mgrp), self.kgrp.shape[0], self.nv,
+                                                pp(xs), _ld(xs), pp(ks), _ld(ks), pp(ms), _ld(ms), c1 - c0, _hip.stream_ptr()),
+                       "ds_spmm_union_km")
         self.counts["apply_K_cols"] += X.shape[1]
         self.counts["apply_M_cols"] += X.shape[1]
 
@@ -590,6 +608,9 @@ class _HipBlockOps:
             self._union32(3, X, out)
         elif self.m_kind == 1 and self.mgrp is not None and self._union_ok(X, out):
             self._union(3, X, out)
+        elif self.m_kind == 1 and self.mgrp is not None and self._union_ok(X, out, wide=True):
+            for c0, c1 in self.col_slices(X.shape[1]):
+                self._union(3, X[:, c0:c1], out[:, c0:c1])
         else:
             self._spmm(self.m_kind, self.ms32, X, out)
         self.counts["apply_M_cols"] += X.shape[1]
@@ -708,8 +729,9 @@ class _HipBlockOps:
         return ws
 
     def residual_fused_ok(self, X, R):
-        return (self.m_kind == 1 and self.mgrp is not None and self._union_ok(X, R)
-                and 3 * self.nv * max(X.stride(0), R.stride(0)) * 4 < 0x7F000000)
+        # (operand blocks of 2 GB and more - configs[4]'s basis buffer - take the kernel's per-panel descriptor variant, as every
+        # other epilogue does: tests/test_hip_kernels.py::test_union_spmm_operands_beyond_2gb)
+        return self.m_kind == 1 and self.mgrp is not None and self._union_ok(X, R, wide=True)
 
     def residual_fused(self, X, lam, R):
         """R <- K X - (M X) diag(lam) and (||R_j||^2, ||X_j||^2) in ONE walk of the neighbour unions (ds_union_residual): K X
@@ -718,11 +740,14 @@ class _HipBlockOps:
         lam64 = lam.to(torch.float64).contiguous()
         pp = _hip.ptr
         g, u = self.sys.groups, self.sys.groups["union"]
-        ws = self._residual_ws(b)
-        _hip.check(self._L.ds_union_residual(self._level_tag, None if u.get("single") else pp(u["utab"]), pp(u["ctab"]), u["ngroups"],
-                                             u["capb"], pp(g["gent"]), pp(self.kgrp), pp(self.mgrp), self.kgrp.shape[0], self.nv,
-                                             pp(X), _ld(X), pp(lam64), pp(R), _ld(R), b, pp(ws), ws.numel(), pp(self._nrm[0]),
-                                             pp(self._nrm[1]), _hip.stream_ptr()), "ds_union_residual")
+        slices = self.col_slices(b)  # (a block wider than one launch takes: column slices, each with its share of the norms)
+        ws = self._residual_ws(max(c1 - c0 for c0, c1 in slices))
+        for c0, c1 in slices:
+            xs, rs = X[:, c0:c1], R[:, c0:c1]
+            _hip.check(self._L.ds_union_residual(self._level_tag, None if u.get("single") else pp(u["utab"]), pp(u["ctab"]), u["ngroups"],
+                                                 u["capb"], pp(g["gent"]), pp(self.kgrp), pp(self.mgrp), self.kgrp.shape[0], self.nv,
+                                                 pp(xs), _ld(xs), pp(lam64[c0:]), pp(rs), _ld(rs), c1 - c0, pp(ws), ws.numel(),
+                                                 pp(self._nrm[0, c0:]), pp(self._nrm[1, c0:]), _hip.stream_ptr()), "ds_union_residual")
         self.counts["apply_K_cols"] += b
         self.counts["apply_M_cols"] += b
         return self._nrm[0, :b].clone(), self._nrm[1, :b].clone()

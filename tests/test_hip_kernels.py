@@ -1148,6 +1148,21 @@ def test_union_spmm_operands_beyond_2gb(dev):
         lambda o: ops._union(1, Xs, o, R0s, 0.31, 0.77, False, Wprev=Wps))
     one(lambda o: (o.copy_(Wpb), ops.cheb_spmm(Xb, o, R0b, 0.31, 0.77, False)),
         lambda o: (o.copy_(Wps), ops.cheb_spmm(Xs, o, R0s, 0.31, 0.77, False)))
+    # round 5: the fused residual (epilogue 4) and [K X | M X] in one walk (epilogue 5) on operands beyond 2 GB as well
+    lam = (torch.rand(ncols, generator=g, device=dev, dtype=torch.float64) + 0.5) * 1e9
+    norms = []
+
+    def resid(X):
+        def go(o):
+            norms.append(ops.residual_fused(X, lam, o))
+        return go
+
+    assert ops.residual_fused_ok(Xb, outw[:, 32:32 + ncols])
+    one(resid(Xb), resid(Xs))
+    assert torch.equal(norms[0][0], norms[1][0]) and torch.equal(norms[0][1], norms[1][1])
+    mw, ms_ = wide[1][:, 200:200 + ncols], torch.zeros((sysd.n, ncols), device=dev)
+    one(lambda o: ops.apply_KM(Xb, o, mw), lambda o: ops.apply_KM(Xs, o, ms_))
+    assert torch.equal(mw, ms_)
     assert all(torch.isfinite(r).all() for r in ref + got)
 
 
