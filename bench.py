@@ -267,6 +267,31 @@ def cpu_baseline(sample_cells, order, modes, full_tets, reps=3, second_cells=0):
     return med
 
 
+def memsafe_curve(full_tets, cpu_model):
+    """the MEMORY-SAFE restatement (tools/cpu_baseline_memsafe.py: element matrices pre-summed over
+    the Gauss points, read-out eight modes at a time under checkpointing - the same arithmetic) MEASURED on the GPU box's host in
+    round 5 at 3 072, 10 368 and 24 576 tets (profiles/r05_cpu_memsafe_*.json; the largest size is 8 minutes, the benchmark mesh
+    would be hours: ARPACK's shift-invert LU grows as tets^2.3 between the last two sizes).  A record, not a measurement of THIS run:
+    it says which CPU it was taken on."""
+    pts = []
+    for c in (8, 12, 16):
+        try:
+            d = json.load(open(os.path.join(ROOT, "profiles", f"r05_cpu_memsafe_{c}.json")))
+            pts.append({"tets": d["tets"], "seconds_per_pass": d["seconds"], "arpack_shift_invert_seconds": d["stage_seconds"]["arpack_shift_invert"],
+                        "threads": d["threads"], "cpu_model": d["cpu_model"]})
+        except (OSError, ValueError, KeyError):
+            pass
+    if len(pts) < 2:
+        return None
+    p = float(np.log(pts[-1]["seconds_per_pass"] / pts[-2]["seconds_per_pass"]) / np.log(pts[-1]["tets"] / pts[-2]["tets"]))
+    t_full = pts[-1]["seconds_per_pass"] * (full_tets / pts[-1]["tets"]) ** p
+    return {"points": pts, "same_cpu_model_as_this_run": bool(cpu_model) and all(q["cpu_model"] == cpu_model for q in pts),
+            "measured_exponent_between_last_two": p,
+            "extrapolated_to_benchmark_mesh": {"seconds_per_pass": t_full, "value": 1.0 / t_full, "unit": "passes/s",
+                                               "how": f"{pts[-1]['seconds_per_pass']:.0f} s at {pts[-1]['tets']} tets x ({full_tets} / {pts[-1]['tets']}) ^ {p:.2f}"},
+            "source": "profiles/r05_cpu_memsafe_{8,12,16}.json (tools/cpu_baseline_memsafe.py on the GPU box's host, 16 threads)"}
+
+
 def cpu_baseline_pass(sample_cells, order, modes, full_tets):
     """The CPU oracle (faithful restatement of the reference loop body) MEASURED on one full
     fwd+bwd pass at a stated size, with per-stage times.  ``value`` is passes/s AT THAT SIZE; the linear extrapolation
@@ -583,6 +608,14 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(a.dist_backend, rank=rank, world_size=world)
+    # host-thread budget of the node: every rank runs `lanes` hypothesis lanes, each ONE host thread that issues launches and solves
+    # the <= 3b x 3b dense problems on ONE LAPACK thread (the lanes pin themselves, pipeline._lane_pool) - ranks x lanes threads
+    # in all, which must fit half the node's hardware threads (the other half: the runtime's own threads, RCCL's proxies)
+    hw_threads = os.cpu_count() or 1
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world))
+    if a.lanes * local_world > max(1, hw_threads // 2):
+        raise SystemExit(f"bench.py: {local_world} ranks x {a.lanes} lanes = {a.lanes * local_world} host threads exceed half of the "
+                         f"node's {hw_threads} hardware threads; lower --lanes")
 
     def barrier():
         if world > 1:
@@ -871,6 +904,17 @@ def main():
         mf_lv = {int(o.nv) for o in (lane_ops[0], getattr(lane_ops[0], "coarse", None))
                  if o is not None and o._mfma is not None and o.kc is not None}
         inpass, rr_inpass, inpass_kinds = summarize_in_pass(inpass_rec, sysd, a.block, stream_gbs, mf_lv)
+        pmc = os.path.join(ROOT, "profiles", "spmm_pmc_bytes_per_launch.json")
+        try:  # PMC bytes per launch of the same forms (records of that file, valid for these kernel sources only)
+            doc = json.load(open(pmc)) if os.path.exists(pmc) else {}
+            for name, key in (("fused_term_bf16", "mfma" if mf_lv else "bf16"), ("lobpcg_kw", "kx"), ("lobpcg_kw_mw", "km"),
+                              ("fused_residual", "resid")):
+                rec = doc.get(f"cells{a.cells}_cols{a.block}_{key}")
+                if name in inpass and isinstance(rec, dict) and rec.get("spmm_source_sha16") == spmm_source_hash():
+                    inpass[name]["traffic"] = rec["bytes"]
+                    inpass[name]["traffic_over_algorithmic"] = rec["bytes"] / inpass[name]["algorithmic_bytes_per_launch"]
+        except (OSError, ValueError, KeyError):
+            pass
         # PMC bytes of one such launch: a figure measured in its own rocprofv3 --pmc passes (tools/collect_profiles.sh)
         # and valid ONLY for the kernel sources it was measured on - another source hash means stale, reported as null
         traffic, traffic_note = None, "no PMC figure under profiles/ for this shape"
@@ -994,9 +1038,14 @@ def main():
             "step_completion_intervals_s": [round(b - a_, 4) for a_, b in zip(on_step.stamps[:-1], on_step.stamps[1:])],
             "amortised": amortised,
             "collective": (f"{a.dist_backend} all-reduce of the scalar loss over {world} ranks" if world > 1 else "none (1 rank)"),
+            "process_group": ({"backend": dist.get_backend(), "world_size": dist.get_world_size(),
+                               "is_rccl": dist.get_backend() == "nccl"} if world > 1 else None),
+            "host_threads": {"hardware_threads": hw_threads, "ranks_on_node": local_world, "lanes_per_rank": min(a.lanes, a.hyp_per_gpu),
+                             "lane_threads_on_node": local_world * min(a.lanes, a.hyp_per_gpu), "lapack_threads_per_lane": 1},
         }
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.cpu_sample_cells, a.order, a.modes, sysd.T, a.cpu_reps, a.cpu_second_cells)
+            out["cpu_baseline"]["memory_safe_restatement"] = memsafe_curve(sysd.T, out["cpu_baseline"].get("cpu_model"))
         print(json.dumps(out))
     if world > 1:
         barrier()  # rank 0's solo kernel timings above ran while the others wait here (a shared device stays quiet)

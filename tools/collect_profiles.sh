@@ -3,9 +3,11 @@
 #   <tag>_bench_n1.json                 bench.py default run (with the CPU baseline)
 #   <tag>_bench_kernel_stats.csv        rocprofv3 --kernel-trace --stats of the default run (4 lanes)
 #   <tag>_bench_lanes1_kernel_stats.csv the same with one hypothesis at a time (clean per-kernel durations)
-#   <tag>_spmm_pmc.json                 FETCH_SIZE / WRITE_SIZE per fused Chebyshev-term launch (separate passes)
+#   <tag>_spmm_pmc_<kind>.json          FETCH_SIZE / WRITE_SIZE per launch of the SpMM forms (separate passes): fused term fp32 / bf16 / mfma,
+#                                       K W (kx), [K W | M W] (km), the fused residual (resid)
 #   <tag>_gram_mix.txt                  Gram / mix timings at the solver's shapes
-#   <tag>_gram_mix_pmc.json             MFMA counters of the Gram / mix kernels
+#   <tag>_rr_pmc_<shape>.json, <tag>_gram_mix_mfma_util.json   matrix-pipe counters of the Rayleigh-Ritz kernels per shape and the
+#                                       derived utilisation (-> profiles/gram_mix_mfma_util.json, quoted by bench.py)
 #   <tag>_symbolic_phase_timing.txt     tools/time_lift.py: ord-2 lifting + symbolic phase per topology, warm
 #   <tag>_c5_bench.json / _c5_kernel_stats.csv   bench.py --workload c5 (configs[4]) under rocprofv3 --kernel-trace --stats
 #   <tag>_mb_kx.txt / _mb_corner.txt / _m32_diag.txt   the eigensolver's own products alone, the corner-node level, per-wave cycles
@@ -41,13 +43,13 @@ python3 tools/summarize_prof.py /tmp/prof_solo $out/${tag}_bench_solo_kernel_sta
 fi
 if [ $part = 2 ] || [ $part = all ]; then
 # PMC bytes of the fused term (two passes: the TCC counters do not fit one)
-for kind in fp32 bf16 mfma kx; do
+for kind in fp32 bf16 mfma kx km resid; do
   rm -rf /tmp/pmc_b
   for c in FETCH_SIZE WRITE_SIZE; do
     timeout -k 10 200 rocprofv3 --kernel-include-regex "spmm_union" --pmc $c --output-format csv -d /tmp/pmc_b/$c -o p -- python3 tools/mb_cheb_only.py 6 $kind > /tmp/pmc_log_$c.txt 2>&1 || { tail -5 /tmp/pmc_log_$c.txt; exit 1; }
     echo "$kind $c done"
   done
-  kname="spmm_union_kernel"; [ $kind = mfma ] && kname="spmm_union_mfma_kernel"
+  kname="spmm_union_kernel<"; [ $kind = mfma ] && kname="spmm_union_mfma_kernel"
   python3 tools/pmc_summary.py /tmp/pmc_b "$kname" > $out/${tag}_spmm_pmc_$kind.json; cat $out/${tag}_spmm_pmc_$kind.json
 done
 python3 tools/pmc_bytes.py $tag > $out/${tag}_spmm_pmc_bytes_per_launch.json   # -> profiles/spmm_pmc_bytes_per_launch.json (keyed by the kernel-source hash)
@@ -57,13 +59,20 @@ python3 tools/time_lift.py > $out/${tag}_symbolic_phase_timing.txt 2>&1; cat $ou
 # EXTRA=-DDS_DIAG libds_m32diag.so - built in the container, it travels with the snapshot)
 python3 tools/mb_kx.py 2>&1 | grep -v amdgpu.ids > $out/${tag}_mb_kx.txt; cat $out/${tag}_mb_kx.txt
 python3 tools/mb_corner_time.py 2>&1 | grep -v amdgpu.ids > $out/${tag}_mb_corner.txt; cat $out/${tag}_mb_corner.txt
+python3 tools/mb_solver_spmm.py 2>&1 | grep -v amdgpu.ids > $out/${tag}_mb_solver_spmm.txt; cat $out/${tag}_mb_solver_spmm.txt
 if [ -f diffsound_amd/csrc/libds_m32diag.so ]; then
   DS_EXP_LIB=$PWD/diffsound_amd/csrc/libds_m32diag.so python3 tools/m32_diag.py 2>&1 | grep -v amdgpu.ids > $out/${tag}_m32_diag.txt; cat $out/${tag}_m32_diag.txt
 fi
 python3 tools/mb_gram_mix.py > $out/${tag}_gram_mix.txt 2>&1; cat $out/${tag}_gram_mix.txt
-rm -rf /tmp/pmc_g
-timeout -k 10 300 rocprofv3 --kernel-include-regex "gram32_partial|mix_lds" --pmc SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d /tmp/pmc_g -o p -- python3 tools/mb_gram_mix.py > /tmp/pmc_log_g.txt 2>&1 || { tail -5 /tmp/pmc_log_g.txt; exit 1; }
-python3 tools/pmc_summary.py /tmp/pmc_g "gram32_partial_kernel" "mix_lds_kernel<10>" "mix_lds_kernel<5>" > $out/${tag}_gram_mix_pmc.json; cat $out/${tag}_gram_mix_pmc.json
+# matrix-pipe counters of the Rayleigh-Ritz kernels, ONE shape per profiled process (the iteration's shapes on the raw basis and the
+# explicit route's) -> profiles/gram_mix_mfma_util.json, which bench.py quotes (roofline.rayleigh_ritz.mfma_busy)
+for shape in gram_256x160 mix_256x160 gram_256x80 gram_240x80 mix_256x80 mix_240x160; do
+  rm -rf /tmp/pmc_g
+  timeout -k 10 200 rocprofv3 --kernel-include-regex "gram32_partial|mix_lds" --pmc SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d /tmp/pmc_g -o p -- python3 tools/mb_rr_shapes.py $shape > /tmp/pmc_log_g.txt 2>&1 || { tail -5 /tmp/pmc_log_g.txt; exit 1; }
+  python3 tools/pmc_summary.py /tmp/pmc_g "gram32_partial_kernel" "mix_lds_kernel" > $out/${tag}_rr_pmc_$shape.json
+  echo "$shape counters done"
+done
+python3 tools/mfma_util.py $tag > $out/${tag}_gram_mix_mfma_util.json; cat $out/${tag}_gram_mix_mfma_util.json
 fi
 if [ $part = 3 ] || [ $part = all ]; then
 # configs[4]: the 1M-tet / 128-mode / fp64 stress with its kernel table

@@ -18,12 +18,12 @@ import bench  # noqa: E402
 
 tag = sys.argv[1]
 out = {"_comment": __doc__.split("\n\n")[1].replace("\n", " ")}
-for kind in ("fp32", "bf16", "mfma", "kx"):
+for kind in ("fp32", "bf16", "mfma", "kx", "km", "resid"):
     path = os.path.join(ROOT, "gpurun_out", f"{tag}_spmm_pmc_{kind}.json")
     if not os.path.exists(path):
         continue
     doc = json.load(open(path))
-    (name, c), = doc.items()
+    (name, c), = [(k_, v_) for k_, v_ in doc.items() if "FETCH_SIZE" in v_][:1]
     nbytes = int(round((2 * c["FETCH_SIZE"]["mean"] + c["WRITE_SIZE"]["mean"]) * 1024))
     out[f"cells26_cols80_{kind}"] = {"bytes": nbytes, "kernel": name, "launches": c["FETCH_SIZE"]["n"],
                                      "spmm_source_sha16": bench.spmm_source_hash(),
