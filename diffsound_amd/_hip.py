@@ -35,6 +35,7 @@ _SIGNATURES = {
     "ds_dpattern_export": (_I, [_P] * 13),
     "ds_dpattern_free": (None, [_P]),
     "ds_spmm_f64_polish": (_I, [_P, _P, _P, _P, _P, _I64, _P, _I64, _P, _P, _P, _I64, _I, _P]),
+    "ds_spmm_f64_polish_f32out": (_I, [_P, _P, _P, _P, _P, _I64, _P, _I64, _P, _P, _P, _I64, _I, _P]),
     "ds_pack_kc": (_I, [_P, _P, _I64, _P, _P]),
     "ds_spmm_union16m": (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _I64, _I64, _I, _I, _I64, _P, _I64, _P, _I64, _I, _P, _I64, _P, _I, _F,
                               _F, _I, _P, _I64, _P]),

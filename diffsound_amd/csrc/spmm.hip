@@ -531,11 +531,15 @@ __global__ void __launch_bounds__(256)
 // order are unchanged: results bit-identical to the three separate launches, as before.
 constexpr int PL_CHUNK = 32;  // blocks of a row staged per pass
 constexpr int PL_WIN = 4;     // panels per gather window (two windows: 8 in flight)
+// TY: the type the three results are STORED in - double, or float (round 5: the sums are formed in fp64 either way and rounded
+// once; the fp32 blocks halve the 0.86 GB the kernel writes and the Gram launch behind it reads, and that Gram then runs on the
+// fp32 matrix-core path; a result entry carries 6e-8 of relative rounding, the Gram entries ~1e-10 - see polish_products)
+template <typename TY>
 __global__ void __launch_bounds__(256)
     spmm_f64_polish_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx,
                            const double* __restrict__ va, const double* __restrict__ vb, const double* __restrict__ vm,
-                           int64_t nv, const float* __restrict__ X, int64_t ldx, double* __restrict__ Ya,
-                           double* __restrict__ Yb, double* __restrict__ Ym, int64_t ldy, int lpn, unsigned nblk) {
+                           int64_t nv, const float* __restrict__ X, int64_t ldx, TY* __restrict__ Ya,
+                           TY* __restrict__ Yb, TY* __restrict__ Ym, int64_t ldy, int lpn, unsigned nblk) {
     using d2 = __attribute__((ext_vector_type(2))) double;
     using xv4 = __attribute__((ext_vector_type(4))) float;
     __shared__ double s_a[4][PL_CHUNK * 9], s_b[4][PL_CHUNK * 9], s_m[4][PL_CHUNK];
@@ -648,12 +652,18 @@ __global__ void __launch_bounds__(256)
     }
     if (active) {
         const int64_t o = (node * 3 + g) * ldy + cl * 4;
-        *reinterpret_cast<d2*>(Ya + o) = d2{oa[0], oa[1]};
-        *reinterpret_cast<d2*>(Ya + o + 2) = d2{oa[2], oa[3]};
-        *reinterpret_cast<d2*>(Yb + o) = d2{ob[0], ob[1]};
-        *reinterpret_cast<d2*>(Yb + o + 2) = d2{ob[2], ob[3]};
-        *reinterpret_cast<d2*>(Ym + o) = d2{am[0], am[1]};
-        *reinterpret_cast<d2*>(Ym + o + 2) = d2{am[2], am[3]};
+        if constexpr (sizeof(TY) == 8) {
+            *reinterpret_cast<d2*>(Ya + o) = d2{oa[0], oa[1]};
+            *reinterpret_cast<d2*>(Ya + o + 2) = d2{oa[2], oa[3]};
+            *reinterpret_cast<d2*>(Yb + o) = d2{ob[0], ob[1]};
+            *reinterpret_cast<d2*>(Yb + o + 2) = d2{ob[2], ob[3]};
+            *reinterpret_cast<d2*>(Ym + o) = d2{am[0], am[1]};
+            *reinterpret_cast<d2*>(Ym + o + 2) = d2{am[2], am[3]};
+        } else {
+            *reinterpret_cast<xv4*>(Ya + o) = xv4{(float)oa[0], (float)oa[1], (float)oa[2], (float)oa[3]};
+            *reinterpret_cast<xv4*>(Yb + o) = xv4{(float)ob[0], (float)ob[1], (float)ob[2], (float)ob[3]};
+            *reinterpret_cast<xv4*>(Ym + o) = xv4{(float)am[0], (float)am[1], (float)am[2], (float)am[3]};
+        }
     }
 }
 
@@ -1253,8 +1263,28 @@ extern "C" int ds_spmm_f64_polish(const int32_t* rowptr, const int32_t* colidx, 
                "ds_spmm_f64_polish: rows must be 16-byte aligned");
     DS_REQUIRE(Ya != Yb && Ya != Ym && Yb != Ym, "ds_spmm_f64_polish: the three results must be different buffers");
     const unsigned nblk = (unsigned)ds::ceil_div(nv, 4);
-    spmm_f64_polish_kernel<<<nblk, 256, 0, ds::as_stream(stream)>>>(rowptr, colidx, a, b, m, nv, X, ldx, Ya, Yb, Ym, ldy,
-                                                                    ncols / 4, nblk);
+    spmm_f64_polish_kernel<double><<<nblk, 256, 0, ds::as_stream(stream)>>>(rowptr, colidx, a, b, m, nv, X, ldx, Ya, Yb, Ym, ldy,
+                                                                            ncols / 4, nblk);
     DS_LAUNCH_CHECK("spmm_f64_polish_kernel");
+    return DS_OK;
+}
+
+// the same products, stored as fp32 blocks (sums in fp64, one rounding)
+extern "C" int ds_spmm_f64_polish_f32out(const int32_t* rowptr, const int32_t* colidx, const double* a, const double* b,
+                                         const double* m, int64_t nv, const float* X, int64_t ldx, float* Ya, float* Yb,
+                                         float* Ym, int64_t ldy, int ncols, ds_stream_t stream) {
+    DS_REQUIRE(rowptr && colidx && a && b && m && X && Ya && Yb && Ym, "ds_spmm_f64_polish_f32out: null pointer");
+    DS_REQUIRE(nv > 0 && ncols > 0 && ncols % 4 == 0 && ncols <= 84, "ds_spmm_f64_polish_f32out: ncols must be a multiple of 4 <= 84");
+    DS_REQUIRE(ldx >= ncols && ldy >= ncols, "ds_spmm_f64_polish_f32out: leading dimension smaller than ncols");
+    const uintptr_t ya = reinterpret_cast<uintptr_t>(Ya) | reinterpret_cast<uintptr_t>(Yb) | reinterpret_cast<uintptr_t>(Ym) |
+                         (uintptr_t)(ldy * 4);
+    DS_REQUIRE(((reinterpret_cast<uintptr_t>(X) | (uintptr_t)(ldx * 4) | ya) & 15) == 0,
+               "ds_spmm_f64_polish_f32out: rows must be 16-byte aligned");
+    DS_REQUIRE(Ya != Yb && Ya != Ym && Yb != Ym && Ya != X && Yb != X && Ym != X,
+               "ds_spmm_f64_polish_f32out: X and the three results must be different buffers");
+    const unsigned nblk = (unsigned)ds::ceil_div(nv, 4);
+    spmm_f64_polish_kernel<float><<<nblk, 256, 0, ds::as_stream(stream)>>>(rowptr, colidx, a, b, m, nv, X, ldx, Ya, Yb, Ym, ldy,
+                                                                           ncols / 4, nblk);
+    DS_LAUNCH_CHECK("spmm_f64_polish_kernel<float>");
     return DS_OK;
 }

@@ -908,12 +908,19 @@ class _HipBlockOps:
             # K_lambda X, K_mu X and M_s X in one walk of the pattern (ds_spmm_f64_polish): one gather of X instead of three;
             # the three results sit side by side in ONE (n x 3c) block, so their Gram products with X are one launch that
             # reads X once (round 4; three launches before)
-            Y3 = self._scratch("polish3", (X.shape[0], 3 * c), torch.float64)
+            # The three results are fp64 blocks.  ``polish_f32_blocks`` (round 5, OFF): the same fp64 sums stored as fp32 blocks - half
+            # the bytes written here and read by the Gram launch, which then takes the fp32 matrix-core path (1.10 -> ~0.7 ms per
+            # pass at the benchmark size, 1.8 % of a pass).  Built, tested (tests/test_hip_kernels.py) and NOT adopted: the polish
+            # then returns eigenvalues and quadratic forms with ~3e-8 of relative noise instead of values accurate to second order
+            # in the iteration error (two solves whose fp32 blocks differ in rounding agreed to 3.6e-8 instead of < 1e-9) - inside
+            # the stated 1e-4, but a precision cut in the one stage whose job is precision
+            f64 = not bool(getattr(self, "polish_f32_blocks", False))
+            Y3 = self._scratch("polish3", (X.shape[0], 3 * c), torch.float64 if f64 else torch.float32)
             p = _hip.ptr
             ya, yb, ym = Y3[:, :c], Y3[:, c:2 * c], Y3[:, 2 * c:]
-            _hip.check(self._L.ds_spmm_f64_polish(p(self.rowptr), p(self.colidx), p(kterms[0][1]), p(kterms[1][1]), p(mvals),
-                                                  self.nv, p(X), _ld(X), p(ya), p(yb), p(ym), 3 * c, c, _hip.stream_ptr()),
-                       "ds_spmm_f64_polish")
+            fn = self._L.ds_spmm_f64_polish if f64 else self._L.ds_spmm_f64_polish_f32out
+            _hip.check(fn(p(self.rowptr), p(self.colidx), p(kterms[0][1]), p(kterms[1][1]), p(mvals),
+                          self.nv, p(X), _ld(X), p(ya), p(yb), p(ym), 3 * c, c, _hip.stream_ptr()), "ds_spmm_f64_polish")
             G3 = self.gram(X, Y3)
             return ([G3[:, :c].contiguous(), G3[:, c:2 * c].contiguous()], [kterms[0][2], kterms[1][2]],
                     G3[:, 2 * c:].contiguous())

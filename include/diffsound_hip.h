@@ -202,6 +202,12 @@ int ds_scalar_csr_spmm(const int32_t* rowptr, const int32_t* colidx, const float
 int ds_spmm_f64_polish(const int32_t* rowptr, const int32_t* colidx, const double* a, const double* b, const double* m,
                        int64_t nv, const float* X, int64_t ldx, double* Ya, double* Yb, double* Ym, int64_t ldy, int ncols,
                        ds_stream_t stream);
+/* The same three products stored as fp32 blocks (ABI 28): the sums are formed in fp64 and rounded once.  Halves what the
+ * kernel writes and the Gram product behind it reads; an OPTION of the eigensolver's polish (off by default: the polish then
+ * carries ~3e-8 of relative noise instead of being accurate to second order in the iteration error). */
+int ds_spmm_f64_polish_f32out(const int32_t* rowptr, const int32_t* colidx, const double* a, const double* b,
+                              const double* m, int64_t nv, const float* X, int64_t ldx, float* Ya, float* Yb, float* Ym,
+                              int64_t ldy, int ncols, ds_stream_t stream);
 int ds_pack_groups(const float* vals_t, const int32_t* kperm, int64_t nnzb, float* kgrp, ds_stream_t stream);
 /* Neighbour-union form of ds_spmm_bsr3 / ds_cheb_spmm / ds_spmm_residual for ncols <= 84 (the eigensolver's
  * b-column products and every preconditioner term): one wavefront per group of 4 consecutive nodes walks the UNION

@@ -919,14 +919,30 @@ def test_fused_polish_products_match_separate_launches(dev):
                                         X.stride(0), p(got[0]), p(got[1]), p(got[2]), c, c, _hip.stream_ptr()), "ds_spmm_f64_polish")
         for a, b in zip(got, ref):
             assert torch.equal(a, b)
-    # and through the ops: the read-out's Gram matrices are what the separate launches gave
+        # round 5: the same sums stored as fp32 blocks - exactly the fp64 results rounded once
+        got32 = torch.full((3, sysd.n, c), float("nan"), dtype=torch.float32, device=dev)
+        _hip.check(L.ds_spmm_f64_polish_f32out(p(sysd.rowptr), p(sysd.colidx), p(sysd.klam), p(sysd.kmu), p(sysd.ms), sysd.nv, p(X),
+                                               X.stride(0), p(got32[0]), p(got32[1]), p(got32[2]), c, c, _hip.stream_ptr()),
+                   "ds_spmm_f64_polish_f32out")
+        for a, b in zip(got32, ref):
+            assert torch.equal(a, b.float())
+    # and through the ops: with fp64 blocks (the default) the read-out's Gram matrices are bit for bit what the separate launches
+    # gave; with the optional fp32 blocks (fp32 matrix-core Gram behind them) they agree to ~1e-9 of |X_i| |Y_j|
     X = torch.randn((sysd.n, 64), generator=torch.Generator(device=dev).manual_seed(1), device=dev)
-    GK, coef, GM = ops.polish_products(X)
     Y = torch.empty((sysd.n, 64), dtype=torch.float64, device=dev)
-    for (kind, vals), G in zip(((2, sysd.klam), (2, sysd.kmu), (3, sysd.ms)), GK + [GM]):
-        ops._spmm(kind, vals, X, Y)
-        assert torch.equal(G, ops.gram(X, Y))
-    assert coef == list(ops.lame)
+    for f64 in (True, False):
+        ops.polish_f32_blocks = not f64
+        GK, coef, GM = ops.polish_products(X)
+        for (kind, vals), G in zip(((2, sysd.klam), (2, sysd.kmu), (3, sysd.ms)), GK + [GM]):
+            ops._spmm(kind, vals, X, Y)
+            ref_g = ops.gram(X, Y)
+            if f64:
+                assert torch.equal(G, ref_g)
+            else:
+                scale = torch.sqrt(torch.outer((X.double() ** 2).sum(0), (Y ** 2).sum(0)))
+                assert float(((G - ref_g).abs() / scale).max()) < 2e-8  # (few rows here: the 48-row folds average out at size)
+        assert coef == list(ops.lame)
+    ops.polish_f32_blocks = False
 
 
 def test_polish_products(case, dev):
