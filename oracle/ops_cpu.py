@@ -119,6 +119,31 @@ class CpuModalOps:
         out.copy_(torch.from_numpy(self.Md @ X.numpy()))
         self.counts["apply_M_cols"] += X.shape[1]
 
+    # -- the fused forms of the HIP operators (same signatures; round 5: with them the solver's Python loop takes the
+    #    Rayleigh-Ritz step on the raw basis on the CPU as well) ---------------------------------------------------------
+    fused = False  # set True to offer residual_fused / apply_KM (the stand-in of ds_union_residual / ds_spmm_union_km)
+
+    def residual_fused_ok(self, X, R):
+        return self.fused
+
+    def residual_fused(self, X, lam, R):
+        Xc = np.ascontiguousarray(X.numpy())
+        r = torch.from_numpy(self.Kd @ Xc) - torch.from_numpy(self.Md @ Xc) * lam.to(self.dtype)[None, :]
+        R.copy_(r)
+        self.counts["apply_K_cols"] += X.shape[1]
+        self.counts["apply_M_cols"] += X.shape[1]
+        return (r.double() ** 2).sum(0), (X.double() ** 2).sum(0)
+
+    def apply_KM_ok(self, X, KX, MX):
+        return self.fused
+
+    def apply_KM(self, X, KX, MX):
+        Xc = np.ascontiguousarray(X.numpy())
+        KX.copy_(torch.from_numpy(self.Kd @ Xc))
+        MX.copy_(torch.from_numpy(self.Md @ Xc))
+        self.counts["apply_K_cols"] += X.shape[1]
+        self.counts["apply_M_cols"] += X.shape[1]
+
     # -- tall-skinny dense ---------------------------------------------------------------
     def gram(self, A, B, symmetric=False):
         self.counts["gram"] += 1
