@@ -610,11 +610,11 @@ def main():
         dist.init_process_group(a.dist_backend, rank=rank, world_size=world)
     # host-thread budget of the node: every rank runs `lanes` hypothesis lanes, each ONE host thread that issues launches and solves
     # the <= 3b x 3b dense problems on ONE LAPACK thread (the lanes pin themselves, pipeline._lane_pool) - ranks x lanes threads
-    # in all, which must fit half the node's hardware threads (the other half: the runtime's own threads, RCCL's proxies)
+    # in all; they should fit half the node's hardware threads (the other half: the runtime's own threads, RCCL's proxies)
     hw_threads = os.cpu_count() or 1
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world))
-    if a.lanes * local_world > max(1, hw_threads // 2):
-        raise SystemExit(f"bench.py: {local_world} ranks x {a.lanes} lanes = {a.lanes * local_world} host threads exceed half of the "
+    if a.lanes * local_world > hw_threads:  # (outright oversubscription; between a half and all of them the line says so)
+        raise SystemExit(f"bench.py: {local_world} ranks x {a.lanes} lanes = {a.lanes * local_world} host threads exceed the "
                          f"node's {hw_threads} hardware threads; lower --lanes")
 
     def barrier():
@@ -1041,7 +1041,8 @@ def main():
             "process_group": ({"backend": dist.get_backend(), "world_size": dist.get_world_size(),
                                "is_rccl": dist.get_backend() == "nccl"} if world > 1 else None),
             "host_threads": {"hardware_threads": hw_threads, "ranks_on_node": local_world, "lanes_per_rank": min(a.lanes, a.hyp_per_gpu),
-                             "lane_threads_on_node": local_world * min(a.lanes, a.hyp_per_gpu), "lapack_threads_per_lane": 1},
+                             "lane_threads_on_node": local_world * min(a.lanes, a.hyp_per_gpu), "lapack_threads_per_lane": 1,
+                             "within_half_of_hardware_threads": local_world * min(a.lanes, a.hyp_per_gpu) <= hw_threads // 2},
         }
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.cpu_sample_cells, a.order, a.modes, sysd.T, a.cpu_reps, a.cpu_second_cells)
