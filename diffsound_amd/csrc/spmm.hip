@@ -1117,7 +1117,7 @@ static int launch_mfma(int epilogue, int y_f32, const int32_t* gptr, const int32
 
 // entries per batch on the corner-node level (level_tag 1): DS_MF_BATCH, or twice that (one wave's chain of dependent round
 // trips is what a level with about as many groups as the device has wave slots is made of; measured at C3's corner level,
-// 2 461 groups: see DESIGN.md section 6)
+// 2 461 groups: see profiles/r04_corner_batch_ab.txt)
 #ifndef DS_MF_CORNER_BATCH
 #define DS_MF_CORNER_BATCH DS_MF_BATCH
 #endif

@@ -950,7 +950,7 @@ class HipModalOps(_HipBlockOps):
     # the VALU neighbour-union kernel.  OFF: built, parity-green and measured in round 4 - at C3 K X takes 263 us against
     # 229 us (M X 246 against 151): v_mfma_f32_16x16x4_f32 runs at the fp32 VECTOR rate and the 16 x 4 tile of 3x3 blocks on
     # a 4-node union is 3/4 x 0.43 full, so the matrix pipe needs 125-150 us for what the VALU does in 40, on top of the
-    # LDS staging the form requires (DESIGN.md section 6, profiles/r04_mfma32_*.txt)
+    # LDS staging the form requires (DESIGN.md section 4, profiles/r04_mfma32_*.txt)
     mfma32 = False
 
     def __init__(self, system: TetSystem, lam, mu, two_level=None, _level=0, mfma_groups=None, mfma32=None):

@@ -81,7 +81,7 @@ def test_c5_workload_line(ndev):
 def test_loss_is_bit_identical_across_runs(ndev, one_rank):
     """Concurrent hypothesis lanes on separate streams must not change a single bit of any pass: the loss sum of a
     second, identical run equals the first exactly (the check that exposed the MFMA / packed-FMA interaction of
-    DESIGN.md 5b in round 2), here with 4 lanes on a mesh large enough for the lanes' kernels to overlap."""
+    DESIGN.md section 4; found in round 2), here with 4 lanes on a mesh large enough for the lanes' kernels to overlap."""
     args = ["--gpus", "1", "--hyp-per-gpu", "8", "--lanes", "4", "--steps", "2", "--warmup", "0", "--cells", "12", "--modes", "32",
             "--block", "40", "--no-cpu-baseline", "--amortised-cycle", "0"]
     a, b = _bench(*args), _bench(*args)
