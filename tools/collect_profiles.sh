@@ -11,7 +11,9 @@
 #   <tag>_symbolic_phase_timing.txt     tools/time_lift.py: ord-2 lifting + symbolic phase per topology, warm
 #   <tag>_c5_bench.json / _c5_kernel_stats.csv   bench.py --workload c5 (configs[4]) under rocprofv3 --kernel-trace --stats
 #   <tag>_mb_kx.txt / _mb_corner.txt / _m32_diag.txt   the eigensolver's own products alone, the corner-node level, per-wave cycles
-# Copy what is to be judged into profiles/.
+# Copy what is to be judged into profiles/ - in particular <tag>_spmm_pmc_bytes_per_launch.json -> profiles/spmm_pmc_bytes_per_launch.json
+# and <tag>_gram_mix_mfma_util.json -> profiles/gram_mix_mfma_util.json (the two records bench.py quotes, keyed by source hashes: collect
+# part 2 AFTER the last change to the kernel sources / modal_ops.py, then part 1, so that the bench line carries them).
 # A gpurun call is capped at 20 minutes: tools/collect_profiles.sh <tag> <part>, part = 1 (the bench line), 1b (rocprofv3 kernel
 # tables of the 8-lane / one-lane / kernel-alone runs + busy fraction), 2 (PMC passes, microbenchmarks, diagnostics),
 # 3 (configs[4]) or all.
