@@ -454,11 +454,14 @@ def main_c5(a):
     try:
         ops.apply_K64(X64, Y64)  # (forms the combined array)
         record("K X fp64 values and vectors, 80 columns", nnzb * 76 + (nv + 1) * 4 + 2 * n * 80 * 8,
-               timed(lambda: ops.apply_K64(X64, Y64), 2), "one spmm_f64_node launch on the combined fp64 K array: the refinement's K W")
+               timed(lambda: ops.apply_K64(X64, Y64), 2),
+               "spmm_f64_union_kernel<0> on the combined fp64 K array in group order: the refinement's K W (round 5; the wave-per-node kernel before)")
+        record("M X fp64 values and vectors, 80 columns", nnzb * 12 + (nv + 1) * 4 + 2 * n * 80 * 8,
+               timed(lambda: ops.apply_M64(X64, Y64), 2), "spmm_f64_union_kernel<1>, node-scalar values: the refinement's M W")
     finally:
         ops.combined_k64(False)
-    record("M X fp64 values and vectors, 80 columns", nnzb * 12 + (nv + 1) * 4 + 2 * n * 80 * 8,
-           timed(lambda: ops.apply_M64(X64, Y64), 2), "spmm_f64_node, node-scalar values")
+    record("M X fp64 values and vectors, 80 columns, wave-per-node kernel", nnzb * 12 + (nv + 1) * 4 + 2 * n * 80 * 8,
+           timed(lambda: ops.apply_M64(X64, Y64), 2), "spmm_f64_node, node-scalar values (outside the refinement)")
     del X64, Y64
     torch.cuda.empty_cache()
     # ---- the solve

@@ -35,6 +35,7 @@ _SIGNATURES = {
     "ds_dpattern_export": (_I, [_P] * 13),
     "ds_dpattern_free": (None, [_P]),
     "ds_spmm_f64_polish": (_I, [_P, _P, _P, _P, _P, _I64, _P, _I64, _P, _P, _P, _I64, _I, _P]),
+    "ds_spmm_f64_union": (_I, [_I, _I, _P, _P, _I64, _I, _P, _P, _I64, _I64, _P, _I64, _P, _I64, _I, _P]),
     "ds_spmm_f64_polish_f32out": (_I, [_P, _P, _P, _P, _P, _I64, _P, _I64, _P, _P, _P, _I64, _I, _P]),
     "ds_pack_kc": (_I, [_P, _P, _I64, _P, _P]),
     "ds_spmm_union16m": (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _I64, _I64, _I, _I, _I64, _P, _I64, _P, _I64, _I, _P, _I64, _P, _I, _F,
@@ -67,6 +68,9 @@ _SIGNATURES = {
     "ds_union_residual": (_I, [_I, _P, _P, _I64, _I, _P, _P, _P, _I64, _I64, _P, _I64, _P, _P, _I64, _I, _P, _I64, _P, _P, _P]),
     "ds_mix": (_I, [_P, _I64, _I, _P, _I, _P, _I64, _I64, _F, _F, _P]),
     "ds_gram64_blocks": (_I, [_I, _P, _I, _P, _I64, _I, _P, _P, _I64, _P]),
+    "ds_residual64_workspace_doubles": (_I64, [_I]),
+    "ds_residual64_norms": (_I, [_P, _I64, _P, _I64, _P, _I64, _P, _I64, _I, _P, _I64, _P, _P, _P]),
+    "ds_residual64_scaled": (_I, [_P, _I64, _P, _I64, _P, _P, _P, _I, _P, _I64, _I64, _P]),
     "ds_mix64": (_I, [_I, _P, _P, _I64, _I, _P, _I64, _I64, _D, _D, _P]),
     "ds_osc_bank_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _D, _P, _P]),
     "ds_osc_bank_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _D, _P, _P, _P, _P, _P]),

@@ -378,6 +378,7 @@ int launch_wn(const int32_t* rowptr, const int32_t* colidx, const void* vals, co
 #include "spmm_mfma.inc"
 #include "spmm_mfma32.inc"
 #include "spmm_narrow.inc"
+#include "spmm_f64_union.inc"
 
 template <int KIND>
 int launch_fast(const int32_t* rowptr, const int32_t* colidx, const void* vals, const void* vals_t, int64_t nv,
@@ -452,7 +453,7 @@ __global__ void __launch_bounds__(256)
             constexpr int NSL = (F64_CHUNK * 9 + 63) / 64;
             double stg[NSL];
 #pragma unroll
-            for (int i = 0; i < NSL; ++i) stg[i] = pv[min(lane + 64 * i, cnt * 9 - 1)];
+            for (int i = 0; i < NSL; ++i) stg[i] = __builtin_nontemporal_load(pv + min(lane + 64 * i, cnt * 9 - 1));  // (read once: spmm_union.inc)
 #pragma unroll
             for (int i = 0; i < NSL; ++i)
                 if (lane + 64 * i < cnt * 9) sv[lane + 64 * i] = stg[i];
@@ -514,8 +515,8 @@ __global__ void __launch_bounds__(256)
     }
     if (active) {
         double* yp = Y + (node * 3 + g) * ldy + cl * 4;
-        *reinterpret_cast<d2*>(yp) = d2{out[0], out[1]};
-        *reinterpret_cast<d2*>(yp + 2) = d2{out[2], out[3]};
+        __builtin_nontemporal_store(d2{out[0], out[1]}, reinterpret_cast<d2*>(yp));  // (written once)
+        __builtin_nontemporal_store(d2{out[2], out[3]}, reinterpret_cast<d2*>(yp + 2));
     }
 }
 
@@ -573,7 +574,7 @@ __global__ void __launch_bounds__(256)
 #pragma unroll
             for (int i = 0; i < NSL; ++i) {
                 const int t = min(lane + 64 * i, cnt * 9 - 1);
-                ra[i] = pa[t], rb[i] = pb[t];
+                ra[i] = __builtin_nontemporal_load(pa + t), rb[i] = __builtin_nontemporal_load(pb + t);  // (read once)
             }
             const double rm = vm[kc + min(lane, cnt - 1)];
 #pragma unroll
@@ -653,12 +654,12 @@ __global__ void __launch_bounds__(256)
     if (active) {
         const int64_t o = (node * 3 + g) * ldy + cl * 4;
         if constexpr (sizeof(TY) == 8) {
-            *reinterpret_cast<d2*>(Ya + o) = d2{oa[0], oa[1]};
-            *reinterpret_cast<d2*>(Ya + o + 2) = d2{oa[2], oa[3]};
-            *reinterpret_cast<d2*>(Yb + o) = d2{ob[0], ob[1]};
-            *reinterpret_cast<d2*>(Yb + o + 2) = d2{ob[2], ob[3]};
-            *reinterpret_cast<d2*>(Ym + o) = d2{am[0], am[1]};
-            *reinterpret_cast<d2*>(Ym + o + 2) = d2{am[2], am[3]};
+            __builtin_nontemporal_store(d2{oa[0], oa[1]}, reinterpret_cast<d2*>(Ya + o));  // (written once)
+            __builtin_nontemporal_store(d2{oa[2], oa[3]}, reinterpret_cast<d2*>(Ya + o + 2));
+            __builtin_nontemporal_store(d2{ob[0], ob[1]}, reinterpret_cast<d2*>(Yb + o));
+            __builtin_nontemporal_store(d2{ob[2], ob[3]}, reinterpret_cast<d2*>(Yb + o + 2));
+            __builtin_nontemporal_store(d2{am[0], am[1]}, reinterpret_cast<d2*>(Ym + o));
+            __builtin_nontemporal_store(d2{am[2], am[3]}, reinterpret_cast<d2*>(Ym + o + 2));
         } else {
             *reinterpret_cast<xv4*>(Ya + o) = xv4{(float)oa[0], (float)oa[1], (float)oa[2], (float)oa[3]};
             *reinterpret_cast<xv4*>(Yb + o) = xv4{(float)ob[0], (float)ob[1], (float)ob[2], (float)ob[3]};
@@ -1249,6 +1250,38 @@ extern "C" int ds_mf_diag(unsigned long long* out, int nwaves) {  // the bf16 te
     return ds::check_hip(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_mf_dbg), (size_t)nwaves * 8 * sizeof(unsigned long long)), "ds_mf_diag read");
 }
 #endif
+
+// fp64 values (and fp64 or fp32 vectors) on the neighbour-union tables (spmm_f64_union.inc): the fp64 refinement's K W / M W
+extern "C" int ds_spmm_f64_union(int kind, int x_f64, const int32_t* utab, const int32_t* ctab, int64_t ngroups, int cap_blocks,
+                                 const int32_t* gent, const double* vals, int64_t nnzb, int64_t nv, const void* X, int64_t ldx,
+                                 double* Y, int64_t ldy, int ncols, ds_stream_t stream) {
+    DS_REQUIRE(ctab && gent && vals && X && Y, "ds_spmm_f64_union: null pointer");
+    DS_REQUIRE(kind == 0 || kind == 1, "ds_spmm_f64_union: kind must be 0 (3x3 blocks in group order, transposed) or 1 (node scalars)");
+    DS_REQUIRE(nv > 0 && ngroups == (nv + 3) / 4 && nnzb > 0 && ncols > 0 && ncols % 4 == 0 && ncols <= 84,
+               "ds_spmm_f64_union: ncols must be a multiple of 4 <= 84 and ngroups = ceil(nv / 4)");
+    DS_REQUIRE(cap_blocks > 0 && cap_blocks <= DS_UNION_CAP, "ds_spmm_f64_union: a chunk of %d blocks exceeds the LDS image", cap_blocks);
+    DS_REQUIRE(ldx >= ncols && ldy >= ncols, "ds_spmm_f64_union: leading dimension smaller than ncols");
+    DS_REQUIRE(static_cast<const void*>(Y) != X, "ds_spmm_f64_union: X and Y must be different buffers");
+    const int xb = x_f64 ? 8 : 4;
+    DS_REQUIRE(((reinterpret_cast<uintptr_t>(X) | (uintptr_t)(ldx * xb) | reinterpret_cast<uintptr_t>(Y) | (uintptr_t)(ldy * 8) |
+                 reinterpret_cast<uintptr_t>(ctab)) & 15) == 0, "ds_spmm_f64_union: rows and ctab must be 16-byte aligned");
+    hipStream_t st = ds::as_stream(stream);
+    const unsigned nwg = (unsigned)ds::ceil_div(ngroups, 4);
+    const int lpn = ncols / 4;
+    const int2* ut = reinterpret_cast<const int2*>(utab);
+    const int4* ct = reinterpret_cast<const int4*>(ctab);
+#define DS_F64U(K, T) spmm_f64_union_kernel<K, T><<<nwg, 256, 0, st>>>(ut, ct, (unsigned)ngroups, gent, vals, nv, static_cast<const T*>(X), ldx, Y, ldy, lpn, nwg)
+    if (kind == 0) {
+        if (x_f64) DS_F64U(0, double);
+        else DS_F64U(0, float);
+    } else {
+        if (x_f64) DS_F64U(1, double);
+        else DS_F64U(1, float);
+    }
+#undef DS_F64U
+    DS_LAUNCH_CHECK("spmm_f64_union_kernel");
+    return DS_OK;
+}
 
 // Ya = A X, Yb = B X (fp64 3x3 block values), Ym = (m (x) I3) X (fp64 node scalars) for one fp32 block X in one walk.
 extern "C" int ds_spmm_f64_polish(const int32_t* rowptr, const int32_t* colidx, const double* a, const double* b,

@@ -887,9 +887,15 @@ class ModalSolver:
         since = refresh  # the first step forms everything from the vectors
         hist = []
         for it in range(cfg.refine_maxit + 1):
-            R = torch.addcmul(KX, MX, lam[None, :], value=-1.0)
-            rn = torch.linalg.vector_norm(R, dim=0)
-            rel = rn / (torch.linalg.vector_norm(X, dim=0) * (A_norm + lam.abs() * B_norm))
+            fused64 = hasattr(ops, "residual64")  # (the HIP operators: norms in one pass, no fp64 residual block)
+            if fused64:
+                rn2, xn2 = ops.residual64(KX, MX, X, lam)
+                rn, R = torch.sqrt(rn2), None
+                rel = rn / (torch.sqrt(xn2) * (A_norm + lam.abs() * B_norm))
+            else:
+                R = torch.addcmul(KX, MX, lam[None, :], value=-1.0)
+                rn = torch.linalg.vector_norm(R, dim=0)
+                rel = rn / (torch.linalg.vector_norm(X, dim=0) * (A_norm + lam.abs() * B_norm))
             worst = float(rel[:k].max())
             hist.append(worst)
             if worst < cfg.refine_tol or it == cfg.refine_maxit:
@@ -904,7 +910,10 @@ class ModalSolver:
                 pad = rest_[torch.argsort(rel[rest_], descending=True)[:4 - idx.numel() % 4]]
                 idx = torch.sort(torch.cat([idx, pad])).values
             # W = B R in fp32 (columns scaled to unit norm: the preconditioner is linear), promoted to fp64
-            R32 = (R[:, idx] / rn[idx].clamp(min=1e-300)[None, :]).float().contiguous()
+            if fused64:
+                R32 = ops.residual64_scaled(KX, MX, lam, 1.0 / rn.clamp(min=1e-300), idx)
+            else:
+                R32 = (R[:, idx] / rn[idx].clamp(min=1e-300)[None, :]).float().contiguous()
             W32 = torch.empty_like(R32)
             self.precond_apply(R32, W32)
             for _ in range(max(0, int(getattr(cfg, "refine_sweeps", 1)) - 1)):

@@ -715,6 +715,37 @@ class _HipBlockOps:
         self.counts["mix64"] += 1
         return out
 
+    # ------------------------------------------------------------------ fp64 refinement: fused element-wise passes
+    def residual64(self, KX, MX, X, lam):
+        """(||K x_j - lam_j M x_j||^2, ||x_j||^2) of every column of the fp64 blocks in ONE pass (ds_residual64_norms)."""
+        b = X.shape[1]
+        if b % 2 or b > 512 or any(t.dtype != torch.float64 or t.stride(1) != 1 or (t.data_ptr() | (t.stride(0) * 8)) % 16
+                                   for t in (KX, MX, X)):
+            R = torch.addcmul(KX, MX, lam[None, :], value=-1.0)
+            return (R * R).sum(0), (X * X).sum(0)
+        pp = _hip.ptr
+        need = self._L.ds_residual64_workspace_doubles(b)
+        ws = self._scratch("residual64_ws", (need,), torch.float64)
+        out = torch.empty((2, b), dtype=torch.float64, device=self.device)
+        lam = lam.to(torch.float64).contiguous()
+        _hip.check(self._L.ds_residual64_norms(pp(KX), _ld(KX), pp(MX), _ld(MX), pp(X), _ld(X), pp(lam), self.n, b, pp(ws), need,
+                                               pp(out[0]), pp(out[1]), _hip.stream_ptr()), "ds_residual64_norms")
+        return out[0], out[1]
+
+    def residual64_scaled(self, KX, MX, lam, scale, idx):
+        """(n x len(idx)) fp32 block of the residual columns ``idx`` of the fp64 blocks, each times ``scale[col]``
+        (ds_residual64_scaled): the scaled input of the fp32 preconditioner, without an fp64 residual block in between."""
+        nact = int(idx.numel())
+        if nact % 4:
+            raise ValueError("residual64_scaled: a multiple of 4 columns")
+        pp = _hip.ptr
+        R = torch.empty((self.n, nact), dtype=torch.float32, device=self.device)
+        cols = idx.to(torch.int32).contiguous()
+        lam, scale = lam.to(torch.float64).contiguous(), scale.to(torch.float64).contiguous()
+        _hip.check(self._L.ds_residual64_scaled(pp(KX), _ld(KX), pp(MX), _ld(MX), pp(lam), pp(scale), pp(cols), nact, pp(R), nact,
+                                                self.n, _hip.stream_ptr()), "ds_residual64_scaled")
+        return R
+
     def mix_inplace(self, W, T):
         if T.shape[1] <= 160:  # ds_mix reads a row tile completely before writing it
             self.mix(W, T, W)
@@ -865,6 +896,7 @@ class _HipBlockOps:
                                             _ld(xs), p(os_), _ld(os_), c1 - c0, _hip.stream_ptr()), "ds_spmm_bsr3(f64)")
 
     _k64 = None
+    _k64grp = _m64grp = None  # the combined fp64 K / the fp64 mass scalars in the union tables' group order (ds_spmm_f64_union)
 
     def combined_k64(self, on):
         """fp64 refinement: while ``on``, ``apply_K64`` multiplies by ONE fp64 block array K = sum c_i K_i, formed on the
@@ -872,12 +904,44 @@ class _HipBlockOps:
         The caller brackets a phase in which neither the material nor the assembled terms change, and switches it off
         afterwards (the array is released)."""
         self._k64 = False if on else None
+        self._k64grp = self._m64grp = None
+
+    def _union64_ok(self, X, out):
+        g = getattr(getattr(self, "sys", None), "groups", None)
+        return (g is not None and g.get("union") is not None and X.dtype == torch.float64 and out.dtype == torch.float64
+                and X.shape == out.shape and X.shape[1] % 4 == 0 and X.stride(1) == 1 and out.stride(1) == 1
+                and (X.data_ptr() | (X.stride(0) * 8) | out.data_ptr() | (out.stride(0) * 8)) % 16 == 0)
+
+    def _union64(self, kind, vals_grp, X, out):
+        """out (fp64) <- A X on the neighbour-union tables (ds_spmm_f64_union), values in group order; column slices of <= 84."""
+        pp = _hip.ptr
+        g, u = self.sys.groups, self.sys.groups["union"]
+        for c0, c1 in self.col_slices(X.shape[1]):
+            xs, os_ = X[:, c0:c1], out[:, c0:c1]
+            _hip.check(self._L.ds_spmm_f64_union(kind, 1, None if u.get("single") else pp(u["utab"]), pp(u["ctab"]), u["ngroups"],
+                                                 u["capb"], pp(g["gent"]), pp(vals_grp), vals_grp.shape[0], self.nv, pp(xs), _ld(xs),
+                                                 pp(os_), _ld(os_), c1 - c0, _hip.stream_ptr()), "ds_spmm_f64_union")
 
     def apply_K64(self, X, out, terms=False):
         """out <- K X, all fp64 (fp64 block values).  ``terms``: also return the list of the separate K_i X."""
         kterms, _ = self.polish_terms()
         if self._k64 is not None and not terms and len({kt[0] for kt in kterms}) == 1:
             if self._k64 is False:
+                k = kterms[0][1] * float(kterms[0][2])
+                for _, vals, c in kterms[1:]:
+                    k.add_(vals, alpha=float(c))
+                if kterms[0][0] == 2 and self._union64_ok(X, out):
+                    # round 5: the combined array in the union tables' group order, blocks transposed - the refinement's K W then
+                    # walks the unions of 4 rows (ds_spmm_f64_union) instead of gathering every neighbour's panel once per row
+                    kp = self.sys.groups["kperm64"]
+                    self._k64grp = k[kp].reshape(-1, 3, 3).transpose(1, 2).reshape(-1, 9).contiguous()
+                    self._m64grp = None
+                    k = True  # (the BSR-order array is not kept beside it)
+                self._k64 = k
+            if self._k64 is True and self._union64_ok(X, out):
+                self._union64(0, self._k64grp, X, out)
+                return []
+            if self._k64 is True:  # (a block the union kernel does not take: the BSR-order array after all)
                 k = kterms[0][1] * float(kterms[0][2])
                 for _, vals, c in kterms[1:]:
                     k.add_(vals, alpha=float(c))
@@ -896,6 +960,12 @@ class _HipBlockOps:
 
     def apply_M64(self, X, out):
         _, (mkind, mvals) = self.polish_terms()
+        if self._k64 is not None and self._k64 is not False and mkind == 3 and getattr(self, "_k64grp", None) is not None \
+                and self._union64_ok(X, out):
+            if self._m64grp is None:  # (inside a combined_k64 phase the assembled terms do not change)
+                self._m64grp = mvals[self.sys.groups["kperm64"]].contiguous()
+            self._union64(1, self._m64grp, X, out)
+            return
         self._spmm64(mkind, mvals, X, out)
 
     def rigid64(self):
@@ -995,7 +1065,7 @@ class HipModalOps(_HipBlockOps):
             self.coarse.set_material(lam, mu)
         p = _hip.ptr
         self.lame = (float(lam), float(mu))
-        self._k64 = None  # (a combined fp64 K array of the previous material must never outlive it)
+        self._k64 = self._k64grp = self._m64grp = None  # (a combined fp64 K array of the previous material must never outlive it)
         _hip.check(self._L.ds_combine_material(p(s.klam), p(s.kmu), p(s.ms), s.nnzb, p(s.diagidx), s.nv,
                                                float(lam), float(mu), p(self.k32), p(self.k32t), p(self.ms32),
                                                p(self.dinv), _hip.stream_ptr()), "ds_combine_material")

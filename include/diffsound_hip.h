@@ -202,6 +202,15 @@ int ds_scalar_csr_spmm(const int32_t* rowptr, const int32_t* colidx, const float
 int ds_spmm_f64_polish(const int32_t* rowptr, const int32_t* colidx, const double* a, const double* b, const double* m,
                        int64_t nv, const float* X, int64_t ldx, double* Ya, double* Yb, double* Ym, int64_t ldy, int ncols,
                        ds_stream_t stream);
+/* fp64 values with fp64 (x_f64 != 0) or fp32 vectors on the neighbour-union tables of ds_spmm_union (ABI 28): Y (fp64) = A X for a
+ * block of <= 84 columns, one wave per group of 4 nodes walking the union of their neighbours - the fp64 refinement's K W / M W
+ * (ds_spmm_bsr3 kinds 4 / 5 gather every neighbour's panel once per ROW: 2.2 x the panels).  vals: kind 0 = the 3x3 blocks in
+ * the tables' group order, TRANSPOSED (vals[p][g][i] = A_block[i][g], 9 doubles per block, i.e. ds_pack_groups' layout in fp64);
+ * kind 1 = node scalars in that order (A = a (x) I3).  Equal to ds_spmm_bsr3's results to fp64 rounding (another summation order).
+ * (reference: torch.sparse.mm of src/lobpcg/_linalg_utils.py:36-37 in fp64) */
+int ds_spmm_f64_union(int kind, int x_f64, const int32_t* utab, const int32_t* ctab, int64_t ngroups, int cap_blocks,
+                      const int32_t* gent, const double* vals, int64_t nnzb, int64_t nv, const void* X, int64_t ldx, double* Y,
+                      int64_t ldy, int ncols, ds_stream_t stream);
 /* The same three products stored as fp32 blocks (ABI 28): the sums are formed in fp64 and rounded once.  Halves what the
  * kernel writes and the Gram product behind it reads; an OPTION of the eigensolver's polish (off by default: the polish then
  * carries ~3e-8 of relative noise instead of being accurate to second order in the iteration error). */
@@ -442,6 +451,20 @@ int ds_lobpcg_iterate(ds_lobpcg_t* p, const ds_lapack_t* lapack, ds_stream_t str
  * written.  (reference: X <- S Z etc., _lobpcg.py:463-466) */
 int ds_mix(const float* A, int64_t lda, int p, const float* C, int q, float* Out, int64_t ldo,
            int64_t n, float alpha, float beta, ds_stream_t stream);
+
+/* Element-wise passes of the fp64 refinement fused (ABI 28, csrc/refine64.hip; reference: update_residual /
+ * update_converged_count of src/lobpcg/_lobpcg.py:301-333 in fp64).  KX, MX, X: (n x b) fp64 blocks, b even <= 512, rows 16-byte
+ * aligned; lam: b Ritz values on the device.
+ *   ds_residual64_norms   rn2[j] = ||K x_j - lam_j M x_j||^2, xn2[j] = ||x_j||^2 in ONE pass over the three blocks (no residual
+ *                         block is written); work: ds_residual64_workspace_doubles(b) doubles; fixed-order sums
+ *   ds_residual64_scaled  R (n x nact fp32, nact a multiple of 4) = the residual columns cols[0 .. nact) (ascending or not),
+ *                         each multiplied by scale[col] (e.g. 1 / its norm): the input of the fp32 preconditioner */
+int64_t ds_residual64_workspace_doubles(int b);
+int ds_residual64_norms(const double* KX, int64_t ldk, const double* MX, int64_t ldm, const double* X, int64_t ldx,
+                        const double* lam, int64_t n, int b, double* work, int64_t work_doubles, double* rn2, double* xn2,
+                        ds_stream_t stream);
+int ds_residual64_scaled(const double* KX, int64_t ldk, const double* MX, int64_t ldm, const double* lam, const double* scale,
+                         const int32_t* cols, int nact, float* R, int64_t ldr, int64_t n, ds_stream_t stream);
 
 /* A basis held as a list of fp64 blocks (ds_gram64_blocks, ds_mix64). */
 #define DS_MIX64_MAX_BLOCKS 4

@@ -737,6 +737,92 @@ def test_narrow_union_kernel_matches_the_production_kernel(dev, mesh, order, nco
     torch.cuda.synchronize()
 
 
+@pytest.mark.parametrize("n,b", [(30000, 136), (4999, 80), (777, 6), (64, 2)])
+def test_fused_fp64_residual_passes_match_torch(dev, n, b):
+    """csrc/refine64.hip (round 5): the fp64 refinement's element-wise passes - residual norms and ||x|| of every column in ONE pass
+    over K X, M X, X (ds_residual64_norms), the scaled fp32 residual columns of an index list in ONE more (ds_residual64_scaled) -
+    against the torch formulation they replace (addcmul, two norms, column gather, division, cast); operands are column ranges of
+    wider buffers; the norms are reproducible to the last bit."""
+    from diffsound_amd.modal_ops import _HipBlockOps
+
+    ops = _HipBlockOps()
+    ops._init_common(None, None, (n + 2) // 3, dev)
+    ops.n = n
+    g = torch.Generator(device=dev).manual_seed(n + b)
+    wide = [torch.randn((n, b + 6), generator=g, device=dev, dtype=torch.float64) for _ in range(3)]
+    KX, MX, X = (w[:, 2:2 + b] for w in wide)
+    lam = torch.rand(b, generator=g, device=dev, dtype=torch.float64) * 3 + 0.5
+    R = torch.addcmul(KX, MX, lam[None, :], value=-1.0)
+    rn2, xn2 = ops.residual64(KX, MX, X, lam)
+    assert float(((rn2 - (R * R).sum(0)) / (R * R).sum(0)).abs().max()) < 1e-13
+    assert float(((xn2 - (X * X).sum(0)) / (X * X).sum(0)).abs().max()) < 1e-13
+    a2, b2 = ops.residual64(KX, MX, X, lam)
+    assert torch.equal(a2, rn2) and torch.equal(b2, xn2)
+    if b >= 4:
+        idx = torch.arange(b, device=dev)[torch.randperm(b, generator=g, device=dev)[:(b // 4) * 4 // 2 * 2 or 4]]
+        idx = torch.sort(idx[:(idx.numel() // 4) * 4]).values
+        scale = 1.0 / torch.sqrt(rn2)
+        got = ops.residual64_scaled(KX, MX, lam, scale, idx)
+        ref = (R[:, idx] * scale[idx][None, :])
+        assert got.dtype == torch.float32 and got.shape == (n, idx.numel())
+        assert float((got.double() - ref).abs().max()) < 2e-7 * float(ref.abs().max())  # one fp32 rounding (fma in the kernel)
+
+
+@pytest.mark.parametrize("mesh,order,ncols", [(6, 2, 80), (6, 2, 72), (6, 2, 8), (10, 2, 80), (3, 2, 4), (12, 1, 80), (5, 1, 24)])
+def test_fp64_union_spmm_matches_the_node_kernel(dev, mesh, order, ncols):
+    """ds_spmm_f64_union (round 5: fp64 values and fp64 / fp32 vectors on the neighbour-union tables, one wave per 4 nodes) against the
+    wave-per-node kernels of ds_spmm_bsr3 (kinds 4 / 5, and 2 / 3 for an fp32 X): equal to fp64 rounding of another summation order
+    (1e-13 of the row's scale); written into a column range of a wider buffer, nothing else touched; and through the operators - inside
+    a combined_k64 phase apply_K64 / apply_M64 take it (136 columns: two slices)."""
+    from diffsound_amd import _hip, meshgen
+    from diffsound_amd.diffelastic.mesh import TetMesh
+    from diffsound_amd.modal_ops import HipModalOps, TetSystem
+
+    v, t = meshgen.kuhn_box(mesh)
+    tm = TetMesh(torch.from_numpy(v).to(dev), torch.from_numpy(t).long().to(dev)).to_high_order(order)
+    sysd = TetSystem(tm.vertices, tm.tets, order, 2700.0)
+    ops = HipModalOps(sysd, 2e10, 3e10, two_level=False)
+    L, p = _hip.lib(), _hip.ptr
+    gr, u = sysd.groups, sysd.groups["union"]
+    kp = gr["kperm64"]
+    k64 = 2e10 * sysd.klam + 3e10 * sysd.kmu
+    kgrp = k64[kp].reshape(-1, 3, 3).transpose(1, 2).reshape(-1, 9).contiguous()
+    mgrp = sysd.ms[kp].contiguous()
+    g = torch.Generator(device=dev).manual_seed(mesh * 10 + ncols)
+    for xdt in (torch.float64, torch.float32):
+        big = torch.full((sysd.n, ncols + 12), float("nan"), dtype=xdt, device=dev)
+        X = big[:, 4:4 + ncols]
+        X.copy_(torch.randn((sysd.n, ncols), generator=g, device=dev, dtype=torch.float64).to(xdt))
+        for kind, vals_grp, vals_bsr, bkind in ((0, kgrp, k64, 4 if xdt == torch.float64 else 2), (1, mgrp, sysd.ms, 5 if xdt == torch.float64 else 3)):
+            ref = torch.empty((sysd.n, ncols), dtype=torch.float64, device=dev)
+            _hip.check(L.ds_spmm_bsr3(bkind, p(sysd.rowptr), p(sysd.colidx), p(vals_bsr), None, sysd.nv, p(X), X.stride(0), p(ref),
+                                      ref.stride(0), ncols, _hip.stream_ptr()), "ds_spmm_bsr3")
+            wide = torch.full((sysd.n, ncols + 4), float("nan"), dtype=torch.float64, device=dev)
+            Y = wide[:, 2:2 + ncols]
+            rc = L.ds_spmm_f64_union(kind, int(xdt == torch.float64), None if u["single"] else p(u["utab"]), p(u["ctab"]), u["ngroups"],
+                                     u["capb"], p(gr["gent"]), p(vals_grp), vals_grp.shape[0], sysd.nv, p(X), X.stride(0), p(Y),
+                                     Y.stride(0), ncols, _hip.stream_ptr())
+            assert rc == 0, L.ds_last_error()
+            assert bool(torch.isnan(wide[:, :2]).all()) and bool(torch.isnan(wide[:, 2 + ncols:]).all())
+            assert float((Y - ref).abs().max()) < 1e-13 * float(ref.abs().max()), (xdt, kind)
+    # through the operators, a block wider than one launch takes
+    X = torch.randn((sysd.n, 136), generator=g, device=dev, dtype=torch.float64)
+    refK, refM = torch.empty_like(X), torch.empty_like(X)
+    ops.apply_K64(X, refK)   # (outside a combined phase: term by term on the wave-per-node kernel)
+    ops.apply_M64(X, refM)
+    ops.combined_k64(True)
+    try:
+        outK, outM = torch.empty_like(X), torch.empty_like(X)
+        ops.apply_K64(X, outK)
+        ops.apply_M64(X, outM)
+        assert ops._k64grp is not None and ops._m64grp is not None
+    finally:
+        ops.combined_k64(False)
+    assert ops._k64grp is None
+    assert float((outK - refK).abs().max()) < 1e-12 * float(refK.abs().max())
+    assert float((outM - refM).abs().max()) < 1e-13 * float(refM.abs().max())
+
+
 def test_mfma_entry_point_refuses_what_it_does_not_serve(dev):
     """ds_spmm_union16m validates on the host before any launch: group size, table limits, aliasing, alignment."""
     from diffsound_amd import _hip, meshgen
