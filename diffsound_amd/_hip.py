@@ -13,7 +13,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DS_EXP_LIB") or os.path.join(_HERE, "csrc", "libdiffsound_hip.so")  # (DS_EXP_LIB: A/B builds, experiments)
-ABI_VERSION = 28  # DS_ABI_VERSION of include/diffsound_hip.h
+ABI_VERSION = 29  # DS_ABI_VERSION of include/diffsound_hip.h
 
 c_i32p = ctypes.POINTER(ctypes.c_int32)
 _P = ctypes.c_void_p
@@ -38,7 +38,7 @@ _SIGNATURES = {
     "ds_spmm_f64_union": (_I, [_I, _I, _P, _P, _I64, _I, _P, _P, _I64, _I64, _P, _I64, _P, _I64, _I, _P]),
     "ds_spmm_f64_polish_f32out": (_I, [_P, _P, _P, _P, _P, _I64, _P, _I64, _P, _P, _P, _I64, _I, _P]),
     "ds_pack_kc": (_I, [_P, _P, _I64, _P, _P]),
-    "ds_spmm_union16m": (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _I64, _I64, _I, _I, _I64, _P, _I64, _P, _I64, _I, _P, _I64, _P, _I, _F,
+    "ds_spmm_union16m": (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _P, _I64, _I64, _I, _I, _I64, _P, _I64, _P, _I64, _I, _P, _I64, _P, _I, _F,
                               _F, _I, _P, _I64, _P]),
     "ds_spmm_union32m": (_I, [_I, _I, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I, _I, _I64, _P, _I64, _P, _I64, _I, _P]),
     "ds_edge_table": (_I, [_P, _I64, _I64, _P, _P, _P, ctypes.POINTER(_I64), _P]),
@@ -98,7 +98,7 @@ class LevelDesc(ctypes.Structure):
                 ("degree", ctypes.c_int32), ("gent", _P), ("kgrp", _P), ("nnzb", _I64), ("nv", _I64), ("dinv", _P),
                 ("lmax", _D), ("lmin", _D), ("mf_group_nodes", ctypes.c_int32), ("mf_max_entries", ctypes.c_int32),
                 ("mf_max_batch_blocks", ctypes.c_int32), ("level_tag", ctypes.c_int32),
-                ("mf_gptr", _P), ("mf_gcol", _P), ("mf_gmeta", _P), ("mf_gbase", _P), ("mf_kc", _P),
+                ("mf_gptr", _P), ("mf_gcol", _P), ("mf_gmeta", _P), ("mf_gbase", _P), ("mf_ghead", _P), ("mf_kc", _P),
                 ("m32_max_entries", ctypes.c_int32), ("m32_max_batch_blocks", ctypes.c_int32),
                 ("m32_gptr", _P), ("m32_gcol", _P), ("m32_gmeta", _P), ("m32_gbase", _P), ("m32_k", _P), ("m32_m", _P)]
 

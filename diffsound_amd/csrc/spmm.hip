@@ -1100,18 +1100,18 @@ extern "C" int ds_pack_kc(const float* k32, const int32_t* kperm, int64_t nnzb, 
     return DS_OK;
 }
 
-template <int G, int NT, int BATCH, int LVL>
+template <int G, int NT, int BATCH, int LVL, int TAIL>
 static int launch_mfma(int epilogue, int y_f32, const int32_t* gptr, const int32_t* gcol, const int32_t* gmeta,
-                       const int32_t* gbase, const void* kc, int64_t nnzb, int64_t ngroups, int64_t nv, const float* X,
+                       const int32_t* gbase, const int32_t* ghead, const void* kc, int64_t nnzb, int64_t ngroups, int64_t nv, const float* X,
                        int64_t ldx, float* Y, int64_t ldy, int lpn, int acap, hipStream_t st, const ChebEpilogue& epi) {
     const char* kcp = static_cast<const char*>(kc);
-    const size_t lds = (size_t)mf_panel_bytes(lpn * 4, G, BATCH) + (size_t)acap + 32;
+    const size_t lds = (size_t)mf_panel_bytes(lpn * 4, G, BATCH, TAIL) + (size_t)acap + 32;
     if (epilogue == 2)
-        spmm_union_mfma_kernel<G, NT, 2, false, BATCH, LVL><<<(unsigned)ngroups, 64, lds, st>>>(gptr, gcol, gmeta, gbase, kcp, nnzb, (unsigned)ngroups, nv, X, ldx, Y, ldy, lpn, acap, epi);
+        spmm_union_mfma_kernel<G, NT, 2, false, BATCH, LVL, TAIL><<<(unsigned)ngroups, 64, lds, st>>>(gptr, gcol, gmeta, gbase, ghead, kcp, nnzb, (unsigned)ngroups, nv, X, ldx, Y, ldy, lpn, acap, epi);
     else if (y_f32)
-        spmm_union_mfma_kernel<G, NT, 1, true, BATCH, LVL><<<(unsigned)ngroups, 64, lds, st>>>(gptr, gcol, gmeta, gbase, kcp, nnzb, (unsigned)ngroups, nv, X, ldx, Y, ldy, lpn, acap, epi);
+        spmm_union_mfma_kernel<G, NT, 1, true, BATCH, LVL, TAIL><<<(unsigned)ngroups, 64, lds, st>>>(gptr, gcol, gmeta, gbase, ghead, kcp, nnzb, (unsigned)ngroups, nv, X, ldx, Y, ldy, lpn, acap, epi);
     else
-        spmm_union_mfma_kernel<G, NT, 1, false, BATCH, LVL><<<(unsigned)ngroups, 64, lds, st>>>(gptr, gcol, gmeta, gbase, kcp, nnzb, (unsigned)ngroups, nv, X, ldx, Y, ldy, lpn, acap, epi);
+        spmm_union_mfma_kernel<G, NT, 1, false, BATCH, LVL, TAIL><<<(unsigned)ngroups, 64, lds, st>>>(gptr, gcol, gmeta, gbase, ghead, kcp, nnzb, (unsigned)ngroups, nv, X, ldx, Y, ldy, lpn, acap, epi);
     DS_LAUNCH_CHECK("spmm_union_mfma_kernel");
     return DS_OK;
 }
@@ -1124,12 +1124,13 @@ static int launch_mfma(int epilogue, int y_f32, const int32_t* gptr, const int32
 #endif
 
 extern "C" int ds_spmm_union16m(int epilogue, int group_nodes, int level_tag, const int32_t* gptr, const int32_t* gcol,
-                                const int32_t* gmeta, const int32_t* gbase, const void* kc, int64_t nnzb,
+                                const int32_t* gmeta, const int32_t* gbase, const int32_t* ghead, const void* kc, int64_t nnzb,
                                 int64_t ngroups, int max_entries, int max_batch_blocks, int64_t nv, const void* X,
                                 int64_t ldx, void* Y,
                                 int64_t ldy, int y_f32, const void* R0, int64_t ldr, const float* dinv, int ncols,
                                 float c1, float c2, int first, const void* Wprev, int64_t ldp, ds_stream_t stream) {
-    DS_REQUIRE(gptr && gcol && gmeta && gbase && kc && X && Y && R0, "ds_spmm_union16m: null pointer");
+    DS_REQUIRE(gptr && gcol && gmeta && gbase && ghead && kc && X && Y && R0, "ds_spmm_union16m: null pointer");
+    DS_REQUIRE((reinterpret_cast<uintptr_t>(ghead) & 3) == 0 && ngroups * 512 < (int64_t)1 << 40, "ds_spmm_union16m: bad ghead");
     DS_REQUIRE(epilogue == 1 || epilogue == 2, "ds_spmm_union16m: epilogue must be 1 (Chebyshev term) or 2 (residual)");
     DS_REQUIRE(epilogue != 1 || dinv, "ds_spmm_union16m: the Chebyshev epilogue needs dinv");
     // (4-node groups were slower on both levels; only the 8-node kernel is built)
@@ -1165,8 +1166,13 @@ extern "C" int ds_spmm_union16m(int epilogue, int group_nodes, int level_tag, co
     constexpr int CB = DS_MF_CORNER_BATCH;
     const int acap = ((max_batch_blocks * 24 + 1023) / 1024) * 1024;  // whole 1 KiB staging pieces
     const int acapc = (((CB / DS_MF_BATCH) * max_batch_blocks * 24 + 1023) / 1024) * 1024;
-#define DS_MF_GO(N) return launch_mfma<8, N, DS_MF_BATCH, 0>(epilogue, y_f32, gptr, gcol, gmeta, gbase, kc, nnzb, ngroups, nv, Xf, ldx, Yf, ldy, lpn, acap, st, epi)
-#define DS_MF_GOC(N) return launch_mfma<8, N, CB, 1>(epilogue, y_f32, gptr, gcol, gmeta, gbase, kc, nnzb, ngroups, nv, Xf, ldx, Yf, ldy, lpn, acapc, st, epi)
+    // groups of at most 128 entries: the form whose last batch takes DS_MF_TAIL entries more (see spmm_mfma.inc)
+    const bool tail = max_entries <= 128 && max_batch_blocks * 24 <= 2048;
+    constexpr int CT = CB == DS_MF_BATCH ? DS_MF_TAIL : 0;
+#define DS_MF_ARGS(ACAP) epilogue, y_f32, gptr, gcol, gmeta, gbase, ghead, kc, nnzb, ngroups, nv, Xf, ldx, Yf, ldy, lpn, ACAP, st, epi
+    // (blocks of >= 49 columns only: with fewer accumulator tiles the compiler spills the tail form at three waves per SIMD)
+#define DS_MF_GO(N) return tail ? launch_mfma<8, N, DS_MF_BATCH, 0, (N >= 4 ? DS_MF_TAIL : 0)>(DS_MF_ARGS(acap)) : launch_mfma<8, N, DS_MF_BATCH, 0, 0>(DS_MF_ARGS(acap))
+#define DS_MF_GOC(N) return tail ? launch_mfma<8, N, CB, 1, (N >= 4 ? CT : 0)>(DS_MF_ARGS(acapc)) : launch_mfma<8, N, CB, 1, 0>(DS_MF_ARGS(acapc))
     auto go = [&]() -> int {
         if (level_tag == 1) {
             switch (nt) {
@@ -1181,6 +1187,7 @@ extern "C" int ds_spmm_union16m(int epilogue, int group_nodes, int level_tag, co
     };
 #undef DS_MF_GO
 #undef DS_MF_GOC
+#undef DS_MF_ARGS
     ds::ProfScope prof((epilogue == 1 && !y_f32) ? stream : nullptr, DS_PROF_TERM, nv, nnzb, ncols, (first ? 1 : 0) | (2 << 8));
     return go();
 }

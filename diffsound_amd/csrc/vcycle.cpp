@@ -57,7 +57,7 @@ int union16(const ds_level_t& L, int epilogue, const void* X, int64_t ldx, void*
             int64_t ldr, const float* dinv, int ncols, float c1, float c2, int first, const void* Wprev, int64_t ldp,
             ds_stream_t stream) {
     if (L.mf_group_nodes)
-        return ds_spmm_union16m(epilogue, L.mf_group_nodes, L.level_tag, L.mf_gptr, L.mf_gcol, L.mf_gmeta, L.mf_gbase, L.mf_kc, L.nnzb,
+        return ds_spmm_union16m(epilogue, L.mf_group_nodes, L.level_tag, L.mf_gptr, L.mf_gcol, L.mf_gmeta, L.mf_gbase, L.mf_ghead, L.mf_kc, L.nnzb,
                                 (L.nv + L.mf_group_nodes - 1) / L.mf_group_nodes, L.mf_max_entries, L.mf_max_batch_blocks, L.nv, X, ldx, Y,
                                 ldy, y_f32,
                                 R0, ldr, dinv, ncols, c1, c2, first, Wprev, ldp, stream);

@@ -882,6 +882,17 @@ class ModalSolver:
         lam, C = _small(gen_eigh, dev, GA, GB)
         X, KX, MX = ops.mix64([X], C), ops.mix64([KX], C), ops.mix64([MX], C)
         P = KP = MP = None
+        # Every n-sized block of a step lives in a POOL of (n x b) buffers allocated once and used through column views (round 5):
+        # the number of active columns changes from step to step, and blocks of ever new sizes - 2 to 4.5 GB each at configs[4] -
+        # made the caching allocator release and re-request device memory in the middle of the steps (0.3 s of run-to-run spread)
+        pool = {}
+
+        def buf(name, cols, dtype=torch.float64):
+            t = pool.get(name)
+            if t is None:
+                t = pool[name] = torch.empty((n, b), dtype=dtype, device=dev)
+            return t[:, :cols]
+
         G0A = G0B = None  # Gram blocks among [Y | X | P] of the current basis (fp64, m0 x m0), by recurrence
         refresh = max(1, int(getattr(cfg, "refine_refresh", 8)))
         since = refresh  # the first step forms everything from the vectors
@@ -910,26 +921,27 @@ class ModalSolver:
                 pad = rest_[torch.argsort(rel[rest_], descending=True)[:4 - idx.numel() % 4]]
                 idx = torch.sort(torch.cat([idx, pad])).values
             # W = B R in fp32 (columns scaled to unit norm: the preconditioner is linear), promoted to fp64
+            nact = int(idx.numel())
+            R32 = buf("R32", nact, torch.float32)
             if fused64:
-                R32 = ops.residual64_scaled(KX, MX, lam, 1.0 / rn.clamp(min=1e-300), idx)
+                ops.residual64_scaled(KX, MX, lam, 1.0 / rn.clamp(min=1e-300), idx, out=R32)
             else:
-                R32 = (R[:, idx] / rn[idx].clamp(min=1e-300)[None, :]).float().contiguous()
-            W32 = torch.empty_like(R32)
+                R32.copy_(R[:, idx] / rn[idx].clamp(min=1e-300)[None, :])
+            W32 = buf("W32", nact, torch.float32)
             self.precond_apply(R32, W32)
             for _ in range(max(0, int(getattr(cfg, "refine_sweeps", 1)) - 1)):
                 # one more sweep of the preconditioned Richardson iteration: W <- W + B (R - K W), all fp32.  A step of
                 # the fp64 phase is dominated by its dense n x b products, not by the preconditioner: a stronger
                 # correction per step buys fewer steps
-                T32 = torch.empty_like(R32)
+                T32, D32 = buf("T32", nact, torch.float32), buf("D32", nact, torch.float32)
                 ops.apply_K(W32, T32)
-                T32 = R32 - T32
-                D32 = torch.empty_like(R32)
+                torch.sub(R32, T32, out=T32)
                 self.precond_apply(T32, D32)
                 W32 += D32
-                del T32, D32
-            W = W32.double()
-            del R32, W32, R
-            KW, MW = torch.empty_like(W), torch.empty_like(W)
+            W = buf("W", nact)
+            W.copy_(W32)
+            del R
+            KW, MW = buf("KW", nact), buf("MW", nact)
             ops.apply_M64(W, MW)
             ops.apply_K64(W, KW)
             # (unit M-norm columns of W - a well scaled pencil - without touching the vectors: the scale wn comes off the
@@ -991,8 +1003,10 @@ class ModalSolver:
             news = []
             for which in range(3):  # the vectors, their K-products, their M-products
                 parts = [h[which] for h in head] + [(W, KW, MW)[which]]
-                Xn = ops.mix64(parts, Zu)
-                Pd = ops.mix64([(blk, offs[i_]) for i_, blk in enumerate(parts) if i_ != xi], Tu)  # (X's rows of Tu are zero)
+                # (two sets of pool buffers, alternating: a step reads the set the previous one wrote)
+                Xn = ops.mix64(parts, Zu, out=buf(f"X{which}_{it & 1}", b))
+                Pd = ops.mix64([(blk, offs[i_]) for i_, blk in enumerate(parts) if i_ != xi], Tu,
+                               out=buf(f"P{which}_{it & 1}", nact))  # (X's rows of Tu are zero)
                 news.append((Xn, Pd))
             (X, P), (KX, KP), (MX, MP) = news
             del news

@@ -20,6 +20,7 @@ DS_F32, DS_F64 = 0, 1
 import threading
 
 MF_BATCH = 16  # entries per LDS batch of the MFMA kernel (DS_MF_BATCH of include/diffsound_hip.h)
+MF_TAIL = 2  # entries a group's last batch may take beyond MF_BATCH when no group has more than 128 (DS_MF_TAIL)
 MF32_BATCH = 8  # entries per LDS batch of the fp32 MFMA kernel (DS_MF32_BATCH), groups of MF32_G = 4 nodes
 MF32_G = 4
 _MFMA_TABLES_LOCK = threading.Lock()
@@ -177,11 +178,24 @@ class TetSystem:
         eidx = torch.arange(ekey.numel(), device=dev)
         # (a group of more than 256 entries is not served by the kernel; its tail is lumped into the last slot here)
         nslot = 256 // mf_batch
-        batch = (ekey // nv) * nslot + ((eidx - torch.repeat_interleave(gptr[:-1], ne_g)) // mf_batch).clamp(max=nslot - 1)
+        ewithin = eidx - torch.repeat_interleave(gptr[:-1], ne_g)
+        slot = (ewithin // mf_batch).clamp(max=nslot - 1)
+        if int(ne_g.max()) <= 128 and mf_batch == MF_BATCH:
+            # the kernel's TAIL form: a group's last batch also takes up to MF_TAIL entries beyond mf_batch (ds_spmm_union16m)
+            nb_g = ((ne_g - MF_TAIL + mf_batch - 1) // mf_batch).clamp(min=1)
+            slot = torch.minimum(slot, torch.repeat_interleave(nb_g, ne_g) - 1)
+        batch = (ekey // nv) * nslot + slot
         per_batch = torch.zeros(ng * nslot, dtype=torch.int64, device=dev).scatter_add_(0, batch, counts)
+        gcol = (ekey % nv).to(torch.int32).contiguous()
+        gmeta = (mask | (within << 8)).to(torch.int32).contiguous()
+        # fixed-stride record of each group's first 64 entries (ids, then meta words; zero behind the last): what a wave asks for
+        # before it knows where its group's entries start
+        ghead = torch.zeros((ng, 128), dtype=torch.int32, device=dev)
+        sel = ewithin < 64
+        ghead[(ekey // nv)[sel], ewithin[sel]] = gcol[sel]
+        ghead[(ekey // nv)[sel], 64 + ewithin[sel]] = gmeta[sel]
         return dict(G=G, batch=mf_batch, ngroups=ng, max_entries=int(ne_g.max()), max_batch_blocks=int(per_batch.max()),
-                    gptr=gptr.to(torch.int32), gcol=(ekey % nv).to(torch.int32).contiguous(),
-                    gmeta=(mask | (within << 8)).to(torch.int32).contiguous(), gbase=gbase.to(torch.int32).contiguous(),
+                    gptr=gptr.to(torch.int32), gcol=gcol, gmeta=gmeta, gbase=gbase.to(torch.int32).contiguous(), ghead=ghead,
                     kperm=order.to(torch.int32).contiguous())
 
     def with_own_values(self):
@@ -375,7 +389,7 @@ class _HipBlockOps:
         mt = self._mfma
         if mt is not None and self.kc is not None:  # the level's bf16 terms run on the matrix cores (ds_spmm_union16m)
             d.mf_group_nodes, d.mf_max_entries, d.mf_max_batch_blocks = mt["G"], mt["max_entries"], mt["max_batch_blocks"]
-            d.mf_gptr, d.mf_gcol, d.mf_gmeta, d.mf_gbase = (mt[k].data_ptr() for k in ("gptr", "gcol", "gmeta", "gbase"))
+            d.mf_gptr, d.mf_gcol, d.mf_gmeta, d.mf_gbase, d.mf_ghead = (mt[k].data_ptr() for k in ("gptr", "gcol", "gmeta", "gbase", "ghead"))
             d.mf_kc = self.kc.data_ptr()
         else:
             d.mf_group_nodes = 0
@@ -732,17 +746,19 @@ class _HipBlockOps:
                                                pp(out[0]), pp(out[1]), _hip.stream_ptr()), "ds_residual64_norms")
         return out[0], out[1]
 
-    def residual64_scaled(self, KX, MX, lam, scale, idx):
+    def residual64_scaled(self, KX, MX, lam, scale, idx, out=None):
         """(n x len(idx)) fp32 block of the residual columns ``idx`` of the fp64 blocks, each times ``scale[col]``
         (ds_residual64_scaled): the scaled input of the fp32 preconditioner, without an fp64 residual block in between."""
         nact = int(idx.numel())
         if nact % 4:
             raise ValueError("residual64_scaled: a multiple of 4 columns")
         pp = _hip.ptr
-        R = torch.empty((self.n, nact), dtype=torch.float32, device=self.device)
+        R = torch.empty((self.n, nact), dtype=torch.float32, device=self.device) if out is None else out
+        if R.dtype != torch.float32 or R.shape != (self.n, nact) or R.stride(1) != 1:
+            raise ValueError("residual64_scaled: out is (n x len(idx)) fp32 with unit column stride")
         cols = idx.to(torch.int32).contiguous()
         lam, scale = lam.to(torch.float64).contiguous(), scale.to(torch.float64).contiguous()
-        _hip.check(self._L.ds_residual64_scaled(pp(KX), _ld(KX), pp(MX), _ld(MX), pp(lam), pp(scale), pp(cols), nact, pp(R), nact,
+        _hip.check(self._L.ds_residual64_scaled(pp(KX), _ld(KX), pp(MX), _ld(MX), pp(lam), pp(scale), pp(cols), nact, pp(R), _ld(R),
                                                 self.n, _hip.stream_ptr()), "ds_residual64_scaled")
         return R
 
@@ -830,7 +846,7 @@ class _HipBlockOps:
         pp = _hip.ptr
         mt = self._mfma
         if mt is not None and self.kc is not None:
-            _hip.check(self._L.ds_spmm_union16m(1, mt["G"], self._level_tag, pp(mt["gptr"]), pp(mt["gcol"]), pp(mt["gmeta"]), pp(mt["gbase"]),
+            _hip.check(self._L.ds_spmm_union16m(1, mt["G"], self._level_tag, pp(mt["gptr"]), pp(mt["gcol"]), pp(mt["gmeta"]), pp(mt["gbase"]), pp(mt["ghead"]),
                                                 pp(self.kc), self.kc.shape[0], mt["ngroups"], mt["max_entries"], mt["max_batch_blocks"],
                                                 self.nv, pp(Wk), _ld(Wk), pp(Wprev), _ld(Wprev), 0, pp(R0), _ld(R0), pp(self.dinv), Wk.shape[1],
                                                 float(c1), float(c2), int(bool(first)), None, 0, _hip.stream_ptr()),

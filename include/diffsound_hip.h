@@ -40,7 +40,7 @@ enum { DS_OK = 0, DS_ERR_ARG = 1, DS_ERR_HIP = 2, DS_ERR_NOMEM = 3 };
 /* Thread-local text of the last error returned on this thread ("" if none). */
 const char* ds_last_error(void);
 /* Library ABI version (bumped on any signature change); ds_abi_version() returns the value the library was built with. */
-#define DS_ABI_VERSION 28
+#define DS_ABI_VERSION 29
 int ds_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------------
@@ -293,7 +293,7 @@ typedef struct {
     int32_t mf_max_batch_blocks;
     int32_t level_tag;     /* 0: fine level, 1: corner-node level - selects kernel instantiations whose SYMBOLS differ, so
                               that a rocprofv3 kernel table separates the two levels' launches (same code otherwise) */
-    const int32_t *mf_gptr, *mf_gcol, *mf_gmeta, *mf_gbase;
+    const int32_t *mf_gptr, *mf_gcol, *mf_gmeta, *mf_gbase, *mf_ghead;
     const void* mf_kc;
     /* fp32 matrix-core form of the level's own products K X / M X (ds_spmm_union32m): m32_gptr != NULL enables it in
      * ds_lobpcg_iterate; tables for groups of 4 nodes, m32_k / m32_m the values in the tables' order (with 16 bytes of
@@ -354,11 +354,16 @@ int ds_spmm_union16(int epilogue, const int32_t* utab, const int32_t* ctab, int6
  * BSR block of every position of the group / entry / node order.  ds_pack_kc writes kc (nnzb x 3 x 4 bf16: the rows of
  * the blocks in that order, padded to 8 bytes) from the BSR values k32 - once per material.  max_entries = the largest
  * group's entry count (<= 256); max_batch_blocks = the largest number of blocks in DS_MF_BATCH = 16 consecutive entries
- * of a group (batches counted from the group's first entry; it sizes the wavefront's LDS). */
+ * of a group (batches counted from the group's first entry; it sizes the wavefront's LDS) - when max_entries <= 128 the LAST
+ * batch of a group also takes up to DS_MF_TAIL entries beyond the 16 (a group of 65 entries is four batches, not five), and
+ * max_batch_blocks counts the blocks of the batches so formed.  ghead (ngroups x 128): per group
+ * a record of FIXED stride with the first 64 entries of gcol (words 0..63) and of gmeta (words 64..127), zero behind the
+ * group's last entry - a wavefront asks for it before it knows where the group's entries start (ABI 29). */
 #define DS_MF_BATCH 16
+#define DS_MF_TAIL 2
 int ds_pack_kc(const float* k32, const int32_t* kperm, int64_t nnzb, void* kc, ds_stream_t stream);
 int ds_spmm_union16m(int epilogue, int group_nodes, int level_tag, const int32_t* gptr, const int32_t* gcol,
-                     const int32_t* gmeta, const int32_t* gbase, const void* kc, int64_t nnzb, int64_t ngroups, int max_entries,
+                     const int32_t* gmeta, const int32_t* gbase, const int32_t* ghead, const void* kc, int64_t nnzb, int64_t ngroups, int max_entries,
                      int max_batch_blocks, int64_t nv, const void* X, int64_t ldx, void* Y, int64_t ldy, int y_f32,
                      const void* R0, int64_t ldr,
                      const float* dinv, int ncols, float c1, float c2, int first, const void* Wprev, int64_t ldp,

@@ -142,3 +142,37 @@ def test_library_issues_no_packed_fp32_and_no_double_rate_bf16_mfma(tmp_path):
     assert counts["v_pk_fma_f32"] == counts["v_pk_mul_f32"] == counts["v_pk_add_f32"] == 0, counts
     assert counts["v_mfma_f32_16x16x32_bf16"] == 0 and counts["v_mfma_f32_16x16x16_bf16"] > 100, counts
     assert counts["v_fma_f32"] > 1000, counts
+
+
+def test_mfma_spmm_window_registers_do_not_move_between_issue_sites(tmp_path):
+    """The bf16 term kernel (csrc/spmm_mfma.inc) keeps a batch's panel loads in flight across its loop: the window registers are
+    written by loads issued in front of the loop (first batch) and inside it (next batch), and read behind counted waits.  That
+    only works if BOTH issue sites name the same registers - a compiler that peels a trip off the loop, or joins the sites
+    through copies, moves values whose loads have not landed (seen in round 5 with the tail form at 84 columns: wrong results, no
+    fault).  Checked on the ISA of the shipped binary: per instantiation one loop's worth of sites, identical destinations."""
+    import re
+    import shutil
+    import subprocess
+
+    objdump = shutil.which("llvm-objdump") or "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(objdump):
+        pytest.skip("llvm-objdump not found")
+    from diffsound_amd import _hip
+
+    seen = 0
+    for i, blob in enumerate(_gfx950_code_objects(_hip.LIB_PATH)):
+        if b"spmm_union_mfma_kernel" not in blob:
+            continue
+        path = tmp_path / f"co{i}.o"
+        path.write_bytes(blob)
+        text = subprocess.run([objdump, "-d", str(path)], capture_output=True, text=True, check=True).stdout
+        for m in re.finditer(r"<(_ZN12_GLOBAL__N_122spmm_union_mfma_kernelILi8ELi(\d)ELi(\d)ELb([01])ELi(\d+)ELi([01])ELi(\d)E[^>]*)>:\n(.*?)s_endpgm",
+                             text, re.S):
+            batch, tail, body = int(m.group(5)), int(m.group(7)), m.group(8)
+            dst = re.findall(r"buffer_load_dwordx2 (v\[\d+:\d+\])", body)
+            win = batch + tail
+            assert len(dst) >= 2 * win, (m.group(1), len(dst))
+            assert dst[:win] == dst[win:2 * win], (m.group(1), dst[:win], dst[win:2 * win])
+            assert len(set(dst[:win])) == win, m.group(1)
+            seen += 1
+    assert seen >= 36, seen  # 6 widths x 3 epilogue forms x 2 levels, plus the tail forms

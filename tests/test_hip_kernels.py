@@ -491,9 +491,10 @@ def test_mfma_union_terms_match_valu_terms(dev, mesh, ncols, G, order):
                                      sysd.nv, p(X), ncols, p(out), out.stride(0), int(y32), p(R0), ncols, p(ops.dinv), ncols, 0.31,
                                      0.77, int(first), p(wprev), 0 if wprev is None else ncols, _hip.stream_ptr()), "ds_spmm_union16")
 
-    def mfma(epi, out, y32, first, wprev=None):
-        _hip.check(L.ds_spmm_union16m(epi, G, 0, p(mt["gptr"]), p(mt["gcol"]), p(mt["gmeta"]), p(mt["gbase"]), p(kc), sysd.nnzb,
-                                      mt["ngroups"], mt["max_entries"], mt["max_batch_blocks"], sysd.nv, p(X), ncols, p(out), out.stride(0), int(y32), p(R0),
+    def mfma(epi, out, y32, first, wprev=None, plain=False):
+        # (plain: a max_entries bound above 128 sends the launch to the form WITHOUT the tail batch - the bound only has to hold)
+        _hip.check(L.ds_spmm_union16m(epi, G, 0, p(mt["gptr"]), p(mt["gcol"]), p(mt["gmeta"]), p(mt["gbase"]), p(mt["ghead"]), p(kc), sysd.nnzb,
+                                      mt["ngroups"], 129 if plain else mt["max_entries"], mt["max_batch_blocks"], sysd.nv, p(X), ncols, p(out), out.stride(0), int(y32), p(R0),
                                       ncols, p(ops.dinv), ncols, 0.31, 0.77, int(first), p(wprev), 0 if wprev is None else ncols,
                                       _hip.stream_ptr()), "ds_spmm_union16m")
 
@@ -519,6 +520,16 @@ def test_mfma_union_terms_match_valu_terms(dev, mesh, ncols, G, order):
     br2 = torch.empty_like(X)
     mfma(2, br2, False, False)
     assert torch.equal(br, br2)  # deterministic
+    # the form whose last batch takes two entries more (round 5: groups of <= 128 entries, >= 49 columns) and the plain form keep
+    # every entry in its K-step slot and in its place of the accumulation order: the same bits
+    assert mt["max_entries"] <= 128
+    mfma(2, br2, False, False, plain=True)
+    assert torch.equal(br, br2)
+    c32 = torch.empty((sysd.n, ncols), device=dev)
+    d32 = torch.empty((sysd.n, ncols), device=dev)
+    mfma(1, c32, True, False, wprev=Wp)
+    mfma(1, d32, True, False, wprev=Wp, plain=True)
+    assert torch.equal(c32, d32)
 
 
 @pytest.mark.parametrize("mesh,order,ncols", [(6, 2, 80), (6, 2, 40), (6, 2, 84), (6, 2, 52), (3, 2, 80), (10, 2, 80), (5, 2, 16),
@@ -838,7 +849,7 @@ def test_mfma_entry_point_refuses_what_it_does_not_serve(dev):
     Y, R0 = torch.empty_like(X), torch.empty_like(X)
 
     def call(G=8, max_entries=None, mbb=None, x=X, y=Y, ncols=80, epi=1, dinv=ops.dinv, y32=0):
-        return L.ds_spmm_union16m(epi, G, 0, p(mt["gptr"]), p(mt["gcol"]), p(mt["gmeta"]), p(mt["gbase"]), p(ops.kc), sysd.nnzb,
+        return L.ds_spmm_union16m(epi, G, 0, p(mt["gptr"]), p(mt["gcol"]), p(mt["gmeta"]), p(mt["gbase"]), p(mt["ghead"]), p(ops.kc), sysd.nnzb,
                                   (sysd.nv + G - 1) // G, mt["max_entries"] if max_entries is None else max_entries,
                                   mt["max_batch_blocks"] if mbb is None else mbb, sysd.nv, p(x), x.stride(0), p(y), y.stride(0), y32,
                                   p(R0), 80, None if dinv is None else p(dinv), ncols, 0.3, 0.7, 0, None, 0, _hip.stream_ptr())
