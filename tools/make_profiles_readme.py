@@ -37,8 +37,8 @@ util = json.load(open(P("gram_mix_mfma_util.json")))
 l1 = f"{TAG}_bench_lanes1_kernel_stats.csv"
 stream_l1 = d["roofline"]["stream_triad"]  # (the one-lane table holds the passes' own launches only: no triad in it)
 solo = f"{TAG}_bench_solo_kernel_stats.csv"
-fine = kernel_row(l1, "spmm_union_mfma_kernel<8, 5, 1, false, 16, 0>")
-fine_solo = kernel_row(solo, "spmm_union_mfma_kernel<8, 5, 1, false, 16, 0>")
+fine = kernel_row(l1, "spmm_union_mfma_kernel<8, 5, 1, false, 16, 0,")
+fine_solo = kernel_row(solo, "spmm_union_mfma_kernel<8, 5, 1, false, 16, 0,")
 km = kernel_row(l1, "spmm_union_kernel<20, 5, 140, false, false, true, 0>")
 res = kernel_row(l1, "spmm_union_kernel<20, 4, 140, false, false, true, 0>")
 kx = kernel_row(l1, "spmm_union_kernel<20, 0, 140, false, false, true, 0>")
@@ -81,6 +81,7 @@ Collected by `tools/collect_profiles.sh r05 <part>` on the GPU box (this file: `
 | `r05_bench_lanes1_kernel_stats.csv` | the same with `--lanes 1 --hyp-per-gpu 2 --steps 4`: one hypothesis at a time, every kernel alone on the device but between the other kernels of a pass — **the table to read in-pass kernel durations from** (last template argument of the SpMM symbols: 0 fine level, 1 corner-node level) |
 | `r05_bench_solo_kernel_stats.csv` | the bench line's kernel-ALONE figures under the profiler |
 | `r05_raw_rr_ab_off.json`, `r05_raw_rr_ab_on.json` | **A/B on one box of the round's main change — the Ritz step on the raw basis (`--raw-rr 0 / 1`): 54.4 → 60.3 passes/s**, same iteration counts; the lines carry the in-pass tables of both routes (explicit: K W 192 µs + M W 162 µs + two Gram + two updates per iteration; raw: one `[K W \\| M W]` walk 234 µs + one Gram + one update) |
+| `r05_mf_tail.txt` | the bf16 term kernel's round trips: a wave's head in ONE (fixed-stride records of a group's first 64 entries: 110.9–112.6 → 108.0–109.2 µs), what the fifth batch of a 65-entry group costs (a timing-only build without it: 106.3 → 94.3 µs), the tail form (the last batch takes two entries more, bit-identical): **97.7–98.0 µs = 0.489 of 8 TB/s** |
 | `r05_nt_hint_ab.txt`, `r05_nt_epi_ab.txt` | four library builds on one box: non-temporal hints on the value / table loads (nt1), on the result stores (nt2), both (nt3) — K W 182 → 177 / 169 µs, M W 149 → 130 / 129, bf16 term 117 → 112 (loads) / 111 (both), corner-node level +4 % with the load hint (kept off there); the same hint on the epilogue's once-read operands costs 6 % (not adopted) |
 | `spmm_pmc_bytes_per_launch.json`, `r05_spmm_pmc_{{fp32,bf16,mfma,kx,km,resid}}.json` | HBM-side traffic per launch from separate `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes; bytes = (2·FETCH + WRITE)·1024 (gfx950 correction of `guides/MI355X_MICROARCH.md`); keyed by the hash of the SpMM sources + `modal_ops.py` — `bench.py` reports a record with another hash as stale |
 | `gram_mix_mfma_util.json`, `r05_gram_mix.txt` | matrix-pipe utilisation of the Rayleigh-Ritz kernels per shape (one shape per profiled process: `SQ_VALU_MFMA_BUSY_CYCLES` ÷ (`GRBM_GUI_ACTIVE`/8 × 1 024 SIMDs)), keyed by the hash of `gram.hip` + `blockops.hip`; timings at the solver's shapes |
