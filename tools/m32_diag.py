@@ -76,3 +76,28 @@ print(f"bf16 term (8-node groups, batches of {MF_BATCH}): launch {us:.1f} us by 
 print(f"   cycles per wave {life.mean():.0f} ({life.mean() / clock:.1f} us): head {head.mean():.0f}, per-batch wait + LDS writes + issue "
       f"{wait.mean():.0f}, fragments + MFMAs {m.mean():.0f}, epilogue {tail.mean():.0f}; batches per group {ops8._mfma['gcol'].numel() / n / MF_BATCH:.1f}",
       flush=True)
+
+# the same kernel on the corner-node level (2 461 groups at C3: every wave resident at once, a launch = one wave lifetime)
+opsc = HipModalOps(sysd, 2e10, 2e10).coarse
+mkc = lambda: torch.randn(opsc.n, 80, device=dev).bfloat16()
+Wk, Wp, R0 = mkc(), mkc(), mkc()
+for _ in range(20):
+    opsc.cheb_spmm16(Wk, Wp, R0, 0.3, 0.7, False)
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+opsc.cheb_spmm16(Wk, Wp, R0, 0.3, 0.7, False)
+e1.record()
+torch.cuda.synchronize()
+n = opsc._mfma["ngroups"]
+rec = np.zeros((n, 8), dtype=np.uint64)
+L.ds_mf_diag(rec.ctypes.data, n)
+t0, t1, rt, wait, a, m, head, tail = rec.astype(np.float64).T
+life = t1 - t0
+clock = life.sum() / rt.sum() * 100.0
+us = e0.elapsed_time(e1) * 1e3
+print(f"bf16 term, corner-node level ({n} groups): launch {us:.1f} us by events; in-kernel clock {clock:.0f} MHz; cycles per wave {life.mean():.0f} "
+      f"({life.mean() / clock:.1f} us; longest {life.max() / clock:.1f} us): head {head.mean():.0f}, per-batch wait + LDS writes + issue {wait.mean():.0f}, "
+      f"fragments + MFMAs {m.mean():.0f}, epilogue {tail.mean():.0f}; batches per group {opsc._mfma['gcol'].numel() / n / MF_BATCH:.1f}", flush=True)
+# start of each wave relative to the earliest wave of its XCD is not comparable across XCDs (s_memtime is per XCD); the spread of the
+# starts inside the launch = how long the dispatcher takes to place the grid
