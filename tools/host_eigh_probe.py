@@ -44,3 +44,14 @@ with threadpool_limits(limits=1):
     Bt, Ct = torch.from_numpy(B), torch.from_numpy(C)
     t = best(lambda: Bt @ Ct)[0]
     print(f"dgemm 256 x 256 x 240 (torch/MKL):      {t:.3f} ms = {2 * 256 * 256 * 240 / t / 1e6:.1f} GF/s")
+
+# more than one BLAS thread for the one problem (a single hypothesis at a time leaves the host's other cores idle)
+for nthr in (1, 2, 4, 8):
+    with threadpool_limits(limits=nthr):
+        torch.set_num_threads(nthr)
+        for n in (240, 160):
+            A = rng.standard_normal((n, n))
+            A = np.asfortranarray(A + A.T + np.diag(np.arange(n) * 3.0))
+            At = torch.from_numpy(np.ascontiguousarray(A))
+            print(f"{nthr} threads, n = {n}: scipy dsyevd %.3f / %.3f ms;" % best(lambda: la.dsyevd(A, compute_v=1, lower=1)),
+                  "torch.linalg.eigh (MKL) %.3f / %.3f ms" % best(lambda: torch.linalg.eigh(At)))
