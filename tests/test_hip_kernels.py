@@ -457,6 +457,50 @@ def test_bf16_union_terms_match_fp32_terms(dev, ncols):
     assert torch.equal(W16, Wf.bfloat16())
 
 
+@pytest.mark.parametrize("mesh,order", [(6, 2), (3, 2), (12, 1), (26, 2)])
+def test_mfma_tables_head_records_and_batch_partition(dev, mesh, order):
+    """Topology tables of ds_spmm_union16m against an independent count from the BSR pattern: the unions of every group of 8 rows,
+    the fixed-stride head records (a group's first 64 entries, zero behind its last), and max_batch_blocks of the batch partition
+    the kernel walks - batches of 16 entries, the last one of a group up to 2 entries longer when no group has more than 128."""
+    from diffsound_amd import meshgen
+    from diffsound_amd.diffelastic.mesh import TetMesh
+    from diffsound_amd.modal_ops import MF_BATCH, MF_TAIL, TetSystem
+
+    v, t = meshgen.kuhn_box(mesh)
+    tm = TetMesh(torch.from_numpy(v).to(dev), torch.from_numpy(t).long().to(dev)).to_high_order(order)
+    sysd = TetSystem(tm.vertices, tm.tets, order, 2700.0)
+    mt = sysd.mfma_tables(8)
+    rowptr, col = sysd.rowptr.cpu().numpy().astype(np.int64), sysd.colidx.cpu().numpy().astype(np.int64)
+    gptr, gcol, gmeta = (mt[k].cpu().numpy().astype(np.int64) for k in ("gptr", "gcol", "gmeta"))
+    ghead, gbase = mt["ghead"].cpu().numpy().astype(np.int64), mt["gbase"].cpu().numpy().astype(np.int64)
+    ng = (sysd.nv + 7) // 8
+    assert mt["ngroups"] == ng and ghead.shape == (ng, 128)
+    worst, most = 0, 0
+    for g in range(ng):
+        rows = range(8 * g, min(8 * g + 8, sysd.nv))
+        nb = {r - 8 * g: set(col[rowptr[r]:rowptr[r + 1]].tolist()) for r in rows}
+        union = sorted(set().union(*nb.values()))
+        e0, e1 = gptr[g], gptr[g + 1]
+        assert gcol[e0:e1].tolist() == union
+        mask = [sum(1 << s for s, cs in nb.items() if c in cs) for c in union]
+        assert (gmeta[e0:e1] & 0xff).tolist() == mask
+        first = np.concatenate([[0], np.cumsum([bin(m).count("1") for m in mask])])
+        assert (gmeta[e0:e1] >> 8).tolist() == first[:-1].tolist() and gbase[g] == rowptr[8 * g]
+        ne = len(union)
+        head = min(ne, 64)
+        assert ghead[g, :head].tolist() == union[:head] and not ghead[g, head:64].any()
+        assert ghead[g, 64:64 + head].tolist() == gmeta[e0:e0 + head].tolist() and not ghead[g, 64 + head:].any()
+        most = max(most, ne)
+        per_entry = np.diff(first)
+        nbatch = max(1, (ne - MF_TAIL + MF_BATCH - 1) // MF_BATCH)
+        for b in range(nbatch):
+            hi = ne if b == nbatch - 1 else (b + 1) * MF_BATCH
+            assert hi - b * MF_BATCH <= MF_BATCH + MF_TAIL
+            worst = max(worst, int(per_entry[b * MF_BATCH:hi].sum()))
+    assert most == mt["max_entries"] <= 128  # (the tail partition is what these meshes get)
+    assert worst == mt["max_batch_blocks"]
+
+
 @pytest.mark.parametrize("mesh,ncols,G,order", [(6, 80, 8, 2), (6, 40, 8, 2), (6, 84, 8, 2), (6, 52, 8, 2), (3, 80, 8, 2), (10, 80, 8, 2),
                                                 (5, 16, 8, 2), (12, 80, 8, 1), (26, 80, 8, 1)])
 def test_mfma_union_terms_match_valu_terms(dev, mesh, ncols, G, order):
