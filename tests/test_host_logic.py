@@ -174,3 +174,52 @@ def test_largest_connected_component_matches_scipy():
     # a single body comes back untouched
     a, b = largest_connected_component(torch.from_numpy(v1), torch.from_numpy(t1))
     assert a.shape[0] == len(v1) and b.shape[0] == len(t1)
+
+
+def test_mfma_table_builder_on_the_host():
+    """The topology tables of the MFMA term kernel are plain tensor algebra (modal_ops.TetSystem._build_mfma_tables): run here
+    on CPU tensors for a random symmetric pattern with groups of very different sizes - unions, presence masks, block offsets,
+    the fixed-stride head records and the blocks of the fullest batch under the partition the kernel walks (with and without the
+    tail batch).  The device run of the same builder is checked against the BSR pattern in tests/test_hip_kernels.py."""
+    from types import SimpleNamespace
+
+    from diffsound_amd.modal_ops import MF_BATCH, MF_TAIL, TetSystem
+
+    rng = np.random.default_rng(3)
+    for nv, deg, expect_tail in ((203, 9, True), (160, 70, False)):
+        A = np.zeros((nv, nv), dtype=bool)
+        for r in range(nv):
+            A[r, rng.choice(nv, size=rng.integers(1, deg), replace=False)] = True
+        A |= A.T
+        A[np.arange(nv), np.arange(nv)] = True
+        rowptr = np.concatenate([[0], np.cumsum(A.sum(1))]).astype(np.int32)
+        colidx = np.concatenate([np.flatnonzero(A[r]) for r in range(nv)]).astype(np.int32)
+        fake = SimpleNamespace(nv=nv, device=torch.device("cpu"), rowptr=torch.from_numpy(rowptr), colidx=torch.from_numpy(colidx))
+        mt = TetSystem._build_mfma_tables(fake, 8, MF_BATCH)
+        gptr, gcol, gmeta, ghead = (mt[k].numpy().astype(np.int64) for k in ("gptr", "gcol", "gmeta", "ghead"))
+        ng = (nv + 7) // 8
+        assert mt["ngroups"] == ng and gptr[-1] == gcol.size
+        assert np.array_equal(np.sort(mt["kperm"].numpy()), np.arange(colidx.size))  # every block exactly once
+        most = worst_tail = worst_plain = 0
+        for g in range(ng):
+            rows = np.arange(8 * g, min(8 * g + 8, nv))
+            union = np.flatnonzero(A[rows].any(0))
+            e0, e1 = gptr[g], gptr[g + 1]
+            assert np.array_equal(gcol[e0:e1], union)
+            mask = (A[rows][:, union] * (1 << np.arange(rows.size))[:, None]).sum(0)
+            assert np.array_equal(gmeta[e0:e1] & 0xff, mask)
+            per_entry = A[rows][:, union].sum(0)
+            assert np.array_equal(gmeta[e0:e1] >> 8, np.concatenate([[0], np.cumsum(per_entry)[:-1]]))
+            ne = union.size
+            h = min(ne, 64)
+            assert np.array_equal(ghead[g, :h], union[:h]) and not ghead[g, h:64].any()
+            assert np.array_equal(ghead[g, 64:64 + h], gmeta[e0:e0 + h]) and not ghead[g, 64 + h:].any()
+            most = max(most, ne)
+            nb = max(1, (ne - MF_TAIL + MF_BATCH - 1) // MF_BATCH)
+            for b in range(nb):
+                hi = ne if b == nb - 1 else (b + 1) * MF_BATCH
+                worst_tail = max(worst_tail, int(per_entry[b * MF_BATCH:hi].sum()))
+            for b in range(0, ne, MF_BATCH):
+                worst_plain = max(worst_plain, int(per_entry[b:b + MF_BATCH].sum()))
+        assert mt["max_entries"] == most and (most <= 128) == expect_tail
+        assert mt["max_batch_blocks"] == (worst_tail if expect_tail else worst_plain)
