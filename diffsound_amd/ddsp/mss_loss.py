@@ -15,8 +15,9 @@ third-party Sinkhorn solver ``geomloss.SamplesLoss("sinkhorn", p=2, blur=0.01)``
 requirements.txt:46).  It stays on PyTorch: the spectrograms come from ``ds_stft_power``,
 the point clouds are torch ops, the solver is imported WHEN THE LOSS IS CALLED - constructing the module never needs
 the package, calling it without the package raises ImportError naming it.
-PARITY UNPINNED against the reference module itself (it needs torchaudio / torchvision / geomloss, absent from the
-build image, and ships no vectors): checked against oracle/mss_loss.py and against torch.stft.
+Parity (round 5): values and gradients of the reference module itself - run in the build container with torchaudio's
+Spectrogram restated (torchaudio==2.0.2, absent from the image) - are the fixture G9; the kernels meet it to 2e-5
+(tests/test_mss_loss.py), beside the checks against oracle/mss_loss.py and torch.stft.
 """
 import numpy as np
 import torch

@@ -5,8 +5,11 @@ The reference builds its spectrograms with torchaudio.transforms.Spectrogram(n_f
 a third-party dependency absent from this image (torchaudio==2.0.2, requirements.txt:172); its documented
 defaults are restated here with NumPy: periodic Hann window of n_fft samples, frames centred by reflect-padding
 n_fft // 2 samples on both sides, one-sided FFT, power 2, no normalisation.
-PARITY UNPINNED: the reference module cannot be imported here (torchaudio, torchvision, geomloss missing) and
-ships no test vectors; this restatement is checked against the formulas only.
+PINNED (round 5) by G9 (tests/golden/g9_mss_loss.npz): values and gradients of the reference's OWN MSSLoss, run in the build
+container with torchaudio's Spectrogram supplied to it as a restatement of torchaudio 2.0.2 and inert stand-ins for torchvision /
+geomloss (tests/golden/_ref_harness.install_spectral).  What the fixture pins is every line of the reference on this path -
+weights, log2, eps, alpha, hop lengths, band clipping, the sum over the scales; the Spectrogram underneath remains a restated
+third-party algorithm (torch.stft semantics), which tests/test_mss_loss.py checks against torch.stft itself.
 """
 import numpy as np
 

@@ -2,7 +2,8 @@
 
 Used ONLY by tests/golden/make_golden.py, in the build container where
 /root/reference exists.  It never runs on the GPU box and is never imported by
-the product package.  It installs three shims:
+the product package.  It installs three shims and, for the
+spectral loss only (``install_spectral``, round 5), three more:
 
   1. a stand-in ``torch_scatter`` module exposing ``scatter(src, index, dim,
      dim_size, reduce)`` (reference call sites: src/diffelastic/deform.py:165,
@@ -11,6 +12,17 @@ the product package.  It installs three shims:
      ``.msh`` files (reference call sites: src/diffelastic/mesh.py:38,50,187),
   3. ``Tensor.cuda`` / ``Module.cuda`` as no-ops (the reference hard-codes
      ``.cuda()`` everywhere).
+  4. a stand-in ``torchaudio`` whose ``transforms.Spectrogram`` restates the
+     published algorithm of torchaudio 2.0.2 (requirements.txt:172;
+     ``torchaudio.functional.spectrogram``: torch.stft with a periodic Hann
+     window of n_fft samples, centred frames, reflect padding, one-sided,
+     not normalised, ``abs().pow(power)`` with power 2) - the reference's call
+     site is src/ddsp/mss_loss.py:79-80.  What G9 pins is therefore the
+     reference's OWN lines (weights, log2, eps, alpha, hop, the sum over the
+     scales) run for real; the Spectrogram underneath is a restatement,
+  5. ``torchvision.transforms.functional.gaussian_blur`` and
+  6. ``geomloss.SamplesLoss``: imported by the module, never called on the
+     'l1_loss' / 'rmse_loss' paths - stand-ins that raise when called.
 """
 import struct
 import sys
@@ -108,3 +120,56 @@ def install():
     torch.nn.Module.cuda = lambda self, *a, **k: self
     if REFERENCE_ROOT not in sys.path:
         sys.path.insert(0, REFERENCE_ROOT)
+
+
+class _Spectrogram(torch.nn.Module):
+    """torchaudio.transforms.Spectrogram of torchaudio 2.0.2, restated (constructor defaults and forward of
+    torchaudio/transforms/_transforms.py + functional.spectrogram; normalized=False, pad=0 as the reference uses it)."""
+
+    def __init__(self, n_fft=400, win_length=None, hop_length=None, pad=0, window_fn=torch.hann_window, power=2.0,
+                 normalized=False, wkwargs=None, center=True, pad_mode="reflect", onesided=True):
+        super().__init__()
+        assert pad == 0 and not normalized and power is not None
+        self.n_fft = n_fft
+        self.win_length = win_length if win_length is not None else n_fft
+        self.hop_length = hop_length if hop_length is not None else self.win_length // 2
+        self.register_buffer("window", window_fn(self.win_length) if wkwargs is None else window_fn(self.win_length, **wkwargs),
+                             persistent=False)
+        self.power, self.center, self.pad_mode, self.onesided = power, center, pad_mode, onesided
+
+    def forward(self, waveform):
+        shape = waveform.size()
+        x = waveform.reshape(-1, shape[-1])
+        spec = torch.stft(x, self.n_fft, self.hop_length, self.win_length, self.window, self.center, self.pad_mode, False,
+                          self.onesided, return_complex=True)
+        spec = spec.reshape(shape[:-1] + spec.shape[-2:])
+        return spec.abs() if self.power == 1.0 else spec.abs().pow(self.power)
+
+
+def _never(name):
+    def f(*a, **k):
+        raise RuntimeError(f"{name}: stand-in of the golden harness - not part of the 'l1_loss' / 'rmse_loss' paths")
+    return f
+
+
+def install_spectral():
+    """Shims 4-6: what src/ddsp/mss_loss.py imports at module level."""
+    ta, tt = types.ModuleType("torchaudio"), types.ModuleType("torchaudio.transforms")
+    tt.Spectrogram = _Spectrogram
+    ta.transforms = tt
+    sys.modules["torchaudio"], sys.modules["torchaudio.transforms"] = ta, tt
+    tv, tvt, tvf = (types.ModuleType(n) for n in ("torchvision", "torchvision.transforms", "torchvision.transforms.functional"))
+    tvf.gaussian_blur = _never("torchvision.transforms.functional.gaussian_blur")
+    tv.transforms, tvt.functional = tvt, tvf
+    for m in (tv, tvt, tvf):
+        sys.modules[m.__name__] = m
+    gl = types.ModuleType("geomloss")
+
+    class SamplesLoss:  # (constructed by SSSLoss.__init__, called on the 'geomloss' path only)
+        def __init__(self, *a, **k):
+            pass
+
+        __call__ = _never("geomloss.SamplesLoss")
+
+    gl.SamplesLoss = SamplesLoss
+    sys.modules["geomloss"] = gl

@@ -398,15 +398,50 @@ def mesh_file_fixture():
     print("g8 done", m.vertices.shape, m.tets.shape)
 
 
+def spectral_loss():
+    """G9 (round 5): the reference's MSSLoss (src/ddsp/mss_loss.py:125-147 over SSSLoss :69-122 and weighted_l1_loss :50-62), types
+    'l1_loss' (what material_sync_train.py:123-125 builds for its late epochs) and 'rmse_loss' (with and without a clipped band),
+    run on two batches of decaying partials - value and gradient w.r.t. the predicted audio.  The module's third-party imports are
+    absent from the image: _ref_harness.install_spectral() supplies torchaudio's Spectrogram as a restatement of torchaudio 2.0.2
+    (what G9 pins is the reference's own arithmetic around it) and inert stand-ins for torchvision / geomloss."""
+    _ref_harness.install_spectral()
+    from src.ddsp.mss_loss import MSSLoss
+
+    sr, n = 16000, 6000
+    g = torch.Generator().manual_seed(91)
+    t = torch.arange(n, dtype=torch.float64) / sr
+
+    def partials(nm, seed_shift):
+        f = 200.0 + 3800.0 * torch.rand((2, nm), generator=g, dtype=torch.float64)
+        d = 4.0 + 60.0 * torch.rand((2, nm), generator=g, dtype=torch.float64)
+        a = torch.rand((2, nm), generator=g, dtype=torch.float64) / nm
+        return (a[..., None] * torch.exp(-d[..., None] * t) * torch.sin(2 * np.pi * f[..., None] * t)).sum(1).float()
+
+    x_true = partials(12, 0)
+    x_pred = (0.7 * x_true + 0.3 * partials(12, 1) + 1e-3 * torch.randn((2, n), generator=g)).contiguous()
+    out = dict(x_pred=x_pred.numpy(), x_true=x_true.numpy(), sample_rate=sr)
+    for tag, ffts, kind, scale in (("l1", [1024, 512, 256, 128, 64], "l1_loss", 1.0), ("l1_big", [2048, 1024], "l1_loss", 1.0),
+                                   ("rmse", [1024, 512, 256, 128, 64], "rmse_loss", 1.0), ("rmse_half", [1024, 256], "rmse_loss", 0.5)):
+        xp = x_pred.clone().requires_grad_(True)
+        loss = MSSLoss(ffts, sr, type=kind)(xp, x_true, scale=scale)
+        loss.backward()
+        out[f"{tag}_n_ffts"], out[f"{tag}_scale"] = np.array(ffts), scale
+        out[f"{tag}_loss"], out[f"{tag}_grad"] = loss.detach().double().numpy(), xp.grad.numpy()
+        print("g9", tag, float(loss), float(xp.grad.abs().max()))
+    np.savez_compressed(os.path.join(HERE, "g9_mss_loss.npz"), **out)
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="")
     ap.add_argument("--skip-ord2-bowl", action="store_true")
     a = ap.parse_args()
-    todo = a.only.split(",") if a.only else ["g1", "g2", "g3o1", "g3o2", "g4", "g5", "g6", "g7", "g8"]
+    todo = a.only.split(",") if a.only else ["g1", "g2", "g3o1", "g3o2", "g4", "g5", "g6", "g7", "g8", "g9"]
     torch.set_num_threads(8)
     if "g8" in todo:
         mesh_file_fixture()
+    if "g9" in todo:
+        spectral_loss()
     if "g1" in todo:
         constants()
     if "g2" in todo:
