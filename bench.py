@@ -1027,6 +1027,10 @@ def main():
                                 + (f" after a nested start (mean {np.mean(cits):.1f} corner-node level iterations to "
                                    f"{a.nested_tol:g})" if a.nested_tol > 0 else "")
                                 + f", backward-error tolerance {tol:g}"),
+                "warm_power_iteration": (lambda st: {"estimates": st[0], "mean_steps": round(st[1] / max(1, st[0]), 2),
+                                                     "what": "lambda_max(T K) of the two Chebyshev intervals per pass, from the previous "
+                                                             "material's block: steps until its columns' growth factors agree to 1 % (at most 3)"}
+                                         )(__import__("diffsound_amd.lobpcg.modal_solver", fromlist=["x"]).ChebyshevBlockJacobi.warm_stats),
                 "symbolic_seconds_not_timed": t_sym,
                 "symbolic_phase": ("pattern + contribution lists + neighbour-union tables on the device (ds_dpattern_build), "
                                    "plus the corner-node level, operators and first assembly; once per topology"),

@@ -204,3 +204,33 @@ def test_raw_basis_transform_equals_the_explicit_orthonormalisation():
     assert np.abs(V.T @ M @ Sa[:, nxp:]).max() < 1e-9                              # W_o is M-orthogonal to [Y X_l X_a P]
     ref = Sa.T @ K @ Sa
     assert np.abs(G.numpy() - ref).max() < 1e-9 * np.abs(ref).max()
+
+
+def test_warm_power_iteration_stops_when_the_block_is_still_converged(cube):
+    """The Chebyshev interval's end lambda_max(T K) from the previous estimate's block: ONE step when the columns' growth factors
+    agree (same operator: the block is converged), the full count when the early exit is switched off or the block is far from
+    the new operator's dominant vectors - and the estimate stays within the 1.2 safety factor of the cold 30-step one."""
+    from diffsound_amd.lobpcg.modal_solver import ChebyshevBlockJacobi as C
+
+    ops = CpuModalOps(cube["Kl"], cube["Km"], cube["M3"], cube["v"], cube["lam"], cube["mu"])
+    cold = C(ops, 4, 100.0, power_iters=400)  # (long enough for every column of the block to sit in the top of the spectrum)
+    assert getattr(ops, "_power_block", None) is not None
+    st0 = list(C.warm_stats)
+    warm = C(ops, 4, 100.0, power_iters=30)
+    assert C.warm_stats[0] - st0[0] == 1 and C.warm_stats[1] - st0[1] == 1  # one estimate, one step
+    assert abs(warm.lmax / cold.lmax - 1) < 0.02
+    saved = C.warm_spread
+    try:
+        C.warm_spread = 0.0
+        st0 = list(C.warm_stats)
+        C(ops, 4, 100.0, power_iters=30)
+        assert C.warm_stats[1] - st0[1] == C.warm_power_iters
+    finally:
+        C.warm_spread = saved
+    # a block that has nothing to do with the operator (fresh noise handed over as if it were warm) spreads its columns
+    g = torch.Generator().manual_seed(5)
+    ops._power_block = torch.randn((ops.n, 8), generator=g, dtype=ops.dtype)
+    st0 = list(C.warm_stats)
+    stale = C(ops, 4, 100.0, power_iters=30)
+    assert C.warm_stats[1] - st0[1] == C.warm_power_iters
+    assert 0.5 * cold.lmax < stale.lmax <= 1.001 * cold.lmax  # (a power iteration's estimate is a lower bound of the true one)
