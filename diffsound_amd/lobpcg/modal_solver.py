@@ -351,8 +351,9 @@ class ChebyshevBlockJacobi:
             # collapsed onto the dominant vector, so their growth factors agree; a block that the new material (or new geometry)
             # has left behind spreads them and takes the remaining steps.  (The host reads 8 numbers: one more small transfer.)
             if warm and i + 1 < power_iters and ChebyshevBlockJacobi.warm_spread > 0.0:
-                lo, hi = float(nrm.min()), float(lm)
+                lo, hi = torch.stack((nrm.min(), lm)).tolist()  # (one transfer)
                 if hi - lo < ChebyshevBlockJacobi.warm_spread * hi:
+                    lm = hi
                     break
         if warm:  # (diagnostic counters, read by bench.py: estimates from a warm block, steps they took)
             ChebyshevBlockJacobi.warm_stats[0] += 1
