@@ -671,13 +671,25 @@ class ModalSolver:
         if nx0 < b:
             X[:, nx0:].copy_(torch.randn((n, b - nx0), generator=g, dtype=torch.float32, device=dev).to(dt))
         # operator norm estimates with a random block, as the reference does (_lobpcg.py:280-285)
-        G0 = torch.randn((n, 8), generator=g, dtype=torch.float32, device=dev).to(dt)
-        G1 = torch.empty_like(G0)
-        gn = torch.linalg.vector_norm(G0.double())
+        # (The probe block is the same every time - same seed, same number of columns drawn before it - and ||M G0|| depends on
+        # the geometry only: operators that can name their geometry's generation keep the block, its norm and ||M G0|| / ||G0||
+        # from one solve to the next; a pass then multiplies the block by K alone.  Same numbers, bit for bit.)
+        pkey = getattr(ops, "norm_probe_key", None)
+        pkey = None if pkey is None else (pkey(), cfg.seed, b - nx0, n, str(dt))
+        kept = getattr(ops, "_norm_probe", None)
+        if pkey is not None and kept is not None and kept[0] == pkey:
+            _, G0, gn, B_norm = kept
+            G1 = torch.empty_like(G0)
+        else:
+            G0 = torch.randn((n, 8), generator=g, dtype=torch.float32, device=dev).to(dt)
+            G1 = torch.empty_like(G0)
+            gn = torch.linalg.vector_norm(G0.double())
+            ops.apply_M(G0, G1)
+            B_norm = torch.linalg.vector_norm(G1.double()) / gn
+            if pkey is not None:
+                ops._norm_probe = (pkey, G0, gn, B_norm)
         ops.apply_K(G0, G1)
         A_norm = torch.linalg.vector_norm(G1.double()) / gn
-        ops.apply_M(G0, G1)
-        B_norm = torch.linalg.vector_norm(G1.double()) / gn
         state.fvars.update(A_norm=float(A_norm), B_norm=float(B_norm))
         tol = cfg.tol or (2e-6 if dt == torch.float32 else 1e-10)
         self._orthonormalize(X, S[:, :ny], MW, VW=S[:, :ny + b] if ny else None)

@@ -269,13 +269,14 @@ class TetSystem:
         if vertices is not None:
             v = vertices.detach().to(torch.float32)
             self.vertices = (v if self.perm is None else v[self.perm]).contiguous()
+            self.geometry_generation = getattr(self, "geometry_generation", 0) + 1  # (what depends on the geometry only is kept per generation)
         L = _hip.lib()
         p = _hip.ptr
         _hip.check(L.ds_assemble_kml(p(self.vertices), p(self.tets), self.T, self.N, self.nv, p(self.cptr),
                                      p(self.clist), self.nnzb, p(self.dtab), p(self.mtab), p(self._tetgeo),
                                      p(self.klam), p(self.kmu), p(self.ms), _hip.stream_ptr()), "ds_assemble_kml")
         if getattr(self, "_coarse", None) is not None:
-            self._coarse["sys"].assemble(self.vertices[self._coarse["corners"]])
+            self._coarse["sys"].assemble(self.vertices[self._coarse["corners"]] if vertices is not None else None)
 
     def geometry_grad(self, U, gk, gm, lam, mu):
         """d/dx sum_i gk_i u_i^T K u_i - gm_i u_i^T M u_i  ->  (nv, 3) fp64 in the caller's node numbering.
@@ -1074,6 +1075,10 @@ class HipModalOps(_HipBlockOps):
                 self._mfma32 = m4
         self.set_material(lam, mu)
         self.rigid = self._rigid_basis() if _level == 0 else None
+
+    def norm_probe_key(self):
+        """What the solver's cached norm probe (random block, ||M G0|| / ||G0||) is valid for: this system's geometry."""
+        return (id(self.sys), getattr(self.sys, "geometry_generation", 0))
 
     def set_material(self, lam, mu):
         s = self.sys

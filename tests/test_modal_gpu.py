@@ -226,3 +226,43 @@ def test_rayleigh_ritz_on_the_raw_basis_changes_nothing_but_rounding(dev, native
     M3, _ = fem.assemble_mass(v, t, order, MAT[0])
     ev = modal.eigsh_shift_invert(K, M3, k)[0]
     assert float(np.abs(res[True].eigenvalues.cpu().numpy() / ev - 1).max()) < EIG_TOL
+
+
+def test_norm_probe_and_power_block_are_kept_per_geometry(dev):
+    """What a pass re-uses from the previous hypothesis on the same geometry (round 5): the random probe block of the operator-norm
+    estimates with ||M G0|| / ||G0|| - same numbers as a fresh computation, bit for bit - and the power iteration's block; new
+    coordinates start a new generation, and the estimates are recomputed."""
+    from diffsound_amd import meshgen
+    from diffsound_amd.diffelastic.mesh import TetMesh
+    from diffsound_amd.lobpcg.modal_solver import ModalSolver, SolverConfig, SolverState
+    from diffsound_amd.modal_ops import HipModalOps, TetSystem
+
+    v, t = meshgen.kuhn_box(6)
+    tm = TetMesh(torch.from_numpy(v).to(dev), torch.from_numpy(t).long().to(dev)).to_high_order(2)
+    sysd = TetSystem(tm.vertices, tm.tets, 2, MAT[0])
+    lam, mu = fem.lame(MAT[1], MAT[2])
+    ops = HipModalOps(sysd, lam, mu)
+    cfg = SolverConfig(block=24, tol=1e-5)
+
+    def solve():
+        st = SolverState({}, {}, {})
+        res = ModalSolver(ops, cfg).solve(16, state=st)
+        return st.fvars["A_norm"], st.fvars["B_norm"], res.eigenvalues.clone()
+
+    a0, b0, e0 = solve()
+    key0, G0 = ops._norm_probe[0], ops._norm_probe[1]
+    a1, b1, e1 = solve()  # same material, same geometry: the kept block, identical estimates (the interval of the
+    # preconditioner now comes from the warm power block, so the iterates differ in rounding)
+    assert ops._norm_probe[1] is G0 and (a1, b1) == (a0, b0) and torch.allclose(e0, e1, rtol=1e-6)
+    del ops._norm_probe
+    a2, b2, _ = solve()   # recomputed from scratch: the same numbers
+    assert (a2, b2) == (a0, b0)
+    lam2, mu2 = fem.lame(2 * MAT[1], 0.3)
+    ops.set_material(lam2, mu2)
+    sysd.assemble()       # numeric assembly on the same coordinates: same generation
+    a3, b3, _ = solve()
+    assert ops._norm_probe[0] == key0 and b3 == b0 and a3 != a0
+    sysd.assemble(tm.vertices * 1.1)  # (coordinates in the caller's numbering)
+    ops.set_material(lam2, mu2)
+    a4, b4, _ = solve()
+    assert ops._norm_probe[0] != key0 and abs(b4 / b0 - 1.1 ** 3) < 1e-3  # (mass entries scale with the volume)
