@@ -1075,6 +1075,7 @@ class HipModalOps(_HipBlockOps):
                 self._mfma32 = m4
         self.set_material(lam, mu)
         self.rigid = self._rigid_basis() if _level == 0 else None
+        self._rigid_generation = getattr(system, "geometry_generation", 0)
 
     def norm_probe_key(self):
         """What the solver's cached norm probe (random block, ||M G0|| / ||G0||) is valid for: this system's geometry."""
@@ -1084,6 +1085,11 @@ class HipModalOps(_HipBlockOps):
         s = self.sys
         if self.coarse is not None:
             self.coarse.set_material(lam, mu)
+        # New coordinates (TetSystem.assemble(vertices)) since the rigid-body basis was formed: the rotations are fields of the
+        # coordinates and the basis is M-orthonormal in the OLD mass matrix - re-form it (round 5; until then an operator object that
+        # outlived a geometry update deflated the previous geometry's rotations).  The corner-node level forms its basis on demand.
+        gen = getattr(s, "geometry_generation", 0)
+        regen = getattr(self, "_rigid_generation", gen) != gen
         p = _hip.ptr
         self.lame = (float(lam), float(mu))
         self._k64 = self._k64grp = self._m64grp = None  # (a combined fp64 K array of the previous material must never outlive it)
@@ -1112,6 +1118,9 @@ class HipModalOps(_HipBlockOps):
                     if self.m4 is None:
                         self.m4 = torch.zeros((s.nnzb + 4,), dtype=torch.float32, device=self.device)
                     torch.index_select(self.ms32, 0, self._kperm4, out=self.m4[:s.nnzb])
+        if regen:  # (the new mass values are in place)
+            self._rigid_generation = gen
+            self.rigid = self._rigid_basis() if self._level_tag == 0 else None
 
     def _rigid_basis(self):
         """Translations + rotations about the centroid, M-orthonormalised in fp64; stored (n, 8) fp32 with
