@@ -266,17 +266,24 @@ class TetSystem:
     def assemble(self, vertices=None):
         """Numeric phase only (pattern reused): refresh K_lambda, K_mu, M_s from the coordinates
         (given in the caller's node numbering)."""
+        changed = False
         if vertices is not None:
             v = vertices.detach().to(torch.float32)
-            self.vertices = (v if self.perm is None else v[self.perm]).contiguous()
-            self.geometry_generation = getattr(self, "geometry_generation", 0) + 1  # (what depends on the geometry only is kept per generation)
+            v = (v if self.perm is None else v[self.perm]).contiguous()
+            # (what depends on the geometry only - the rigid-body basis, the solver's norm probe - is kept per GENERATION of the
+            # coordinates; a caller that hands the same coordinates over again, as DiffSoundObj.eigen_decomposition does on every
+            # call, stays in the generation)
+            changed = v.shape != self.vertices.shape or not bool(torch.equal(v, self.vertices))
+            self.vertices = v
+            if changed:
+                self.geometry_generation = getattr(self, "geometry_generation", 0) + 1
         L = _hip.lib()
         p = _hip.ptr
         _hip.check(L.ds_assemble_kml(p(self.vertices), p(self.tets), self.T, self.N, self.nv, p(self.cptr),
                                      p(self.clist), self.nnzb, p(self.dtab), p(self.mtab), p(self._tetgeo),
                                      p(self.klam), p(self.kmu), p(self.ms), _hip.stream_ptr()), "ds_assemble_kml")
         if getattr(self, "_coarse", None) is not None:
-            self._coarse["sys"].assemble(self.vertices[self._coarse["corners"]] if vertices is not None else None)
+            self._coarse["sys"].assemble(self.vertices[self._coarse["corners"]] if changed else None)
 
     def geometry_grad(self, U, gk, gm, lam, mu):
         """d/dx sum_i gk_i u_i^T K u_i - gm_i u_i^T M u_i  ->  (nv, 3) fp64 in the caller's node numbering.

@@ -596,3 +596,32 @@ def test_lobpcg_callable_A_iK_and_standard_problem(golden, dev):
     assert np.abs(E5.cpu().numpy() - ws[:12]).max() / ws[11] < 1e-3
     X5d = X5.double().cpu().numpy()
     assert np.abs(X5d.T @ X5d - np.eye(12)).max() < 1e-3
+
+
+@pytest.mark.parametrize("order", [1, 2])
+def test_shape_loop_on_one_object_matches_fresh_objects(golden, dev, order):
+    """The loop of the reference's geometry experiments on ONE DiffSoundObj (experiments/geometry_train.py:231-252: move the
+    vertices, eigen_decomposition(), read get_vals()): after every move the object must return what an object built on the moved
+    mesh from scratch returns - nothing that depends on the coordinates (mass values, rigid-body basis, the solver's probes and
+    warm blocks) may survive the move."""
+    from src.diffelastic.diff_model import DiffSoundObj, FixedLinear
+
+    g = golden("g4_cube4_geometry.npz")
+    mat = tuple(float(x) for x in g["mat"])
+    v0 = torch.from_numpy(g["verts"]).to(dev)
+    t = torch.from_numpy(g["tets"]).to(dev)
+    obj = DiffSoundObj(vertices=v0.clone(), tets=t, mode_num=8, mat=mat, order=order, mat_model=FixedLinear, task="gt")
+    obj.eigen_decomposition()
+    base = obj.get_vals().detach().clone()
+    for step, (sx, sy, sz) in enumerate([(1.25, 1.0, 0.85), (0.9, 1.3, 1.1), (1.0, 1.0, 1.0)]):
+        scale = torch.tensor([sx, sy, sz], device=dev)
+        moved = (v0 * scale + 0.05 * step).contiguous()
+        fresh = DiffSoundObj(vertices=moved.clone(), tets=t, mode_num=8, mat=mat, order=order, mat_model=FixedLinear, task="gt")
+        fresh.eigen_decomposition()
+        with torch.no_grad():  # the experiment scripts move the mesh's vertices in place / re-assign them
+            obj.tetmesh.vertices = fresh.tetmesh.vertices.clone()
+        obj.eigen_decomposition()
+        a, b = obj.get_vals().detach(), fresh.get_vals().detach()
+        assert float(((a - b).abs() / b.abs()).max()) < 2e-5, (step, a.flatten()[:3], b.flatten()[:3])
+        assert float(obj.eigenvalues[0]) > 1e-3 * float(obj.eigenvalues[-1])  # (no rigid mode in the elastic spectrum)
+    assert float(((obj.get_vals().detach() - base).abs() / base.abs()).max()) < 2e-5  # (back on the first geometry)
