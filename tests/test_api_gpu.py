@@ -600,10 +600,11 @@ def test_lobpcg_callable_A_iK_and_standard_problem(golden, dev):
 
 @pytest.mark.parametrize("order", [1, 2])
 def test_shape_loop_on_one_object_matches_fresh_objects(golden, dev, order):
-    """The loop of the reference's geometry experiments on ONE DiffSoundObj (experiments/geometry_train.py:231-252: move the
-    vertices, eigen_decomposition(), read get_vals()): after every move the object must return what an object built on the moved
-    mesh from scratch returns - nothing that depends on the coordinates (mass values, rigid-body basis, the solver's probes and
-    warm blocks) may survive the move."""
+    """A geometry loop on ONE DiffSoundObj - move the vertices, eigen_decomposition(), read get_vals(); the reference's own
+    experiments build a new object per iteration (experiments/geometry_train.py:231), re-using one is what its
+    update_mass_matrix() / update_stiff_matrix() pair allows: after every move the object must return what an object built on
+    the moved mesh from scratch returns - nothing that depends on the coordinates (mass values, rigid-body basis, the solver's
+    probes and warm blocks) may survive the move."""
     from src.diffelastic.diff_model import DiffSoundObj, FixedLinear
 
     g = golden("g4_cube4_geometry.npz")
