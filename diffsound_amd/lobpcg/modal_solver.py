@@ -332,7 +332,12 @@ class ChebyshevBlockJacobi:
         # through a power iteration hands its block over and a quarter of the steps re-converge the bound (the
         # eigensolve itself still starts cold; only this spectral bound of the preconditioner is warm).
         x = getattr(ops, "_power_block", None)
-        warm = x is not None and x.shape == (n, 8) and x.dtype == dt
+        # (warm only on the geometry the block was iterated on: its 8 columns have long collapsed onto ONE dominant vector, whose
+        # growth factors agree under any operator - after a move of the mesh the early exit below would accept a stale vector's
+        # Rayleigh quotient, a LOWER bound that the 1.2 safety factor need not cover.  New coordinates: the full count again.)
+        pkey = getattr(ops, "norm_probe_key", None)
+        pkey = None if pkey is None else pkey()
+        warm = x is not None and x.shape == (n, 8) and x.dtype == dt and getattr(ops, "_power_block_key", None) == pkey
         if warm:
             power_iters = max(1, min(power_iters, ChebyshevBlockJacobi.warm_power_iters))
         else:
@@ -359,7 +364,7 @@ class ChebyshevBlockJacobi:
             ChebyshevBlockJacobi.warm_stats[0] += 1
             ChebyshevBlockJacobi.warm_stats[1] += i + 1
         try:
-            ops._power_block = x
+            ops._power_block, ops._power_block_key = x, pkey
         except AttributeError:
             pass
         # power iteration under-estimates; an under-estimated lmax makes the polynomial blow up on

@@ -262,9 +262,16 @@ def test_norm_probe_and_power_block_are_kept_per_geometry(dev):
     sysd.assemble()       # numeric assembly on the same coordinates: same generation
     a3, b3, _ = solve()
     assert ops._norm_probe[0] == key0 and b3 == b0 and a3 != a0
+    from diffsound_amd.lobpcg.modal_solver import ChebyshevBlockJacobi as C
+
+    warm_before = C.warm_stats[0]
+    solve()
+    assert C.warm_stats[0] > warm_before  # (same geometry: the intervals' ends come from the kept power block)
     sysd.assemble(tm.vertices * 1.1)  # (coordinates in the caller's numbering)
     ops.set_material(lam2, mu2)
+    warm_before = C.warm_stats[0]
     a4, b4, _ = solve()
+    assert C.warm_stats[0] == warm_before  # (new coordinates: the power iteration starts over, no warm estimate)
     assert ops._norm_probe[0] != key0 and abs(b4 / b0 - 1.1 ** 3) < 1e-3  # (mass entries scale with the volume)
 
 
