@@ -75,6 +75,9 @@ def parse():
     ap.add_argument("--lanes", type=int, default=8,
                     help="hypotheses in flight at once per GPU (own HIP stream + host thread each), so one lane's "
                          "host-side Rayleigh-Ritz step overlaps the other lane's kernels")
+    ap.add_argument("--host-wait", default="sleep", choices=["sleep", "spin"],
+                    help="how a lane's host thread waits for its stream: sleep (poll 20 us, then a blocking event; default with "
+                         "several lanes) or spin (the HIP runtime's stream synchronisation)")
     ap.add_argument("--step-barrier", action="store_true",
                     help="join all hypothesis lanes after every step (the schedule of rounds 1-2). Default: a lane runs its "
                          "hypotheses' passes of consecutive steps back to back - a hypothesis' next step depends on its own "
@@ -600,6 +603,13 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert world == a.gpus
+    # (before anything creates the device's context: with several lanes every wait of a host thread for the device sleeps)
+    sleeping_waits = False
+    if a.host_wait == "sleep" and a.lanes > 1:
+        from diffsound_amd.pipeline import prefer_sleeping_waits
+
+        ndev_ = torch.cuda.device_count()  # (does not initialise the device)
+        sleeping_waits = prefer_sleeping_waits(local_rank % max(1, ndev_) if a.share_devices else local_rank)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (there is no CPU path)")
     if a.share_devices:
@@ -646,6 +656,7 @@ def main():
 
         loss_fn = MSSLoss([1024, 512, 256, 128, 64], 32000, type="l1_loss")
     pipe = ModalPipeline(mesh.vertices, mesh.tets, a.order, a.modes, MAT, solver_config=cfg, loss_fn=loss_fn)
+    pipe.host_wait = a.host_wait
     torch.cuda.synchronize()
     t_sym = time.time() - t_sym
     nhyp = a.hyp_per_gpu * world
@@ -1027,6 +1038,11 @@ def main():
                                 + (f" after a nested start (mean {np.mean(cits):.1f} corner-node level iterations to "
                                    f"{a.nested_tol:g})" if a.nested_tol > 0 else "")
                                 + f", backward-error tolerance {tol:g}"),
+                "host_wait": (f"{a.host_wait}: " + ("a lane's host thread sleeps while it waits for its stream - the native solve polls "
+                                                   "20 us, then waits on a blocking event (ds_host_wait_mode 1); every other wait through "
+                                                   f"hipDeviceScheduleBlockingSync ({'set' if sleeping_waits else 'NOT set: the context existed'}) - "
+                                                   "waiting lanes leave their cores to the computing ones"
+                                                   if a.host_wait == "sleep" and a.lanes > 1 else "hipStreamSynchronize (the runtime spins)")),
                 "warm_power_iteration": (lambda st: {"estimates": st[0], "mean_steps": round(st[1] / max(1, st[0]), 2),
                                                      "what": "lambda_max(T K) of the two Chebyshev intervals per pass, from the previous "
                                                              "material's block: steps until its columns' growth factors agree to 1 % (at most 3)"}

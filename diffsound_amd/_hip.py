@@ -13,7 +13,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DS_EXP_LIB") or os.path.join(_HERE, "csrc", "libdiffsound_hip.so")  # (DS_EXP_LIB: A/B builds, experiments)
-ABI_VERSION = 29  # DS_ABI_VERSION of include/diffsound_hip.h
+ABI_VERSION = 30  # DS_ABI_VERSION of include/diffsound_hip.h
 
 c_i32p = ctypes.POINTER(ctypes.c_int32)
 _P = ctypes.c_void_p
@@ -196,6 +196,7 @@ _SIGNATURES["ds_spmm_union16"] = (_I, [_I, _P, _P, _I64, _I, _P, _P, _I64, _I64,
 _SIGNATURES["ds_cheb_init16"] = (_I, [_P, _I, _I64, _P, _I64, _P, _I64, _P, _I64, _I, _F, _P])
 _SIGNATURES["ds_scalar_csr_spmm16"] = (_I, [_P, _P, _P, _I64, _P, _I64, _P, _I64, _I, _F, _P])
 _SIGNATURES["ds_lobpcg_iterate"] = (_I, [ctypes.POINTER(LobpcgDesc), ctypes.POINTER(LapackTable), _P])
+_SIGNATURES["ds_host_wait_mode"] = (_I, [_I])
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 _lib = None
 

@@ -10,6 +10,7 @@
 // host synchronisations (float(torch.norm(..)) :655,663; the Python loop over a device tensor :323-328) are the two
 // small device-to-host copies of this loop (residual norms, Gram blocks).  Semantics are those of the Python loop it
 // replaces, statement for statement; tests/test_modal_gpu.py runs both and compares.
+#include <atomic>
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -29,7 +30,31 @@ struct Tm {
     int nsync = 0, neigh = 0;
 };
 thread_local Tm g_tm;
+
 inline double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+// How the host thread of a solve waits for its stream (ds_host_wait_mode; process-wide).  0: hipStreamSynchronize - under the
+// runtime's default policy a SPIN whenever the host has more cores than devices.  1: a short poll, then a sleep on an event created
+// with hipEventBlockingSync.  Eight hypothesis lanes spend four fifths of their time waiting for the device: spinning, they hold
+// eight cores for nothing, and on a host that has only a few to give (a container under CPU quota beside busy neighbours) the
+// lanes' dense steps queue behind the spinners - 52 passes/s against 60 with sleeping waits on four cores; with cores to spare
+// the wake-up latency of a sleep costs 2 % (profiles/r05_host_wait_mode.txt).  One solve at a time keeps the spin.
+std::atomic<int> g_wait_mode{0};
+thread_local hipEvent_t g_wait_event = nullptr;
+
+hipError_t wait_for_stream(hipStream_t st) {
+    if (g_wait_mode.load(std::memory_order_relaxed) == 0) return hipStreamSynchronize(st);
+    if (!g_wait_event) {
+        const hipError_t e = hipEventCreateWithFlags(&g_wait_event, hipEventBlockingSync | hipEventDisableTiming);
+        if (e != hipSuccess) return e;
+    }
+    hipError_t e = hipEventRecord(g_wait_event, st);
+    if (e != hipSuccess) return e;
+    const double t0 = now_s();
+    while ((e = hipEventQuery(g_wait_event)) == hipErrorNotReady && now_s() - t0 < 20e-6) {}  // (what is about to finish needs no sleep)
+    if (e != hipErrorNotReady) return e;
+    return hipEventSynchronize(g_wait_event);
+}
 
 // ---------------------------------------------------------------------------------------------------------------
 // small dense algebra, row-major double
@@ -267,7 +292,7 @@ struct Ctx {
         rc = hip(hipMemcpyAsync(stage, p->gbuf, sizeof(double) * (size_t)pc * qc, hipMemcpyDeviceToHost, st),
                  "ds_lobpcg_iterate: Gram block to host");
         if (rc != DS_OK) return rc;
-        { const double t0 = now_s(); rc = hip(hipStreamSynchronize(st), "ds_lobpcg_iterate: stream synchronise"); g_tm.sync += now_s() - t0; ++g_tm.nsync; }
+        { const double t0 = now_s(); rc = hip(wait_for_stream(st), "ds_lobpcg_iterate: stream synchronise"); g_tm.sync += now_s() - t0; ++g_tm.nsync; }
         if (rc == DS_OK) std::memcpy(out.a.data(), stage, sizeof(double) * (size_t)pc * qc);
         return rc;
     }
@@ -438,6 +463,12 @@ struct Ctx {
 
 }  // namespace
 
+extern "C" int ds_host_wait_mode(int mode) {
+    DS_REQUIRE(mode == 0 || mode == 1, "ds_host_wait_mode: 0 (the runtime's stream synchronisation) or 1 (poll, then sleep on a blocking event)");
+    g_wait_mode.store(mode, std::memory_order_relaxed);
+    return DS_OK;
+}
+
 extern "C" int ds_lobpcg_iterate(ds_lobpcg_t* p, const ds_lapack_t* lapack, ds_stream_t stream) {
     DS_REQUIRE(p && lapack && lapack->dsyevd && lapack->dgemm, "ds_lobpcg_iterate: null descriptor or LAPACK table");
     DS_REQUIRE(p->S && p->S2 && p->KS && p->KS2 && p->R && p->MX && p->MW && p->lam && p->rerr && p->gbuf && p->cbuf &&
@@ -493,7 +524,7 @@ extern "C" int ds_lobpcg_iterate(ds_lobpcg_t* p, const ds_lapack_t* lapack, ds_s
         if ((rc = c.hip(hipMemcpyAsync(nrm, p->nrm, sizeof(double) * 2048, hipMemcpyDeviceToHost, c.st),
                         "ds_lobpcg_iterate: residual norms to host")) != DS_OK)
             return rc;
-        { const double t0 = now_s(); rc = c.hip(hipStreamSynchronize(c.st), "ds_lobpcg_iterate: stream synchronise"); g_tm.sync += now_s() - t0; ++g_tm.nsync; }
+        { const double t0 = now_s(); rc = c.hip(wait_for_stream(c.st), "ds_lobpcg_iterate: stream synchronise"); g_tm.sync += now_s() - t0; ++g_tm.nsync; }
         if (rc != DS_OK) return rc;
         for (int j = 0; j < na; ++j)
             rel[ncl + j] = std::sqrt(nrm[j] / nrm[1024 + j]) / (p->A_norm + std::fabs(lam[ncl + j]) * p->B_norm);

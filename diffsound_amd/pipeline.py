@@ -20,6 +20,7 @@ import torch.nn as nn
 from .ddsp.oscillator import TraditionalDampedOscillator
 from .diffelastic.material_model import Material
 from .lobpcg.modal_solver import ModalSolver, SolverConfig
+from . import _hip
 from .modal_ops import HipModalOps, TetSystem
 
 
@@ -252,6 +253,25 @@ class _Lane:
                                                pipe.mat)
 
 
+def prefer_sleeping_waits(device=None):
+    """Ask the HIP runtime to SLEEP, not spin, whenever a host thread of this process waits for the device
+    (hipSetDeviceFlags(hipDeviceScheduleBlockingSync)) - for processes that run several hypothesis lanes: every wait of a lane,
+    the interpreter's included, then leaves its core to the lanes that are computing.  Must run BEFORE the process first touches
+    the device (the flag belongs to the device's primary context); returns False when it is too late or the runtime refuses -
+    the native solve's own waits sleep regardless (ds_host_wait_mode, set when the lane pool is built).
+    Measured on the benchmark (8 lanes): 61.8 passes/s on FOUR host cores against 52 - 53 with spinning waits, 62.4 against 63.1
+    with cores to spare (profiles/r05_host_wait_mode.txt)."""
+    import ctypes
+
+    try:
+        hip = ctypes.CDLL("libamdhip64.so")
+        if device is not None and int(hip.hipSetDevice(ctypes.c_int(int(device)))) != 0:  # (the flag goes to the CURRENT device)
+            return False
+        return int(hip.hipSetDeviceFlags(ctypes.c_uint(0x4))) == 0
+    except (OSError, AttributeError):
+        return False
+
+
 def _lane_pool(pipe, lanes):
     """The pipeline's persistent lane threads; a pool that is too small is shut down (its threads and their thread-local
     pinned staging rings released) before a larger one replaces it."""
@@ -265,6 +285,11 @@ def _lane_pool(pipe, lanes):
 
         pool = pipe._lane_pool = ThreadPoolExecutor(max_workers=lanes, thread_name_prefix="ds-lane",
                                                     initializer=pin_thread_to_one_core)
+    # Several lanes: a lane's host thread SLEEPS while it waits for its stream (round 5, ds_host_wait_mode) - the lanes wait four
+    # fifths of the time, and spinning they would hold one core each, which a host under CPU quota or beside busy neighbours does
+    # not have to give (on four cores the benchmark runs 60 passes/s with sleeping waits against 52 with spinning ones; with
+    # cores to spare the sleep's wake-up costs 2 %).  ``host_wait`` = "spin" keeps the runtime's own synchronisation.
+    _hip.check(_hip.lib().ds_host_wait_mode(0 if getattr(pipe, "host_wait", "sleep") == "spin" or lanes <= 1 else 1), "ds_host_wait_mode")
     return pool
 
 

@@ -40,7 +40,7 @@ enum { DS_OK = 0, DS_ERR_ARG = 1, DS_ERR_HIP = 2, DS_ERR_NOMEM = 3 };
 /* Thread-local text of the last error returned on this thread ("" if none). */
 const char* ds_last_error(void);
 /* Library ABI version (bumped on any signature change); ds_abi_version() returns the value the library was built with. */
-#define DS_ABI_VERSION 29
+#define DS_ABI_VERSION 30
 int ds_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------------
@@ -450,6 +450,11 @@ typedef struct {
     int32_t result_in_s2;     /* out */
 } ds_lobpcg_t;
 int ds_lobpcg_iterate(ds_lobpcg_t* p, const ds_lapack_t* lapack, ds_stream_t stream);
+/* How the host thread of ds_lobpcg_iterate waits for its stream (ABI 30; process-wide, default 0).  0: hipStreamSynchronize (the
+ * runtime spins when the host has more cores than devices); 1: a 20 us poll, then a sleep on an event created with
+ * hipEventBlockingSync - for callers that run several solves on several streams and threads at once (the hypothesis lanes of
+ * diffsound_amd/pipeline.py): waiting lanes then leave their cores to the lanes that are computing. */
+int ds_host_wait_mode(int mode);
 
 /* Out <- alpha * A C + beta * Out,  A (n x p) f32, C (p x q) f32 row-major device, Out (n x q) f32.
  * Out may overlap A (e.g. be a column range of it) when q <= 160: every row tile is read completely before it is

@@ -315,3 +315,24 @@ def test_rigid_basis_follows_the_geometry(dev):
     e_fresh = ModalSolver(fresh, cfg).solve(16).eigenvalues
     assert float(((e_kept - e_fresh).abs() / e_fresh).max()) < 1e-5
     assert float(e_kept[0]) > 1e6  # (no rigid mode leaked into the elastic spectrum)
+
+
+def test_host_wait_mode_changes_nothing_but_the_waiting(dev):
+    """ds_host_wait_mode: the native solve's waits for its stream as a poll followed by a sleep on a blocking event (what the lane
+    pool of the pipeline selects) against hipStreamSynchronize - the same results bit for bit; other modes are refused."""
+    from diffsound_amd import _hip
+
+    L = _hip.lib()
+    from diffsound_amd import meshgen
+
+    vv, tt = meshgen.kuhn_box(5)
+    vv, tt = torch.from_numpy(vv), torch.from_numpy(tt).long()
+    try:
+        assert L.ds_host_wait_mode(0) == 0
+        _, _, r0 = _solve(vv, tt, 1, 12, dev, block=16, tol=1e-5)
+        assert L.ds_host_wait_mode(1) == 0
+        _, _, r1 = _solve(vv, tt, 1, 12, dev, block=16, tol=1e-5)
+        assert torch.equal(r0.eigenvalues, r1.eigenvalues) and torch.equal(r0.vectors, r1.vectors) and r0.iterations == r1.iterations
+        assert L.ds_host_wait_mode(2) != 0 and L.ds_last_error()
+    finally:
+        L.ds_host_wait_mode(0)
