@@ -1043,6 +1043,11 @@ def main():
                                                    f"hipDeviceScheduleBlockingSync ({'set' if sleeping_waits else 'NOT set: the context existed'}) - "
                                                    "waiting lanes leave their cores to the computing ones"
                                                    if a.host_wait == "sleep" and a.lanes > 1 else "hipStreamSynchronize (the runtime spins)")),
+                "raw_start": (lambda st: {"taken": st[0], "explicit_route": st[1],
+                                          "what": "start blocks (corner-node level: random; fine level: the prolonged corner-level vectors) "
+                                                  "orthonormalised and rotated in coefficients from one [K X0 | M X0] walk and one Gram launch; "
+                                                  "a block too ill-conditioned for one sweep takes the explicit route"}
+                              )(__import__("diffsound_amd.lobpcg.modal_solver", fromlist=["x"]).ModalSolver.raw_start_stats),
                 "warm_power_iteration": (lambda st: {"estimates": st[0], "mean_steps": round(st[1] / max(1, st[0]), 2),
                                                      "what": "lambda_max(T K) of the two Chebyshev intervals per pass, from the previous "
                                                              "material's block: steps until its columns' growth factors agree to 1 % (at most 3)"}

@@ -77,6 +77,10 @@ class SolverConfig:
     # basis.  Per iteration: [K W | M W], Gram, update - instead of M W, Gram, update of W, K W, Gram, update.  An iteration whose
     # W is too ill-conditioned for a single sweep (eps x amplification >= ortho_tol) takes the explicit route.
     raw_rr: bool = True
+    # ... and the same for the START block (round 5): its projection against the rigid block, its M-orthonormalisation and its first
+    # Ritz step from ONE [K X0 | M X0] walk, ONE Gram launch and ONE update (needs raw_rr's operators; a start block too
+    # ill-conditioned for one sweep takes the explicit route)
+    raw_start: bool = True
     # storage of the preconditioner's internal blocks (V-cycle iterates, residuals, corner-level vectors): "bf16" halves
     # the bytes of every fused term - the cycle is bound by them - and leaves the outer iteration counts unchanged
     # (fp32 arithmetic in registers; the cycle's input R and output W stay fp32); "fp32" keeps everything in fp32
@@ -260,6 +264,8 @@ def _small(fn, dev, *mats):
     host = [m.cpu() for m in mats]
     with _one_thread():
         out = fn(*host)
+    if out is None:
+        return None
     if isinstance(out, tuple):
         return tuple(o.to(dev, non_blocking=True) if torch.is_tensor(o) else o for o in out)
     return out.to(dev, non_blocking=True)
@@ -516,6 +522,8 @@ class SolverState:
 
 
 class ModalSolver:
+    raw_start_stats = [0, 0]
+
     def __init__(self, ops, cfg: Optional[SolverConfig] = None, precond=None, precond_object=None):
         """precond: optional callable (R, W) -> None writing the preconditioned residual into W
         (the ``iK`` argument of the reference API); default Chebyshev block-Jacobi.  precond_object: an already built
@@ -606,7 +614,8 @@ class ModalSolver:
         ccfg = SolverConfig(block=b, guard=cfg.guard, tol=cfg.nested_tol, maxit=cfg.nested_maxit, seed=cfg.seed,
                             cheb_degree=cfg.nested_cheb_degree, cheb_ratio=cfg.nested_cheb_ratio,
                             power_iters=cfg.power_iters, lmax_safety=cfg.lmax_safety,
-                            lmax_cap=min(cfg.lmax_cap, 4.0) if cfg.lmax_cap > 0 else 0.0, precond="chebyshev")
+                            lmax_cap=min(cfg.lmax_cap, 4.0) if cfg.lmax_cap > 0 else 0.0, precond="chebyshev",
+                            raw_rr=cfg.raw_rr, raw_start=cfg.raw_start, kx_fresh=cfg.kx_fresh, fused_residual=cfg.fused_residual)
         pre = self.precond.coarse if isinstance(self.precond, TwoLevelChebyshev) else None
         if pre is not None and (pre.degree != ccfg.cheb_degree
                                 or abs(pre.lmax / pre.lmin - ccfg.cheb_ratio) > 1e-6 * ccfg.cheb_ratio):
@@ -697,15 +706,54 @@ class ModalSolver:
         A_norm = torch.linalg.vector_norm(G1.double()) / gn
         state.fvars.update(A_norm=float(A_norm), B_norm=float(B_norm))
         tol = cfg.tol or (2e-6 if dt == torch.float32 else 1e-10)
-        self._orthonormalize(X, S[:, :ny], MW, VW=S[:, :ny + b] if ny else None)
         KS2 = wide(3 * b)
-        ops.apply_K(X, KS[:, :b])
-        lam, Z = _small(lambda G: torch.linalg.eigh(_sym(G)), dev, ops.gram(X, KS[:, :b], symmetric=True))
-        lam = lam.clone()
-        ops.mix(X, Z, S2[:, ny:ny + b])
-        S, S2 = S2, S
-        ops.mix(KS[:, :b], Z, KS2[:, :b])  # K X of the rotated block
-        KS, KS2 = KS2, KS
+        lam = None
+        if (cfg.raw_rr and cfg.raw_start and ny and getattr(ops, "apply_KM_ok", None) is not None and b % 4 == 0
+                and ops.apply_KM_ok(X, KS[:, :b], KS[:, b:2 * b])):
+            # The start block's projection against Y, its M-orthonormalisation and its first Ritz step IN COEFFICIENTS (round 5,
+            # the raw-basis idea of the iteration applied to the start): K X0 and M X0 in ONE walk, [Y X0]^T [K X0 | M X0] in ONE
+            # Gram launch, then on the host C = Y^T M X0, B = X0^T M X0 - C^T C, the Cholesky-QR transform T of B, the Ritz pairs
+            # of T^T (X0^T K X0 - C^T (Y^T K X0) - (Y^T K X0)^T C) T, and ONE update X = [Y X0] [-C T Z; T Z] (K X = (K X0) T Z:
+            # K Y = 0).  Before: M X0, a Gram, an update, K X, a Gram, two updates - and twice the first three when the block
+            # was far from orthonormal.  A block too ill-conditioned for one sweep takes that explicit route as before.
+            ops.apply_KM(X, KS[:, :b], KS[:, b:2 * b])
+            eps_ = 6e-8 if dt == torch.float32 else 1.1e-16
+
+            def start(G_, ny_=ny, b_=b):
+                Gyk, Cy = G_[:ny_, :b_], G_[:ny_, b_:]
+                A, B0 = _sym(G_[ny_:, :b_]), _sym(G_[ny_:, b_:])
+                CtC = Cy.transpose(0, 1) @ Cy
+                Bp = B0 - CtC
+                if bool((Bp.diagonal() <= 1e-9 * B0.diagonal().abs()).any()) or not bool(torch.isfinite(Bp).all()):
+                    return None
+                T, amp = _orthonormalizer_q(torch.cat([Bp, CtC.diagonal()[None, :]], 0))
+                if not (cfg.ortho_tol > 0.0 and eps_ * amp < cfg.ortho_tol):
+                    return None  # (one sweep would leave eps * amp in the block's orthogonality: the explicit route repairs it)
+                A1 = A - Cy.transpose(0, 1) @ Gyk - Gyk.transpose(0, 1) @ Cy
+                E_, Z_ = torch.linalg.eigh(_sym(T.transpose(0, 1) @ A1 @ T))
+                Cx = T @ Z_
+                return E_, torch.cat([-(Cy @ Cx), Cx], 0).contiguous(), Cx.contiguous(), amp
+
+            got = _small(start, dev, ops.gram(S[:, :ny + b], KS[:, :2 * b]))
+            ModalSolver.raw_start_stats[0 if got is not None else 1] += 1  # (diagnostic counters: taken, handed to the explicit route)
+            if got is not None:
+                lam, coef, Cx, amp = got
+                lam = lam.clone()
+                self.ortho_log.append(amp)
+                ops.mix(S[:, :ny + b], coef, S2[:, ny:ny + b])
+                S, S2 = S2, S
+                ops.mix(KS[:, :b], Cx, KS2[:, :b])  # K X of the new block (K Y = 0)
+                KS, KS2 = KS2, KS
+                X = S[:, ny:ny + b]
+        if lam is None:
+            self._orthonormalize(X, S[:, :ny], MW, VW=S[:, :ny + b] if ny else None)
+            ops.apply_K(X, KS[:, :b])
+            lam, Z = _small(lambda G: torch.linalg.eigh(_sym(G)), dev, ops.gram(X, KS[:, :b], symmetric=True))
+            lam = lam.clone()
+            ops.mix(X, Z, S2[:, ny:ny + b])
+            S, S2 = S2, S
+            ops.mix(KS[:, :b], Z, KS2[:, :b])  # K X of the rotated block
+            KS, KS2 = KS2, KS
         history = []
         it = 0
         ncl = 0  # locked (converged) leading columns, kept a multiple of 4 for 16-byte aligned slices

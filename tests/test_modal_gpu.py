@@ -336,3 +336,27 @@ def test_host_wait_mode_changes_nothing_but_the_waiting(dev):
         assert L.ds_host_wait_mode(2) != 0 and L.ds_last_error()
     finally:
         L.ds_host_wait_mode(0)
+
+
+@pytest.mark.parametrize("mesh,order,k,block,nested", [(6, 2, 16, 24, 3e-3), (8, 1, 12, 16, 0.0), (5, 2, 8, 16, 0.0)])
+def test_start_block_in_coefficients_changes_nothing_but_rounding(dev, mesh, order, k, block, nested):
+    """The start block's projection, orthonormalisation and first Ritz step from one [K X0 | M X0] walk, one Gram launch and one
+    update (SolverConfig.raw_start, round 5) against the explicit sequence: the same eigenvalues to the solve's accuracy, the same
+    iteration counts, and the start was taken (not handed to the explicit route) on these well-conditioned blocks."""
+    from diffsound_amd import meshgen
+    from diffsound_amd.diffelastic.mesh import TetMesh
+    from diffsound_amd.lobpcg.modal_solver import ModalSolver
+
+    v, t = meshgen.kuhn_box(mesh)
+    tm = TetMesh(torch.from_numpy(v).to(dev), torch.from_numpy(t).long().to(dev)).to_high_order(order)
+    out = {}
+    for raw in (True, False):
+        taken = ModalSolver.raw_start_stats[0]
+        _, ops, res = _solve(tm.vertices, tm.tets, order, k, dev, block=block, tol=1e-6, nested_tol=nested, raw_start=raw)
+        out[raw] = res
+        assert (ModalSolver.raw_start_stats[0] > taken) == raw
+    a, b = out[True], out[False]
+    assert float(((a.eigenvalues - b.eigenvalues).abs() / b.eigenvalues).max()) < 2e-6
+    assert abs(a.iterations - b.iterations) <= 1
+    ref = modal.reference_eigs(ops, k) if hasattr(modal, "reference_eigs") else None
+    assert ref is None or float(((a.eigenvalues.cpu() - ref).abs() / ref).max()) < EIG_TOL

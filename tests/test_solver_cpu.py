@@ -234,3 +234,22 @@ def test_warm_power_iteration_stops_when_the_block_is_still_converged(cube):
     stale = C(ops, 4, 100.0, power_iters=30)
     assert C.warm_stats[1] - st0[1] == C.warm_power_iters
     assert 0.5 * cold.lmax < stale.lmax <= 1.001 * cold.lmax  # (a power iteration's estimate is a lower bound of the true one)
+
+
+@pytest.mark.parametrize("dtype,tol_eig", [(torch.float64, 1e-7), (torch.float32, 2e-5)])
+def test_start_block_in_coefficients_on_the_cpu(cube, dtype, tol_eig):
+    """SolverConfig.raw_start on the oracle's operators: the start block orthonormalised against the rigid block and rotated to
+    its Ritz basis in coefficients (one [K X0 | M X0] product, one Gram product, one update) converges to ARPACK's eigenvalues like
+    the explicit sequence, in the same number of iterations (within two)."""
+    res = {}
+    for raw in (True, False):
+        ops = CpuModalOps(cube["Kl"], cube["Km"], cube["M3"], cube["v"], cube["lam"], cube["mu"], dtype=dtype)
+        ops.fused = True  # (the CPU stand-ins of the fused operators the raw forms need)
+        seen, taken = sum(ModalSolver.raw_start_stats), ModalSolver.raw_start_stats[0]
+        tol = 0.0 if dtype == torch.float32 else 5e-8
+        res[raw] = ModalSolver(ops, SolverConfig(block=24, lmax_cap=10.0, tol=tol, raw_start=raw)).solve(16)
+        assert (sum(ModalSolver.raw_start_stats) > seen) == raw
+        if raw and dtype == torch.float64:  # (a random fp32 block may be too ill-conditioned for one sweep: the explicit route then)
+            assert ModalSolver.raw_start_stats[0] > taken
+        assert np.abs(res[raw].eigenvalues.numpy() / cube["ref"] - 1).max() < 100 * tol_eig, raw
+    assert abs(res[True].iterations - res[False].iterations) <= 2
