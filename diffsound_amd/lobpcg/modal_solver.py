@@ -615,7 +615,7 @@ class ModalSolver:
                             cheb_degree=cfg.nested_cheb_degree, cheb_ratio=cfg.nested_cheb_ratio,
                             power_iters=cfg.power_iters, lmax_safety=cfg.lmax_safety,
                             lmax_cap=min(cfg.lmax_cap, 4.0) if cfg.lmax_cap > 0 else 0.0, precond="chebyshev",
-                            raw_rr=cfg.raw_rr, raw_start=cfg.raw_start, kx_fresh=cfg.kx_fresh, fused_residual=cfg.fused_residual)
+                            raw_rr=cfg.raw_rr, raw_start=cfg.raw_start)
         pre = self.precond.coarse if isinstance(self.precond, TwoLevelChebyshev) else None
         if pre is not None and (pre.degree != ccfg.cheb_degree
                                 or abs(pre.lmax / pre.lmin - ccfg.cheb_ratio) > 1e-6 * ccfg.cheb_ratio):
