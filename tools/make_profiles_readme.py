@@ -54,6 +54,8 @@ def frac(nbytes, row):
 
 
 def ipl(key):
+    if key not in ip:  # (since the start block went into coefficients a pass launches K W / M W only inside [K W | M W])
+        return "not launched in a pass any more (the start block's K X0 and M X0 come out of the one-walk form too)"
     v = ip[key]
     t = f"{v['launches']} launches, avg {v['avg_launch_ms'] * 1e3:.1f} us (min {v['min_launch_ms'] * 1e3:.1f}) -> {v['achieved']:.0f} GB/s = {100 * v['frac']:.1f} % of 8 TB/s, {100 * v['frac_of_stream']:.1f} % of STREAM"
     if v.get("traffic"):
