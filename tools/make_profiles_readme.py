@@ -86,6 +86,7 @@ Collected by `tools/collect_profiles.sh r05 <part>` on the GPU box (this file: `
 | `r05_m32_diag.txt`, `r05_precond_sweep.txt` | per-wave `s_memtime` stamps of the bf16 term on both levels (diagnostic build: slower than production, the SHARES are what it is for — fine level: head 15 %, batches 35 %, fragments + MFMAs 22 %, epilogue 23 %; corner-node level 18 / 32 / 18 / 28 %); passes/s against the preconditioner's degrees on the new kernels, two interleaved repeats (the defaults 22 / 350 / 3 stay: 62.4 / 61.5) |
 | `r05_launch_gaps.txt`, `r05_vcycle_kernel_stats.csv` | do launch gaps matter for one hypothesis at a time? Under rocprofv3 every 15.9 µs corner-level term is followed by ~10 µs of idle device; unprofiled the V-cycle's 32 launches take 1 104 µs against 1 067 µs of kernel time (1.2 µs per launch) — the gaps are the profiler's; a captured graph of the cycle would buy 3 % and was not built |
 | `r05_deflated_corner_experiment.txt` | an algorithmic try at the corner-node level's 21 launches per cycle: its solve exact on the span of the nested start's 80 corner-level eigenvectors and a polynomial of lower degree on the rest — degree 12 / ratio 60 needs 7 fine iterations with the deflation and 7 without (production 22 / 350: 5); not pursued |
+| `r05_raw_start_ab.txt` | the start block's projection / orthonormalisation / first Ritz step in coefficients (`SolverConfig.raw_start`: one `[K X0 \| M X0]` walk, one Gram launch, one update) against the explicit sequence: 59.6 / 60.7 / 63.3 → 62.6 / 63.6 / 65.2 passes/s in three interleaved pairs; taken in every start block of a run |
 | `r05_warm_power_ab.txt`, `r05_warm_power_jump.txt`, `r05_norm_probe_ab.txt` | what a pass keeps from the previous hypothesis on the same geometry: the warm power iteration of the Chebyshev intervals stops after ONE step when its block is still converged (61.3 / 62.5 → 63.4 / 63.0 passes/s, interleaved); how low that one-step estimate falls under jumps of the Poisson ratio (worst 0.878 of the 200-step value, three steps 0.881: the 1.2 safety factor covers both); the operator-norm probe kept per geometry generation |
 | `r05_host_wait_mode.txt` | two boxes of the pool ran the default benchmark at 50–54 passes/s with every one-stream figure normal: eight spinning lanes on a host with few free cores (a fast box restricted to four CPUs: 52–53). Sleeping waits (`hipDeviceScheduleBlockingSync` + `ds_host_wait_mode 1`): **63.0 on four CPUs**, 63.0 against 63.8 with cores to spare |
 | `r05_mf_tail.txt` | the bf16 term kernel's round trips: a wave's head in ONE (fixed-stride records of a group's first 64 entries: 110.9–112.6 → 108.0–109.2 µs), what the fifth batch of a 65-entry group costs (a timing-only build without it: 106.3 → 94.3 µs), the tail form (the last batch takes two entries more, bit-identical): **97.7–98.0 µs = 0.489 of 8 TB/s** |
