@@ -523,6 +523,9 @@ class SolverState:
 
 class ModalSolver:
     raw_start_stats = [0, 0]
+    # ``ModalResult.block_vectors`` - the whole converged block, rotated to its Ritz basis: what a warm start of the next solve takes.
+    # A caller that starts every solve cold switches it off and saves one (n x b) update per solve.
+    keep_block = True
 
     def __init__(self, ops, cfg: Optional[SolverConfig] = None, precond=None, precond_object=None):
         """precond: optional callable (R, W) -> None writing the preconditioned residual into W
@@ -605,7 +608,7 @@ class ModalSolver:
                 break
 
     # ------------------------------------------------------------------ main entry
-    def _nested_start(self, k, b):
+    def _nested_start(self, k, b, out=None):
         """Start block of the fine solve from a short solve on the corner-node level (see SolverConfig.nested_tol)."""
         ops, cfg = self.ops, self.cfg
         co = ops.coarse
@@ -623,6 +626,9 @@ class ModalSolver:
         cs = ModalSolver(co, ccfg, precond_object=pre)
         rc = cs.solve(k, polish=False)
         self.nested_iterations = rc.iterations
+        if out is not None and hasattr(ops, "prolong") and out.dtype == ops.dtype:
+            ops.prolong(rc.block_vectors, out)
+            return out
         X0 = torch.zeros((ops.n, b), dtype=ops.dtype, device=ops.device)
         ops.prolong_add(rc.block_vectors, X0)
         return X0
@@ -635,9 +641,8 @@ class ModalSolver:
         if X0 is not None and X0.shape[1] > b:
             b = ((X0.shape[1] + 3) // 4) * 4
         self.nested_iterations = 0
-        if (X0 is None and cfg.nested_tol > 0.0 and getattr(ops, "coarse", None) is not None
-                and hasattr(ops, "prolong_add") and ops.coarse.n >= 3 * b + 6):
-            X0 = self._nested_start(k, b)
+        nested = (X0 is None and cfg.nested_tol > 0.0 and getattr(ops, "coarse", None) is not None
+                  and hasattr(ops, "prolong_add") and ops.coarse.n >= 3 * b + 6)
         Y = ops.rigid
         nrigid = 0 if Y is None else 6
         if n < 3 * b + nrigid:
@@ -679,8 +684,10 @@ class ModalSolver:
 
         X = S[:, ny:ny + b]
         g = torch.Generator(device=dev).manual_seed(cfg.seed)
+        if nested:  # (the prolongated corner-level block goes straight into the basis buffer)
+            X0 = self._nested_start(k, b, out=X)
         nx0 = 0 if X0 is None else X0.shape[1]
-        if nx0:
+        if nx0 and X0 is not X:
             X[:, :nx0].copy_(X0.to(dt))
         if nx0 < b:
             X[:, nx0:].copy_(torch.randn((n, b - nx0), generator=g, dtype=torch.float32, device=dev).to(dt))
@@ -1141,6 +1148,8 @@ class ModalSolver:
         a = qs[0]
         bq = qs[1] if len(GK) > 1 else None
         m = qs[-1]
-        Xb = torch.empty_like(X)
-        ops.mix(X, C, Xb)
+        Xb = None
+        if self.keep_block or self.cfg.refine_tol > 0.0:  # (the whole rotated block: a warm start's or the refinement's input)
+            Xb = torch.empty_like(X)
+            ops.mix(X, C, Xb)
         return ModalResult(E, U, a, bq, m, iterations=it, rerr=rerr, history=history, block_vectors=Xb)

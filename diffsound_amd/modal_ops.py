@@ -896,6 +896,11 @@ class _HipBlockOps:
         t = self._xfer
         self._transfer(t["pptr"], t["pcol"], t["pw"], self.nv, Ec, Wf, 1.0)
 
+    def prolong(self, Ec, Wf):
+        """Wf <- P Ec (nothing of Wf is read: the nested start writes its block straight into the solver's basis buffer)."""
+        t = self._xfer
+        self._transfer(t["pptr"], t["pcol"], t["pw"], self.nv, Ec, Wf, 0.0)
+
     def _cheb_spmm_launch(self, Wk, Wprev, R0, c1, c2, first):
         if self._union_ok(Wk, Wprev, R0):
             self._union(1, Wk, Wprev, R0, c1, c2, first)

@@ -123,6 +123,7 @@ class ModalPipeline:
         if timing:
             lap("assemble + set_material")
         solver = ModalSolver(holder.ops, self.cfg)
+        solver.keep_block = bool(getattr(self, "keep_blocks", True))
         if timing:
             lap("preconditioner set-up (power iterations)")
         res = solver.solve(self.modes, X0=warm)
@@ -361,6 +362,7 @@ def _run_steps(pipe, hyps, steps, lanes=2, on_step=None, warm_start=False, backw
     if steps <= 0 or n == 0:
         return []
     lanes = max(1, min(lanes, n))
+    pipe.keep_blocks = bool(warm_start)  # (cold passes do not form the block a warm start would take)
     while len(pipe._lanes) < lanes:
         pipe._lanes.append(_Lane(pipe, ops=pipe.ops if not pipe._lanes else None))
     main = torch.cuda.current_stream(pipe.device)
@@ -411,6 +413,7 @@ def _run_steps(pipe, hyps, steps, lanes=2, on_step=None, warm_start=False, backw
     finally:
         for f in futures:
             f.result()
+        pipe.keep_blocks = True  # (what single passes and batches outside this loop get, as before)
     if errs:
         raise errs[0]
     for e in done:
