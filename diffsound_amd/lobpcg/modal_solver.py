@@ -698,19 +698,31 @@ class ModalSolver:
         pkey = getattr(ops, "norm_probe_key", None)
         pkey = None if pkey is None else (pkey(), cfg.seed, b - nx0, n, str(dt))
         kept = getattr(ops, "_norm_probe", None)
+        terms = None
         if pkey is not None and kept is not None and kept[0] == pkey:
-            _, G0, gn, B_norm = kept
-            G1 = torch.empty_like(G0)
+            _, G0, gn, B_norm, terms = kept
         else:
             G0 = torch.randn((n, 8), generator=g, dtype=torch.float32, device=dev).to(dt)
-            G1 = torch.empty_like(G0)
             gn = torch.linalg.vector_norm(G0.double())
-            ops.apply_M(G0, G1)
-            B_norm = torch.linalg.vector_norm(G1.double()) / gn
+            # operators of the form K = sum c_i K_i with geometry-only terms (the linear material: lam K_lambda + mu K_mu) hand over
+            # K_i G0 and M G0 of ONE walk; ||K G0|| of every material on this geometry is then a small vector operation
+            prods = ops.probe_products(G0) if pkey is not None and hasattr(ops, "probe_products") else None
+            if prods is not None:
+                terms = (prods[0], prods[1])
+                B_norm = torch.linalg.vector_norm(prods[2]) / gn
+            else:
+                G1 = torch.empty_like(G0)
+                ops.apply_M(G0, G1)
+                B_norm = torch.linalg.vector_norm(G1.double()) / gn
             if pkey is not None:
-                ops._norm_probe = (pkey, G0, gn, B_norm)
-        ops.apply_K(G0, G1)
-        A_norm = torch.linalg.vector_norm(G1.double()) / gn
+                ops._norm_probe = (pkey, G0, gn, B_norm, terms)
+        if terms is not None:
+            cl, cm = ops.lame
+            A_norm = torch.linalg.vector_norm(torch.add(terms[0] * float(cl), terms[1], alpha=float(cm))) / gn
+        else:
+            G1 = torch.empty_like(G0)
+            ops.apply_K(G0, G1)
+            A_norm = torch.linalg.vector_norm(G1.double()) / gn
         state.fvars.update(A_norm=float(A_norm), B_norm=float(B_norm))
         tol = cfg.tol or (2e-6 if dt == torch.float32 else 1e-10)
         KS2 = wide(3 * b)

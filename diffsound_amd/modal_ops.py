@@ -1089,6 +1089,22 @@ class HipModalOps(_HipBlockOps):
         self.rigid = self._rigid_basis() if _level == 0 else None
         self._rigid_generation = getattr(system, "geometry_generation", 0)
 
+    def probe_products(self, G0):
+        """(K_lambda G0, K_mu G0, M G0) in fp64 for an fp32 probe block G0 of a multiple of 4 columns - ONE walk of the pattern
+        (ds_spmm_f64_polish).  Geometry only: the solver keeps them per geometry generation and forms ||K G0|| of every material
+        as ||lam K_lambda G0 + mu K_mu G0||.  None when the operator is not of that two-term form."""
+        kterms, (mkind, mvals) = self.polish_terms()
+        c = G0.shape[1]
+        if not (len(kterms) == 2 and kterms[0][0] == 2 and kterms[1][0] == 2 and mkind == 3 and G0.dtype == torch.float32
+                and c % 4 == 0 and c <= 84 and G0.stride(1) == 1 and (G0.data_ptr() | (G0.stride(0) * 4)) % 16 == 0):
+            return None
+        Y3 = torch.empty((G0.shape[0], 3 * c), dtype=torch.float64, device=self.device)
+        p = _hip.ptr
+        _hip.check(self._L.ds_spmm_f64_polish(p(self.rowptr), p(self.colidx), p(kterms[0][1]), p(kterms[1][1]), p(mvals), self.nv,
+                                              p(G0), _ld(G0), p(Y3[:, :c]), p(Y3[:, c:2 * c]), p(Y3[:, 2 * c:]), 3 * c, c,
+                                              _hip.stream_ptr()), "ds_spmm_f64_polish")
+        return Y3[:, :c], Y3[:, c:2 * c], Y3[:, 2 * c:]
+
     def norm_probe_key(self):
         """What the solver's cached norm probe (random block, ||M G0|| / ||G0||) is valid for: this system's geometry."""
         return (id(self.sys), getattr(self.sys, "geometry_generation", 0))

@@ -251,6 +251,12 @@ def test_norm_probe_and_power_block_are_kept_per_geometry(dev):
 
     a0, b0, e0 = solve()
     key0, G0 = ops._norm_probe[0], ops._norm_probe[1]
+    # ||K G0|| formed from the kept geometry-only products lam K_lambda G0 + mu K_mu G0 (fp64 values) = the fp32 product's norm
+    G1 = torch.empty_like(G0)
+    ops.apply_K(G0, G1)
+    assert abs(float(torch.linalg.vector_norm(G1.double()) / torch.linalg.vector_norm(G0.double())) / a0 - 1) < 1e-5
+    ops.apply_M(G0, G1)
+    assert abs(float(torch.linalg.vector_norm(G1.double()) / torch.linalg.vector_norm(G0.double())) / b0 - 1) < 1e-5
     a1, b1, e1 = solve()  # same material, same geometry: the kept block, identical estimates (the interval of the
     # preconditioner now comes from the warm power block, so the iterates differ in rounding)
     assert ops._norm_probe[1] is G0 and (a1, b1) == (a0, b0) and torch.allclose(e0, e1, rtol=1e-6)
