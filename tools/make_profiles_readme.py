@@ -97,6 +97,7 @@ Collected by `tools/collect_profiles.sh r05 <part>` on the GPU box (this file: `
 | `r05_host_time_one_lane.txt`, `r05_host_eigh_probe.txt` | where the host time of ONE hypothesis at a time goes (`DS_EXP_TIMING=1`: per solve, waiting for the stream / `dsyevd` / `dgemm` / rest; per pass, by stage with a synchronisation per stage; the first pass of the file is the set-up pass) and host LAPACK timings of the Ritz problem on the EPYC host (dsyevd 240: 2.35 ms standalone, ssyevd 1.52, dsyevr lowest third 4.6, torch/MKL 2.9; dgemm 119 GF/s on one thread) |
 | `r05_cpu_memsafe_8.json`, `_12`, `_16` | **the memory-safe CPU restatement on the GPU box's host** (EPYC 9575F, 16 threads): 18.5 s, 67.4 s, 496.5 s per pass at 3 072 / 10 368 / 24 576 tets; ARPACK's shift-invert 11.5 / 47.3 / 449.5 s; exponent {ms["measured_exponent_between_last_two"]:.2f} between the last two → {ms["extrapolated_to_benchmark_mesh"]["seconds_per_pass"]:.0f} s at the benchmark mesh |
 | `r05_barrier_probe.txt` | `tools/probes/barrier_probe.hip`: a device-wide barrier for 2 461 single-wave workgroups costs 41 µs (616 four-wave workgroups: 15 µs) with per-wave agent-scope fences — against 16.4 µs for the launch it would replace: why the corner-node level's polynomial is not one persistent launch |
+| `r05_rocprof_lanes_stress_30_sleeping_waits.txt` | the same stress on the round's final library (lanes sleep while they wait for the device): 0 of 30 profiled 8-lane runs failed |
 | `r05_rocprof_lanes_stress_14.txt`, `r05_rocprof_lanes_stress_40.txt` | 54 profiled 8-lane runs with python's faulthandler on: 2 SIGSEGV, both inside the profiler's interception of a HIP call made from `ds_lobpcg_iterate` on a lane thread (backtraces in the file); no unprofiled run has ever shown it |
 | `r05_c5_bench.json`, `r05_c5_kernel_stats.csv`, `r05_c5_bench_noprof.json` | **configs[4]** (`bench.py --workload c5`, under rocprofv3 and plain): fp32 phase 0.75 s, with the fp64 refinement 2.2-2.5 s over the round's runs (run-to-run spread, identical step counts); the 136-column block on the union kernels and the native driver (two 68-column slices), the refinement's fp64 K W / M W on the union tables (37-38 % of STREAM; wave-per-node kernel 27-29 %) |
 | `r05_symbolic_phase_timing.txt` | ord-2 lifting and the symbolic phase per topology at C3 |
