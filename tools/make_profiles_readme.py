@@ -89,6 +89,7 @@ Collected by `tools/collect_profiles.sh r05 <part>` on the GPU box (this file: `
 | `r05_raw_start_ab.txt` | the start block's projection / orthonormalisation / first Ritz step in coefficients (`SolverConfig.raw_start`: one `[K X0 \| M X0]` walk, one Gram launch, one update) against the explicit sequence: 59.6 / 60.7 / 63.3 → 62.6 / 63.6 / 65.2 passes/s in three interleaved pairs; taken in every start block of a run |
 | `r05_warm_power_ab.txt`, `r05_warm_power_jump.txt`, `r05_norm_probe_ab.txt` | what a pass keeps from the previous hypothesis on the same geometry: the warm power iteration of the Chebyshev intervals stops after ONE step when its block is still converged (61.3 / 62.5 → 63.4 / 63.0 passes/s, interleaved); how low that one-step estimate falls under jumps of the Poisson ratio (worst 0.878 of the 200-step value, three steps 0.881: the 1.2 safety factor covers both); the operator-norm probe kept per geometry generation |
 | `r05_host_wait_mode.txt` | two boxes of the pool ran the default benchmark at 50–54 passes/s with every one-stream figure normal: eight spinning lanes on a host with few free cores (a fast box restricted to four CPUs: 52–53). Sleeping waits (`hipDeviceScheduleBlockingSync` + `ds_host_wait_mode 1`): **63.0 on four CPUs**, 63.0 against 63.8 with cores to spare |
+| `r05_order_ab.txt`, `r05_nested_knobs.txt`, `r05_lanes_sync_sweep.txt`, `r05_concurrency_profile.txt`, `r05_device_slots_experiment.txt`, `r05_host_profile_one_lane.txt` | experiments of the round that changed nothing in the product: bricks along a Hilbert curve (same kernel times, 2.5 % more traffic); the nested start's own polynomial (flat optimum); 12 / 16 hypotheses in flight and the host's wait modes (slower than 8); how many kernels overlap in the 8-lane run and where the device idles; a gate that lets only 8 solves on the device of 16 hypotheses in flight (+3 % for twice the HBM); cProfile of one hypothesis at a time (`ds_lobpcg_iterate` 83 % of a pass's host time) |
 | `r05_mf_tail.txt` | the bf16 term kernel's round trips: a wave's head in ONE (fixed-stride records of a group's first 64 entries: 110.9–112.6 → 108.0–109.2 µs), what the fifth batch of a 65-entry group costs (a timing-only build without it: 106.3 → 94.3 µs), the tail form (the last batch takes two entries more, bit-identical): **97.7–98.0 µs = 0.489 of 8 TB/s** |
 | `r05_nt_hint_ab.txt`, `r05_nt_epi_ab.txt` | four library builds on one box: non-temporal hints on the value / table loads (nt1), on the result stores (nt2), both (nt3) — K W 182 → 177 / 169 µs, M W 149 → 130 / 129, bf16 term 117 → 112 (loads) / 111 (both), corner-node level +4 % with the load hint (kept off there); the same hint on the epilogue's once-read operands costs 6 % (not adopted) |
 | `spmm_pmc_bytes_per_launch.json`, `r05_spmm_pmc_{{fp32,bf16,mfma,kx,km,resid}}.json` | HBM-side traffic per launch from separate `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes; bytes = (2·FETCH + WRITE)·1024 (gfx950 correction of `guides/MI355X_MICROARCH.md`); keyed by the hash of the SpMM sources + `modal_ops.py` — `bench.py` reports a record with another hash as stale |
