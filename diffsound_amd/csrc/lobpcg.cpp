@@ -40,20 +40,42 @@ inline double now_s() { return std::chrono::duration<double>(std::chrono::steady
 // lanes' dense steps queue behind the spinners - 52 passes/s against 60 with sleeping waits on four cores; with cores to spare
 // the wake-up latency of a sleep costs 2 % (profiles/r05_host_wait_mode.txt).  One solve at a time keeps the spin.
 std::atomic<int> g_wait_mode{0};
-thread_local hipEvent_t g_wait_event = nullptr;
+
+// One blocking event per (host thread, device), created on the device of the stream it first records and destroyed when the
+// thread ends (a single thread_local event belonged to whatever device was current at its creation - a thread that
+// later solved on a stream of another device got hipErrorInvalidResourceHandle - and was never destroyed: one leaked event per
+// replaced lane pool).
+struct WaitEvents {
+    static constexpr int MAX_DEV = 64;
+    hipEvent_t ev[MAX_DEV] = {};
+    ~WaitEvents() {
+        for (hipEvent_t e : ev)
+            if (e) (void)hipEventDestroy(e);
+    }
+};
+thread_local WaitEvents g_wait_events;
 
 hipError_t wait_for_stream(hipStream_t st) {
     if (g_wait_mode.load(std::memory_order_relaxed) == 0) return hipStreamSynchronize(st);
-    if (!g_wait_event) {
-        const hipError_t e = hipEventCreateWithFlags(&g_wait_event, hipEventBlockingSync | hipEventDisableTiming);
+    int dev = 0;
+    hipError_t e = hipStreamGetDevice(st, &dev);  // (the stream's own device, not the thread's current one)
+    if (e != hipSuccess) return e;
+    if (dev < 0 || dev >= WaitEvents::MAX_DEV) return hipStreamSynchronize(st);
+    hipEvent_t& ev = g_wait_events.ev[dev];
+    if (!ev) {
+        int cur = 0;
+        if ((e = hipGetDevice(&cur)) != hipSuccess) return e;
+        if (cur != dev && (e = hipSetDevice(dev)) != hipSuccess) return e;
+        e = hipEventCreateWithFlags(&ev, hipEventBlockingSync | hipEventDisableTiming);
+        if (cur != dev) (void)hipSetDevice(cur);
         if (e != hipSuccess) return e;
     }
-    hipError_t e = hipEventRecord(g_wait_event, st);
+    e = hipEventRecord(ev, st);
     if (e != hipSuccess) return e;
     const double t0 = now_s();
-    while ((e = hipEventQuery(g_wait_event)) == hipErrorNotReady && now_s() - t0 < 20e-6) {}  // (what is about to finish needs no sleep)
+    while ((e = hipEventQuery(ev)) == hipErrorNotReady && now_s() - t0 < 20e-6) {}  // (what is about to finish needs no sleep)
     if (e != hipErrorNotReady) return e;
-    return hipEventSynchronize(g_wait_event);
+    return hipEventSynchronize(ev);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -242,6 +264,7 @@ int for_col_slices(int c, F&& fn) {
 
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int COEF_SLOTS = 8;
+constexpr int LAM_SLOT = 256;  // doubles of the pinned staging area kept for the Ritz values (>= the widest block, 160)
 
 struct PinnedRing {  // per host thread, grown on demand, released when the thread ends
     ~PinnedRing() {
@@ -288,7 +311,7 @@ struct Ctx {
                          stream);
         if (rc != DS_OK) return rc;
         out = Mat(pc, qc);
-        double* stage = ring->back + 2048 + 128;
+        double* stage = ring->back + 2048 + LAM_SLOT;
         rc = hip(hipMemcpyAsync(stage, p->gbuf, sizeof(double) * (size_t)pc * qc, hipMemcpyDeviceToHost, st),
                  "ds_lobpcg_iterate: Gram block to host");
         if (rc != DS_OK) return rc;
@@ -453,7 +476,7 @@ struct Ctx {
                     ds::set_error("ds_lobpcg_iterate: dsyevd failed in the orthonormalisation");
                     return DS_ERR_ARG;
                 }
-                if ((rc = mix(W, ld, na, T, W, ld)) != DS_OK) return rc;  // in place: na <= 84 columns
+                if ((rc = mix(W, ld, na, T, W, ld)) != DS_OK) return rc;  // in place: na <= b <= 160 columns, what ds_mix takes aliased
             }
             if (p->ortho_tol > 0.0 && eps * amp < p->ortho_tol) break;
         }
@@ -474,8 +497,10 @@ extern "C" int ds_lobpcg_iterate(ds_lobpcg_t* p, const ds_lapack_t* lapack, ds_s
     DS_REQUIRE(p->S && p->S2 && p->KS && p->KS2 && p->R && p->MX && p->MW && p->lam && p->rerr && p->gbuf && p->cbuf &&
                    p->nrm && p->lam_dev && p->gram_work && p->mgrp,
                "ds_lobpcg_iterate: null buffer");
-    DS_REQUIRE(p->b > 0 && p->b <= 168 && p->b % 4 == 0 && p->k > 0 && p->k <= p->b && (p->ny == 0 || p->ny % 4 == 0),
-               "ds_lobpcg_iterate: block width must be a multiple of 4 <= 168 (got %d)", p->b);
+    // (<= 160: the in-place updates of the orthonormalisation go through ds_mix, which takes an aliased result only up to 160
+    // columns - blocks of 164 / 168 columns stay on the Python loop, which splits that update: ADVICE r05)
+    DS_REQUIRE(p->b > 0 && p->b <= 160 && p->b % 4 == 0 && p->k > 0 && p->k <= p->b && (p->ny == 0 || p->ny % 4 == 0),
+               "ds_lobpcg_iterate: block width must be a multiple of 4 <= 160 (got %d)", p->b);
     DS_REQUIRE(p->n == 3 * p->nv && p->n >= 3 * p->b + p->ny, "ds_lobpcg_iterate: bad problem size");
     DS_REQUIRE(p->twolevel || (p->pa && p->pb), "ds_lobpcg_iterate: no preconditioner scratch");
     // (the periodic full refresh multiplies K by [X P W], up to 3 b columns, in column slices through the union kernels: the
@@ -485,7 +510,7 @@ extern "C" int ds_lobpcg_iterate(ds_lobpcg_t* p, const ds_lapack_t* lapack, ds_s
     {   // cbuf holds COEF_SLOTS slots of (ny + 3 b) x 2 b floats
         int rcr = g_ring.reserve((size_t)(ny + 3 * b) * 2 * b);
         if (rcr != DS_OK) return rcr;
-        rcr = g_ring.reserve_back(2048 + 128 + (size_t)(ny + 3 * b) * 3 * b);  // norms | Ritz values | Gram block
+        rcr = g_ring.reserve_back(2048 + LAM_SLOT + (size_t)(ny + 3 * b) * 3 * b);  // norms | Ritz values | Gram block
         if (rcr != DS_OK) return rcr;
     }
     const int64_t n = p->n, lds = p->lds, ldks = p->ldks, ldr = p->ldr;

@@ -47,6 +47,10 @@ class SolverConfig:
     cheb_degree: int = 8  # terms of the Chebyshev polynomial preconditioner (1 = plain block-Jacobi)
     cheb_ratio: float = 100.0  # the polynomial targets the interval [lmax/ratio, lmax] of T K
     power_iters: int = 30
+    # estimates from the previous material's dominant block (same geometry): stop when two successive estimates agree to
+    # ``warm_power_spread`` (at least two steps); spread 0: exactly ``warm_power_iters`` steps
+    warm_power_iters: int = 3
+    warm_power_spread: float = 0.003
     lmax_safety: float = 1.2
     lmax_cap: float = 0.0  # rigorous bound lambda_max(T K) <= nodes per element (4 / 10); 0 = none
     # Two-level preconditioner (ops with a ``coarse`` level, i.e. ord-2 meshes): symmetric V-cycle with a
@@ -318,14 +322,33 @@ def _rr_step(GA, na):
     return E_[:na].contiguous(), Z1, _orthonormal_columns(Tm).contiguous()
 
 
+def _stats(ops, name):
+    """The two diagnostic counters ``name`` of an operator object (created on first use).  They live on the OPERATORS - one
+    object per hypothesis lane, touched by that lane's thread only - not on a class: round 5 kept them as class attributes that
+    eight lane threads incremented without a lock and that two pipelines in one process would have shared."""
+    st = getattr(ops, name, None)
+    if st is None:
+        st = [0, 0]
+        try:
+            setattr(ops, name, st)
+        except AttributeError:
+            pass
+    return st
+
+
 class ChebyshevBlockJacobi:
     """W = p(T K) T R with T = inverse 3x3 diagonal blocks of K and p the degree-(d-1) Chebyshev
     polynomial that approximates 1/x on [lmax/ratio, lmax] (Saad, Iterative Methods, Alg. 12.1).
     Costs d-1 block-SpMMs with K per application; symmetric and fixed, as LOBPCG requires."""
 
-    def __init__(self, ops, degree, ratio, power_iters=30, seed=0, safety=1.2, cap=0.0):
+    def __init__(self, ops, degree, ratio, power_iters=30, seed=0, safety=1.2, cap=0.0, warm_iters=None, warm_spread=None):
+        """``warm_iters`` / ``warm_spread``: SolverConfig.warm_power_iters / warm_power_spread of the solve this preconditioner
+        belongs to (None: the class defaults) - per solver, nothing process-wide (round 6: bench.py used to write the class
+        attributes, which two pipelines in one process would have fought over)."""
         self.ops = ops
         self.degree = max(1, int(degree))
+        warm_iters = ChebyshevBlockJacobi.warm_power_iters if warm_iters is None else int(warm_iters)
+        warm_spread = ChebyshevBlockJacobi.warm_spread if warm_spread is None else float(warm_spread)
         if power_iters <= 0:  # no estimate: the rigorous bound lambda_max(T K) <= nodes per element is the interval's end
             if cap <= 0.0:
                 raise ValueError("ChebyshevBlockJacobi: power_iters = 0 needs a rigorous bound (lmax_cap)")
@@ -335,40 +358,44 @@ class ChebyshevBlockJacobi:
             return
         n, dev, dt = ops.n, ops.device, ops.dtype
         # The dominant vectors of T K barely move when the material changes, so an ops object that already went
-        # through a power iteration hands its block over and a quarter of the steps re-converge the bound (the
+        # through a power iteration hands its block over and a few steps re-converge the bound (the
         # eigensolve itself still starts cold; only this spectral bound of the preconditioner is warm).
         x = getattr(ops, "_power_block", None)
-        # (warm only on the geometry the block was iterated on: its 8 columns have long collapsed onto ONE dominant vector, whose
-        # growth factors agree under any operator - after a move of the mesh the early exit below would accept a stale vector's
-        # Rayleigh quotient, a LOWER bound that the 1.2 safety factor need not cover.  New coordinates: the full count again.)
+        # (warm only on the geometry the block was iterated on: new coordinates take the full count again)
         pkey = getattr(ops, "norm_probe_key", None)
         pkey = None if pkey is None else pkey()
         warm = x is not None and x.shape == (n, 8) and x.dtype == dt and getattr(ops, "_power_block_key", None) == pkey
-        if warm:
-            power_iters = max(1, min(power_iters, ChebyshevBlockJacobi.warm_power_iters))
-        else:
+        if not warm:
             g = torch.Generator(device=dev).manual_seed(seed + 17)  # device-side RNG: no 100 MB host round trip
             x = torch.randn((n, 8), generator=g, dtype=torch.float32, device=dev).to(dt)
         y = torch.empty_like(x)
         z = torch.empty_like(x)
-        lm = None
+        lm = prev = None
         for i in range(power_iters):  # largest eigenvalue of T K by block power iteration
             ops.apply_K(x, y)
             ops.cheb_init(y, z, x, 1.0)  # x = T y
             nrm = torch.linalg.vector_norm(x.double(), dim=0)
             lm = nrm.max()
             x = (x / nrm.to(dt)[None, :]).contiguous()
-            # A warm block that is still converged shows it after ONE step (round 5): its 8 columns - never orthogonalised - have all
-            # collapsed onto the dominant vector, so their growth factors agree; a block that the new material (or new geometry)
-            # has left behind spreads them and takes the remaining steps.  (The host reads 8 numbers: one more small transfer.)
-            if warm and i + 1 < power_iters and ChebyshevBlockJacobi.warm_spread > 0.0:
-                lo, hi = torch.stack((nrm.min(), lm)).tolist()  # (one transfer)
-                if hi - lo < ChebyshevBlockJacobi.warm_spread * hi:
-                    lm = hi
+            # A warm block stops as soon as the estimate has stopped moving: SUCCESSIVE estimates (the growth factor of step i
+            # against step i - 1) agree to ``warm_spread``, after at least two steps and at least ``warm_iters`` unless they
+            # agree earlier.  Round 5 took the agreement AMONG the 8 columns after one step as the sign of convergence - but the
+            # columns, never orthogonalised, have all collapsed onto the previous material's dominant vector, and vectors that are
+            # equal agree under ANY operator: a jump nu 0.45 -> 0.12 left the one-step estimate at 0.878 of
+            # lambda_max, 1.05 x under the safety factor.  The growth factor of a block that the new material has left behind
+            # keeps rising from step to step; it is compared with itself.  (The host reads one number per step.)
+            if warm and warm_spread > 0.0:
+                cur = float(lm)
+                if prev is not None and abs(cur - prev) < warm_spread * cur:
+                    lm = cur
                     break
-        if warm:  # (diagnostic counters, read by bench.py: estimates from a warm block, steps they took)
-            ChebyshevBlockJacobi.warm_stats[0] += 1
-            ChebyshevBlockJacobi.warm_stats[1] += i + 1
+                prev = cur
+            elif warm and i + 1 >= max(1, warm_iters):
+                break
+        if warm:  # (diagnostic counters of THIS operator object, read by bench.py: estimates from a warm block, steps they took)
+            st = _stats(ops, "warm_stats")
+            st[0] += 1
+            st[1] += i + 1
         try:
             ops._power_block, ops._power_block_key = x, pkey
         except AttributeError:
@@ -386,9 +413,8 @@ class ChebyshevBlockJacobi:
     # power iterations when the ops hand over the block of an earlier estimate (another material on the same mesh):
     # lambda_max(T K) depends on the Poisson ratio only, and mildly (3.1 ... 3.6 over nu = 0.12 ... 0.38 on the
     # benchmark mesh), the dominant vectors hardly at all
-    warm_power_iters = 3  # (7, 4, 2 and 1 give the same outer iteration counts on the benchmark; the 1.2 safety factor stays)
-    warm_stats = [0, 0]
-    warm_spread = 0.01    # a warm block whose columns' growth factors agree to this after a step is not iterated further (0: always)
+    warm_power_iters = 3  # steps of a warm estimate when ``warm_spread`` is 0 (7, 4, 2 and 1 give the same outer iteration counts on the benchmark)
+    warm_spread = 0.003   # a warm estimate stops when two successive estimates agree to this (at least two steps); 0: warm_power_iters steps
 
     def apply(self, R, W, from_guess=False):
         """W <- p(T K) T R (R may be destroyed).  ``from_guess``: W holds an initial guess W_0 and the same
@@ -464,9 +490,10 @@ class TwoLevelChebyshev:
         self.storage = cfg.precond_storage
         self._buf16 = None
         args = (cfg.power_iters, cfg.seed, cfg.lmax_safety)
-        self.smooth = ChebyshevBlockJacobi(ops, cfg.smooth_degree, cfg.smooth_ratio, *args, cap=cfg.lmax_cap)
+        warm = dict(warm_iters=getattr(cfg, "warm_power_iters", None), warm_spread=getattr(cfg, "warm_power_spread", None))
+        self.smooth = ChebyshevBlockJacobi(ops, cfg.smooth_degree, cfg.smooth_ratio, *args, cap=cfg.lmax_cap, **warm)
         self.coarse = ChebyshevBlockJacobi(ops.coarse, cfg.coarse_degree, cfg.coarse_ratio, *args,
-                                           cap=min(cfg.lmax_cap, 4.0) if cfg.lmax_cap > 0 else 0.0)
+                                           cap=min(cfg.lmax_cap, 4.0) if cfg.lmax_cap > 0 else 0.0, **warm)
         self.lmax = self.smooth.lmax
         self._buf = None
 
@@ -522,7 +549,6 @@ class SolverState:
 
 
 class ModalSolver:
-    raw_start_stats = [0, 0]
     # ``ModalResult.block_vectors`` - the whole converged block, rotated to its Ritz basis: what a warm start of the next solve takes.
     # A caller that starts every solve cold switches it off and saves one (n x b) update per solve.
     keep_block = True
@@ -549,7 +575,8 @@ class ModalSolver:
             else:
                 self.precond = ChebyshevBlockJacobi(ops, self.cfg.cheb_degree, self.cfg.cheb_ratio,
                                                     self.cfg.power_iters, self.cfg.seed, self.cfg.lmax_safety,
-                                                    self.cfg.lmax_cap)
+                                                    self.cfg.lmax_cap, warm_iters=self.cfg.warm_power_iters,
+                                                    warm_spread=self.cfg.warm_power_spread)
             self.precond_apply = self.precond.apply
 
     # ------------------------------------------------------------------ helpers
@@ -618,7 +645,8 @@ class ModalSolver:
                             cheb_degree=cfg.nested_cheb_degree, cheb_ratio=cfg.nested_cheb_ratio,
                             power_iters=cfg.power_iters, lmax_safety=cfg.lmax_safety,
                             lmax_cap=min(cfg.lmax_cap, 4.0) if cfg.lmax_cap > 0 else 0.0, precond="chebyshev",
-                            raw_rr=cfg.raw_rr, raw_start=cfg.raw_start)
+                            raw_rr=cfg.raw_rr, raw_start=cfg.raw_start, warm_power_iters=cfg.warm_power_iters,
+                            warm_power_spread=cfg.warm_power_spread)
         pre = self.precond.coarse if isinstance(self.precond, TwoLevelChebyshev) else None
         if pre is not None and (pre.degree != ccfg.cheb_degree
                                 or abs(pre.lmax / pre.lmin - ccfg.cheb_ratio) > 1e-6 * ccfg.cheb_ratio):
@@ -754,7 +782,7 @@ class ModalSolver:
                 return E_, torch.cat([-(Cy @ Cx), Cx], 0).contiguous(), Cx.contiguous(), amp
 
             got = _small(start, dev, ops.gram(S[:, :ny + b], KS[:, :2 * b]))
-            ModalSolver.raw_start_stats[0 if got is not None else 1] += 1  # (diagnostic counters: taken, handed to the explicit route)
+            _stats(ops, "raw_start_stats")[0 if got is not None else 1] += 1  # (diagnostic counters: taken, handed to the explicit route)
             if got is not None:
                 lam, coef, Cx, amp = got
                 lam = lam.clone()

@@ -115,7 +115,9 @@ class TetSystem:
             self.tets = self.inv_perm[tets.long()].to(torch.int32).contiguous()
         else:
             self.perm = self.inv_perm = None
-            self.vertices = vertices.detach().to(torch.float32).contiguous()
+            # (a PRIVATE copy: an fp32 contiguous input would otherwise be kept by reference, and a caller that later moves its
+            # coordinates in place would move this snapshot with them - assemble(vertices) could then never see a change)
+            self.vertices = vertices.detach().to(torch.float32).contiguous().clone()
             self.tets = tets.to(torch.int32).contiguous()
         self.nv = self.vertices.shape[0]
         self.n = 3 * self.nv
@@ -269,7 +271,8 @@ class TetSystem:
         changed = False
         if vertices is not None:
             v = vertices.detach().to(torch.float32)
-            v = (v if self.perm is None else v[self.perm]).contiguous()
+            # (without a permutation ``v`` may BE the caller's storage: the kept snapshot is always a copy of our own)
+            v = v.contiguous().clone() if self.perm is None else v[self.perm].contiguous()
             # (what depends on the geometry only - the rigid-body basis, the solver's norm probe - is kept per GENERATION of the
             # coordinates; a caller that hands the same coordinates over again, as DiffSoundObj.eigen_decomposition does on every
             # call, stays in the generation)
@@ -283,7 +286,9 @@ class TetSystem:
                                      p(self.clist), self.nnzb, p(self.dtab), p(self.mtab), p(self._tetgeo),
                                      p(self.klam), p(self.kmu), p(self.ms), _hip.stream_ptr()), "ds_assemble_kml")
         if getattr(self, "_coarse", None) is not None:
-            self._coarse["sys"].assemble(self.vertices[self._coarse["corners"]] if changed else None)
+            # (the corner-node level always receives the coordinates it is to be assembled on when the caller handed any over:
+            # its own change detection decides whether its generation moves)
+            self._coarse["sys"].assemble(self.vertices[self._coarse["corners"]] if vertices is not None else None)
 
     def geometry_grad(self, U, gk, gm, lam, mu):
         """d/dx sum_i gk_i u_i^T K u_i - gm_i u_i^T M u_i  ->  (nv, 3) fp64 in the caller's node numbering.
@@ -484,7 +489,7 @@ class _HipBlockOps:
 
         g = getattr(getattr(self, "sys", None), "groups", None)
         if (g is None or g.get("union") is None or self.kgrp is None or self.mgrp is None or self.m_kind != 1
-                or b > 168 or b % 4 or ny % 4 or not self._union_ok(R, MX, MW, S[:, ny:ny + b], KS[:, :b], wide=True)):
+                or b > 160 or b % 4 or ny % 4 or not self._union_ok(R, MX, MW, S[:, ny:ny + b], KS[:, :b], wide=True)):
             return None
         dev = self.device
         d = _hip.LobpcgDesc()

@@ -408,7 +408,7 @@ typedef struct {
 } ds_lapack_t;
 typedef struct {
     int64_t n, nv;            /* n = 3 nv rows */
-    int32_t b, k, ny;         /* block width (multiple of 4, <= 168: products of more than 84 columns run in column slices),
+    int32_t b, k, ny;         /* block width (multiple of 4, <= 160: products of more than 84 columns run in column slices),
                                  wanted pairs, rigid columns */
     int32_t maxit, lock, ortho_passes, rr_refresh, gram_exact;
     int32_t kx_fresh;         /* != 0: K X' of the new Ritz block by ONE product K X' (b columns) instead of the update

@@ -207,33 +207,50 @@ def test_raw_basis_transform_equals_the_explicit_orthonormalisation():
 
 
 def test_warm_power_iteration_stops_when_the_block_is_still_converged(cube):
-    """The Chebyshev interval's end lambda_max(T K) from the previous estimate's block: ONE step when the columns' growth factors
-    agree (same operator: the block is converged), the full count when the early exit is switched off or the block is far from
-    the new operator's dominant vectors - and the estimate stays within the 1.2 safety factor of the cold 30-step one."""
+    """The Chebyshev interval's end lambda_max(T K) from the previous estimate's block: TWO steps when successive estimates agree
+    (same operator: the block is converged), a fixed count when the early exit is switched off, and as many steps as the estimate
+    keeps moving when the block is far from the new operator's dominant vectors - the estimate stays within the 1.2 safety
+    factor of the cold one.  The counters live on the operator object (round 6), not on the class."""
     from diffsound_amd.lobpcg.modal_solver import ChebyshevBlockJacobi as C
 
     ops = CpuModalOps(cube["Kl"], cube["Km"], cube["M3"], cube["v"], cube["lam"], cube["mu"])
     cold = C(ops, 4, 100.0, power_iters=400)  # (long enough for every column of the block to sit in the top of the spectrum)
     assert getattr(ops, "_power_block", None) is not None
-    st0 = list(C.warm_stats)
+    assert getattr(ops, "warm_stats", None) is None and not hasattr(C, "warm_stats")  # (cold: nothing counted; no class counters)
     warm = C(ops, 4, 100.0, power_iters=30)
-    assert C.warm_stats[0] - st0[0] == 1 and C.warm_stats[1] - st0[1] == 1  # one estimate, one step
+    assert ops.warm_stats == [1, 2]  # one estimate, two steps (the second confirms the first)
     assert abs(warm.lmax / cold.lmax - 1) < 0.02
-    saved = C.warm_spread
-    try:
-        C.warm_spread = 0.0
-        st0 = list(C.warm_stats)
-        C(ops, 4, 100.0, power_iters=30)
-        assert C.warm_stats[1] - st0[1] == C.warm_power_iters
-    finally:
-        C.warm_spread = saved
-    # a block that has nothing to do with the operator (fresh noise handed over as if it were warm) spreads its columns
+    C(ops, 4, 100.0, power_iters=30, warm_spread=0.0, warm_iters=3)
+    assert ops.warm_stats == [2, 5]
+    # a block that has nothing to do with the operator (fresh noise handed over as if it were warm): its estimate keeps rising
+    # from step to step and the iteration goes on until it has settled
     g = torch.Generator().manual_seed(5)
     ops._power_block = torch.randn((ops.n, 8), generator=g, dtype=ops.dtype)
-    st0 = list(C.warm_stats)
     stale = C(ops, 4, 100.0, power_iters=30)
-    assert C.warm_stats[1] - st0[1] == C.warm_power_iters
-    assert 0.5 * cold.lmax < stale.lmax <= 1.001 * cold.lmax  # (a power iteration's estimate is a lower bound of the true one)
+    assert ops.warm_stats[0] == 3 and ops.warm_stats[1] - 5 > 3
+    assert 0.9 * cold.lmax < stale.lmax <= 1.001 * cold.lmax  # (a power iteration's estimate is a lower bound of the true one)
+
+
+def test_warm_power_iteration_after_an_extreme_material_jump(cube):
+    """columns that have collapsed onto the OLD dominant vector agree with each other under any operator, so their
+    agreement says nothing about the new material.  After nu 0.49 -> 0.05 (and back) the warm estimate, which now compares
+    successive estimates, stays within 10 % below the converged value (measured 6 %: the power iteration crawls on this small mesh) - inside the 1.2 safety factor - where a single step
+    would have been accepted at whatever it gave."""
+    from diffsound_amd.lobpcg.modal_solver import ChebyshevBlockJacobi as C
+
+    E = 5e10
+    lame = lambda nu: (E * nu / ((1 + nu) * (1 - 2 * nu)), E / (2 * (1 + nu)))
+    for nu0, nu1 in ((0.49, 0.05), (0.05, 0.49)):
+        ops = CpuModalOps(cube["Kl"], cube["Km"], cube["M3"], cube["v"], *lame(nu0))
+        C(ops, 4, 100.0, power_iters=400)
+        new = CpuModalOps(cube["Kl"], cube["Km"], cube["M3"], cube["v"], *lame(nu1))
+        truth = C(new, 4, 100.0, power_iters=600, safety=1.0).lmax
+        new._power_block, new._power_block_key = ops._power_block, getattr(ops, "_power_block_key", None)
+        one = C(new, 4, 100.0, power_iters=30, safety=1.0, warm_spread=0.0, warm_iters=1).lmax
+        new._power_block = ops._power_block
+        warm = C(new, 4, 100.0, power_iters=30, safety=1.0).lmax
+        assert warm <= truth * (1 + 1e-9) and warm > 0.90 * truth, (nu0, nu1, one / truth, warm / truth)
+        assert warm >= one
 
 
 @pytest.mark.parametrize("dtype,tol_eig", [(torch.float64, 1e-7), (torch.float32, 2e-5)])
@@ -245,11 +262,11 @@ def test_start_block_in_coefficients_on_the_cpu(cube, dtype, tol_eig):
     for raw in (True, False):
         ops = CpuModalOps(cube["Kl"], cube["Km"], cube["M3"], cube["v"], cube["lam"], cube["mu"], dtype=dtype)
         ops.fused = True  # (the CPU stand-ins of the fused operators the raw forms need)
-        seen, taken = sum(ModalSolver.raw_start_stats), ModalSolver.raw_start_stats[0]
         tol = 0.0 if dtype == torch.float32 else 5e-8
         res[raw] = ModalSolver(ops, SolverConfig(block=24, lmax_cap=10.0, tol=tol, raw_start=raw)).solve(16)
-        assert (sum(ModalSolver.raw_start_stats) > seen) == raw
+        st = getattr(ops, "raw_start_stats", [0, 0])  # (the counters of THIS operator object)
+        assert (sum(st) > 0) == raw
         if raw and dtype == torch.float64:  # (a random fp32 block may be too ill-conditioned for one sweep: the explicit route then)
-            assert ModalSolver.raw_start_stats[0] > taken
+            assert st[0] > 0
         assert np.abs(res[raw].eigenvalues.numpy() / cube["ref"] - 1).max() < 100 * tol_eig, raw
     assert abs(res[True].iterations - res[False].iterations) <= 2
