@@ -144,6 +144,17 @@ def parse():
     ap.add_argument("--amortised-cycle", type=int, default=15,
                     help="also time the amortised variant the reference trains with (eigendecomposition every this many "
                          "passes, material_sync_train.py:135-141: EIGEN_DECOMPOSE_CYCLE = 15); 0 = skip")
+    ap.add_argument("--no-affinity", action="store_true",
+                    help="do not bind the rank to the CPUs of its device's NUMA node (diffsound_amd.hostcpu; default: bind, from sysfs, "
+                         "before the first GPU call)")
+    ap.add_argument("--no-api-path", action="store_true",
+                    help="skip the legs behind the timed region that time the path a reference user runs: one hypothesis at a time, and "
+                         "the literal loop body of experiments/material_sync_train.py:137-168 through DiffSoundObj / "
+                         "TraditionalDampedOscillator / MSSLoss / Adam")
+    ap.add_argument("--api-epochs", type=int, default=30, help="epochs of the EIGEN_DECOMPOSE_CYCLE = 15 leg of the API loop")
+    ap.add_argument("--same-material", action="store_true",
+                    help="every step repeats each hypothesis' (E, nu) exactly (rounds 1-5); default: the material moves every step, "
+                         "E (1 + 1e-3 s), nu (1 - 5e-4 s), as an optimiser's would - no pass sees the material its lane saw before")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-reps", type=int, default=3, help="full passes of the CPU oracle (a fresh process each)")
@@ -183,10 +194,9 @@ def solver_config(a=None, **over):
         cfg.raw_rr = bool(a.raw_rr)
     cfg.tol = a.tol
     cfg.power_iters = a.power_iters
-    if a.warm_power_iters > 0:
-        from diffsound_amd.lobpcg.modal_solver import ChebyshevBlockJacobi
-
-        ChebyshevBlockJacobi.warm_power_iters = a.warm_power_iters
+    if a.warm_power_iters > 0:  # (a field of THIS configuration - round 5 wrote a class attribute of the library)
+        cfg.warm_power_iters = a.warm_power_iters
+        cfg.warm_power_spread = 0.0
     if getattr(a, "ortho_tol", -1.0) >= 0:
         cfg.ortho_tol = a.ortho_tol
     if getattr(a, "ortho_passes", -1) > 0:
@@ -525,6 +535,11 @@ def in_pass_profile(pipe, hyps, dev, block, passes=2):
         lane, stream = None, torch.cuda.Stream(device=dev)
     cap = 6000 * passes
     torch.cuda.synchronize()
+    from diffsound_amd.pipeline import set_wait_mode
+
+    holder = lane if lane is not None else pipe
+    if holder.ops is not None:
+        set_wait_mode(holder.ops, 0)  # (one at a time: the solve's waits spin, as in the one-hypothesis leg; run_batch sets the lanes' mode again)
     with torch.cuda.stream(stream):
         pipe.run_pass(*hyps[0], _lane=lane)  # (untimed: the stream's first pass after the lanes' concurrent run)
         stream.synchronize()
@@ -591,6 +606,161 @@ def summarize_in_pass(rec, sysd, block, stream_gbs, mf_levels):
     return out, rr, by_kind
 
 
+def pipeline_ops(pipe):
+    """Every operator object of a pipeline (one per hypothesis lane, plus their corner-node levels)."""
+    out = [ln.ops for ln in pipe._lanes if ln.ops is not None] or ([pipe.ops] if pipe.ops is not None else [])
+    return out + [o.coarse for o in out if getattr(o, "coarse", None) is not None]
+
+
+def summed_stats(pipe, name):
+    tot = [0, 0]
+    for o in pipeline_ops(pipe):
+        st = getattr(o, name, None) or [0, 0]
+        tot[0] += st[0]
+        tot[1] += st[1]
+    return tot
+
+
+def one_hypothesis_leg(pipe, hyps, dev, passes=8, steps_done=0):
+    """ONE hypothesis at a time: complete cold passes back to back on one stream and one host thread - the
+    latency a user sees who runs a single material (the headline keeps 8 in flight).  The native solve's waits spin here (one
+    thread has a core to itself).  Every pass a material this lane has not seen."""
+    from diffsound_amd.pipeline import set_wait_mode
+
+    lane = pipe._lanes[0] if pipe._lanes else None
+    holder = lane if lane is not None else pipe
+    stream = lane.stream if lane is not None else torch.cuda.current_stream(dev)
+    saved = getattr(holder.ops, "host_wait_mode", 0)
+    set_wait_mode(holder.ops, 0)
+    its, cits = [], []
+    try:
+        with torch.cuda.stream(stream):
+            E, nu = hyps[0]
+            pipe.run_pass(E * 1.37, nu * 0.93, _lane=lane)  # (untimed: the stream's first pass after the lanes' concurrent run)
+            stream.synchronize()
+            t0 = time.time()
+            for i in range(passes):
+                E, nu = hyps[(i + 1) % len(hyps)]
+                s = steps_done + i + 7
+                r, _, _ = pipe.run_pass(E * (1 + 1e-3 * s), nu * (1 - 5e-4 * s), _lane=lane)
+                its.append(r.iterations)
+                cits.append(r.coarse_iterations)
+            stream.synchronize()
+            dt = (time.time() - t0) / passes
+    finally:
+        set_wait_mode(holder.ops, saved)
+    return {"passes_per_s": 1.0 / dt, "ms_per_pass": 1e3 * dt, "passes_timed": passes, "mean_fine_iterations": float(np.mean(its)),
+            "mean_corner_level_iterations": float(np.mean(cits)),
+            "what": "complete cold-start passes (assembly + eigensolve + read-out + render + loss + backward) one after the other on ONE "
+                    "stream and ONE host thread, a new material every pass; the host thread's waits spin"}
+
+
+def kernel_stats_leg(pipe, hyps, dev, passes=2):
+    """Kernel time and launch count of one pass, one hypothesis at a time, from torch's own kernel tracer (kineto over roctracer):
+    every device kernel of the passes, the library's and torch's.  None when the tracer is not available (e.g. the process already
+    runs under rocprofv3) - the rocprofv3 one-lane table under profiles/ is the reference figure."""
+    if any(k.startswith("ROCPROF") or k.startswith("ROCP_") for k in os.environ):
+        return None
+    try:
+        from torch.profiler import ProfilerActivity, profile
+
+        lane = pipe._lanes[0] if pipe._lanes else None
+        stream = lane.stream if lane is not None else torch.cuda.current_stream(dev)
+        with torch.cuda.stream(stream):
+            pipe.run_pass(*hyps[0], _lane=lane)
+            stream.synchronize()
+            with profile(activities=[ProfilerActivity.CUDA]) as prof:
+                for i in range(passes):
+                    pipe.run_pass(*hyps[(i + 1) % len(hyps)], _lane=lane)
+                stream.synchronize()
+        ev = [e for e in prof.events() if getattr(e, "device_type", None) is not None and "cuda" in str(e.device_type).lower()]
+        kern = [e for e in ev if not any(w in e.name.lower() for w in ("memcpy", "memset", "copybuffer"))] if ev else []
+        if not ev:
+            return None
+        tot_us = sum(float(getattr(e, "device_time", 0.0) or getattr(e, "cuda_time", 0.0) or 0.0) for e in ev)
+        own = sum(1 for e in kern if ("ds_" in e.name or "kernel" in e.name) and "at::" not in e.name)
+        return {"kernel_ms_per_pass": tot_us / 1e3 / passes, "launches_per_pass": len(ev) / passes,
+                "copies_per_pass": (len(ev) - len(kern)) / passes, "passes": passes,
+                "source": "torch.profiler (kineto / roctracer), device activities of one-at-a-time passes"}
+    except Exception as ex:  # the tracer is optional evidence, never a reason to lose the line
+        return {"error": f"{type(ex).__name__}: {ex}"[:300]}
+
+
+def api_path_leg(a, verts, tets, dev, cfg):
+    """The path a user of the reference runs, literally: the loop body of experiments/material_sync_train.py:137-168 through the
+    reference's own names - ``src.diffelastic.diff_model.build_model`` / ``DiffSoundObj.eigen_decomposition`` /
+    ``get_undamped_freqs``, ``src.ddsp.oscillator.TraditionalDampedOscillator``, ``src.ddsp.mss_loss.MSSLoss([1024 ... 64],
+    'l1_loss')``, Adam + StepLR - on the benchmark mesh, with EIGEN_DECOMPOSE_CYCLE = 1 and = 15 (the script's value).  The early
+    epochs' Sinkhorn loss (geomloss, a third-party package the image lacks) is not part of it: the late loss from epoch 0.
+    The model runs the benchmark's eigensolver settings (``cfg``)."""
+    from torch.optim import Adam, lr_scheduler
+
+    from src.ddsp.mss_loss import MSSLoss
+    from src.ddsp.oscillator import TraditionalDampedOscillator
+    from src.diffelastic.diff_model import Material, build_model
+
+    gt_coeff = [MAT[0], 6.2e10, 0.27, MAT[3], MAT[4]]
+    init_coeff = [MAT[0], 4.6e10, 0.31, MAT[3], MAT[4]]
+    forces = torch.zeros((1, 150), device=dev)
+    forces[0, 0] = 1
+    t_build = time.time()
+    gt_osc = TraditionalDampedOscillator(forces, 1, a.modes, 8000, 32000, Material(gt_coeff)).cuda()
+    gt = build_model(None, mode_num=a.modes, order=a.order, mat=gt_coeff, task="gt", vertices=verts, tets=tets)
+    gt.solver_config = cfg
+    gt.eigen_decomposition()
+    with torch.no_grad():
+        gt_audios = gt_osc(gt.get_undamped_freqs().float())
+    del gt
+    torch.manual_seed(0)
+    model = build_model(None, mode_num=a.modes, order=a.order, mat=init_coeff, task="material", vertices=verts, tets=tets)
+    model.solver_config = cfg
+    osc = TraditionalDampedOscillator(forces, len(gt_audios), a.modes, 8000, 32000, Material(init_coeff)).cuda()
+    late = MSSLoss([1024, 512, 256, 128, 64], 32000, type="l1_loss").cuda()
+    torch.cuda.synchronize()
+    t_build = time.time() - t_build
+    out = {"what": ("experiments/material_sync_train.py:137-168, literally: every CYCLE-th epoch model.eigen_decomposition() (numeric "
+                    "assembly + eigensolve; DiffSoundObj starts it from the previous block, the reference's ARPACK call starts cold), "
+                    "every epoch get_undamped_freqs -> TraditionalDampedOscillator -> MSSLoss([1024..64], 'l1_loss')(pred, gt, "
+                    "damped_freq, 1) -> zero_grad / backward / Adam.step / StepLR.step; task='material' (E and nu trainable)"),
+           "build_seconds_not_timed": t_build}
+    for cycle, epochs in ((1, 8), (15, max(15, a.api_epochs))):
+        opt = Adam(model.parameters(), lr=5e-3)
+        sched = lr_scheduler.StepLR(opt, step_size=100, gamma=0.9)
+        losses, t_eig, n_eig, its = [], 0.0, 0, []
+        for epoch in range(-1, epochs):  # (epoch -1: untimed - first calls allocate)
+            if epoch == 0:
+                torch.cuda.synchronize()
+                t0 = time.time()
+                t_eig, n_eig, its = 0.0, 0, []
+            if epoch % cycle == 0 or epoch == -1:
+                torch.cuda.synchronize()
+                te = time.time()
+                model.eigen_decomposition()
+                torch.cuda.synchronize()
+                t_eig += time.time() - te
+                n_eig += 1
+                its.append(model.last_result.iterations)
+            f = model.get_undamped_freqs().float()
+            pred = osc(f)
+            loss = late(pred, gt_audios, osc.damped_freq, 1)
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+            sched.step()
+            losses.append(float(loss.detach()))
+        torch.cuda.synchronize()
+        dt = time.time() - t0
+        if not np.isfinite(losses).all():
+            raise SystemExit("bench.py: non-finite loss in the API loop")
+        out[f"cycle_{cycle}"] = {"eigen_decompose_cycle": cycle, "epochs": epochs, "ms_per_epoch": 1e3 * dt / epochs,
+                                 "epochs_per_s": epochs / dt, "eigen_decompositions": n_eig,
+                                 "ms_per_eigen_decomposition": 1e3 * t_eig / max(1, n_eig), "mean_iterations": float(np.mean(its)),
+                                 "ms_per_epoch_outside_eigen_decomposition": 1e3 * (dt - t_eig) / epochs,
+                                 "loss_first_last": [losses[1], losses[-1]]}
+    out["youngs_poisson_after"] = [float(model.material_model.youngs()), float(model.material_model.poisson())]
+    return out
+
+
 def main():
     a = parse()
     if a.workload == "c5":
@@ -603,6 +773,14 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert world == a.gpus
+    # CPU placement of this rank, from sysfs alone and BEFORE the process touches the GPU (threads the HIP runtime and RCCL start
+    # later inherit the mask): the CPUs of the NUMA node its device hangs off, its share of them when ranks share the node
+    from diffsound_amd import hostcpu
+
+    local_world_ = int(os.environ.get("LOCAL_WORLD_SIZE", world))
+    affinity = ({"bound": False, "why": "--no-affinity"} if a.no_affinity else
+                hostcpu.bind_rank_to_device_numa(local_rank % max(1, torch.cuda.device_count()) if a.share_devices else local_rank,
+                                                 1 if a.share_devices else local_world_, min_cpus=max(4, min(a.lanes, a.hyp_per_gpu) + 2)))
     # (before anything creates the device's context: with several lanes every wait of a host thread for the device sleeps)
     sleeping_waits = False
     if a.host_wait == "sleep" and a.lanes > 1:
@@ -647,16 +825,13 @@ def main():
     mesh = TetMesh(torch.from_numpy(v).to(dev), torch.from_numpy(t).long().to(dev)).to_high_order(a.order)
     cfg = solver_config(a)
     t_sym = time.time()
-    from diffsound_amd.modal_ops import HipModalOps
-
-    HipModalOps.mfma_groups = tuple(int(x) for x in a.mfma_groups.split(","))
     loss_fn = None
     if a.loss == "mss":
         from diffsound_amd.ddsp.mss_loss import MSSLoss
 
         loss_fn = MSSLoss([1024, 512, 256, 128, 64], 32000, type="l1_loss")
-    pipe = ModalPipeline(mesh.vertices, mesh.tets, a.order, a.modes, MAT, solver_config=cfg, loss_fn=loss_fn)
-    pipe.host_wait = a.host_wait
+    pipe = ModalPipeline(mesh.vertices, mesh.tets, a.order, a.modes, MAT, solver_config=cfg, loss_fn=loss_fn,
+                         mfma_groups=tuple(int(x) for x in a.mfma_groups.split(",")), host_wait=a.host_wait)
     torch.cuda.synchronize()
     t_sym = time.time() - t_sym
     nhyp = a.hyp_per_gpu * world
@@ -696,21 +871,31 @@ def main():
 
     on_step.stamps = []
 
+    steps_done = [0]  # steps run so far (warm-up included): the material of a step depends on its global number
+
+    def moved(s, E, nu):
+        """(E, nu) of a hypothesis at global step s: an optimiser's small move per step (the amortised leg below moves the material
+        the same way) - every pass of the run assembles, solves and differentiates a material nobody has seen before, so no warm
+        estimate (power block, norm probe) finds its own previous operator again.  --same-material: the repetition of rounds 1-5."""
+        return (E, nu) if a.same_material else (E * (1 + 1e-3 * (s + 1)), nu * (1 - 5e-4 * (s + 1)))
+
     def run_steps(nsteps, warm):
         """``nsteps`` steps (one pass of every hypothesis of this rank per step; every pass runs its own numeric assembly).
         Default: the hypothesis lanes run their passes of consecutive steps back to back (ModalPipeline.run_steps - a
         hypothesis' next step depends on its own previous one only); --step-barrier: all lanes join after every step."""
         if nsteps <= 0:
             return warm
+        s0 = steps_done[0]
+        steps_done[0] += nsteps
         if a.step_barrier:
             for s in range(nsteps):
-                outs = pipe.run_batch(hyps, lanes=a.lanes, warm=warm if a.warm_start else None)
+                outs = pipe.run_batch([moved(s0 + s, E, nu) for E, nu in hyps], lanes=a.lanes, warm=warm if a.warm_start else None)
                 if a.warm_start:
                     warm = [res.block_vectors for _, res, _ in outs]
                 on_step(s, outs)
             return warm
         outs = pipe.run_steps(hyps, nsteps, lanes=a.lanes, on_step=on_step, warm_start=a.warm_start,
-                              warm_init=warm if a.warm_start else None)
+                              warm_init=warm if a.warm_start else None, material_at=lambda s, i, E, nu: moved(s0 + s, E, nu))
         return [res.block_vectors for _, res, _ in outs[-1]] if a.warm_start else None
 
     warm = run_steps(max(a.warmup, 0), None)
@@ -747,7 +932,11 @@ def main():
     free_b, total_b = torch.cuda.mem_get_info(dev)
     gathered = gather_rank_stats([len(mine), np.sum(iters), np.max(iters), own_dt,
                                   torch.cuda.max_memory_allocated(dev) / 2 ** 30, (total_b - free_b) / 2 ** 30, local_rank], dev)
-    per_rank = [{"rank": r, "device": int(g[6]), "hypotheses_per_step": int(g[0]), "fine_iterations": int(g[1]),
+    aff_all = [affinity]
+    if world > 1:
+        aff_all = [None] * world
+        dist.all_gather_object(aff_all, affinity)
+    per_rank = [{"rank": r, "device": int(g[6]), "cpu_affinity": aff_all[r], "hypotheses_per_step": int(g[0]), "fine_iterations": int(g[1]),
                  "max_iterations_of_a_pass": int(g[2]), "busy_seconds": round(float(g[3]), 4),
                  "idle_fraction": round(max(0.0, 1 - float(g[3]) / dt), 4),
                  "hbm_peak_allocated_gib": round(float(g[4]), 3), "hbm_in_use_on_device_gib": round(float(g[5]), 3)}
@@ -781,6 +970,17 @@ def main():
                               f"backward) followed by {cyc - 1} passes of read-out + render + loss + backward on the kept "
                               f"eigenvectors with (E, nu) moved by 0.1 % / 0.05 % per pass - the reference's training loop "
                               f"with EIGEN_DECOMPOSE_CYCLE = {cyc} (experiments/material_sync_train.py:135-167)")}
+
+    # ---- the path a user of the reference runs: one hypothesis at a time, its kernel time and launch
+    #      count, and the literal loop of experiments/material_sync_train.py through the drop-in API - rank 0 of a 1-rank job
+    one_hyp = kstats = api = None
+    if world == 1 and not a.no_api_path:
+        one_hyp = one_hypothesis_leg(pipe, hyps, dev, passes=8, steps_done=steps_done[0])
+        kstats = kernel_stats_leg(pipe, hyps, dev)
+        v0, t0_ = meshgen.kuhn_box(a.cells)
+        api = api_path_leg(a, torch.from_numpy(v0).to(dev), torch.from_numpy(t0_).long().to(dev), dev, cfg)
+        del v0, t0_
+        torch.cuda.empty_cache()
 
     sysd = pipe.system
     roof = None
@@ -953,9 +1153,17 @@ def main():
                 kw_traffic = rec["bytes"]
         except Exception:
             pass
-        roof = {"bound": "hbm", "achieved": solo, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": solo / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,
-                "stream_triad": stream_gbs, "frac_of_stream": solo / stream_gbs,
+        # The figure a pass sees: ``achieved`` / ``frac`` / ``avg_launch_ms`` are the dominant kernel's launches INSIDE
+        # complete passes (one at a time, every launch bracketed by HIP events on its own stream); the kernel's steady state in a
+        # back-to-back series - the best case, what rounds 1-5 quoted - is kept beside it as ``*_alone``.
+        ip = inpass.get("fused_term_bf16") if isinstance(inpass, dict) else None
+        in_ms = ip["avg_launch_ms"] if ip else solo_ms
+        in_gbs = fine_bytes / (in_ms * 1e-3) / 1e9
+        roof = {"bound": "hbm", "achieved": in_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": in_gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,
+                "stream_triad": stream_gbs, "frac_of_stream": in_gbs / stream_gbs,
+                "achieved_alone": solo, "frac_alone": solo / HBM_PEAK_GBS, "frac_of_stream_alone": solo / stream_gbs,
+                "launches_timed_in_pass": (ip or {}).get("launches"),
                 "kernel": ((f"spmm_union_mfma_kernel<8,{(a.block + 15) // 16},1>: W' = W + c1(W - W_prev) + c2 T(R0 - K W) on a "
                             f"{a.block}-column block, fine level (bf16 K blocks and iterates, block products on the matrix "
                             "cores with fp32 accumulation, fp32 epilogue)")
@@ -963,10 +1171,13 @@ def main():
                            (f"spmm_union_kernel<{a.block // 4},1,...,{'bf16' if bf else 'fp32'} blocks>: W' = W + c1(W - W_prev) + "
                             f"c2 T(R0 - K W) on a {a.block}-column block, fine level (fp32 K blocks, "
                             f"{'bf16' if bf else 'fp32'} iterates, fp32 arithmetic)")),
-                "algorithmic_bytes_per_launch": fine_bytes, "avg_launch_ms": solo_ms, "avg_launch_ms_first_30": solo_ms_first,
+                "algorithmic_bytes_per_launch": fine_bytes, "avg_launch_ms": in_ms, "avg_launch_ms_alone": solo_ms,
+                "avg_launch_ms_first_30": solo_ms_first,
                 "stream_triad_first_30": 3.0 * ne * 4 / (triad_first * 1e-3) / 1e9,
-                "how": ("'achieved' = algorithmic bytes of ONE fine-level fused-term launch / its HIP-event time with the "
-                        "kernel alone on the device, on the compact blocks the V-cycle runs it on, right after the timed "
+                "how": ("'achieved' = algorithmic bytes of ONE fine-level fused-term launch / the mean HIP-event time of its launches "
+                        "inside complete passes run one at a time ('in_pass', below: each launch alone on the device but between "
+                        "the other kernels of a pass); 'achieved_alone' / 'avg_launch_ms_alone' = the same kernel "
+                        "alone on the device, on the compact blocks the V-cycle runs it on, right after the timed "
                         "region: 100 back-to-back launches after 230 untimed ones - the steady state; the first 30 launches "
                         "after the synchronising end of the timed region run 5-10 % longer (a transient of ~100 launches, "
                         "'avg_launch_ms_first_30'; rounds 1-3 quoted that figure); 'stream_triad' = ds_stream_triad on 3 x 1 GiB "
@@ -1047,11 +1258,11 @@ def main():
                                           "what": "start blocks (corner-node level: random; fine level: the prolonged corner-level vectors) "
                                                   "orthonormalised and rotated in coefficients from one [K X0 | M X0] walk and one Gram launch; "
                                                   "a block too ill-conditioned for one sweep takes the explicit route"}
-                              )(__import__("diffsound_amd.lobpcg.modal_solver", fromlist=["x"]).ModalSolver.raw_start_stats),
+                              )(summed_stats(pipe, "raw_start_stats")),
                 "warm_power_iteration": (lambda st: {"estimates": st[0], "mean_steps": round(st[1] / max(1, st[0]), 2),
                                                      "what": "lambda_max(T K) of the two Chebyshev intervals per pass, from the previous "
-                                                             "material's block: steps until its columns' growth factors agree to 1 % (at most 3)"}
-                                         )(__import__("diffsound_amd.lobpcg.modal_solver", fromlist=["x"]).ChebyshevBlockJacobi.warm_stats),
+                                                             "material's block: steps until two successive estimates agree to 0.3 % (at least 2)"}
+                                         )(summed_stats(pipe, "warm_stats")),
                 "symbolic_seconds_not_timed": t_sym,
                 "symbolic_phase": ("pattern + contribution lists + neighbour-union tables on the device (ds_dpattern_build), "
                                    "plus the corner-node level, operators and first assembly; once per topology"),
@@ -1059,6 +1270,16 @@ def main():
                                      f"(worst {worst[0]:.3g}), iterations < {cfg.maxit}, finite loss and gradients"),
             },
             "roofline": roof,
+            # one hypothesis at a time (the headline keeps `lanes` in flight), its kernel time / launches, and the reference's own
+            # training loop through the drop-in API: VERDICT r05 items 1 and 5
+            "one_hypothesis_passes_per_s": None if one_hyp is None else one_hyp["passes_per_s"],
+            "one_hypothesis": one_hyp,
+            "kernel_ms_per_pass": (kstats or {}).get("kernel_ms_per_pass"),
+            "launches_per_pass": (kstats or {}).get("launches_per_pass"),
+            "kernel_stats": kstats,
+            "api_path": api,
+            "materials": ("every step each hypothesis' material moves: E (1 + 1e-3 s), nu (1 - 5e-4 s) at global step s (warm-up "
+                          "included) - no pass repeats a material" if not a.same_material else "the same (E, nu) every step"),
             "loss_sum_last_step": total,
             "ranks": per_rank,
             # wall-clock seconds between the completions of consecutive steps on rank 0 (warm-up steps first): shows whether the

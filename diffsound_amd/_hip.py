@@ -13,7 +13,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DS_EXP_LIB") or os.path.join(_HERE, "csrc", "libdiffsound_hip.so")  # (DS_EXP_LIB: A/B builds, experiments)
-ABI_VERSION = 30  # DS_ABI_VERSION of include/diffsound_hip.h
+ABI_VERSION = 31  # DS_ABI_VERSION of include/diffsound_hip.h
 
 c_i32p = ctypes.POINTER(ctypes.c_int32)
 _P = ctypes.c_void_p
@@ -113,8 +113,8 @@ class TwoLevelDesc(ctypes.Structure):
 
 
 class LapackTable(ctypes.Structure):
-    """ds_lapack_t: Fortran-convention dsyevd / dgemm entry points."""
-    _fields_ = [("dsyevd", _P), ("dgemm", _P)]
+    """ds_lapack_t: Fortran-convention dsyevd / dgemm entry points, and (ABI 31, optional) the stages of dsyevd."""
+    _fields_ = [("dsyevd", _P), ("dgemm", _P), ("dsytrd", _P), ("dstedc", _P), ("dormtr", _P)]
 
 
 class LobpcgDesc(ctypes.Structure):
@@ -128,7 +128,8 @@ class LobpcgDesc(ctypes.Structure):
                 ("rowptr", _P), ("colidx", _P), ("k32", _P), ("k32t", _P), ("twolevel", ctypes.POINTER(TwoLevelDesc)),
                 ("pa", _P), ("pb", _P), ("ldp", _I64), ("pr16", _P), ("gbuf", _P), ("cbuf", _P), ("nrm", _P), ("lam_dev", _P),
                 ("res_work", _P), ("res_work_bytes", _I64), ("gram_work", _P), ("gram_work_bytes", _I64), ("lam", ctypes.POINTER(_D)), ("rerr", ctypes.POINTER(_D)),
-                ("history", ctypes.POINTER(_D)), ("history_cap", _i32), ("iterations", _i32), ("result_in_s2", _i32)]
+                ("history", ctypes.POINTER(_D)), ("history_cap", _i32), ("iterations", _i32), ("result_in_s2", _i32),
+                ("wait_mode", _i32)]
 
 
 _lapack = None
@@ -148,7 +149,10 @@ def lapack_table():
         get.restype, get.argtypes = ctypes.c_void_p, [ctypes.py_object, ctypes.c_char_p]
         name.restype, name.argtypes = ctypes.c_char_p, [ctypes.py_object]
         addr = lambda cap: get(cap, name(cap))
-        _lapack = LapackTable(addr(cl.__pyx_capi__["dsyevd"]), addr(cb.__pyx_capi__["dgemm"]))
+        stages = [addr(cl.__pyx_capi__[nm]) if nm in cl.__pyx_capi__ else None for nm in ("dsytrd", "dstedc", "dormtr")]
+        if not all(stages):
+            stages = [None, None, None]
+        _lapack = LapackTable(addr(cl.__pyx_capi__["dsyevd"]), addr(cb.__pyx_capi__["dgemm"]), *stages)
     return _lapack
 
 
@@ -197,6 +201,7 @@ _SIGNATURES["ds_cheb_init16"] = (_I, [_P, _I, _I64, _P, _I64, _P, _I64, _P, _I64
 _SIGNATURES["ds_scalar_csr_spmm16"] = (_I, [_P, _P, _P, _I64, _P, _I64, _P, _I64, _I, _F, _P])
 _SIGNATURES["ds_lobpcg_iterate"] = (_I, [ctypes.POINTER(LobpcgDesc), ctypes.POINTER(LapackTable), _P])
 _SIGNATURES["ds_host_wait_mode"] = (_I, [_I])
+_SIGNATURES["ds_selftest_dense"] = (_I, [ctypes.POINTER(LapackTable), _I, _I, ctypes.c_uint, ctypes.POINTER(_D)])
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 _lib = None
 

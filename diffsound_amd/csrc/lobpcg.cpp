@@ -55,8 +55,11 @@ struct WaitEvents {
 };
 thread_local WaitEvents g_wait_events;
 
+thread_local int g_solve_wait_mode = -1;  // wait mode of the solve running on this thread (ds_lobpcg_t.wait_mode); -1: the process default
+
 hipError_t wait_for_stream(hipStream_t st) {
-    if (g_wait_mode.load(std::memory_order_relaxed) == 0) return hipStreamSynchronize(st);
+    const int mode = g_solve_wait_mode >= 0 ? g_solve_wait_mode : g_wait_mode.load(std::memory_order_relaxed);
+    if (mode == 0) return hipStreamSynchronize(st);
     int dev = 0;
     hipError_t e = hipStreamGetDevice(st, &dev);  // (the stream's own device, not the thread's current one)
     if (e != hipSuccess) return e;
@@ -117,21 +120,33 @@ Mat gemm(const ds_lapack_t& la, const Mat& A, bool ta, const Mat& B, bool tb) {
     return C;
 }
 
+// sum of a[k] * b[k * sb], k < n, on four independent accumulators: the compiler keeps a floating-point reduction in its
+// source order, i.e. one dependent chain of 4-cycle multiply-adds - the factorisations below spent 0.07 ms each on an 80 x 80
+// block that way, seven of them per iteration: most of the "rest" of profiles/r05_host_time_one_lane.txt (0.4 ms per iteration)
+inline double dot4(const double* a, const double* b, int sb, int n) {
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int k = 0;
+    for (; k + 4 <= n; k += 4) {
+        s0 += a[k] * b[(size_t)k * sb];
+        s1 += a[k + 1] * b[(size_t)(k + 1) * sb];
+        s2 += a[k + 2] * b[(size_t)(k + 2) * sb];
+        s3 += a[k + 3] * b[(size_t)(k + 3) * sb];
+    }
+    for (; k < n; ++k) s0 += a[k] * b[(size_t)k * sb];
+    return (s0 + s1) + (s2 + s3);
+}
+
 // lower Cholesky factor of a symmetric matrix (row-major L, L L^T = A); false on breakdown
 bool cholesky(const Mat& A, Mat& L) {
     const int n = A.r;
     L = Mat(n, n);
+    double* l = L.a.data();
     for (int j = 0; j < n; ++j) {
-        double d = A(j, j);
-        for (int k = 0; k < j; ++k) d -= L(j, k) * L(j, k);
+        const double d = A(j, j) - dot4(l + (size_t)j * n, l + (size_t)j * n, 1, j);
         if (!(d > 0.0) || !std::isfinite(d)) return false;
         const double ljj = std::sqrt(d);
         L(j, j) = ljj;
-        for (int i = j + 1; i < n; ++i) {
-            double s = A(i, j);
-            for (int k = 0; k < j; ++k) s -= L(i, k) * L(j, k);
-            L(i, j) = s / ljj;
-        }
+        for (int i = j + 1; i < n; ++i) L(i, j) = (A(i, j) - dot4(l + (size_t)i * n, l + (size_t)j * n, 1, j)) / ljj;
     }
     return all_finite(L);
 }
@@ -139,13 +154,12 @@ bool cholesky(const Mat& A, Mat& L) {
 Mat lower_inverse(const Mat& L) {
     const int n = L.r;
     Mat X(n, n);
+    const double* l = L.a.data();
+    double* x = X.a.data();
     for (int j = 0; j < n; ++j) {
         X(j, j) = 1.0 / L(j, j);
-        for (int i = j + 1; i < n; ++i) {
-            double s = 0.0;
-            for (int k = j; k < i; ++k) s -= L(i, k) * X(k, j);
-            X(i, j) = s / L(i, i);
-        }
+        for (int i = j + 1; i < n; ++i)  // (X's column j is walked with stride n: 80 x 80 doubles sit in the L1)
+            X(i, j) = -dot4(l + (size_t)i * n + j, x + (size_t)j * n + j, n, i - j) / L(i, i);
     }
     return X;
 }
@@ -170,6 +184,47 @@ bool eigh(const ds_lapack_t& la, const Mat& Gsym, std::vector<double>& w, Mat& Z
     Z = Mat(n, n);  // column-major eigenvector j = A[j * n + i]  ->  Z(i, j)
     for (int j = 0; j < n; ++j)
         for (int i = 0; i < n; ++i) Z(i, j) = A[(size_t)j * n + i];
+    return true;
+}
+
+// The LOWEST m eigenpairs of a symmetric matrix: w = all n eigenvalues ascending, Zm (n x m, row-major) = the first m eigenvectors.
+// The Ritz step wants a third of the vectors of its 3 na x 3 na problem.  dsyevd is tridiagonalisation + divide and conquer on the
+// tridiagonal matrix + back-transformation of ALL n vectors (dormtr, 2 n^3 flops); with the three stages called one by one only
+// the wanted m columns are back-transformed: 13 % of the call at n = 240, m = 80 (the divide-and-conquer stage, which has no
+// subset form, is half of it).  (dsyevr / dsyevx on the index range and the MRRR tridiagonal solver dstemr are slower in SciPy's
+// OpenBLAS: profiles/r05_host_eigh_probe.txt, profiles/r06_host_eigh_stages.txt.)  Falls back to dsyevd when the table has no stages.
+bool eigh_lowest(const ds_lapack_t& la, const Mat& Gsym, int m, std::vector<double>& w, Mat& Zm) {
+    const int n = Gsym.r;
+    if (!la.dsytrd || !la.dstedc || !la.dormtr || m >= n || n < 32) {
+        Mat Z;
+        if (!eigh(la, Gsym, w, Z)) return false;
+        Zm = Mat(n, std::min(m, n));
+        for (int i = 0; i < n; ++i)
+            for (int j = 0; j < Zm.c; ++j) Zm(i, j) = Z(i, j);
+        return true;
+    }
+    struct T_ { double t0 = now_s(); ~T_() { g_tm.eigh += now_s() - t0; ++g_tm.neigh; } } t_;
+    thread_local std::vector<double> A, e, tau, work, Zt;
+    thread_local std::vector<int> iwork;
+    A = Gsym.a;  // symmetric: row-major == column-major
+    w.assign(n, 0.0);
+    e.assign(n, 0.0), tau.assign(n, 0.0);
+    int nn = n, lda = n, info = 0;
+    int lwork = std::max(64 * n, 1 + 4 * n + n * n), liwork = 3 + 5 * n;
+    if ((int)work.size() < lwork) work.resize(lwork);
+    if ((int)iwork.size() < liwork) iwork.resize(liwork);
+    if (Zt.size() < (size_t)n * n) Zt.resize((size_t)n * n);
+    char lo = 'L', compz = 'I', side = 'L', notr = 'N';
+    la.dsytrd(&lo, &nn, A.data(), &lda, w.data(), e.data(), tau.data(), work.data(), &lwork, &info);
+    if (info != 0) return false;
+    la.dstedc(&compz, &nn, w.data(), e.data(), Zt.data(), &lda, work.data(), &lwork, iwork.data(), &liwork, &info);
+    if (info != 0) return false;
+    int mm = m;
+    la.dormtr(&side, &lo, &notr, &nn, &mm, A.data(), &lda, tau.data(), Zt.data(), &lda, work.data(), &lwork, &info);
+    if (info != 0) return false;
+    Zm = Mat(n, m);
+    for (int j = 0; j < m; ++j)
+        for (int i = 0; i < n; ++i) Zm(i, j) = Zt[(size_t)j * n + i];
     return true;
 }
 
@@ -486,6 +541,59 @@ struct Ctx {
 
 }  // namespace
 
+// Self-check of the host-side dense steps (no device): on a seeded random symmetric positive definite n x n matrix,
+// errs[0] = max |w_staged - w_dsyevd| / |w|_max and errs[1] = max |G Z - Z diag(w)| / |G|_max of the lowest m pairs from the staged
+// eigensolver (eigh_lowest), errs[2] = max |L L^T - G| / |G|_max of the Cholesky factor, errs[3] = max |L^-1 L - I|,
+// errs[4] = max |Q^T Q - I| of orthonormal_columns on n x m random columns; errs[5] = 1 when the staged path ran (the table has
+// the three stages), else 0.
+extern "C" int ds_selftest_dense(const ds_lapack_t* lapack, int n, int m, unsigned seed, double* errs) {
+    DS_REQUIRE(lapack && lapack->dsyevd && lapack->dgemm && errs && n >= 2 && m >= 1 && m <= n, "ds_selftest_dense: bad arguments");
+    unsigned long long st = seed * 2654435761ull + 12345ull;
+    auto rnd = [&]() {
+        st = st * 6364136223846793005ull + 1442695040888963407ull;
+        return ((st >> 11) & ((1ull << 53) - 1)) / double(1ull << 53) - 0.5;
+    };
+    Mat B(n, n);
+    for (double& v : B.a) v = rnd();
+    Mat G = gemm(*lapack, B, false, B, true);
+    for (int i = 0; i < n; ++i) G(i, i) += 0.05 * (i + 1);
+    symmetrize(G);
+    double gmax = 0.0;
+    for (double v : G.a) gmax = std::max(gmax, std::fabs(v));
+    std::vector<double> w, wf;
+    Mat Zm, Zf;
+    if (!eigh_lowest(*lapack, G, m, w, Zm) || !eigh(*lapack, G, wf, Zf)) {
+        ds::set_error("ds_selftest_dense: LAPACK reported failure");
+        return DS_ERR_ARG;
+    }
+    errs[0] = errs[1] = errs[2] = errs[3] = errs[4] = 0.0;
+    for (int j = 0; j < n; ++j) errs[0] = std::max(errs[0], std::fabs(w[j] - wf[j]) / std::fabs(wf[n - 1]));
+    const Mat GZ = gemm(*lapack, G, false, Zm, false);
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < m; ++j) errs[1] = std::max(errs[1], std::fabs(GZ(i, j) - Zm(i, j) * w[j]) / gmax);
+    Mat L;
+    if (!cholesky(G, L)) {
+        ds::set_error("ds_selftest_dense: Cholesky broke down on a positive definite matrix");
+        return DS_ERR_ARG;
+    }
+    const Mat LLt = gemm(*lapack, L, false, L, true);
+    for (size_t i = 0; i < G.a.size(); ++i) errs[2] = std::max(errs[2], std::fabs(LLt.a[i] - G.a[i]) / gmax);
+    const Mat Li = lower_inverse(L), I1 = gemm(*lapack, Li, false, L, false);
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) errs[3] = std::max(errs[3], std::fabs(I1(i, j) - (i == j ? 1.0 : 0.0)));
+    Mat Tm(n, m), Q;
+    for (double& v : Tm.a) v = rnd();
+    if (!orthonormal_columns(*lapack, Tm, Q)) {
+        ds::set_error("ds_selftest_dense: orthonormal_columns broke down");
+        return DS_ERR_ARG;
+    }
+    const Mat QtQ = gemm(*lapack, Q, true, Q, false);
+    for (int i = 0; i < m; ++i)
+        for (int j = 0; j < m; ++j) errs[4] = std::max(errs[4], std::fabs(QtQ(i, j) - (i == j ? 1.0 : 0.0)));
+    errs[5] = (lapack->dsytrd && lapack->dstedc && lapack->dormtr && m < n && n >= 32) ? 1.0 : 0.0;
+    return DS_OK;
+}
+
 extern "C" int ds_host_wait_mode(int mode) {
     DS_REQUIRE(mode == 0 || mode == 1, "ds_host_wait_mode: 0 (the runtime's stream synchronisation) or 1 (poll, then sleep on a blocking event)");
     g_wait_mode.store(mode, std::memory_order_relaxed);
@@ -494,6 +602,8 @@ extern "C" int ds_host_wait_mode(int mode) {
 
 extern "C" int ds_lobpcg_iterate(ds_lobpcg_t* p, const ds_lapack_t* lapack, ds_stream_t stream) {
     DS_REQUIRE(p && lapack && lapack->dsyevd && lapack->dgemm, "ds_lobpcg_iterate: null descriptor or LAPACK table");
+    DS_REQUIRE((!lapack->dsytrd) == (!lapack->dstedc) && (!lapack->dsytrd) == (!lapack->dormtr),
+               "ds_lobpcg_iterate: the staged eigensolver needs dsytrd, dstedc and dormtr together (or none of them)");
     DS_REQUIRE(p->S && p->S2 && p->KS && p->KS2 && p->R && p->MX && p->MW && p->lam && p->rerr && p->gbuf && p->cbuf &&
                    p->nrm && p->lam_dev && p->gram_work && p->mgrp,
                "ds_lobpcg_iterate: null buffer");
@@ -506,6 +616,12 @@ extern "C" int ds_lobpcg_iterate(ds_lobpcg_t* p, const ds_lapack_t* lapack, ds_s
     // (the periodic full refresh multiplies K by [X P W], up to 3 b columns, in column slices through the union kernels: the
     // plain BSR arrays are no longer needed for it - every width the loop forms is a multiple of 4)
     Ctx c{p, ds::as_stream(stream), stream, *lapack, p->S, p->S2, p->KS, p->KS2};
+    DS_REQUIRE(p->wait_mode >= -1 && p->wait_mode <= 1, "ds_lobpcg_iterate: wait_mode is -1 (the process default), 0 or 1");
+    struct WaitScope {  // this solve's own way of waiting for its stream (round 6: per solve, i.e. per hypothesis lane)
+        int saved;
+        explicit WaitScope(int m) : saved(g_solve_wait_mode) { g_solve_wait_mode = m; }
+        ~WaitScope() { g_solve_wait_mode = saved; }
+    } wait_scope(p->wait_mode);
     const int b = p->b, k = p->k, ny = p->ny;
     {   // cbuf holds COEF_SLOTS slots of (ny + 3 b) x 2 b floats
         int rcr = g_ring.reserve((size_t)(ny + 3 * b) * 2 * b);
@@ -528,27 +644,33 @@ extern "C" int ds_lobpcg_iterate(ds_lobpcg_t* p, const ds_lapack_t* lapack, ds_s
     // Rayleigh-Ritz on the raw basis: K X' must not be needed from K [X P W] (kx_fresh) and comes from the fused residual
     const bool raw = p->raw_rr && fused_res && !p->gram_exact;
     double worst = std::numeric_limits<double>::infinity();
-    for (it = 0; it <= p->maxit; ++it) {
-        int na = b - ncl;
-        float* X = c.S + ny;
-        float* Xa = X + ncl;
+    // The residual R = K X - (M X) diag(lam) of the CURRENT Ritz block and its norms: launched at the end of an iteration, right
+    // behind the update that wrote the block (and once before the loop) - the host algebra that only the NEXT Ritz step needs
+    // ([X' P']^T K [X' P'], below) then runs while the device works on the update and this residual, instead of in front of them
+    // (round 6: one lane alone is bound by the host's serial steps).
+    auto launch_residual = [&]() -> int {
+        const int na = b - ncl;
+        float* Xa = c.S + ny + ncl;
         double* lam_pin = g_ring.back + 2048;  // (the previous iteration's copy completed before its last synchronise)
         std::memcpy(lam_pin, lam.data() + ncl, sizeof(double) * na);
-        if ((rc = c.hip(hipMemcpyAsync(p->lam_dev, lam_pin, sizeof(double) * na, hipMemcpyHostToDevice, c.st),
-                        "ds_lobpcg_iterate: Ritz values to device")) != DS_OK)
-            return rc;
+        int rc_ = c.hip(hipMemcpyAsync(p->lam_dev, lam_pin, sizeof(double) * na, hipMemcpyHostToDevice, c.st),
+                        "ds_lobpcg_iterate: Ritz values to device");
+        if (rc_ != DS_OK) return rc_;
         if (fused_res) {  // R = K X - (M X) diag(lam) and the norms in one walk of the unions; K X, M X never reach memory
-            if ((rc = c.residual_fused(Xa, lds, p->R, ldr, na)) != DS_OK) return rc;
+            if ((rc_ = c.residual_fused(Xa, lds, p->R, ldr, na)) != DS_OK) return rc_;
         } else {
-            if ((rc = c.apply_M(Xa, lds, p->MX, ldr, na)) != DS_OK) return rc;
-            if ((rc = ds_residual(c.KS + k0, ldks, p->R, ldr, p->MX, ldr, Xa, lds, p->lam_dev, n, na, p->nrm, p->nrm + 1024,
-                                  stream)) != DS_OK)
-                return rc;
+            if ((rc_ = c.apply_M(Xa, lds, p->MX, ldr, na)) != DS_OK) return rc_;
+            if ((rc_ = ds_residual(c.KS + k0, ldks, p->R, ldr, p->MX, ldr, Xa, lds, p->lam_dev, n, na, p->nrm, p->nrm + 1024,
+                                   stream)) != DS_OK)
+                return rc_;
         }
+        return c.hip(hipMemcpyAsync(g_ring.back, p->nrm, sizeof(double) * 2048, hipMemcpyDeviceToHost, c.st),
+                     "ds_lobpcg_iterate: residual norms to host");
+    };
+    if ((rc = launch_residual()) != DS_OK) return rc;
+    for (it = 0; it <= p->maxit; ++it) {
+        int na = b - ncl;
         double* nrm = g_ring.back;
-        if ((rc = c.hip(hipMemcpyAsync(nrm, p->nrm, sizeof(double) * 2048, hipMemcpyDeviceToHost, c.st),
-                        "ds_lobpcg_iterate: residual norms to host")) != DS_OK)
-            return rc;
         { const double t0 = now_s(); rc = c.hip(wait_for_stream(c.st), "ds_lobpcg_iterate: stream synchronise"); g_tm.sync += now_s() - t0; ++g_tm.nsync; }
         if (rc != DS_OK) return rc;
         for (int j = 0; j < na; ++j)
@@ -613,9 +735,12 @@ extern "C" int ds_lobpcg_iterate(ds_lobpcg_t* p, const ds_lapack_t* lapack, ds_s
                 for (int j = 0; j < na; ++j) Gp(i, j) = G0(i, j) - CtC(i, j);
             for (int i = 0; i < na; ++i)
                 if (Gp(i, i) <= 1e-9 * std::fabs(G0(i, i))) ok = false;
-            Mat Lc, T;
+            Mat T;
             double amp = 0.0;
-            if (ok && all_finite(Gp) && cholesky(Gp, Lc)) {
+            // (the factorisation of the diagonally scaled block inside orthonormalizer_q is the breakdown test: a block that is not
+            // positive definite comes back with amp = inf and takes the explicit route - a separate unscaled Cholesky in front of
+            // it, as the Python loop has, was 0.07 ms of every iteration for the same answer)
+            if (ok && all_finite(Gp)) {
                 std::vector<double> rem(na);
                 for (int i = 0; i < na; ++i) rem[i] = CtC(i, i);
                 ok = orthonormalizer_q(*lapack, Gp, &rem, T, amp) && std::isfinite(amp) && !(p->ortho_tol > 0.0 && 6e-8 * amp >= p->ortho_tol);
@@ -675,14 +800,11 @@ extern "C" int ds_lobpcg_iterate(ds_lobpcg_t* p, const ds_lapack_t* lapack, ds_s
         // (dsyevr on the index range 1..na - the same tridiagonalisation, a third of the vectors - was measured: 3.3 ms per
         // 240 x 240 problem with SciPy's OpenBLAS against 1.45 ms for the full dsyevd; not used)
         std::vector<double> E;
-        Mat Z;
-        if (!eigh(*lapack, G, E, Z)) {
+        Mat Z1;  // (sz x na): only the wanted third of the vectors is back-transformed (eigh_lowest)
+        if (!eigh_lowest(*lapack, G, na, E, Z1)) {
             ds::set_error("ds_lobpcg_iterate: dsyevd failed in the Rayleigh-Ritz step");
             return DS_ERR_ARG;
         }
-        Mat Z1(sz, na);
-        for (int i = 0; i < sz; ++i)
-            for (int j = 0; j < na; ++j) Z1(i, j) = Z(i, j);
         Mat Z1top(na, na);
         for (int i = 0; i < na; ++i)
             for (int j = 0; j < na; ++j) Z1top(i, j) = Z1(i, j);
@@ -704,20 +826,6 @@ extern "C" int ds_lobpcg_iterate(ds_lobpcg_t* p, const ds_lapack_t* lapack, ds_s
                 ZZ(i, j) = Z1(i, j);
                 ZZ(i, na + j) = Zp(i, j);
             }
-        // [X' P']^T K [X' P'] = ZZ^T G ZZ of the new basis.  The columns of Z1 are eigenvectors of G (Z1^T G Z1 = diag(E) to the
-        // rounding of dsyevd), so only the products with Zp are formed: half the flops of the two full products
-        {
-            const Mat GZp = gemm(*lapack, G, false, Zp, false);
-            const Mat Gxz = gemm(*lapack, Z1, true, GZp, false), Gpp = gemm(*lapack, Zp, true, GZp, false);
-            Gxp = Mat(2 * na, 2 * na);
-            for (int i = 0; i < na; ++i) Gxp(i, i) = E[i];
-            for (int i = 0; i < na; ++i)
-                for (int j = 0; j < na; ++j) {
-                    Gxp(i, na + j) = Gxp(na + j, i) = Gxz(i, j);
-                    Gxp(na + i, na + j) = Gpp(i, j);
-                }
-        }
-        symmetrize(Gxp);
         for (int j = 0; j < na; ++j) lam[ncl + j] = E[j];
         if (Qraw.r != 0) {  // the new basis straight from the raw one: [X' P'] = [Y X P W] (Q [Z1 Zp]), Q = [E | Qw]
             Mat Zbot(na, 2 * na);
@@ -754,6 +862,22 @@ extern "C" int ds_lobpcg_iterate(ds_lobpcg_t* p, const ds_lapack_t* lapack, ds_s
         std::swap(c.KS, c.KS2);
         k0 = 0;
         npc = na;
+        if ((rc = launch_residual()) != DS_OK) return rc;  // (of the block just written: the next iteration's first wait)
+        // ---- behind the launches, while the device runs the update and the residual:
+        // [X' P']^T K [X' P'] = ZZ^T G ZZ of the new basis.  The columns of Z1 are eigenvectors of G (Z1^T G Z1 = diag(E) to the
+        // rounding of dsyevd), so only the products with Zp are formed: half the flops of the two full products
+        {
+            const Mat GZp = gemm(*lapack, G, false, Zp, false);
+            const Mat Gxz = gemm(*lapack, Z1, true, GZp, false), Gpp = gemm(*lapack, Zp, true, GZp, false);
+            Gxp = Mat(2 * na, 2 * na);
+            for (int i = 0; i < na; ++i) Gxp(i, i) = E[i];
+            for (int i = 0; i < na; ++i)
+                for (int j = 0; j < na; ++j) {
+                    Gxp(i, na + j) = Gxp(na + j, i) = Gxz(i, j);
+                    Gxp(na + i, na + j) = Gpp(i, j);
+                }
+        }
+        symmetrize(Gxp);
     }
     if (getenv("DS_EXP_TIMING")) {
         g_tm.total = now_s() - t_begin;

@@ -18,7 +18,7 @@ import torch
 import torch.nn as nn
 
 from ..ddsp.oscillator import WeightedParam
-from ..lobpcg.modal_solver import ModalSolver, SolverConfig
+from ..lobpcg.modal_solver import ModalSolver, SolverConfig, tuned_config
 from ..modal_ops import HipModalOps, TetSystem
 from .material_model import Material, MatSet
 from .mesh import TetMesh
@@ -148,7 +148,7 @@ class DiffSoundObj:
         self.mode_num = mode_num
         self.U_hat_full = None
         self.task = task
-        self.solver_config = solver_config or SolverConfig()
+        self.solver_config = solver_config or tuned_config(order)
         self._system = None
         self._ops = None
         self._warm = None

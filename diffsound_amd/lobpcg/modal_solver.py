@@ -108,6 +108,21 @@ class SolverConfig:
     nested_cheb_ratio: float = 550.0
 
 
+def tuned_config(order, **over):
+    """The eigensolver settings the benchmark measures (bench.py) as the library's suggestion for a tet mesh of this order:
+    the rigorous bound lambda_max(T K) <= nodes per element caps the Chebyshev intervals; on ord-2 meshes the two-level
+    V-cycle with Chebyshev(22, ratio 350) on the corner-node level and a nested start to 3e-3.  ``DiffSoundObj`` uses it when the
+    caller gives no ``solver_config`` - a script written against the reference (build_model(...); model.eigen_decomposition())
+    then runs the configuration whose numbers DESIGN.md quotes; ``tol`` stays the library default (2e-6) unless overridden."""
+    cfg = SolverConfig(lmax_cap=float({1: 4, 2: 10}.get(int(order), 0)), coarse_degree=22, coarse_ratio=350.0,
+                       nested_tol=3e-3 if int(order) == 2 else 0.0, nested_maxit=8, nested_cheb_degree=22, nested_cheb_ratio=350.0)
+    for k_, v_ in over.items():
+        if not hasattr(cfg, k_):
+            raise TypeError(f"tuned_config: SolverConfig has no field {k_!r}")
+        setattr(cfg, k_, v_)
+    return cfg
+
+
 @dataclass
 class ModalResult:
     eigenvalues: torch.Tensor  # (k,) fp64, ascending
@@ -248,8 +263,10 @@ class _one_thread:
                 torch.set_num_threads(st.saved)
 
 
-def pin_thread_to_one_core():
+def one_blas_thread_for_this_thread():
     """For a private worker thread (a hypothesis lane): one MKL / OpenMP thread for its whole life, thread-local settings only.
+    (It limits the thread's BLAS / OpenMP team, not the cores it may run on - which CPUs a rank's threads use is decided once per
+    process by diffsound_amd.hostcpu.bind_rank_to_device_numa.  Named ``pin_thread_to_one_core`` until round 6, which it never did.)
     A lane issues launches and solves <= 3b x 3b dense problems; left at the host's full thread count (256 hardware threads on
     the GPU box) any OpenMP region it enters would spin up a team of that size next to the other lanes' teams."""
     fns = _thread_local_setters()
@@ -259,6 +276,9 @@ def pin_thread_to_one_core():
         fns[1](1)
     else:
         torch.set_num_threads(1)
+
+
+pin_thread_to_one_core = one_blas_thread_for_this_thread  # (the old name: kept for callers written against round 5)
 
 
 def _small(fn, dev, *mats):

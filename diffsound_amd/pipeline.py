@@ -71,8 +71,14 @@ class ModalPipeline:
     oscillator, target audio."""
 
     def __init__(self, vertices, tets, order, modes, mat, sample_num=8000, sr=32000, force_frames=150,
-                 solver_config=None, target_freqs=None, loss_fn=None):
+                 solver_config=None, target_freqs=None, loss_fn=None, mfma_groups=None, host_wait="sleep"):
+        """``mfma_groups``: nodes per wavefront of the MFMA form of the preconditioner's bf16 terms on (fine, corner-node) level,
+        handed to every operator object THIS pipeline builds (None: the library default).  ``host_wait``: how this pipeline's
+        lanes wait for their streams when several are in flight ("sleep" | "spin").  Both are per pipeline (round 6): two
+        pipelines in one process - or ranks run as threads - do not share a knob."""
         self.device = vertices.device
+        self.mfma_groups = None if mfma_groups is None else tuple(mfma_groups)
+        self.host_wait = host_wait
         # scalar loss head (audio, target) -> 0-dim tensor; None = the MSE of the headline metric.  The reference's
         # experiments put MSSLoss here (experiments/material_sync_train.py:124,159): pass that module.
         self.loss_fn = loss_fn
@@ -117,7 +123,8 @@ class ModalPipeline:
             holder.system.assemble()
         lam_f, mu_f = float(lam.detach()), float(mu.detach())
         if holder.ops is None:
-            holder.ops = HipModalOps(holder.system, lam_f, mu_f)
+            holder.ops = HipModalOps(holder.system, lam_f, mu_f, mfma_groups=self.mfma_groups)
+            set_wait_mode(holder.ops, getattr(holder, "host_wait_mode", 0))  # (the native solve's waits: this lane's own setting)
         else:
             holder.ops.set_material(lam_f, mu_f)
         if timing:
@@ -250,8 +257,17 @@ class _Lane:
         # the first lane adopts the pipeline's system (and operators); the others assemble into their own arrays
         self.system = pipe.system if ops is not None or not pipe._lanes else pipe.system.with_own_values()
         self.stream = torch.cuda.Stream(device=pipe.device)
+        self.host_wait_mode = 0  # 0: the runtime's stream synchronisation, 1: poll, then sleep on a blocking event (set with the pool)
         self.osc = TraditionalDampedOscillator(pipe.osc._force.clone(), 1, pipe.modes, pipe.osc.sample_num, pipe.osc.sr,
                                                pipe.mat)
+
+
+def set_wait_mode(ops, mode):
+    """How the native solves on this operator object (and on its corner-node level) wait for their stream: 0 = the runtime's
+    stream synchronisation (a spin), 1 = poll, then sleep on a blocking event.  Per operator object, i.e. per lane."""
+    ops.host_wait_mode = int(mode)
+    if getattr(ops, "coarse", None) is not None:
+        ops.coarse.host_wait_mode = int(mode)
 
 
 def prefer_sleeping_waits(device=None):
@@ -282,15 +298,21 @@ def _lane_pool(pipe, lanes):
 
         if pool is not None:
             pool.shutdown(wait=True)
-        from .lobpcg.modal_solver import pin_thread_to_one_core
+        from .lobpcg.modal_solver import one_blas_thread_for_this_thread
 
         pool = pipe._lane_pool = ThreadPoolExecutor(max_workers=lanes, thread_name_prefix="ds-lane",
-                                                    initializer=pin_thread_to_one_core)
+                                                    initializer=one_blas_thread_for_this_thread)
     # Several lanes: a lane's host thread SLEEPS while it waits for its stream (round 5, ds_host_wait_mode) - the lanes wait four
     # fifths of the time, and spinning they would hold one core each, which a host under CPU quota or beside busy neighbours does
     # not have to give (on four cores the benchmark runs 60 passes/s with sleeping waits against 52 with spinning ones; with
     # cores to spare the sleep's wake-up costs 2 %).  ``host_wait`` = "spin" keeps the runtime's own synchronisation.
-    _hip.check(_hip.lib().ds_host_wait_mode(0 if getattr(pipe, "host_wait", "sleep") == "spin" or lanes <= 1 else 1), "ds_host_wait_mode")
+    # Per LANE since round 6 (ds_lobpcg_t.wait_mode; ds_host_wait_mode only sets the default of descriptors that say -1): another
+    # pipeline of the process, or one hypothesis at a time on this one, keeps its own setting.
+    mode = 0 if getattr(pipe, "host_wait", "sleep") == "spin" or lanes <= 1 else 1
+    for ln in pipe._lanes:
+        ln.host_wait_mode = mode
+        if ln.ops is not None:
+            set_wait_mode(ln.ops, mode)
     return pool
 
 
@@ -345,7 +367,7 @@ def _run_batch(pipe, hyps, lanes=2, warm=None, backward=True):
 ModalPipeline.run_batch = _run_batch
 
 
-def _run_steps(pipe, hyps, steps, lanes=2, on_step=None, warm_start=False, backward=True, warm_init=None):
+def _run_steps(pipe, hyps, steps, lanes=2, on_step=None, warm_start=False, backward=True, warm_init=None, material_at=None):
     """``steps`` consecutive passes of every hypothesis WITHOUT a join between the steps: lane ``li`` owns the hypotheses
     ``li, li + lanes, ...`` and runs their passes of step 0, then of step 1, ... back to back on its own stream and thread.
     A hypothesis' step s + 1 depends on nothing but its own step s (the inverse-rendering batch of the reference has one
@@ -355,7 +377,8 @@ def _run_steps(pipe, hyps, steps, lanes=2, on_step=None, warm_start=False, backw
     ``on_step(s, results_of_step_s)`` is called on the CALLER's thread as soon as every lane has finished step s (in step
     order; the lanes keep running meanwhile): that is where the per-step scalar all-reduce of the loss goes.
     ``warm_start``: a hypothesis' step s + 1 starts from the block its step s ended with (``warm_init``: optional list of
-    start blocks for step 0).  Returns ``out[s][i]``."""
+    start blocks for step 0).  ``material_at(s, i, E, nu) -> (E, nu)``: the material hypothesis i runs step s with (an optimiser's
+    move between steps; default: the same (E, nu) every step).  Returns ``out[s][i]``."""
     import threading
 
     n = len(hyps)
@@ -384,7 +407,7 @@ def _run_steps(pipe, hyps, steps, lanes=2, on_step=None, warm_start=False, backw
                     for i in range(li, n, lanes):
                         if errs:  # another lane failed: stop here instead of running every remaining step first
                             return
-                        E, nu = hyps[i]
+                        E, nu = hyps[i] if material_at is None else material_at(s, i, *hyps[i])
                         out[s][i] = pipe.run_pass(E, nu, warm=warm.get(i), backward=backward, _lane=lane)
                         if warm_start:
                             warm[i] = out[s][i][1].block_vectors

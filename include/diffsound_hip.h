@@ -40,7 +40,7 @@ enum { DS_OK = 0, DS_ERR_ARG = 1, DS_ERR_HIP = 2, DS_ERR_NOMEM = 3 };
 /* Thread-local text of the last error returned on this thread ("" if none). */
 const char* ds_last_error(void);
 /* Library ABI version (bumped on any signature change); ds_abi_version() returns the value the library was built with. */
-#define DS_ABI_VERSION 30
+#define DS_ABI_VERSION 31
 int ds_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------------
@@ -405,6 +405,13 @@ typedef struct {
                    int* liwork, int* info);
     void (*dgemm)(char* ta, char* tb, int* m, int* n, int* k, double* alpha, double* a, int* lda, double* b, int* ldb,
                   double* beta, double* c, int* ldc);
+    /* ABI 31, optional (all three or none; NULL = the Ritz step calls dsyevd): the stages of dsyevd one by one, so that only the
+     * wanted third of the eigenvectors of the 3 na x 3 na Ritz problem is back-transformed */
+    void (*dsytrd)(char* uplo, int* n, double* a, int* lda, double* d, double* e, double* tau, double* work, int* lwork, int* info);
+    void (*dstedc)(char* compz, int* n, double* d, double* e, double* z, int* ldz, double* work, int* lwork, int* iwork,
+                   int* liwork, int* info);
+    void (*dormtr)(char* side, char* uplo, char* trans, int* m, int* n, double* a, int* lda, double* tau, double* c, int* ldc,
+                   double* work, int* lwork, int* info);
 } ds_lapack_t;
 typedef struct {
     int64_t n, nv;            /* n = 3 nv rows */
@@ -448,9 +455,19 @@ typedef struct {
     int32_t history_cap;
     int32_t iterations;       /* out */
     int32_t result_in_s2;     /* out */
+    int32_t wait_mode;        /* ABI 31: how THIS solve's host thread waits for its stream - 0: hipStreamSynchronize, 1: a 20 us poll,
+                                 then a sleep on a blocking event, -1: the process default (ds_host_wait_mode).  Per solve, so that
+                                 the hypothesis lanes of one pipeline, another pipeline of the process and a single solve beside
+                                 them each keep their own setting */
 } ds_lobpcg_t;
 int ds_lobpcg_iterate(ds_lobpcg_t* p, const ds_lapack_t* lapack, ds_stream_t stream);
-/* How the host thread of ds_lobpcg_iterate waits for its stream (ABI 30; process-wide, default 0).  0: hipStreamSynchronize (the
+/* ABI 31.  Self-check of the loop's host-side dense steps with the given LAPACK table - no device involved (the CPU test suite
+ * calls it): on a seeded random symmetric positive definite n x n matrix, errs[0] / errs[1] = eigenvalue / residual error of the
+ * lowest m pairs from the staged eigensolver (dsytrd + dstedc + dormtr on m columns) against dsyevd, errs[2] / errs[3] = the
+ * Cholesky factor and its inverse, errs[4] = orthogonality of the twice-applied Cholesky-QR on n x m columns, errs[5] = 1 when the
+ * staged path ran.  errs: 6 doubles. */
+int ds_selftest_dense(const ds_lapack_t* lapack, int n, int m, unsigned seed, double* errs);
+/* How the host thread of ds_lobpcg_iterate waits for its stream when its descriptor says wait_mode = -1 (ABI 30; process-wide default 0).  0: hipStreamSynchronize (the
  * runtime spins when the host has more cores than devices); 1: a 20 us poll, then a sleep on an event created with
  * hipEventBlockingSync - for callers that run several solves on several streams and threads at once (the hypothesis lanes of
  * diffsound_amd/pipeline.py): waiting lanes then leave their cores to the lanes that are computing. */

@@ -176,3 +176,27 @@ def test_mfma_spmm_window_registers_do_not_move_between_issue_sites(tmp_path):
             assert len(set(dst[:win])) == win, m.group(1)
             seen += 1
     assert seen >= 36, seen  # 6 widths x 3 epilogue forms x 2 levels, plus the tail forms
+
+
+@pytest.mark.parametrize("n,m", [(240, 80), (160, 56), (96, 32), (20, 8)])
+def test_host_dense_steps_of_the_native_solver_loop(n, m):
+    """ds_selftest_dense (ABI 31): the dense steps ds_lobpcg_iterate runs on the host between its launches - the staged
+    eigensolver that back-transforms only the wanted third of the Ritz vectors (dsytrd + dstedc + dormtr on m columns) against
+    dsyevd, the Cholesky factor and its inverse on four-accumulator dot products, the twice-applied Cholesky-QR - checked on the
+    CPU with SciPy's LAPACK, the table the product hands in."""
+    import ctypes
+
+    _hip = _lib()
+    errs = (ctypes.c_double * 6)()
+    with _hip.blas_one_thread():
+        _hip.check(_hip.lib().ds_selftest_dense(ctypes.byref(_hip.lapack_table()), n, m, 7, errs), "ds_selftest_dense")
+    e = list(errs)
+    assert e[0] < 1e-13 and e[1] < 1e-13, e     # the same eigenvalues as dsyevd; G z = w z for the m lowest
+    assert e[2] < 1e-13 and e[3] < 1e-11, e     # L L^T = G, L^-1 L = I
+    assert e[4] < 1e-12, e                      # Q^T Q = I
+    assert e[5] == (1.0 if n >= 32 else 0.0)    # SciPy's table carries the stages; tiny problems call dsyevd
+    tbl = _hip.lapack_table()
+    partial = _hip.LapackTable(tbl.dsyevd, tbl.dgemm, tbl.dsytrd, None, None)
+    assert _hip.lib().ds_selftest_dense(ctypes.byref(_hip.LapackTable(tbl.dsyevd, tbl.dgemm, None, None, None)), n, m, 7, errs) == 0
+    assert errs[5] == 0.0 and errs[1] < 1e-13   # no stages in the table: dsyevd, the same answer
+    del partial

@@ -223,3 +223,66 @@ def test_mfma_table_builder_on_the_host():
                 worst_plain = max(worst_plain, int(per_entry[b:b + MF_BATCH].sum()))
         assert mt["max_entries"] == most and (most <= 128) == expect_tail
         assert mt["max_batch_blocks"] == (worst_tail if expect_tail else worst_plain)
+
+
+def _fake_sysfs(tmp_path, gpus):
+    """A KFD topology with one CPU node and the given GPUs [(bus, numa_node, cpulist)] under tmp_path."""
+    nodes = tmp_path / "sys/class/kfd/kfd/topology/nodes"
+    (nodes / "0").mkdir(parents=True)
+    (nodes / "0" / "properties").write_text("cpu_cores_count 64\nsimd_count 0\nlocation_id 0\ndomain 0\n")
+    for i, (bus, numa, cpus) in enumerate(gpus):
+        d = nodes / str(i + 1)
+        d.mkdir()
+        d.joinpath("properties").write_text(f"cpu_cores_count 0\nsimd_count 1024\nlocation_id {bus << 8}\ndomain 0\n")
+        p = tmp_path / f"sys/bus/pci/devices/0000:{bus:02x}:00.0"
+        p.mkdir(parents=True)
+        p.joinpath("numa_node").write_text(f"{numa}\n")
+        p.joinpath("local_cpulist").write_text(cpus + "\n")
+    return str(tmp_path)
+
+
+def test_rank_cpu_affinity_from_sysfs(tmp_path):
+    """diffsound_amd.hostcpu: a rank's CPUs = the NUMA node of ITS device, split among the ranks that share the node, from sysfs
+    alone (no HIP call); unknown topologies leave the affinity untouched and say so."""
+    import os
+
+    from diffsound_amd import hostcpu
+
+    assert hostcpu.parse_cpulist("0-3,8,10-11") == [0, 1, 2, 3, 8, 10, 11]
+    assert hostcpu.compact([0, 1, 2, 3, 8, 10, 11]) == "0-3,8,10-11"
+    ncpu = len(os.sched_getaffinity(0))
+    if ncpu < 8:
+        pytest.skip("needs 8 allowed CPUs")
+    half = ncpu // 2
+    lo, hi = f"0-{half - 1}", f"{half}-{ncpu - 1}"
+    root = _fake_sysfs(tmp_path, [(0x11, 0, lo), (0x21, 0, lo), (0x91, 1, hi), (0xa1, 1, hi)])
+    assert hostcpu.kfd_gpus(root) == ["0000:11:00.0", "0000:21:00.0", "0000:91:00.0", "0000:a1:00.0"]
+    env = {}
+    recs = [hostcpu.bind_rank_to_device_numa(r, 4, min_cpus=2, root=root, env=env, apply=False) for r in range(4)]
+    assert [r["numa_node"] for r in recs] == [0, 0, 1, 1]
+    q = half // 2
+    assert recs[0]["cpu_list"] == hostcpu.compact(range(0, q)) and recs[1]["cpu_list"] == hostcpu.compact(range(q, 2 * q))
+    assert recs[2]["cpu_list"] == hostcpu.compact(range(half, half + (ncpu - half) // 2))
+    assert all(r["cpus"] >= 2 and r["pci"] for r in recs)
+    # a visible-device list re-maps the local ranks
+    r = hostcpu.bind_rank_to_device_numa(0, 1, min_cpus=2, root=root, env={"HIP_VISIBLE_DEVICES": "2"}, apply=False)
+    assert r["numa_node"] == 1 and r["pci"] == "0000:91:00.0"
+    # no topology / a device without a NUMA node of its own: nothing bound, reason given
+    r = hostcpu.bind_rank_to_device_numa(0, 1, root=str(tmp_path / "nowhere"), env=env, apply=False)
+    assert not r["bound"] and "KFD" in r["why"]
+    root2 = _fake_sysfs(tmp_path / "b", [(0x11, -1, f"0-{ncpu - 1}")])
+    r = hostcpu.bind_rank_to_device_numa(0, 1, root=root2, env=env, apply=False)
+    assert not r["bound"] and r["numa_node"] is None
+    # and for real, in a child process so this test's own affinity stays as it is
+    import subprocess
+    import sys
+
+    code = ("import os, json; from diffsound_amd import hostcpu; "
+            f"r = hostcpu.bind_rank_to_device_numa(1, 4, min_cpus=2, root={root!r}, env={{}}); "
+            "print(json.dumps([r['bound'], sorted(os.sched_getaffinity(0))]))")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(__file__)))
+    assert out.returncode == 0, out.stderr
+    import json
+
+    bound, cpus = json.loads(out.stdout.strip().splitlines()[-1])
+    assert bound and cpus == list(range(q, 2 * q))
