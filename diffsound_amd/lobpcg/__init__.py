@@ -11,8 +11,11 @@ is called after every iteration with ``worker.ivars['istep'|'converged_count']``
 iterates with fp64 Rayleigh-Ritz (the reference can only run fp32), default
 ``tol`` = 2e-6 instead of the reference's unreachable 1.5e-8 (dtype-table bug :35-38), a
 Chebyshev block-Jacobi preconditioner when ``iK`` is None (the reference uses none and does not
-converge), ``method`` 'basic' is served by the 'ortho' iteration, ``profiler`` (a TensorBoard log
-dir in the reference) is accepted and ignored - use rocprofv3.
+converge), ``profiler`` (a TensorBoard log dir in the reference) is accepted and ignored - use rocprofv3.
+Round 6: ANY pencil is served - a row count that is not a multiple of 3 is padded with decoupled rows whose eigenvalue sits
+above the spectrum (the kernels work on 3 x 3 node blocks) and the pad rows are cut off the result; dense ``A`` / ``B`` are
+re-blocked like sparse ones; ``method='basic'`` runs the reference's basic iteration (ModalSolver.solve_basic), any other
+method name is a ``ValueError``.
 """
 from typing import Dict, Optional, Tuple
 
@@ -50,12 +53,57 @@ class _CallableOps:
         return [GA], [1.0], b.gram(Xc, MX)
 
 
+def pad_value(A, B):
+    """Eigenvalue of the decoupled pad rows: ||A||_inf / min diag(B) - at least every Rayleigh quotient of a unit vector, i.e. at
+    the top of the spectrum, out of the way of the wanted (lowest) pairs.  A None: the pencil (B, B) of a callable A -> 2."""
+    def coo(T):
+        T = T.to_sparse_coo().coalesce() if T.layout != torch.sparse_coo else T.coalesce()
+        return T.indices(), T.values().double()
+
+    bi, bv = coo(B)
+    bdiag = bv[bi[0] == bi[1]]
+    bmin = float(bdiag.abs().min()) if bdiag.numel() else 1.0
+    if A is None:
+        return 1.0 / max(bmin, 1e-300)
+    ai, av = coo(A)
+    rows = torch.zeros(A.shape[0], dtype=torch.float64, device=av.device).index_add_(0, ai[0], av.abs())
+    return float(rows.max()) / max(bmin, 1e-300)
+
+
+def _pad_pencil(A, B, pad):
+    """(A, B) as sparse COO with ``pad`` extra decoupled rows: diag(A, big B_min I), diag(B, B_min I) - eigenvalue ``big`` each."""
+    def coo(T):
+        return T.to_sparse_coo().coalesce() if T.layout != torch.sparse_coo else T.coalesce()
+
+    A, B = coo(A), coo(B)
+    if not pad:
+        return A, B
+    m = B.shape[-1]
+    big = pad_value(A if A is not B else None, B)
+    bi, bv = B.indices(), B.values()
+    bdiag = bv[bi[0] == bi[1]]
+    bmin = bdiag.abs().min() if bdiag.numel() else torch.ones((), dtype=bv.dtype, device=bv.device)
+    extra = torch.arange(m, m + pad, device=B.device)
+    ex = torch.stack([extra, extra])
+
+    def grow(T, val):
+        return torch.sparse_coo_tensor(torch.cat([T.indices(), ex], 1), torch.cat([T.values(), val.to(T.values().dtype).expand(pad)]),
+                                       (m + pad, m + pad)).coalesce()
+
+    Bp = grow(B, bmin)
+    Ap = Bp if A is B else grow(A, bmin.double() * big)
+    return Ap, Bp
+
+
 def _solve(A, B, k, X, E, n, iK, niter, tol, largest, method, tracker, ortho_iparams, ortho_fparams,
            ortho_bparams, return_rerr):
     from ..modal_ops import HipSparseOps
 
-    if not (isinstance(B, torch.Tensor) and B.layout in (torch.sparse_coo, torch.sparse_csr)):
-        raise TypeError("lobpcg_func: B must be a sparse torch tensor")
+    method = "ortho" if method is None else method
+    if method not in ("ortho", "basic"):
+        raise ValueError(f"lobpcg_func: unknown method {method!r} (the reference implements 'ortho' and 'basic', _lobpcg.py:366-369)")
+    if not isinstance(B, torch.Tensor):
+        raise TypeError("lobpcg_func: B must be a torch tensor (sparse or dense)")
     if not B.is_cuda:
         raise RuntimeError("diffsound_amd.lobpcg: tensors must live on the HIP device (there is no CPU fallback)")
     m = B.shape[-1]
@@ -68,22 +116,44 @@ def _solve(A, B, k, X, E, n, iK, niter, tol, largest, method, tracker, ortho_ipa
     largest = True if largest is None else largest
     sign = -1.0 if largest else 1.0
     a_callable = callable(A) and not isinstance(A, torch.Tensor)
+    pad = (-m) % 3  # the kernels work on 3 x 3 node blocks: a pencil of any other row count gets `pad` decoupled rows
     if a_callable:
-        ops = HipSparseOps(B, B)  # pattern/diagonal from B; K products come from the callable
-        ops = _CallableOps(ops, A, sign)
+        Bp, _ = _pad_pencil(B, B, pad)
+        ops = HipSparseOps(Bp, Bp)  # pattern/diagonal from B; K products come from the callable
+        fn = A
+        if pad:  # the callable sees the caller's m rows; the pad rows carry a value above the spectrum
+            gprobe = torch.randn((m, 4), dtype=torch.float32, device=B.device)
+            big = 4.0 * float(torch.linalg.vector_norm(A(gprobe).double()) / torch.linalg.vector_norm(gprobe.double())) * pad_value(None, B)
+
+            def fn(Xp, A=A, m=m, big=big, sign=sign):
+                out = torch.empty_like(Xp)
+                out[:m] = A(Xp[:m].contiguous())
+                out[m:] = Xp[m:] * (big * sign)
+                return out
+        ops = _CallableOps(ops, fn, sign)
     else:
-        ops = HipSparseOps(A if not largest else -A, B)
+        Ae = A if not largest else -A
+        Ap, Bp = _pad_pencil(Ae, B, pad)
+        ops = HipSparseOps(Ap, Bp)
+    if X is not None and pad:
+        X = torch.cat([X, torch.zeros((pad, X.shape[1]), dtype=X.dtype, device=X.device)], 0)
     cfg = SolverConfig(block=((n + 3) // 4) * 4, maxit=1000 if niter is None else niter, tol=tol or 0.0)
     if largest or a_callable:
         cfg.cheb_degree = 1  # the polynomial preconditioner targets the low end of an SPD spectrum only
     precond = None
     if iK is not None:
         if callable(iK) and not isinstance(iK, torch.Tensor):
-            precond = lambda R, W: W.copy_(iK(R))
+            apply_ik = iK
         elif iK.layout in (torch.sparse_coo, torch.sparse_csr):
-            precond = lambda R, W: W.copy_(torch.sparse.mm(iK.to(R.dtype), R))
+            apply_ik = lambda R: torch.sparse.mm(iK.to(R.dtype), R)
         else:
-            precond = lambda R, W: W.copy_(iK.to(R.dtype) @ R)
+            apply_ik = lambda R: iK.to(R.dtype) @ R
+        if pad:  # the caller's preconditioner sees the caller's m rows; the decoupled pad rows pass through
+            def precond(R, W, m=m):
+                W[:m].copy_(apply_ik(R[:m].contiguous()))
+                W[m:].copy_(R[m:])
+        else:
+            precond = lambda R, W: W.copy_(apply_ik(R))
     iparams = {"m": m, "n": n, "k": k, "niter": cfg.maxit}
     if ortho_iparams:
         iparams.update(ortho_iparams)
@@ -99,10 +169,23 @@ def _solve(A, B, k, X, E, n, iK, niter, tol, largest, method, tracker, ortho_ipa
     solver = ModalSolver(ops, cfg, precond=precond)
     if tracker is not None:
         tracker(state)  # the reference calls the tracker once before the first update (:350-351)
-    res = solver.solve(k, X0=X, tracker=tracker, state=state)
+    if pad and tracker is not None:
+        inner = tracker
+
+        def tracker(st, inner=inner, m=m):  # the tracker sees the caller's m rows
+            Xfull = st.X
+            st.X = None if Xfull is None else Xfull[:m]
+            try:
+                inner(st)
+            finally:
+                st.X = Xfull
+    if method == "basic":
+        res = solver.solve_basic(k, X0=X, tracker=tracker, state=state)
+    else:
+        res = solver.solve(k, X0=X, tracker=tracker, state=state)
     Eo = res.eigenvalues * sign
     out_dtype = torch.float32 if B.dtype not in (torch.float32, torch.float64) else B.dtype
-    Eo, Xo = Eo.to(out_dtype), res.vectors.to(out_dtype)
+    Eo, Xo = Eo.to(out_dtype), res.vectors[:m].to(out_dtype)
     if return_rerr:
         return Eo, Xo, res.rerr
     return Eo, Xo

@@ -983,6 +983,126 @@ class ModalSolver:
                     self.ops.combined_k64(False)
         return res
 
+    # ------------------------------------------------------------------ the reference's "basic" method
+    def solve_basic(self, k, X0=None, tracker=None, state=None):
+        """``method='basic'`` of the reference API (src/lobpcg/_lobpcg.py:390-431, ``_update_basic``): NO explicit orthogonalisation of
+        the search directions - every step's basis S = [X_active | P | W] goes through the Rayleigh-Ritz transform
+        Ri = D^-1/2 chol(D^-1/2 S^T B S D^-1/2)^-T (``_get_rayleigh_ritz_transform``, :479-525) and the eigenvectors of
+        Ri^T (S^T A S) Ri give X' = S Ri Z[:, :n - nc] and P' = S Ri Z[:, n : 2n - nc].  Same convergence test and hard locking of the
+        leading converged pairs as the ortho iteration.  It is the textbook LOBPCG: cheaper per step than 'ortho' and less robust
+        (the Gram matrix of a nearly dependent [X P W] loses its Cholesky factor close to convergence: the step is then repeated
+        without P, and without progress the iteration stops) - the product's own solves use 'ortho'; this exists so that a caller of
+        the reference API who asks for 'basic' gets that iteration (round 6; rounds 1-5 served it by the ortho iteration).  Large
+        operations through ``ops`` (HIP kernels), the <= 3n x 3n dense steps in fp64 on the host.  No rigid-mode deflation."""
+        ops, cfg = self.ops, self.cfg
+        n, dev, dt = ops.n, ops.device, ops.dtype
+        b = cfg.block or ((k + 3) // 4) * 4
+        if X0 is not None and X0.shape[1] > b:
+            b = ((X0.shape[1] + 3) // 4) * 4
+        if n < 3 * b:
+            raise ValueError(
+                "LPBPCG algorithm is not applicable when the number of A rows (={})"
+                " is smaller than 3 x the number of requested eigenpairs (={})".format(n, b))
+        state = state or SolverState({"niter": cfg.maxit, "k": k, "n": b, "m": n}, {}, {})
+        g = torch.Generator(device=dev).manual_seed(cfg.seed)
+        S = torch.empty((n, 3 * b), dtype=dt, device=dev)
+        AS, BS = torch.empty_like(S), torch.empty_like(S)
+        S2 = torch.empty((n, 2 * b), dtype=dt, device=dev)
+        R = torch.empty((n, b), dtype=dt, device=dev)
+        nx0 = 0 if X0 is None else X0.shape[1]
+        if nx0:
+            S[:, :nx0].copy_(X0.to(dt))
+        if nx0 < b:
+            S[:, nx0:b].copy_(torch.randn((n, b - nx0), generator=g, dtype=torch.float32, device=dev).to(dt))
+        G0 = torch.randn((n, 8), generator=g, dtype=torch.float32, device=dev).to(dt)
+        G1 = torch.empty_like(G0)
+        gn = torch.linalg.vector_norm(G0.double())
+        ops.apply_K(G0, G1)
+        A_norm = float(torch.linalg.vector_norm(G1.double()) / gn)
+        ops.apply_M(G0, G1)
+        B_norm = float(torch.linalg.vector_norm(G1.double()) / gn)
+        state.fvars.update(A_norm=A_norm, B_norm=B_norm)
+        tol = cfg.tol or (2e-6 if dt == torch.float32 else 1e-10)
+
+        def transform(GB):
+            """Ri of the reference: None when the scaled Gram matrix has no Cholesky factor."""
+            GB = _sym(GB)
+            d = torch.rsqrt(torch.clamp(GB.diagonal(), min=1e-300))
+            L, info = torch.linalg.cholesky_ex(GB * d[:, None] * d[None, :])
+            if int(info) != 0 or not bool(torch.isfinite(L).all()):
+                return None
+            Li = torch.linalg.solve_triangular(L, torch.eye(L.shape[0], dtype=L.dtype), upper=False)
+            return d[:, None] * Li.transpose(0, 1)
+
+        def ritz(GA, GB, keep):
+            Ri = transform(GB)
+            if Ri is None:
+                return None
+            E_, Z = torch.linalg.eigh(_sym(Ri.transpose(0, 1) @ _sym(GA) @ Ri))
+            return E_, (Ri @ Z[:, :keep]).contiguous()
+
+        lam = torch.zeros(b, dtype=torch.float64, device=dev)
+        rel = torch.full((b,), float("inf"), dtype=torch.float64, device=dev)
+        nc, npc, ns = 0, 0, b  # converged leading columns, columns of P, columns of S in use
+        history = []
+        it = 0
+        for it in range(cfg.maxit + 1):
+            Sa = S[:, nc:ns]
+            w = ns - nc
+            ops.apply_K(Sa, AS[:, :w])
+            ops.apply_M(Sa, BS[:, :w])
+            GA, GB = ops.gram(Sa, AS[:, :w], exact=True), ops.gram(Sa, BS[:, :w], exact=True)
+            na = b - nc
+            keep = na if it == 0 else min(w, 2 * na)
+            out = _small(ritz, dev, GA, GB, keep)
+            if out is None and npc:  # [X P W] numerically dependent: the step without P
+                idx = torch.cat([torch.arange(0, na, device=dev), torch.arange(na + npc, w, device=dev)])
+                keep = na
+                out = _small(ritz, dev, GA[idx][:, idx].contiguous(), GB[idx][:, idx].contiguous(), keep)
+                if out is not None:
+                    Zf = torch.zeros((w, keep), dtype=torch.float64, device=dev)
+                    Zf[idx] = out[1]
+                    out = (out[0], Zf)
+            if out is None:
+                break  # (no factorisation even without P: the block has collapsed; what has converged so far is returned)
+            E_, C = out
+            lam[nc:] = E_[:na]
+            # X' | P' = S_ (Ri Z): one update into the other buffer, then back (the locked columns stay where they are)
+            ops.mix(Sa, C, S2[:, :keep])
+            npc = keep - na
+            S[:, nc:nc + keep].copy_(S2[:, :keep])  # (X' over the active X, P' behind it: S = [X_locked | X' | P' | W])
+            Xa = S[:, nc:b]
+            ops.apply_K(Xa, AS[:, :na])
+            ops.apply_M(Xa, BS[:, :na])
+            rn2, xn2 = ops.residual(R[:, :na], BS[:, :na], Xa, lam[nc:], src=AS[:, :na])
+            rel[nc:] = torch.sqrt(rn2 / xn2) / (A_norm + lam[nc:].abs() * B_norm)
+            relk = rel[:k]
+            nconv = int(torch.cumprod((relk < tol).to(torch.int32), 0).sum())
+            history.append((it, float(relk.max())))
+            state.ivars.update(istep=it, converged_count=nconv, iterations_left=cfg.maxit - it)
+            state.tvars["rerr"] = relk
+            state.E, state.X = lam, S[:, :b]
+            if tracker is not None:
+                tracker(state)
+            if nconv >= k or it == cfg.maxit or state.bvars.get("force_stop", False):
+                break
+            new_nc = (nconv // 4) * 4 if cfg.lock else 0
+            shift = new_nc - nc
+            if shift > 0:  # newly converged leading columns leave the active set (X_active = S[:, nc:b]; P stays at S[:, b:])
+                nc = new_nc
+                na = b - nc
+            Wc = S[:, b + npc:b + npc + na]
+            if shift > 0:
+                Rn = R[:, shift:shift + na].contiguous()
+            else:
+                Rn = R[:, :na]
+            self.precond_apply(Rn, Wc)
+            ns = b + npc + na
+            # layout for the next step: S[:, nc:ns] = [X_active (na) | P (npc) | W (na)]
+        X = S[:, :b]
+        res = self._polish(X, k, it, rel[:k].clone(), history)
+        return res
+
     # ------------------------------------------------------------------ fp64 refinement
     def refine64(self, res, k, A_norm, B_norm):
         """Continue from the converged fp32 block with fp64 vectors (see SolverConfig.refine_tol): LOBPCG steps in

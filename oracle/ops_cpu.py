@@ -145,7 +145,7 @@ class CpuModalOps:
         self.counts["apply_M_cols"] += X.shape[1]
 
     # -- tall-skinny dense ---------------------------------------------------------------
-    def gram(self, A, B, symmetric=False):
+    def gram(self, A, B, symmetric=False, exact=False):
         self.counts["gram"] += 1
         return A.double().transpose(0, 1) @ B.double()
 

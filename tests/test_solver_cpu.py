@@ -270,3 +270,22 @@ def test_start_block_in_coefficients_on_the_cpu(cube, dtype, tol_eig):
             assert st[0] > 0
         assert np.abs(res[raw].eigenvalues.numpy() / cube["ref"] - 1).max() < 100 * tol_eig, raw
     assert abs(res[True].iterations - res[False].iterations) <= 2
+
+
+@pytest.mark.parametrize("dtype,tol_eig", [(torch.float64, 1e-8), (torch.float32, 1e-5)])
+def test_basic_method_on_the_cpu(cube, dtype, tol_eig):
+    """ModalSolver.solve_basic - the reference's ``method='basic'`` (_lobpcg.py:390-431: Rayleigh-Ritz through the transform of
+    the basis' Gram matrix, no explicit orthogonalisation, no deflation) - on the oracle's operators: the six rigid modes come
+    out as ~zero eigenvalues in front, the elastic ones match ARPACK, the vectors are M-orthonormal."""
+    ops = CpuModalOps(cube["Kl"], cube["Km"], cube["M3"], cube["v"], cube["lam"], cube["mu"], dtype=dtype)
+    seen = []
+    res = ModalSolver(ops, SolverConfig(block=28, lmax_cap=10.0, tol=1e-7 if dtype == torch.float64 else 0.0, maxit=200)).solve_basic(
+        20, tracker=lambda st: seen.append((st.ivars["istep"], st.ivars["converged_count"])))
+    ev = res.eigenvalues.numpy()
+    assert np.abs(ev[:6]).max() < 1e-6 * cube["ref"][0]
+    assert np.abs(ev[6:] / cube["ref"][:14] - 1).max() < tol_eig
+    assert res.iterations < 60 and seen and seen[0][0] == 0 and seen[-1][1] >= 20
+    U = res.vectors.double().numpy()
+    assert np.abs(U.T @ (cube["M3"] @ U) - np.eye(20)).max() < 1e-5
+    with pytest.raises(ValueError, match="not applicable"):
+        ModalSolver(ops, SolverConfig(block=ops.n // 2)).solve_basic(8)
