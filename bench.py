@@ -133,10 +133,13 @@ def parse():
     ap.add_argument("--loss", default="mse", choices=["mse", "mss"],
                     help="scalar loss head: mse = the headline metric's; mss = the reference experiments' multi-scale "
                          "spectral loss (MSSLoss [1024..64], 'l1_loss', material_sync_train.py:124) on the STFT kernels")
-    ap.add_argument("--workload", default="c3", choices=["c3", "c5"],
+    ap.add_argument("--geom-iters", type=int, default=200, help="--workload geom: iterations of the shape loop (HBM growth is read over them)")
+    ap.add_argument("--workload", default="c3", choices=["c3", "c5", "geom"],
                     help="c3 = the headline benchmark (BASELINE.json configs[2]); c5 = configs[4], the 1M-tet / 128-mode / fp64 "
                          "stress (one rank): SpMM bandwidth of every product form at that size and the fp32 + fp64-refined "
-                         "solve - its own JSON line, not the headline metric")
+                         "solve - its own JSON line, not the headline metric; geom = the shape loop of SURVEY.md 8(f2, f3) "
+                         "(src/dmtet/geometry/dmtet_thickness.py:237-299): every iteration new vertices AND a new topology, a fresh "
+                         "DiffSoundObj, eigen_decomposition, get_vals, relative MSE, backward to the vertices - its own JSON line")
     ap.add_argument("--no-solo", action="store_true",
                     help="skip the roofline object's kernel-alone measurements (hundreds of launches of the fused term, K W and "
                          "the STREAM triad after the timed region): for a rocprofv3 kernel table that should hold nothing but "
@@ -157,6 +160,7 @@ def parse():
                          "E (1 + 1e-3 s), nu (1 - 5e-4 s), as an optimiser's would - no pass sees the material its lane saw before")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--geom-cpu-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-reps", type=int, default=3, help="full passes of the CPU oracle (a fresh process each)")
     ap.add_argument("--cpu-sample-cells", type=int, default=8,
                     help="the CPU oracle runs ONE full pass on a Kuhn box of this many cells per edge (8 -> 3072 tets, the "
@@ -518,6 +522,168 @@ def main_c5(a):
         "hbm_in_use_gib": (total_b - free_b) / 2 ** 30}))
 
 
+def main_geom(a):
+    """The geometry loop (SURVEY.md 8 rows f2 + f3; reference src/dmtet/geometry/dmtet_thickness.py:237-299 ``getMesh`` + ``tick``,
+    experiments/thickness_train.py:104-106: ord-1, 32 modes): per iteration the marching-tets stage hands over NEW vertices and a NEW
+    topology; a fresh ``DiffSoundObj`` is built on them (symbolic phase: pattern, contribution lists, union / MFMA tables; first numeric
+    assembly), ``eigen_decomposition()`` (assembly + cold eigensolve), ``get_vals()``, the relative MSE against target values,
+    ``backward()`` to the vertices and on to the one shape parameter (the thickness), Adam.  Synthetic stand-in of the marching-tets
+    output (DMTet itself is out of scope): a 32 x 32 x nz-cell shell whose layer count nz cycles 7, 8, 9, 8 - a
+    different tet count and node count every iteration, the size of a resolution-32 grid's output - scaled in z by the thickness.
+    Reports iterations/s, the split of an iteration, HBM at iteration 10 and at the end (handles that leak would show), and the
+    CPU oracle's forward part on one of the meshes."""
+    from diffsound_amd import meshgen
+    from src.diffelastic.diff_model import DiffSoundObj, MatSet
+
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    cells = a.cells if a.cells != 26 else 32
+    modes = a.modes if a.modes != 64 else 32
+    order = 1 if a.order == 2 and "--order" not in sys.argv else a.order
+    layers = (7, 8, 9, 8)
+    meshes = []
+    for nz in layers:
+        v, t = meshgen.kuhn_box(cells, cells, nz, box=(0.10, 0.10, 0.10 * nz / cells))
+        meshes.append((torch.from_numpy(v).to(dev), torch.from_numpy(t).long().to(dev)))
+    mat = MatSet.Ceramic
+    theta = torch.nn.Parameter(torch.tensor(1.0, device=dev))
+    opt = torch.optim.Adam([theta], lr=2e-3)
+    zscale = lambda: torch.stack([torch.ones((), device=dev), torch.ones((), device=dev), theta])
+
+    def iteration(i, target, sync=None):
+        v0, t0 = meshes[i % len(meshes)]
+        verts = v0 * zscale()[None, :]
+        if sync:
+            sync("vertices")
+        obj = DiffSoundObj(verts, t0, mode_num=modes, order=order, mat=mat)
+        _ = obj.system  # (the symbolic phase + first numeric assembly: built on first use)
+        if sync:
+            sync("symbolic + tables")
+        obj.eigen_decomposition()
+        if sync:
+            sync("assembly + eigensolve")
+        vals = obj.get_vals()
+        loss = ((vals - target) ** 2 / target ** 2).mean()
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        if sync:
+            sync("get_vals + loss + backward + Adam")
+        return float(loss.detach()), obj.last_result.iterations, obj.system.T, obj.system.nv
+
+    # target values: the shell at thickness 1.15 (outside the timed region)
+    with torch.no_grad():
+        v0, t0 = meshes[1]
+        gt = DiffSoundObj(v0 * torch.tensor([1.0, 1.0, 1.15], device=dev), t0, mode_num=modes, order=order, mat=mat)
+        gt.eigen_decomposition()
+        target = gt.get_vals().detach().clone()
+        del gt
+    for i in range(6):  # untimed: first calls allocate, kernels load
+        iteration(i, target)
+    torch.cuda.synchronize()
+    # the split of an iteration, with a device synchronisation after every stage (its own short loop: the timed loop has none)
+    stages = {}
+    for i in range(8):
+        clock = [time.time()]
+
+        def sync(name):
+            torch.cuda.synchronize()
+            now = time.time()
+            stages[name] = stages.get(name, 0.0) + (now - clock[0]) / 8
+            clock[0] = now
+
+        torch.cuda.synchronize()
+        clock[0] = time.time()
+        iteration(i, target, sync)
+    import gc
+
+    gc.collect()
+    torch.cuda.synchronize()
+    free10 = alloc10 = None
+    losses, its, sizes = [], [], []
+    t0c = time.time()
+    for i in range(a.geom_iters):
+        if i == 10:
+            gc.collect()
+            torch.cuda.synchronize()
+            alloc10, free10 = torch.cuda.memory_allocated(dev), torch.cuda.mem_get_info(dev)[0]
+            t10 = time.time()
+        lo, it_, T_, nv_ = iteration(i, target)
+        losses.append(lo), its.append(it_), sizes.append((T_, nv_))
+    torch.cuda.synchronize()
+    dt = time.time() - t0c
+    gc.collect()
+    torch.cuda.synchronize()
+    alloc_end, free_end = torch.cuda.memory_allocated(dev), torch.cuda.mem_get_info(dev)[0]
+    if not np.isfinite(losses).all():
+        raise SystemExit("bench.py --workload geom: non-finite loss")
+    out = {"metric": "shape-loop iterations/s: fresh DiffSoundObj on new vertices + new topology, eigen_decomposition, get_vals, backward to vertices",
+           "value": a.geom_iters / dt, "unit": "iterations/s", "n_gpus": 1, "higher_is_better": True, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": (f"{cells} x {cells} x nz-cell Kuhn shell, nz cycling {layers} ({min(s[0] for s in sizes)}-{max(s[0] for s in sizes)} tets, "
+                                   f"{min(s[1] for s in sizes)}-{max(s[1] for s in sizes)} nodes), ord-{order}, {modes} modes, a new topology every iteration"),
+                      "reference_loop": "src/dmtet/geometry/dmtet_thickness.py:237-299 (getMesh + tick), experiments/thickness_train.py:104-106"},
+           "iterations": a.geom_iters, "ms_per_iteration": 1e3 * dt / a.geom_iters, "mean_solver_iterations": float(np.mean(its)),
+           "split_ms_with_a_sync_per_stage": {k_: 1e3 * v_ for k_, v_ in stages.items()},
+           "loss_first_last": [losses[0], losses[-1]], "thickness_after": float(theta.detach()),
+           "hbm": {"torch_allocated_mib_at_iteration_10": alloc10 / 2 ** 20, "torch_allocated_mib_at_end": alloc_end / 2 ** 20,
+                   "device_free_mib_at_iteration_10": free10 / 2 ** 20, "device_free_mib_at_end": free_end / 2 ** 20,
+                   "growth_mib_torch": (alloc_end - alloc10) / 2 ** 20, "growth_mib_device": (free10 - free_end) / 2 ** 20,
+                   "what": f"{a.geom_iters - 10} fresh objects between the two readings: pattern handles, tables or blocks that leaked would show here"}}
+    if not a.no_cpu_baseline:
+        env = dict(os.environ)
+        nthreads = min(os.cpu_count() or 1, 16)
+        env["OMP_NUM_THREADS"] = env["OPENBLAS_NUM_THREADS"] = env["MKL_NUM_THREADS"] = str(nthreads)
+        env["HIP_VISIBLE_DEVICES"] = env["CUDA_VISIBLE_DEVICES"] = ""
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--geom-cpu-child", "--cells", str(cells), "--modes", str(modes),
+                            "--order", str(order)], capture_output=True, text=True, env=env, cwd=ROOT)
+        if r.returncode != 0:
+            raise SystemExit("bench.py: geometry CPU baseline child failed:\n" + r.stderr[-2000:])
+        out["cpu_baseline"] = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    print(json.dumps(out))
+
+
+def geom_cpu_child(a):
+    """The CPU oracle on ONE iteration of the geometry loop at the same size (fresh process, no GPU): shape-function derivatives,
+    faithful K assembly, M assembly, ARPACK shift-invert, get_vals.  FORWARD ONLY: the reference differentiates the whole assembly by
+    autograd (diff_model.py:390-399), which the oracle does not restate - the figure is optimistic for the CPU and says so."""
+    from diffsound_amd import meshgen
+    from oracle import fem, modal
+
+    nthreads = min(os.cpu_count() or 1, 16)
+    torch.set_num_threads(nthreads)
+    cells, nz = a.cells, 8
+    v, t = meshgen.kuhn_box(cells, cells, nz, box=(0.10, 0.10, 0.10 * nz / cells))
+    v, t = torch.from_numpy(v), torch.from_numpy(t).long()
+    mat = (2700.0, 7.2e10, 0.19)
+    stages, clock = {}, [time.time()]
+
+    def lap(name):
+        now = time.time()
+        stages[name] = round(now - clock[0], 3)
+        clock[0] = now
+
+    t0 = clock[0]
+    if a.order > 1:
+        v, t = fem.to_high_order(v, t, a.order)
+    d = fem.OracleDeform(v, t, a.order)
+    lap("shape_function_derivatives")
+    lam, mu = fem.lame(mat[1], mat[2])
+    M3, _ = fem.assemble_mass(v, t, a.order, mat[0])
+    lap("mass_assembly")
+    K = fem.assemble_stiffness_faithful(d, lam, mu)
+    lap("stiffness_assembly")
+    ev, U, _, _ = modal.eigsh_shift_invert(K, M3, a.modes)
+    lap("arpack_shift_invert")
+    _ = modal.get_vals(K, M3, ev, U)
+    lap("get_vals")
+    dt = time.time() - t0
+    print(json.dumps({"value": 1.0 / dt, "unit": f"iterations/s at {t.shape[0]} tets, FORWARD ONLY", "cores": nthreads, "kind": "port",
+                      "sample": (f"ONE forward iteration of the CPU oracle on the {cells} x {cells} x {nz}-cell shell ({t.shape[0]} tets, ord-{a.order}, "
+                                 f"{a.modes} modes): {dt:.1f} s; no backward to the vertices (the oracle does not restate autograd through "
+                                 "the assembly) - optimistic for the CPU"),
+                      "sample_seconds": dt, "stage_seconds": stages}))
+
+
 def in_pass_profile(pipe, hyps, dev, block, passes=2):
     """``roofline.in_pass``: complete passes run ONE AT A TIME on one stream with every SpMM form, Gram and update launch of
     the pass bracketed by HIP events inside the library (ds_profile_stream / ds_profile_kinds) - each kernel alone on the device,
@@ -763,8 +929,12 @@ def api_path_leg(a, verts, tets, dev, cfg):
 
 def main():
     a = parse()
+    if a.geom_cpu_child:
+        return geom_cpu_child(a)
     if a.workload == "c5":
         return main_c5(a)
+    if a.workload == "geom":
+        return main_geom(a)
     if a.cpu_baseline_child:  # one pass of the CPU oracle, nothing else (no GPU, no torch.distributed)
         print(json.dumps(cpu_baseline_pass(a.cpu_sample_cells, a.order, a.modes, 6 * a.cells ** 3)))
         return

@@ -688,3 +688,45 @@ def test_lobpcg_func_rejects_unknown_methods(dev):
         lobpcg_func(A, B, 2, method="davidson")
     with pytest.raises(ValueError, match="not applicable"):
         lobpcg_func(A, B, 30, largest=False)
+
+
+def test_fresh_objects_in_a_shape_loop_leave_the_hbm_flat(dev):
+    """the geometry loop builds a NEW DiffSoundObj on new vertices and a new topology every iteration
+    (src/dmtet/geometry/dmtet_thickness.py:237-299).  200 such objects - pattern handles, contribution lists, union / MFMA tables,
+    operator blocks, the solver's buffers, the autograd node of get_vals - must leave torch's allocated bytes AND the device's free
+    memory where they were after the first few (a leaked native handle or a reference cycle would grow one of them)."""
+    import gc
+
+    from diffsound_amd import meshgen
+    from src.diffelastic.diff_model import DiffSoundObj, MatSet
+
+    meshes = []
+    for nz in (3, 4, 5, 4):
+        v, t = meshgen.kuhn_box(6, 6, nz, box=(0.1, 0.1, 0.1 * nz / 6))
+        meshes.append((torch.from_numpy(v).to(dev), torch.from_numpy(t).long().to(dev)))
+    theta = torch.nn.Parameter(torch.tensor(1.0, device=dev))
+    opt = torch.optim.Adam([theta], lr=1e-3)
+    target = None
+    alloc, free = [], []
+    for i in range(210):
+        v0, t0 = meshes[i % 4]
+        scale = torch.stack([torch.ones((), device=dev), torch.ones((), device=dev), theta])
+        obj = DiffSoundObj(v0 * scale[None, :], t0, mode_num=8, order=1 + (i % 8 == 7), mat=MatSet.Ceramic)  # (an ord-2 object now and then: the two-level tables)
+        obj.eigen_decomposition()
+        vals = obj.get_vals()
+        if target is None:
+            target = (vals.detach() * 1.1).clone()
+        loss = ((vals - target) ** 2 / target ** 2).mean()
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        assert np.isfinite(float(loss.detach()))
+        del obj, vals, loss, scale
+        if i in (9, 209):
+            gc.collect()
+            torch.cuda.synchronize()
+            alloc.append(torch.cuda.memory_allocated(dev))
+            free.append(torch.cuda.mem_get_info(dev)[0])
+    assert theta.grad is not None and float(theta.grad.abs()) > 0
+    assert alloc[1] - alloc[0] <= 1 << 20, (alloc[0], alloc[1])     # torch-side: within 1 MiB over 200 objects
+    assert free[0] - free[1] <= 64 << 20, (free[0], free[1])        # device-side (native handles; the caching allocator may hold one segment more)
