@@ -140,6 +140,8 @@ def _solve(A, B, k, X, E, n, iK, niter, tol, largest, method, tracker, ortho_ipa
     cfg = SolverConfig(block=((n + 3) // 4) * 4, maxit=1000 if niter is None else niter, tol=tol or 0.0)
     if largest or a_callable:
         cfg.cheb_degree = 1  # the polynomial preconditioner targets the low end of an SPD spectrum only
+    else:  # the polynomial's interval ends at a RIGOROUS bound of lambda_max(T A) (HipSparseOps.lmax_bound), not at an estimate
+        cfg.lmax_cap, cfg.power_iters = float(ops.lmax_bound), 0
     precond = None
     if iK is not None:
         if callable(iK) and not isinstance(iK, torch.Tensor):

@@ -829,6 +829,7 @@ class ModalSolver:
         # Gram blocks of the part of the basis that the last Ritz step produced: [X_a P]^T K [X_a P] (host, fp64)
         Gxp = torch.diag(lam.detach().to(torch.float64).cpu()) if dev.type == "cuda" else torch.diag(lam.to(torch.float64))
         since_refresh = 0
+        best_worst = float("inf")
         rel = torch.full((b,), float("inf"), dtype=torch.float64, device=dev)
         # The iteration as ONE native call (ds_lobpcg_iterate) when the ops offer it and nothing needs the interpreter
         # between iterations (no tracker callback, the built-in preconditioners): same kernels, same dense steps, but
@@ -871,6 +872,14 @@ class ModalSolver:
             if tracker is not None:
                 tracker(state)
             if nconv >= k or it == cfg.maxit or state.bvars.get("force_stop", False):
+                break
+            # A tolerance below what the iterates' precision can reach never locks anything; the block then sits converged to
+            # rounding while [X P W] degenerates (W and P are noise), the residuals creep up again and, a few iterations later,
+            # the block collapses (seen on a random pencil with tol = 1e-6 in fp32: 4e-7 at iteration 22, 3e-4 at 28, garbage at
+            # 29).  Stop at the first clear rise above the best residual reached - the block is still good to ~10 x that floor.
+            best_worst = min(best_worst, history[-1][1])
+            if it > 10 and history[-1][1] > 10.0 * best_worst and best_worst < 1e-3:
+                state.bvars["stagnated"] = True
                 break
             # hard locking as in the reference (S_ = S[:, nc:ns], _lobpcg.py:458): converged leading columns
             # leave the Rayleigh-Ritz problem, the residual block and the preconditioner; they stay in V

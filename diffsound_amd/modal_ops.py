@@ -1253,7 +1253,15 @@ class HipSparseOps(_HipBlockOps):
         eye = torch.eye(3, dtype=torch.float64, device=dev)
         bad = torch.linalg.det(diag).abs() < 1e-300
         diag = torch.where(bad[:, None, None], eye, diag)
-        self.dinv = torch.linalg.inv(diag).float().reshape(nv, 9).contiguous()
+        dinv64 = torch.linalg.inv(diag)
+        self.dinv = dinv64.float().reshape(nv, 9).contiguous()
+        # rigorous bound of lambda_max(T A), T = the inverse diagonal blocks: the block-infinity norm max_i sum_j ||T_i A_ij||_F
+        # (an operator norm for the vector norm max_i ||x_i||_2).  The Chebyshev polynomial of lobpcg_func takes it as the end of
+        # its interval: a power-iteration estimate that falls short of the true value makes the polynomial blow up on the top of
+        # the spectrum, and on pencils that are not FEM matrices 30 steps x 1.2 do fall short (round 6, tests/test_api_gpu.py)
+        rows_ = torch.repeat_interleave(torch.arange(nv, device=dev), (rowptr[1:] - rowptr[:-1]))
+        ta = torch.linalg.matrix_norm(dinv64[rows_] @ self.a64.reshape(-1, 3, 3))
+        self.lmax_bound = float(torch.zeros(nv, dtype=torch.float64, device=dev).index_add_(0, rows_, ta).max())
         self.rigid = None
         self.lame = None
 
