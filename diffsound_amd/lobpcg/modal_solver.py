@@ -102,6 +102,13 @@ class SolverConfig:
     refine_maxit: int = 40
     refine_refresh: int = 8  # every this many fp64 steps all Gram blocks are recomputed from the vectors (else by recurrence)
     refine_sweeps: int = 2   # preconditioner sweeps per fp64 step (2: W = B R + B (R - K B R); C5: 21 -> 17 steps, 4.3 -> 3.8 s)
+    # EXPERIMENT (round 6): trade Rayleigh-Ritz steps (host-bound for one hypothesis alone) for preconditioner sweeps (device work):
+    # ``start_sweeps`` applications of the preconditioner to the random start block before its first Ritz step (inverse-power
+    # steps: the block arrives dominated by the low end of the spectrum), ``precond_sweeps`` - W = B R + B (R - K B R) + ... per
+    # iteration (a stronger, still fixed and symmetric preconditioner)
+    start_sweeps: int = 0
+    precond_sweeps: int = 1
+    nested_precond_sweeps: int = 1
     nested_tol: float = 0.0
     nested_maxit: int = 8
     nested_cheb_degree: int = 28
@@ -666,7 +673,8 @@ class ModalSolver:
                             power_iters=cfg.power_iters, lmax_safety=cfg.lmax_safety,
                             lmax_cap=min(cfg.lmax_cap, 4.0) if cfg.lmax_cap > 0 else 0.0, precond="chebyshev",
                             raw_rr=cfg.raw_rr, raw_start=cfg.raw_start, warm_power_iters=cfg.warm_power_iters,
-                            warm_power_spread=cfg.warm_power_spread)
+                            warm_power_spread=cfg.warm_power_spread, start_sweeps=cfg.start_sweeps,
+                            precond_sweeps=getattr(cfg, "nested_precond_sweeps", 1), native=cfg.native)
         pre = self.precond.coarse if isinstance(self.precond, TwoLevelChebyshev) else None
         if pre is not None and (pre.degree != ccfg.cheb_degree
                                 or abs(pre.lmax / pre.lmin - ccfg.cheb_ratio) > 1e-6 * ccfg.cheb_ratio):
@@ -739,6 +747,9 @@ class ModalSolver:
             X[:, :nx0].copy_(X0.to(dt))
         if nx0 < b:
             X[:, nx0:].copy_(torch.randn((n, b - nx0), generator=g, dtype=torch.float32, device=dev).to(dt))
+        for _ in range(cfg.start_sweeps if X0 is None else 0):  # (experiment: inverse-power steps on the random start)
+            R.copy_(X)
+            self.precond_apply(R, X)
         # operator norm estimates with a random block, as the reference does (_lobpcg.py:280-285)
         # (The probe block is the same every time - same seed, same number of columns drawn before it - and ||M G0|| depends on
         # the geometry only: operators that can name their geometry's generation keep the block, its norm and ||M G0|| / ||G0||
@@ -894,6 +905,11 @@ class ModalSolver:
             w0 = ny + b + npc
             W = S[:, w0:w0 + na]
             self.precond_apply(R[:, :na], W)
+            for _ in range(max(0, cfg.precond_sweeps - 1)):  # (experiment: W <- W + B (R - K W))
+                ops.apply_K(W, MW[:, :na])
+                torch.sub(R[:, :na], MW[:, :na], out=MX[:, :na])
+                self.precond_apply(MX[:, :na], MW[:, :na])
+                W += MW[:, :na]
             sz = na + npc + na
             Sa = S[:, ny + ncl:ny + ncl + sz]
             KSa = KS[:, k0:k0 + sz]
@@ -1043,7 +1059,8 @@ class ModalSolver:
             Li = torch.linalg.solve_triangular(L, torch.eye(L.shape[0], dtype=L.dtype), upper=False)
             return d[:, None] * Li.transpose(0, 1)
 
-        def ritz(GA, GB, keep):
+        def ritz(GA, GB, keep=None):
+            keep = GA.shape[0] if keep is None else keep
             Ri = transform(GB)
             if Ri is None:
                 return None
@@ -1063,11 +1080,11 @@ class ModalSolver:
             GA, GB = ops.gram(Sa, AS[:, :w], exact=True), ops.gram(Sa, BS[:, :w], exact=True)
             na = b - nc
             keep = na if it == 0 else min(w, 2 * na)
-            out = _small(ritz, dev, GA, GB, keep)
+            out = _small(lambda a_, b_, keep_=keep: ritz(a_, b_, keep_), dev, GA, GB)
             if out is None and npc:  # [X P W] numerically dependent: the step without P
                 idx = torch.cat([torch.arange(0, na, device=dev), torch.arange(na + npc, w, device=dev)])
                 keep = na
-                out = _small(ritz, dev, GA[idx][:, idx].contiguous(), GB[idx][:, idx].contiguous(), keep)
+                out = _small(lambda a_, b_, keep_=keep: ritz(a_, b_, keep_), dev, GA[idx][:, idx].contiguous(), GB[idx][:, idx].contiguous())
                 if out is not None:
                     Zf = torch.zeros((w, keep), dtype=torch.float64, device=dev)
                     Zf[idx] = out[1]

@@ -97,7 +97,13 @@ def test_steps_without_a_join_give_the_joined_schedule_s_results(ndev, one_rank)
     args[args.index("--steps") + 1] = "3"
     free = _bench(*args)
     joined = _bench(*args, "--step-barrier")
-    assert free["loss_sum_last_step"] == joined["loss_sum_last_step"] == one_rank["loss_sum_last_step"]
+    assert free["loss_sum_last_step"] == joined["loss_sum_last_step"]
+    # (round 6: the material moves from step to step, so the third step's loss is not the first's; with --same-material - the
+    # repetition of rounds 1-5 - three steps end where one step ends)
+    assert free["loss_sum_last_step"] != one_rank["loss_sum_last_step"] and "moves" in free["materials"]
+    same3 = _bench(*args, "--same-material")
+    same1 = _bench("--gpus", "1", "--hyp-per-gpu", "4", "--lanes", "2", *SMALL, "--same-material")
+    assert same3["loss_sum_last_step"] == same1["loss_sum_last_step"]
     assert "no join between steps" in free["config"]["step_schedule"] and "join after every step" in joined["config"]["step_schedule"]
     assert free["steps"] == joined["steps"] == 3
 
