@@ -116,6 +116,9 @@ def parse():
                          "backward error and prolongated (SolverConfig.nested_tol); 0 = start the fine level from the "
                          "random block directly")
     ap.add_argument("--nested-maxit", type=int, default=8)
+    ap.add_argument("--start-sweeps", type=int, default=2,
+                    help="applications of the preconditioner to the random start block before its first Ritz step "
+                         "(SolverConfig.start_sweeps; 0 = rounds 1-5)")
     ap.add_argument("--warm-start", action="store_true", help="amortised variant: reuse the previous block")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (the product); gloo = rehearsal of the N > 1 path without RCCL")
@@ -205,6 +208,7 @@ def solver_config(a=None, **over):
         cfg.ortho_tol = a.ortho_tol
     if getattr(a, "ortho_passes", -1) > 0:
         cfg.ortho_passes = a.ortho_passes
+    cfg.start_sweeps = getattr(a, "start_sweeps", 0)
     cfg.nested_tol, cfg.nested_maxit = a.nested_tol, a.nested_maxit
     cfg.nested_cheb_degree, cfg.nested_cheb_ratio = a.coarse_degree, a.coarse_ratio
     return cfg

@@ -102,10 +102,11 @@ class SolverConfig:
     refine_maxit: int = 40
     refine_refresh: int = 8  # every this many fp64 steps all Gram blocks are recomputed from the vectors (else by recurrence)
     refine_sweeps: int = 2   # preconditioner sweeps per fp64 step (2: W = B R + B (R - K B R); C5: 21 -> 17 steps, 4.3 -> 3.8 s)
-    # EXPERIMENT (round 6): trade Rayleigh-Ritz steps (host-bound for one hypothesis alone) for preconditioner sweeps (device work):
-    # ``start_sweeps`` applications of the preconditioner to the random start block before its first Ritz step (inverse-power
-    # steps: the block arrives dominated by the low end of the spectrum), ``precond_sweeps`` - W = B R + B (R - K B R) + ... per
-    # iteration (a stronger, still fixed and symmetric preconditioner)
+    # Round 6: Rayleigh-Ritz steps (host-bound for one hypothesis alone) traded for preconditioner sweeps (device work).
+    # ``start_sweeps`` applications of the preconditioner to a RANDOM start block before its first Ritz step (inverse-power
+    # steps: the block arrives dominated by the low end of the spectrum; with a nested start it is the corner-node level's block).
+    # ``precond_sweeps`` / ``nested_precond_sweeps`` - W = B R + B (R - K B R) per iteration on the fine / corner-node level: measured
+    # and NOT adopted (one iteration less for twice the cycle: profiles/r06_start_sweeps.txt); Python loop only.
     start_sweeps: int = 0
     precond_sweeps: int = 1
     nested_precond_sweeps: int = 1
@@ -747,9 +748,17 @@ class ModalSolver:
             X[:, :nx0].copy_(X0.to(dt))
         if nx0 < b:
             X[:, nx0:].copy_(torch.randn((n, b - nx0), generator=g, dtype=torch.float32, device=dev).to(dt))
-        for _ in range(cfg.start_sweeps if X0 is None else 0):  # (experiment: inverse-power steps on the random start)
+        # ``start_sweeps`` (round 6): the RANDOM start block is passed through the preconditioner before its first Ritz step - steps of
+        # a preconditioned inverse subspace iteration without the Ritz algebra.  White noise holds every frequency alike; after two
+        # sweeps the block is dominated by the low end of the spectrum and the corner-node level of a nested start reaches its
+        # tolerance in 3 iterations instead of 5 (profiles/r06_start_sweeps.txt) - two sweeps are 0.7 ms of device work, two
+        # iterations 1 ms of device work plus 3.2 ms of Rayleigh-Ritz on the host thread.
+        for _ in range(cfg.start_sweeps if X0 is None else 0):
             R.copy_(X)
-            self.precond_apply(R, X)
+            native_sweep = getattr(ops, "chebyshev_apply16", None)
+            if not (native_sweep is not None and isinstance(self.precond, ChebyshevBlockJacobi) and cfg.precond_storage == "bf16"
+                    and dt == torch.float32 and native_sweep(self.precond, R, X)):
+                self.precond_apply(R, X)
         # operator norm estimates with a random block, as the reference does (_lobpcg.py:280-285)
         # (The probe block is the same every time - same seed, same number of columns drawn before it - and ||M G0|| depends on
         # the geometry only: operators that can name their geometry's generation keep the block, its norm and ||M G0|| / ||G0||

@@ -479,6 +479,20 @@ class _HipBlockOps:
 
     _tl_desc = None
 
+    def chebyshev_apply16(self, precond, R, W):
+        """W <- p(T K) T R through the native one-level driver on bf16 iterates (ds_chebyshev_apply16: the launches the native
+        iteration issues for the same preconditioner) for blocks of <= 84 columns; False when the level or block does not qualify."""
+        d = _hip.LevelDesc()
+        if (precond.degree < 2 or R.shape[1] > 84 or R.shape[1] % 4 or not self._union_ok(R, W)
+                or self.level_desc(d, precond.degree, precond.lmax, precond.lmin) is None or self._mfma is None or self.kc is None):
+            return False
+        b = R.shape[1]
+        scr = self._scratch("native_cheb", (3, self.n, b), torch.bfloat16)
+        _hip.check(self._L.ds_chebyshev_apply16(ctypes.byref(d), R.data_ptr(), _ld(R), W.data_ptr(), _ld(W), scr[0].data_ptr(),
+                                                scr[1].data_ptr(), scr[2].data_ptr(), b, b, _hip.stream_ptr()), "ds_chebyshev_apply16")
+        self.counts["apply_K_cols"] += b * (precond.degree - 1)
+        return True
+
     # ------------------------------------------------------------------ native iteration driver
     def native_lobpcg(self, precond, cfg, k, b, ny, S, S2, KS, KS2, R, MX, MW, lam, A_norm, B_norm, tol):
         """Run the eigensolver's iteration through ds_lobpcg_iterate (csrc/lobpcg.cpp).  Returns None when this
