@@ -1058,12 +1058,18 @@ class ModalSolver:
         state.fvars.update(A_norm=A_norm, B_norm=B_norm)
         tol = cfg.tol or (2e-6 if dt == torch.float32 else 1e-10)
 
+        eps = 6e-8 if dt == torch.float32 else 1.1e-16
+
         def transform(GB):
-            """Ri of the reference: None when the scaled Gram matrix has no Cholesky factor."""
+            """Ri of the reference: None when the scaled Gram matrix has no Cholesky factor - or one so ill-conditioned that
+            S Ri would come out of the fp32 update visibly non-orthonormal (eps x cond(S^T B S) >= 1e-3: the vectors are stored in
+            ``dt``; the reference, which has no such test, then iterates on a basis that is no longer one)."""
             GB = _sym(GB)
             d = torch.rsqrt(torch.clamp(GB.diagonal(), min=1e-300))
             L, info = torch.linalg.cholesky_ex(GB * d[:, None] * d[None, :])
             if int(info) != 0 or not bool(torch.isfinite(L).all()):
+                return None
+            if eps / max(float(L.diagonal().min()), 1e-300) ** 2 >= 1e-3:
                 return None
             Li = torch.linalg.solve_triangular(L, torch.eye(L.shape[0], dtype=L.dtype), upper=False)
             return d[:, None] * Li.transpose(0, 1)
