@@ -759,6 +759,9 @@ class ModalSolver:
             if not (native_sweep is not None and isinstance(self.precond, ChebyshevBlockJacobi) and cfg.precond_storage == "bf16"
                     and dt == torch.float32 and native_sweep(self.precond, R, X)):
                 self.precond_apply(R, X)
+            # (every sweep scales the block by ~1 / ||K||: 1e-10 on the benchmark's stiffness - three of them would leave the range
+            # the preconditioner's bf16 blocks can hold; back to unit size after each)
+            X.mul_(1.0 / X.abs().max().clamp(min=1e-300))
         # operator norm estimates with a random block, as the reference does (_lobpcg.py:280-285)
         # (The probe block is the same every time - same seed, same number of columns drawn before it - and ||M G0|| depends on
         # the geometry only: operators that can name their geometry's generation keep the block, its norm and ||M G0|| / ||G0||
@@ -829,8 +832,12 @@ class ModalSolver:
                 self.ortho_log.append(amp)
                 ops.mix(S[:, :ny + b], coef, S2[:, ny:ny + b])
                 S, S2 = S2, S
-                ops.mix(KS[:, :b], Cx, KS2[:, :b])  # K X of the new block (K Y = 0)
-                KS, KS2 = KS2, KS
+                # K X of the new block (K Y = 0) - which nobody reads when the iteration forms its residuals in one walk of the
+                # unions (fused_residual with kx_fresh: K X' is formed inside that kernel): the update is skipped then (round 6)
+                if not (cfg.fused_residual and cfg.kx_fresh and cfg.rr_refresh > 0 and hasattr(ops, "residual_fused")
+                        and ops.residual_fused_ok(S[:, ny:ny + b], R)):
+                    ops.mix(KS[:, :b], Cx, KS2[:, :b])
+                    KS, KS2 = KS2, KS
                 X = S[:, ny:ny + b]
         if lam is None:
             self._orthonormalize(X, S[:, :ny], MW, VW=S[:, :ny + b] if ny else None)
