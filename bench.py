@@ -551,10 +551,16 @@ def main_geom(a):
         meshes.append((torch.from_numpy(v).to(dev), torch.from_numpy(t).long().to(dev)))
     mat = MatSet.Ceramic
     geom_cfg = None  # (None: DiffSoundObj's own default, lobpcg.modal_solver.tuned_config(order))
-    if "--cheb-degree" in sys.argv or "--cheb-ratio" in sys.argv or "--block" in sys.argv:
+    if any(f in sys.argv for f in ("--cheb-degree", "--cheb-ratio", "--block", "--start-sweeps")):
         from diffsound_amd.lobpcg.modal_solver import tuned_config
 
-        geom_cfg = tuned_config(order, cheb_degree=a.cheb_degree, cheb_ratio=a.cheb_ratio, block=a.block if "--block" in sys.argv else 0)
+        geom_cfg = tuned_config(order)
+        if "--cheb-degree" in sys.argv or "--cheb-ratio" in sys.argv:
+            geom_cfg.cheb_degree, geom_cfg.cheb_ratio = a.cheb_degree, a.cheb_ratio
+        if "--block" in sys.argv:
+            geom_cfg.block = a.block
+        if "--start-sweeps" in sys.argv:
+            geom_cfg.start_sweeps = a.start_sweeps
     theta = torch.nn.Parameter(torch.tensor(1.0, device=dev))
     opt = torch.optim.Adam([theta], lr=2e-3)
     zscale = lambda: torch.stack([torch.ones((), device=dev), torch.ones((), device=dev), theta])
@@ -1431,7 +1437,8 @@ def main():
                 "eigensolver": (f"LOBPCG(ortho) block {a.block}, {precond_desc}, "
                                 f"cold start{' (warm)' if a.warm_start else ''}, mean iterations {np.mean(iters):.1f}"
                                 + (f" after a nested start (mean {np.mean(cits):.1f} corner-node level iterations to "
-                                   f"{a.nested_tol:g})" if a.nested_tol > 0 else "")
+                                   f"{a.nested_tol:g}" + (f", its random block through {cfg.start_sweeps} preconditioner sweeps first" if cfg.start_sweeps else "")
+                                   + ")" if a.nested_tol > 0 else "")
                                 + f", backward-error tolerance {tol:g}"),
                 "host_wait": (f"{a.host_wait}: " + ("a lane's host thread sleeps while it waits for its stream - the native solve polls "
                                                    "20 us, then waits on a blocking event (ds_host_wait_mode 1); every other wait through "

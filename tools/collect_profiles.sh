@@ -32,15 +32,15 @@ if [ $part = 1b ] || [ $part = all ]; then
 rm -rf /tmp/prof_b /tmp/prof_l1
 # (about one in ten profiled 8-lane runs ends in a SIGSEGV inside the runtime's launch path under the profiler's hooks -
 # profiles/README.md, "A note on the profiled runs" - so this step gets one more try)
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_b -o bench -- python3 bench.py --no-cpu-baseline --no-solo --amortised-cycle 1 --steps 8 > $out/${tag}_bench_prof.log 2>&1 || { echo "profiled run failed, once more"; rm -rf /tmp/prof_b; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_b -o bench -- python3 bench.py --no-cpu-baseline --no-solo --amortised-cycle 1 --steps 8 > $out/${tag}_bench_prof.log 2>&1; }
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_b -o bench -- python3 bench.py --no-cpu-baseline --no-solo --no-api-path --amortised-cycle 1 --steps 8 > $out/${tag}_bench_prof.log 2>&1 || { echo "profiled run failed, once more"; rm -rf /tmp/prof_b; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_b -o bench -- python3 bench.py --no-cpu-baseline --no-solo --no-api-path --amortised-cycle 1 --steps 8 > $out/${tag}_bench_prof.log 2>&1; }
 python3 tools/summarize_prof.py /tmp/prof_b $out/${tag}_bench_kernel_stats.csv --top 45
 python3 tools/gpu_busy.py /tmp/prof_b 0.45 0.05 > $out/${tag}_gpu_busy.txt; cat $out/${tag}_gpu_busy.txt  # 55 % .. 95 % of the run: inside the timed steps, without the last step's drain
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_l1 -o bench -- python3 bench.py --no-cpu-baseline --no-solo --lanes 1 --hyp-per-gpu 2 --steps 4 --warmup 1 > $out/${tag}_bench_prof_l1.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_l1 -o bench -- python3 bench.py --no-cpu-baseline --no-solo --no-api-path --lanes 1 --hyp-per-gpu 2 --steps 4 --warmup 1 > $out/${tag}_bench_prof_l1.log 2>&1
 python3 tools/summarize_prof.py /tmp/prof_l1 $out/${tag}_bench_lanes1_kernel_stats.csv --top 45
 # the kernel-alone measurements of the bench line (roofline.avg_launch_ms: hundreds of back-to-back launches after the timed region)
 # under the profiler: a short run whose launches of the fused term, K W and the triad are almost all those
 rm -rf /tmp/prof_solo
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_solo -o bench -- python3 bench.py --no-cpu-baseline --lanes 1 --hyp-per-gpu 1 --steps 1 --warmup 1 --amortised-cycle 1 > $out/${tag}_bench_prof_solo.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_solo -o bench -- python3 bench.py --no-cpu-baseline --no-api-path --lanes 1 --hyp-per-gpu 1 --steps 1 --warmup 1 --amortised-cycle 1 > $out/${tag}_bench_prof_solo.log 2>&1
 python3 tools/summarize_prof.py /tmp/prof_solo $out/${tag}_bench_solo_kernel_stats.csv --top 12
 fi
 if [ $part = 2 ] || [ $part = all ]; then
