@@ -135,25 +135,73 @@ class LobpcgDesc(ctypes.Structure):
 _lapack = None
 
 
-def lapack_table():
-    """ds_lapack_t filled with SciPy's LAPACK / BLAS entry points (scipy.linalg.cython_lapack / cython_blas export them
-    as PyCapsules).  The table changes nothing in the process: the BLAS thread count is the caller's business
-    (``blas_one_thread`` below is what the native solve is wrapped in)."""
+def lapack_table(source=None):
+    """ds_lapack_t for ds_lobpcg_iterate: Fortran-convention dsyevd / dgemm entry points and, where the library has them, the
+    stages dsytrd / dstedc / dormtr.  Sources, in order of preference (``source`` or the environment variable DS_LAPACK names
+    one: "scipy" | "torch"):
+      scipy  scipy.linalg.cython_lapack / cython_blas export every routine as a PyCapsule (OpenBLAS: dsyevd 240 x 240 in
+             2.35 ms on the GPU box's host, and the stages, so the Ritz step back-transforms only the wanted third);
+      torch  the MKL inside libtorch_cpu.so exports dsyevd_ / dgemm_ as plain symbols (2.9 ms; no stages) - so the product does
+             not DEPEND on SciPy's private capsule table: without SciPy, or with a SciPy whose capsules have moved,
+             the solve still runs, 20 % slower on the host side.
+    The table changes nothing in the process: the BLAS thread count is the caller's business (``blas_one_thread`` below is what
+    the native solve is wrapped in)."""
     global _lapack
-    if _lapack is None:
-        import scipy.linalg.cython_blas as cb
-        import scipy.linalg.cython_lapack as cl
+    want = source or os.environ.get("DS_LAPACK") or None
+    if want not in (None, "scipy", "torch"):
+        raise ValueError(f"lapack_table: unknown source {want!r} (scipy | torch)")
+    if _lapack is not None and (want is None or _lapack_source == want):
+        return _lapack
+    errors = []
+    for name in ((want,) if want else ("scipy", "torch")):
+        try:
+            table = _lapack_from_scipy() if name == "scipy" else _lapack_from_torch()
+        except Exception as ex:  # (ImportError, KeyError on a capsule, OSError / AttributeError on a symbol)
+            errors.append(f"{name}: {type(ex).__name__}: {ex}")
+            continue
+        if want is None or _lapack is None:
+            _set_lapack(table, name)
+        return table
+    raise RuntimeError("diffsound_amd: no LAPACK for the eigensolver's dense steps (" + "; ".join(errors) + ")")
 
-        get = ctypes.pythonapi.PyCapsule_GetPointer
-        name = ctypes.pythonapi.PyCapsule_GetName
-        get.restype, get.argtypes = ctypes.c_void_p, [ctypes.py_object, ctypes.c_char_p]
-        name.restype, name.argtypes = ctypes.c_char_p, [ctypes.py_object]
-        addr = lambda cap: get(cap, name(cap))
-        stages = [addr(cl.__pyx_capi__[nm]) if nm in cl.__pyx_capi__ else None for nm in ("dsytrd", "dstedc", "dormtr")]
-        if not all(stages):
-            stages = [None, None, None]
-        _lapack = LapackTable(addr(cl.__pyx_capi__["dsyevd"]), addr(cb.__pyx_capi__["dgemm"]), *stages)
-    return _lapack
+
+_lapack_source = None
+
+
+def _set_lapack(table, name):
+    global _lapack, _lapack_source
+    _lapack, _lapack_source = table, name
+
+
+def lapack_source():
+    """Which library the process-wide table came from ("scipy" | "torch"), None before the first call of lapack_table()."""
+    return _lapack_source
+
+
+def _lapack_from_scipy():
+    import scipy.linalg.cython_blas as cb
+    import scipy.linalg.cython_lapack as cl
+
+    get = ctypes.pythonapi.PyCapsule_GetPointer
+    name = ctypes.pythonapi.PyCapsule_GetName
+    get.restype, get.argtypes = ctypes.c_void_p, [ctypes.py_object, ctypes.c_char_p]
+    name.restype, name.argtypes = ctypes.c_char_p, [ctypes.py_object]
+    addr = lambda cap: get(cap, name(cap))
+    stages = [addr(cl.__pyx_capi__[nm]) if nm in cl.__pyx_capi__ else None for nm in ("dsytrd", "dstedc", "dormtr")]
+    if not all(stages):
+        stages = [None, None, None]
+    return LapackTable(addr(cl.__pyx_capi__["dsyevd"]), addr(cb.__pyx_capi__["dgemm"]), *stages)
+
+
+def _lapack_from_torch():
+    lib = ctypes.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "libtorch_cpu.so"))
+    addr = lambda nm: ctypes.cast(getattr(lib, nm), ctypes.c_void_p).value
+    stages = [None, None, None]
+    try:
+        stages = [addr(nm) for nm in ("dsytrd_", "dstedc_", "dormtr_")]
+    except AttributeError:
+        pass
+    return LapackTable(addr("dsyevd_"), addr("dgemm_"), *stages)
 
 
 class blas_one_thread:

@@ -200,3 +200,23 @@ def test_host_dense_steps_of_the_native_solver_loop(n, m):
     assert _hip.lib().ds_selftest_dense(ctypes.byref(_hip.LapackTable(tbl.dsyevd, tbl.dgemm, None, None, None)), n, m, 7, errs) == 0
     assert errs[5] == 0.0 and errs[1] < 1e-13   # no stages in the table: dsyevd, the same answer
     del partial
+
+
+def test_lapack_table_has_a_source_without_scipy():
+    """the product must not DEPEND on SciPy's private capsule table.  _hip.lapack_table() prefers SciPy's OpenBLAS
+    (faster, and it has the stages of dsyevd) and falls back to the MKL entry points libtorch_cpu.so exports; both tables pass
+    the dense self-check, and the process-wide table can be chosen by name (DS_LAPACK)."""
+    import ctypes
+
+    _hip = _lib()
+    for src in ("scipy", "torch"):
+        tbl = _hip.lapack_table(src)
+        assert tbl.dsyevd and tbl.dgemm
+        errs = (ctypes.c_double * 6)()
+        with _hip.blas_one_thread():
+            _hip.check(_hip.lib().ds_selftest_dense(ctypes.byref(tbl), 96, 32, 11, errs), "ds_selftest_dense")
+        assert errs[1] < 1e-13 and errs[2] < 1e-13 and errs[4] < 1e-12, (src, list(errs))
+        assert errs[5] == (1.0 if src == "scipy" else 0.0)  # (MKL's symbols in libtorch carry no stages: dsyevd then)
+    assert _hip.lapack_table() is not None and _hip.lapack_source() in ("scipy", "torch")
+    with pytest.raises(ValueError, match="unknown source"):
+        _hip.lapack_table("netlib")

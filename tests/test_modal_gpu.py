@@ -404,3 +404,26 @@ def test_start_block_in_coefficients_changes_nothing_but_rounding(dev, mesh, ord
     assert abs(a.iterations - b.iterations) <= 1
     ref = modal.reference_eigs(ops, k) if hasattr(modal, "reference_eigs") else None
     assert ref is None or float(((a.eigenvalues.cpu() - ref).abs() / ref).max()) < EIG_TOL
+
+
+def test_native_solve_on_the_lapack_inside_libtorch(dev):
+    """The native iteration with the MKL entry points of libtorch_cpu.so (dsyevd / dgemm, no stages) instead of SciPy's capsules -
+    the fallback that keeps the product independent of SciPy's private table: the same eigenvalues to the solve's accuracy, the
+    same iteration counts within one."""
+    from diffsound_amd import _hip, meshgen
+    from diffsound_amd.diffelastic.mesh import TetMesh
+
+    v, t = meshgen.kuhn_box(6)
+    tm = TetMesh(torch.from_numpy(v).to(dev), torch.from_numpy(t).long().to(dev)).to_high_order(2)
+    saved = (_hip.lapack_table(), _hip.lapack_source())
+    out = {}
+    try:
+        for src in ("scipy", "torch"):
+            _hip._set_lapack(_hip.lapack_table(src), src)
+            assert _hip.lapack_source() == src
+            _, _, out[src] = _solve(tm.vertices, tm.tets, 2, 16, dev, block=24, tol=1e-6, nested_tol=3e-3, start_sweeps=2)
+    finally:
+        _hip._set_lapack(*saved)
+    a, b = out["scipy"], out["torch"]
+    assert float(((a.eigenvalues - b.eigenvalues).abs() / b.eigenvalues).max()) < 2e-6
+    assert abs(a.iterations - b.iterations) <= 1 and float(b.rerr.max()) < 1e-6
