@@ -289,3 +289,16 @@ def test_basic_method_on_the_cpu(cube, dtype, tol_eig):
     assert np.abs(U.T @ (cube["M3"] @ U) - np.eye(20)).max() < 1e-5
     with pytest.raises(ValueError, match="not applicable"):
         ModalSolver(ops, SolverConfig(block=ops.n // 2)).solve_basic(8)
+
+
+def test_start_sweeps_on_the_cpu(cube):
+    """SolverConfig.start_sweeps (round 6): the random start block through the preconditioner before its first Ritz step - the
+    same eigenvalues as ARPACK, and no more iterations than the plain random start needs (fewer on the benchmark: 3 against 5 on
+    the corner-node level, profiles/r06_start_sweeps.txt)."""
+    its = {}
+    for sweeps in (0, 2):
+        ops = CpuModalOps(cube["Kl"], cube["Km"], cube["M3"], cube["v"], cube["lam"], cube["mu"], dtype=torch.float64)
+        res = ModalSolver(ops, SolverConfig(block=24, lmax_cap=10.0, tol=5e-8, start_sweeps=sweeps)).solve(16)
+        assert np.abs(res.eigenvalues.numpy() / cube["ref"] - 1).max() < 1e-7, sweeps
+        its[sweeps] = res.iterations
+    assert its[2] <= its[0], its
