@@ -821,7 +821,8 @@ def one_hypothesis_leg(pipe, hyps, dev, passes=8, steps_done=0):
             stream.synchronize()
             t0 = time.time()
             for i in range(passes):
-                E, nu = hyps[(i + 1) % len(hyps)]
+                # ONE hypothesis, as a user who fits one material runs it: its material moves from pass to pass as an optimiser's
+                # would (the same move as in the timed region), so every pass is a material this lane has not seen
                 s = steps_done + i + 7
                 r, _, _ = pipe.run_pass(E * (1 + 1e-3 * s), nu * (1 - 5e-4 * s), _lane=lane)
                 its.append(r.iterations)
@@ -832,8 +833,9 @@ def one_hypothesis_leg(pipe, hyps, dev, passes=8, steps_done=0):
         set_wait_mode(holder.ops, saved)
     return {"passes_per_s": 1.0 / dt, "ms_per_pass": 1e3 * dt, "passes_timed": passes, "mean_fine_iterations": float(np.mean(its)),
             "mean_corner_level_iterations": float(np.mean(cits)),
-            "what": "complete cold-start passes (assembly + eigensolve + read-out + render + loss + backward) one after the other on ONE "
-                    "stream and ONE host thread, a new material every pass; the host thread's waits spin"}
+            "what": "complete cold-start passes (assembly + eigensolve + read-out + render + loss + backward) of ONE hypothesis one after the "
+                    "other on ONE stream and ONE host thread, its material moved every pass as in the timed region (E (1 + 1e-3 s), "
+                    "nu (1 - 5e-4 s)); the host thread's waits spin"}
 
 
 def kernel_stats_leg(pipe, hyps, dev, passes=2):

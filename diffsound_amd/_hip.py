@@ -250,6 +250,8 @@ _SIGNATURES["ds_scalar_csr_spmm16"] = (_I, [_P, _P, _P, _I64, _P, _I64, _P, _I64
 _SIGNATURES["ds_lobpcg_iterate"] = (_I, [ctypes.POINTER(LobpcgDesc), ctypes.POINTER(LapackTable), _P])
 _SIGNATURES["ds_host_wait_mode"] = (_I, [_I])
 _SIGNATURES["ds_selftest_dense"] = (_I, [ctypes.POINTER(LapackTable), _I, _I, ctypes.c_uint, ctypes.POINTER(_D)])
+_SIGNATURES["ds_host_start_block"] = (_I, [ctypes.POINTER(LapackTable), _P, _I, _I, _D, _D, _P, _P, _P, ctypes.POINTER(_D), ctypes.POINTER(_I)])
+_SIGNATURES["ds_host_polish"] = (_I, [ctypes.POINTER(LapackTable), _I, _P, _P, _P, _I, _I, _P, _P, _P])
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 _lib = None
 
@@ -275,6 +277,36 @@ def lib():
             fn.argtypes = args
         _lib = handle
     return _lib
+
+
+def host_start_block(G, ny, b, ortho_tol, eps):
+    """ds_host_start_block on a host fp64 tensor G ((ny + b) x 2 b): (lam, coef, cx, amp) as host tensors, or None when the caller
+    has to take the explicit route."""
+    G = G.contiguous()
+    lam = torch.empty(b, dtype=torch.float64)
+    coef = torch.empty((ny + b, b), dtype=torch.float64)
+    cx = torch.empty((b, b), dtype=torch.float64)
+    amp, route = _D(0.0), _I(0)
+    with blas_one_thread():
+        check(lib().ds_host_start_block(ctypes.byref(lapack_table()), G.data_ptr(), ny, b, float(ortho_tol), float(eps), lam.data_ptr(),
+                                        coef.data_ptr(), cx.data_ptr(), ctypes.byref(amp), ctypes.byref(route)), "ds_host_start_block")
+    return None if route.value else (lam, coef, cx, amp.value)
+
+
+def host_polish(GK, coefs, GM, k):
+    """ds_host_polish on host fp64 tensors: GK a list of (b x b) matrices, coefs their weights, GM (b x b): (E (k), C (b x b),
+    qs ((len(GK) + 1) x k))."""
+    b = GM.shape[0]
+    gk = torch.stack([g_.contiguous() for g_ in GK]).contiguous()
+    cf = torch.tensor([float(c) for c in coefs], dtype=torch.float64)
+    GM = GM.contiguous()
+    E = torch.empty(k, dtype=torch.float64)
+    C = torch.empty((b, b), dtype=torch.float64)
+    qs = torch.empty((len(GK) + 1, k), dtype=torch.float64)
+    with blas_one_thread():
+        check(lib().ds_host_polish(ctypes.byref(lapack_table()), len(GK), gk.data_ptr(), cf.data_ptr(), GM.data_ptr(), b, k, E.data_ptr(),
+                                   C.data_ptr(), qs.data_ptr()), "ds_host_polish")
+    return E, C, qs
 
 
 def check(status, what):

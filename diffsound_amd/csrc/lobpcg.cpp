@@ -594,6 +594,122 @@ extern "C" int ds_selftest_dense(const ds_lapack_t* lapack, int n, int m, unsign
     return DS_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The two small dense steps that frame the iteration - the start block's first Ritz step in coefficients and the fp64 polish of
+// the converged block - on the host with the caller's LAPACK table (round 6: they were ~30 torch calls on tiny CPU tensors each,
+// 0.65 ms and 1.1 ms per call on the host thread of a solve; one hypothesis alone waits for every one of them).  Pure host
+// functions: the CPU test suite checks them against the Python forms they replace (lobpcg/modal_solver.py: `start`, `small`).
+
+// G = [Y X0]^T [K X0 | M X0], (ny + b) x 2 b row-major.  Status DS_OK with *route = 0: lam (b), coef ((ny + b) x b: X = [Y X0] coef),
+// cx (b x b: K X = (K X0) cx), *amp filled; *route = 1: the block is too ill-conditioned for one sweep (or its projected Gram matrix
+// broke down) - the caller takes the explicit route; nothing else is written.
+extern "C" int ds_host_start_block(const ds_lapack_t* lapack, const double* Gin, int ny, int b, double ortho_tol, double eps,
+                                   double* lam, double* coef, double* cx, double* amp_out, int* route) {
+    DS_REQUIRE(lapack && lapack->dsyevd && lapack->dgemm && Gin && lam && coef && cx && amp_out && route && ny >= 0 && b > 0,
+               "ds_host_start_block: bad arguments");
+    const ds_lapack_t& la = *lapack;
+    *route = 1;
+    Mat Gyk(ny, b), Cy(ny, b), A(b, b), B0(b, b);
+    const int ld = 2 * b;
+    for (int i = 0; i < ny; ++i)
+        for (int j = 0; j < b; ++j) Gyk(i, j) = Gin[(size_t)i * ld + j], Cy(i, j) = Gin[(size_t)i * ld + b + j];
+    for (int i = 0; i < b; ++i)
+        for (int j = 0; j < b; ++j) A(i, j) = Gin[(size_t)(ny + i) * ld + j], B0(i, j) = Gin[(size_t)(ny + i) * ld + b + j];
+    symmetrize(A), symmetrize(B0);
+    const Mat CtC = ny ? gemm(la, Cy, true, Cy, false) : Mat(b, b);
+    Mat Bp(b, b);
+    for (int i = 0; i < b; ++i)
+        for (int j = 0; j < b; ++j) Bp(i, j) = B0(i, j) - CtC(i, j);
+    for (int i = 0; i < b; ++i)
+        if (Bp(i, i) <= 1e-9 * std::fabs(B0(i, i))) return DS_OK;
+    if (!all_finite(Bp)) return DS_OK;
+    std::vector<double> rem(b);
+    for (int i = 0; i < b; ++i) rem[i] = CtC(i, i);
+    Mat T;
+    double amp = 0.0;
+    if (!orthonormalizer_q(la, Bp, &rem, T, amp)) {
+        ds::set_error("ds_host_start_block: dsyevd failed in the orthonormalisation");
+        return DS_ERR_ARG;
+    }
+    if (!(ortho_tol > 0.0 && eps * amp < ortho_tol)) return DS_OK;  // (one sweep would leave eps * amp: the explicit route repairs it)
+    Mat A1 = A;
+    if (ny) {
+        const Mat CtG = gemm(la, Cy, true, Gyk, false);
+        for (int i = 0; i < b; ++i)
+            for (int j = 0; j < b; ++j) A1(i, j) -= CtG(i, j) + CtG(j, i);
+    }
+    Mat H = gemm(la, gemm(la, T, true, A1, false), false, T, false);
+    symmetrize(H);
+    std::vector<double> E;
+    Mat Z;
+    if (!eigh(la, H, E, Z)) {
+        ds::set_error("ds_host_start_block: dsyevd failed in the first Ritz step");
+        return DS_ERR_ARG;
+    }
+    const Mat Cx = gemm(la, T, false, Z, false);
+    const Mat CyCx = ny ? gemm(la, Cy, false, Cx, false) : Mat(0, b);
+    for (int j = 0; j < b; ++j) lam[j] = E[j];
+    for (int i = 0; i < ny; ++i)
+        for (int j = 0; j < b; ++j) coef[(size_t)i * b + j] = -CyCx(i, j);
+    for (int i = 0; i < b; ++i)
+        for (int j = 0; j < b; ++j) coef[(size_t)(ny + i) * b + j] = cx[(size_t)i * b + j] = Cx(i, j);
+    *amp_out = amp;
+    *route = 0;
+    return DS_OK;
+}
+
+// fp64 polish of a converged block: GK = nterms (b x b) Gram matrices X^T K_i X (row-major, one after the other), coef their
+// weights, GM = X^T M X.  The generalised Ritz problem (sum c_i GK_i) z = e GM z through the Cholesky factor of GM: E (k lowest
+// values), C (b x b generalised eigenvectors, C^T GM C = I, columns ascending), qs ((nterms + 1) x k: the quadratic forms
+// c_j^T GK_i c_j and c_j^T GM c_j of the k wanted vectors).  DS_ERR_ARG with a message when GM is not positive definite.
+extern "C" int ds_host_polish(const ds_lapack_t* lapack, int nterms, const double* GK, const double* coefs, const double* GMin, int b, int k,
+                              double* Eout, double* Cout, double* qs) {
+    DS_REQUIRE(lapack && lapack->dsyevd && lapack->dgemm && GK && coefs && GMin && Eout && Cout && qs && nterms >= 1 && b > 0 && k > 0 && k <= b,
+               "ds_host_polish: bad arguments");
+    const ds_lapack_t& la = *lapack;
+    Mat GA(b, b), GB(b, b);
+    for (int t = 0; t < nterms; ++t)
+        for (size_t i = 0; i < GA.a.size(); ++i) GA.a[i] += coefs[t] * GK[(size_t)t * b * b + i];
+    for (size_t i = 0; i < GB.a.size(); ++i) GB.a[i] = GMin[i];
+    symmetrize(GA), symmetrize(GB);
+    Mat L;
+    if (!cholesky(GB, L)) {
+        ds::set_error("ds_host_polish: X^T M X of the converged block is not positive definite");
+        return DS_ERR_ARG;
+    }
+    const Mat Li = lower_inverse(L);
+    Mat H = gemm(la, gemm(la, Li, false, GA, false), false, Li, true);
+    symmetrize(H);
+    std::vector<double> E;
+    Mat Zt;
+    if (!eigh(la, H, E, Zt)) {
+        ds::set_error("ds_host_polish: dsyevd failed");
+        return DS_ERR_ARG;
+    }
+    const Mat C = gemm(la, Li, true, Zt, false);
+    for (int j = 0; j < k; ++j) Eout[j] = E[j];
+    for (size_t i = 0; i < C.a.size(); ++i) Cout[i] = C.a[i];
+    Mat Ck(b, k);
+    for (int i = 0; i < b; ++i)
+        for (int j = 0; j < k; ++j) Ck(i, j) = C(i, j);
+    for (int t = 0; t <= nterms; ++t) {
+        Mat Gt(b, b);
+        if (t < nterms) {
+            for (size_t i = 0; i < Gt.a.size(); ++i) Gt.a[i] = GK[(size_t)t * b * b + i];
+            symmetrize(Gt);
+        } else {
+            Gt = GB;
+        }
+        const Mat GC = gemm(la, Gt, false, Ck, false);
+        for (int j = 0; j < k; ++j) {
+            double sacc = 0.0;
+            for (int i = 0; i < b; ++i) sacc += Ck(i, j) * GC(i, j);
+            qs[(size_t)t * k + j] = sacc;
+        }
+    }
+    return DS_OK;
+}
+
 extern "C" int ds_host_wait_mode(int mode) {
     DS_REQUIRE(mode == 0 || mode == 1, "ds_host_wait_mode: 0 (the runtime's stream synchronisation) or 1 (poll, then sleep on a blocking event)");
     g_wait_mode.store(mode, std::memory_order_relaxed);

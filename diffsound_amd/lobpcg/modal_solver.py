@@ -418,8 +418,14 @@ class ChebyshevBlockJacobi:
             # lambda_max, 1.05 x under the safety factor.  The growth factor of a block that the new material has left behind
             # keeps rising from step to step; it is compared with itself.  (The host reads one number per step.)
             if warm and warm_spread > 0.0:
-                cur = float(lm)
-                if prev is not None and abs(cur - prev) < warm_spread * cur:
+                if i == 0:
+                    first = lm  # (not read yet: the first two estimates travel to the host together - one wait instead of two)
+                    continue
+                if i == 1:
+                    prev, cur = torch.stack((first, lm)).tolist()
+                else:
+                    cur = float(lm)
+                if abs(cur - prev) < warm_spread * cur:
                     lm = cur
                     break
                 prev = cur
@@ -829,7 +835,17 @@ class ModalSolver:
                 Cx = T @ Z_
                 return E_, torch.cat([-(Cy @ Cx), Cx], 0).contiguous(), Cx.contiguous(), amp
 
-            got = _small(start, dev, ops.gram(S[:, :ny + b], KS[:, :2 * b]))
+            Gs = ops.gram(S[:, :ny + b], KS[:, :2 * b])
+            if dev.type == "cuda" and cfg.native and dt == torch.float32:
+                # (the same algebra on the host thread in ONE native call with the solver loop's LAPACK table - ds_host_start_block -
+                # instead of ~30 torch calls on 80 x 80 CPU tensors: 0.65 -> 0.3 ms per start block, two per pass; round 6)
+                from .. import _hip
+
+                got = _hip.host_start_block(Gs.cpu(), ny, b, cfg.ortho_tol, eps_)
+                if got is not None:
+                    got = (got[0].to(dev), got[1].to(dev), got[2].to(dev), got[3])
+            else:
+                got = _small(start, dev, Gs)
             _stats(ops, "raw_start_stats")[0 if got is not None else 1] += 1  # (diagnostic counters: taken, handed to the explicit route)
             if got is not None:
                 lam, coef, Cx, amp = got
@@ -1375,7 +1391,19 @@ class ModalSolver:
             qs = torch.stack([quad(G) for G in GK_] + [quad(GB_)])
             return E_[:k].clone(), C_, Ck_, qs
 
-        E, C, Ck, qs = _small(small, ops.device, GM, *GK)
+        if ops.device.type == "cuda" and self.cfg.native and ops.dtype == torch.float32:
+            # (ds_host_polish: the same algebra in one native call on the host thread, 1.1 -> 0.5 ms per pass; round 6)
+            from .. import _hip
+
+            try:
+                E, C, qs = _hip.host_polish([G.cpu() for G in GK], coef, GM.cpu(), k)
+            except RuntimeError as ex:  # (X^T M X not positive definite: the error the torch form raises)
+                raise torch.linalg.LinAlgError(str(ex)) from ex
+            Ck = C[:, :k].contiguous()
+            dev_ = ops.device
+            E, C, Ck, qs = E.to(dev_), C.to(dev_), Ck.to(dev_), qs.to(dev_)
+        else:
+            E, C, Ck, qs = _small(small, ops.device, GM, *GK)
         U = torch.empty((ops.n, k), dtype=ops.dtype, device=ops.device)
         ops.mix(X, Ck, U)
         a = qs[0]

@@ -467,6 +467,18 @@ int ds_lobpcg_iterate(ds_lobpcg_t* p, const ds_lapack_t* lapack, ds_stream_t str
  * Cholesky factor and its inverse, errs[4] = orthogonality of the twice-applied Cholesky-QR on n x m columns, errs[5] = 1 when the
  * staged path ran.  errs: 6 doubles. */
 int ds_selftest_dense(const ds_lapack_t* lapack, int n, int m, unsigned seed, double* errs);
+/* ABI 31.  The two small dense steps that frame the iteration, on the HOST with the caller's LAPACK table (no device; reference: the
+ * first Rayleigh-Ritz step of _update_ortho, src/lobpcg/_lobpcg.py:443-448, and the read-out's quadratic forms, diff_model.py:371-399).
+ * ds_host_start_block: G = [Y X0]^T [K X0 | M X0] ((ny + b) x 2 b doubles, row-major) of a start block X0 -> its projection against the
+ *   M-orthonormal Y, its M-orthonormalisation and its first Ritz step in coefficients: lam (b), coef ((ny + b) x b: X = [Y X0] coef),
+ *   cx (b x b: K X = (K X0) cx), *amp (the rounding amplification of the one-sweep orthonormalisation); *route = 1 (nothing else written)
+ *   when eps x amp >= ortho_tol or the projected Gram matrix broke down: the caller orthonormalises explicitly.
+ * ds_host_polish: GK = nterms (b x b) matrices X^T K_i X one after the other, coefs their weights, GM = X^T M X -> E (k lowest values of
+ *   (sum c_i GK_i) z = e GM z), C (b x b, C^T GM C = I), qs ((nterms + 1) x k: c_j^T GK_i c_j, then c_j^T GM c_j). */
+int ds_host_start_block(const ds_lapack_t* lapack, const double* G, int ny, int b, double ortho_tol, double eps, double* lam,
+                        double* coef, double* cx, double* amp, int* route);
+int ds_host_polish(const ds_lapack_t* lapack, int nterms, const double* GK, const double* coefs, const double* GM, int b, int k,
+                   double* E, double* C, double* qs);
 /* How the host thread of ds_lobpcg_iterate waits for its stream when its descriptor says wait_mode = -1 (ABI 30; process-wide default 0).  0: hipStreamSynchronize (the
  * runtime spins when the host has more cores than devices); 1: a 20 us poll, then a sleep on an event created with
  * hipEventBlockingSync - for callers that run several solves on several streams and threads at once (the hypothesis lanes of

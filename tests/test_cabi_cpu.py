@@ -220,3 +220,74 @@ def test_lapack_table_has_a_source_without_scipy():
     assert _hip.lapack_table() is not None and _hip.lapack_source() in ("scipy", "torch")
     with pytest.raises(ValueError, match="unknown source"):
         _hip.lapack_table("netlib")
+
+
+def test_native_start_block_and_polish_match_the_python_forms():
+    """ds_host_start_block / ds_host_polish (ABI 31) against the torch forms they replace on the device path
+    (lobpcg/modal_solver.py: `start` in ModalSolver.solve, `small` in ModalSolver._polish): the same Ritz values, the same
+    coefficient matrices up to the sign of an eigenvector, the same quadratic forms - on a synthetic start block with a rigid
+    block in front, and the explicit-route signal for a block that one sweep cannot orthonormalise."""
+    import torch
+
+    from diffsound_amd.lobpcg.modal_solver import _orthonormalizer_q, _sym
+
+    _hip = _lib()
+    rng = np.random.default_rng(5)
+    n, ny, b, k = 400, 16, 24, 20
+    Bq = rng.standard_normal((n, n))
+    M = Bq @ Bq.T / n + np.eye(n)
+    Kq = rng.standard_normal((n, n))
+    K = Kq @ Kq.T + 5 * np.eye(n)
+    Y = np.linalg.qr(rng.standard_normal((n, 6)))[0]
+    Y = Y @ np.linalg.inv(np.linalg.cholesky(Y.T @ M @ Y)).T           # M-orthonormal rigid block, 6 vectors + 10 zero columns
+    Y = np.concatenate([Y, np.zeros((n, ny - 6))], 1)
+    K = K - K @ Y[:, :6] @ np.linalg.solve(Y[:, :6].T @ K @ Y[:, :6], Y[:, :6].T @ K)  # K Y = 0
+    K = 0.5 * (K + K.T)
+    X0 = rng.standard_normal((n, b))
+    S = np.concatenate([Y, X0], 1)
+    G = torch.from_numpy(np.concatenate([S.T @ K @ X0, S.T @ M @ X0], 1))
+    got = _hip.host_start_block(G, ny, b, 2e-6, 1.1e-16)
+    assert got is not None
+    lam, coef, cx, amp = got
+    # the Python form (as in ModalSolver.solve)
+    Gyk, Cy = G[:ny, :b], G[:ny, b:]
+    A, B0 = _sym(G[ny:, :b]), _sym(G[ny:, b:])
+    CtC = Cy.T @ Cy
+    T, amp_py = _orthonormalizer_q(torch.cat([B0 - CtC, CtC.diagonal()[None, :]], 0))
+    A1 = A - Cy.T @ Gyk - Gyk.T @ Cy
+    E_, Z_ = torch.linalg.eigh(_sym(T.T @ A1 @ T))
+    assert torch.allclose(lam, E_, rtol=1e-11) and abs(amp / amp_py - 1) < 1e-12
+    Cx_py = T @ Z_
+    sign = torch.sign((cx * Cx_py).sum(0))
+    assert torch.allclose(cx * sign[None, :], Cx_py, atol=1e-9 * float(Cx_py.abs().max()))
+    assert torch.allclose(coef[ny:], cx) and torch.allclose(coef[:ny], -(Cy @ cx), atol=1e-12)
+    Xn = S @ coef.numpy()                                                # the new block: M-orthonormal, M-orthogonal to Y, K-diagonal
+    assert np.abs(Xn.T @ M @ Xn - np.eye(b)).max() < 1e-9 and np.abs(Y.T @ M @ Xn).max() < 1e-9
+    assert np.abs(Xn.T @ K @ Xn - np.diag(lam.numpy())).max() < 1e-8 * float(lam.max())
+    # a block with two equal columns: the explicit route
+    Xd = X0.copy()
+    Xd[:, 1] = Xd[:, 0]
+    Gd = torch.from_numpy(np.concatenate([np.concatenate([Y, Xd], 1).T @ K @ Xd, np.concatenate([Y, Xd], 1).T @ M @ Xd], 1))
+    assert _hip.host_start_block(Gd, ny, b, 2e-6, 6e-8) is None
+    # polish: two terms of K, the mass Gram matrix
+    Xc = Xn[:, :b]
+    K1 = 0.3 * K + np.diag(rng.uniform(0, 1, n))
+    K2 = K - 0.5 * K1
+    GK = [torch.from_numpy(Xc.T @ K1 @ Xc), torch.from_numpy(Xc.T @ K2 @ Xc)]
+    GM = torch.from_numpy(Xc.T @ M @ Xc)
+    cf = [0.5, 1.0]
+    E, C, qs = _hip.host_polish(GK, cf, GM, k)
+    GA = _sym(cf[0] * GK[0] + cf[1] * GK[1])
+    L = torch.linalg.cholesky(_sym(GM))
+    Li = torch.linalg.solve_triangular(L, torch.eye(b, dtype=torch.float64), upper=False)
+    Ep, Zt = torch.linalg.eigh(_sym(Li @ GA @ Li.T))
+    assert torch.allclose(E, Ep[:k], rtol=1e-11)
+    Cp = Li.T @ Zt
+    sg = torch.sign((C * Cp).sum(0))
+    assert torch.allclose(C * sg[None, :], Cp, atol=1e-9 * float(Cp.abs().max()))
+    Ck = C[:, :k]
+    for t_, Gt in enumerate(GK + [GM]):
+        assert torch.allclose(qs[t_], ((Ck.T @ _sym(Gt)) * Ck.T).sum(1), rtol=1e-10)
+    assert torch.allclose(C.T @ _sym(GM) @ C, torch.eye(b, dtype=torch.float64), atol=1e-10)
+    with pytest.raises(RuntimeError, match="not positive definite"):
+        _hip.host_polish(GK, cf, GM - 10 * torch.eye(b, dtype=torch.float64), k)
