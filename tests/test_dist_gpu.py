@@ -7,6 +7,7 @@ import os
 import subprocess
 import sys
 
+import numpy as np
 import pytest
 import torch
 
@@ -56,6 +57,18 @@ def test_bench_line_contract(one_rank):
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and 0 < r["frac"] < 1
     assert 3000 < r["stream_triad"] < 8000 and r["in_situ"]["launches_timed"] > 0
     assert "traffic_note" in r and (r["traffic"] is None or r["traffic"] > 0)
+    # round 6: the in-pass figure is `frac`, the kernel's steady state alone `frac_alone`; one hypothesis at a time, the kernel time of
+    # a pass and the reference's training loop through the drop-in API ride in the line
+    assert abs(r["frac_alone"] - r["achieved_alone"] / r["peak"]) < 1e-12 and r["avg_launch_ms"] > 0 and r["avg_launch_ms_alone"] > 0
+    oh = d["one_hypothesis"]
+    assert d["one_hypothesis_passes_per_s"] == oh["passes_per_s"] > 0 and len(oh["ms_per_pass_each"]) == oh["passes_timed"] == 12
+    assert abs(oh["ms_per_pass"] * oh["passes_per_s"] - 1e3) < 1e-6 * 1e3
+    assert d["kernel_stats"] is None or "error" in d["kernel_stats"] or (d["kernel_ms_per_pass"] > 0 and d["launches_per_pass"] > 50)
+    api = d["api_path"]
+    for key in ("cycle_1", "cycle_1_cold_start", "cycle_15"):
+        assert api[key]["ms_per_epoch"] > 0 and api[key]["eigen_decompositions"] >= 1 and np.isfinite(api[key]["loss_first_last"]).all()
+    assert api["cycle_15"]["ms_per_epoch"] < api["cycle_1_cold_start"]["ms_per_epoch"] and api["cycle_15"]["eigen_decompositions"] == 2
+    assert "moves" in d["materials"] and d["ranks"][0]["cpu_affinity"]["bound"] in (True, False)
     # the amortised variant (eigendecomposition every 15 passes) beside the headline, and the per-rank view of the step
     am = d["amortised"]
     assert am["eigen_decompose_cycle"] == 15 and am["unit"] == "passes/s" and am["value"] > d["value"]
@@ -186,3 +199,15 @@ def test_configs3_rehearsal_64_hypotheses_on_the_benchmark_mesh(ndev):
     # the iteration counts are not bit-tied to the sharding: 403 against 405 in the first run)
     assert abs(sum(r["fine_iterations"] for r in ranks) / one["ranks"][0]["fine_iterations"] - 1) < 0.05
     assert abs(four["value"] - 64 / (four["ms_per_step"] * 1e-3)) < 1e-6 * four["value"]
+
+
+def test_geom_workload_line(ndev):
+    """`bench.py --workload geom` (the shape loop: a fresh DiffSoundObj on new vertices and a new topology per iteration, backward
+    to the vertices) on a small stand-in shell: one JSON line with iterations/s, the split of an iteration and flat HBM."""
+    d = _bench("--workload", "geom", "--cells", "8", "--modes", "8", "--geom-iters", "24", "--no-cpu-baseline")
+    assert d["unit"] == "iterations/s" and d["value"] > 0 and d["n_gpus"] == 1 and d["iterations"] == 24
+    assert abs(d["value"] * d["ms_per_iteration"] - 1e3) < 1e-6 * 1e3 and "ord-1" in d["config"]["workload"]
+    assert set(d["split_ms_with_a_sync_per_stage"]) == {"vertices", "symbolic + tables", "assembly + eigensolve",
+                                                        "get_vals + loss + backward + Adam"}
+    assert d["hbm"]["growth_mib_torch"] <= 1.0 and d["hbm"]["growth_mib_device"] <= 64.0
+    assert np.isfinite(d["loss_first_last"]).all() and d["thickness_after"] != 1.0
