@@ -122,13 +122,13 @@ def tuned_config(order, **over):
     V-cycle with Chebyshev(22, ratio 350) on the corner-node level, a nested start to 3e-3 whose random block takes two
     preconditioner sweeps before its first Ritz step; on ord-1 meshes the one-level polynomial Chebyshev(24, ratio 600) (round 6,
     the shape loop of bench.py --workload geom at 50k tets / 32 modes: 10 iterations and 13.0 ms per eigendecomposition against 19
-    and 17.6 with the library's plain default Chebyshev(8, 100)).  ``DiffSoundObj`` uses it when the caller gives no
+    and 17.6 with the library's plain default Chebyshev(8, 100); two start sweeps there as well: 8.3 iterations, 12.5 ms).  ``DiffSoundObj`` uses it when the caller gives no
     ``solver_config`` - a script written against the reference (build_model(...); model.eigen_decomposition()) then runs the
     configuration whose numbers DESIGN.md quotes; ``tol`` stays the library default (2e-6) unless overridden."""
     o2 = int(order) == 2
     cfg = SolverConfig(lmax_cap=float({1: 4, 2: 10}.get(int(order), 0)), coarse_degree=22, coarse_ratio=350.0,
                        nested_tol=3e-3 if o2 else 0.0, nested_maxit=8, nested_cheb_degree=22, nested_cheb_ratio=350.0,
-                       start_sweeps=2 if o2 else 0, cheb_degree=8 if o2 else 24, cheb_ratio=100.0 if o2 else 600.0)
+                       start_sweeps=2, cheb_degree=8 if o2 else 24, cheb_ratio=100.0 if o2 else 600.0)
     for k_, v_ in over.items():
         if not hasattr(cfg, k_):
             raise TypeError(f"tuned_config: SolverConfig has no field {k_!r}")
