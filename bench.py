@@ -813,6 +813,7 @@ def one_hypothesis_leg(pipe, hyps, dev, passes=8, steps_done=0):
     stream = lane.stream if lane is not None else torch.cuda.current_stream(dev)
     saved = getattr(holder.ops, "host_wait_mode", 0)
     set_wait_mode(holder.ops, 0)
+    keep_saved, pipe.keep_blocks = getattr(pipe, "keep_blocks", True), False  # (cold passes: nobody takes the rotated block, as in the timed region)
     its, cits, each = [], [], []
     try:
         with torch.cuda.stream(stream):
@@ -834,6 +835,7 @@ def one_hypothesis_leg(pipe, hyps, dev, passes=8, steps_done=0):
             dt = (time.time() - t0) / passes
     finally:
         set_wait_mode(holder.ops, saved)
+        pipe.keep_blocks = keep_saved
     return {"passes_per_s": 1.0 / dt, "ms_per_pass": 1e3 * dt, "ms_per_pass_median": float(np.median(each)), "ms_per_pass_each": [round(x, 2) for x in each],
             "passes_timed": passes, "mean_fine_iterations": float(np.mean(its)),
             "mean_corner_level_iterations": float(np.mean(cits)),
