@@ -772,7 +772,7 @@ class ModalSolver:
                 self.precond_apply(R, X)
             # (every sweep scales the block by ~1 / ||K||: 1e-10 on the benchmark's stiffness - three of them would leave the range
             # the preconditioner's bf16 blocks can hold; back to unit size after each)
-            X.mul_(1.0 / X.abs().max().clamp(min=1e-300))
+            X.mul_(1.0 / X.abs().max().clamp(min=1e-30))
         # operator norm estimates with a random block, as the reference does (_lobpcg.py:280-285)
         # (The probe block is the same every time - same seed, same number of columns drawn before it - and ||M G0|| depends on
         # the geometry only: operators that can name their geometry's generation keep the block, its norm and ||M G0|| / ||G0||
