@@ -773,6 +773,14 @@ class ModalSolver:
             # (every sweep scales the block by ~1 / ||K||: 1e-10 on the benchmark's stiffness - three of them would leave the range
             # the preconditioner's bf16 blocks can hold; back to unit size after each)
             X.mul_(1.0 / X.abs().max().clamp(min=1e-30))
+            # ... and the rigid modes leave after each: the preconditioner approximates K^-1, so the null vectors of K are amplified by
+            # p(0) - on a small mesh, whose lowest elastic modes lie INSIDE the polynomial's interval, ~30 x more per sweep than
+            # anything wanted; two sweeps later the block is rigid motion with the elastic content in its last fp32 digits, and the
+            # start block's projection in coefficients cannot recover it (six ~zero "eigenvalues" came back on a 4^3 ord-1 cube:
+            # tests/test_api_gpu.py::test_shape_loop_on_one_object_matches_fresh_objects).  X <- X - Y (Y^T M X), Y M-orthonormal.
+            if Y is not None:
+                ops.apply_M(X, MW)
+                ops.mix(Y, ops.gram(Y, MW), X, alpha=-1.0, beta=1.0)
         # operator norm estimates with a random block, as the reference does (_lobpcg.py:280-285)
         # (The probe block is the same every time - same seed, same number of columns drawn before it - and ||M G0|| depends on
         # the geometry only: operators that can name their geometry's generation keep the block, its norm and ||M G0|| / ||G0||
