@@ -103,8 +103,9 @@ class SolverConfig:
     refine_refresh: int = 8  # every this many fp64 steps all Gram blocks are recomputed from the vectors (else by recurrence)
     refine_sweeps: int = 2   # preconditioner sweeps per fp64 step (2: W = B R + B (R - K B R); C5: 21 -> 17 steps, 4.3 -> 3.8 s)
     # Round 6: Rayleigh-Ritz steps (host-bound for one hypothesis alone) traded for preconditioner sweeps (device work).
-    # ``start_sweeps`` applications of the preconditioner to a RANDOM start block before its first Ritz step (inverse-power
-    # steps: the block arrives dominated by the low end of the spectrum; with a nested start it is the corner-node level's block).
+    # ``start_sweeps`` applications of the preconditioner to the RANDOM start block of a nested start's corner-node phase before its
+    # first Ritz step (inverse-power steps: the block arrives dominated by the low end of the spectrum; solves without a nested
+    # start ignore it - nothing would project their swept block again).
     # ``precond_sweeps`` / ``nested_precond_sweeps`` - W = B R + B (R - K B R) per iteration on the fine / corner-node level: measured
     # and NOT adopted (one iteration less for twice the cycle: profiles/r06_start_sweeps.txt); Python loop only.
     start_sweeps: int = 0
@@ -122,13 +123,13 @@ def tuned_config(order, **over):
     V-cycle with Chebyshev(22, ratio 350) on the corner-node level, a nested start to 3e-3 whose random block takes two
     preconditioner sweeps before its first Ritz step; on ord-1 meshes the one-level polynomial Chebyshev(24, ratio 600) (round 6,
     the shape loop of bench.py --workload geom at 50k tets / 32 modes: 10 iterations and 13.0 ms per eigendecomposition against 19
-    and 17.6 with the library's plain default Chebyshev(8, 100); two start sweeps there as well: 8.3 iterations, 12.5 ms).  ``DiffSoundObj`` uses it when the caller gives no
+    and 17.6 with the library's plain default Chebyshev(8, 100); start sweeps apply to the corner-node phase of a nested start only: ModalSolver.solve).  ``DiffSoundObj`` uses it when the caller gives no
     ``solver_config`` - a script written against the reference (build_model(...); model.eigen_decomposition()) then runs the
     configuration whose numbers DESIGN.md quotes; ``tol`` stays the library default (2e-6) unless overridden."""
     o2 = int(order) == 2
     cfg = SolverConfig(lmax_cap=float({1: 4, 2: 10}.get(int(order), 0)), coarse_degree=22, coarse_ratio=350.0,
                        nested_tol=3e-3 if o2 else 0.0, nested_maxit=8, nested_cheb_degree=22, nested_cheb_ratio=350.0,
-                       start_sweeps=2, cheb_degree=8 if o2 else 24, cheb_ratio=100.0 if o2 else 600.0)
+                       start_sweeps=2 if o2 else 0, cheb_degree=8 if o2 else 24, cheb_ratio=100.0 if o2 else 600.0)
     for k_, v_ in over.items():
         if not hasattr(cfg, k_):
             raise TypeError(f"tuned_config: SolverConfig has no field {k_!r}")
@@ -764,7 +765,11 @@ class ModalSolver:
         # sweeps the block is dominated by the low end of the spectrum and the corner-node level of a nested start reaches its
         # tolerance in 3 iterations instead of 5 (profiles/r06_start_sweeps.txt) - two sweeps are 0.7 ms of device work, two
         # iterations 1 ms of device work plus 3.2 ms of Rayleigh-Ritz on the host thread.
-        for _ in range(cfg.start_sweeps if X0 is None else 0):
+        # ONLY in the corner-node phase of a nested start (``polish`` False): the fine level projects and orthonormalises that phase's
+        # result again.  A solve that nothing follows keeps its plain random start - on a small problem the swept block collapses onto
+        # a few low modes, what is left of its other columns is rounding noise with rigid-body remnants in it, and the start block's
+        # normalisation scales that up (two spurious low "eigenvalues" on a 4^3 ord-1 cube when this ran on one-level solves).
+        for _ in range(cfg.start_sweeps if (X0 is None and not polish) else 0):
             R.copy_(X)
             native_sweep = getattr(ops, "chebyshev_apply16", None)
             if not (native_sweep is not None and isinstance(self.precond, ChebyshevBlockJacobi) and cfg.precond_storage == "bf16"
