@@ -295,8 +295,8 @@ def test_start_sweeps_are_ignored_without_a_nested_start(cube):
     """SolverConfig.start_sweeps (round 6) belongs to the corner-node phase of a nested start (the GPU suite runs it through the
     benchmark's configuration: tests/test_parity_gpu.py, tests/test_modal_gpu.py).  A solve that nothing follows ignores the
     setting - its swept block would have nobody to project it again: the same iterates, bit for bit."""
-    plain = CpuModalOps(cube["Kl"], cube["Km"], cube["M3"], cube["v"], cube["lam"], cube["mu"], dtype=torch.float64)
-    a = ModalSolver(plain, SolverConfig(block=24, lmax_cap=10.0, tol=5e-8, start_sweeps=0)).solve(16)
-    b = ModalSolver(plain, SolverConfig(block=24, lmax_cap=10.0, tol=5e-8, start_sweeps=3)).solve(16)
+    mk = lambda: CpuModalOps(cube["Kl"], cube["Km"], cube["M3"], cube["v"], cube["lam"], cube["mu"], dtype=torch.float64)
+    a = ModalSolver(mk(), SolverConfig(block=24, lmax_cap=10.0, tol=5e-8, start_sweeps=0)).solve(16)
+    b = ModalSolver(mk(), SolverConfig(block=24, lmax_cap=10.0, tol=5e-8, start_sweeps=3)).solve(16)  # (fresh operators: no warm estimate)
     assert a.iterations == b.iterations and torch.equal(a.eigenvalues, b.eigenvalues)
     assert np.abs(a.eigenvalues.numpy() / cube["ref"] - 1).max() < 1e-7
