@@ -280,11 +280,19 @@ class TetSystem:
             self.vertices = v
             if changed:
                 self.geometry_generation = getattr(self, "geometry_generation", 0) + 1
+            elif getattr(self, "_assembled_generation", None) == getattr(self, "geometry_generation", 0):
+                # The same coordinates as the last assembly (DiffSoundObj.eigen_decomposition hands them over on every call of a
+                # material-fit loop): K_lambda, K_mu and M_s are functions of the geometry alone and are in place - nothing to do
+                # on either level (round 6; the headline's passes call assemble() WITHOUT coordinates and always assemble: the
+                # numeric assembly is part of the pass the metric defines).
+                self.assemblies_skipped = getattr(self, "assemblies_skipped", 0) + 1
+                return
         L = _hip.lib()
         p = _hip.ptr
         _hip.check(L.ds_assemble_kml(p(self.vertices), p(self.tets), self.T, self.N, self.nv, p(self.cptr),
                                      p(self.clist), self.nnzb, p(self.dtab), p(self.mtab), p(self._tetgeo),
                                      p(self.klam), p(self.kmu), p(self.ms), _hip.stream_ptr()), "ds_assemble_kml")
+        self._assembled_generation = getattr(self, "geometry_generation", 0)
         if getattr(self, "_coarse", None) is not None:
             # (the corner-node level always receives the coordinates it is to be assembled on when the caller handed any over:
             # its own change detection decides whether its generation moves)

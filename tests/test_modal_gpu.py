@@ -357,9 +357,17 @@ def test_in_place_vertex_update_without_reordering_is_seen(dev):
     e_fresh = ModalSolver(fresh, cfg).solve(16).eigenvalues
     assert float(((e_kept - e_fresh).abs() / e_fresh).max()) < 1e-5
     assert float(e_kept[0]) > 1e6
-    # the same coordinates again: no new generation (DiffSoundObj.eigen_decomposition hands them over on every call)
+    # the same coordinates again: no new generation (DiffSoundObj.eigen_decomposition hands them over on every call) - and no new
+    # assembly either (round 6: K_lambda, K_mu, M_s depend on the geometry alone and are in place)
+    skipped = getattr(sysd, "assemblies_skipped", 0)
+    kept = sysd.klam.clone()
+    sysd.klam.zero_()  # (would be rewritten by an assembly)
     sysd.assemble(verts)
-    assert getattr(sysd, "geometry_generation", 0) == gen0 + 1
+    assert getattr(sysd, "geometry_generation", 0) == gen0 + 1 and sysd.assemblies_skipped == skipped + 1
+    assert float(sysd.klam.abs().max()) == 0.0
+    sysd.klam.copy_(kept)
+    sysd.assemble()    # without coordinates (a pass of the pipeline): always assembles
+    assert torch.equal(sysd.klam, kept)
 
 
 def test_host_wait_mode_changes_nothing_but_the_waiting(dev):
