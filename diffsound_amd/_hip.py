@@ -13,7 +13,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DS_EXP_LIB") or os.path.join(_HERE, "csrc", "libdiffsound_hip.so")  # (DS_EXP_LIB: A/B builds, experiments)
-ABI_VERSION = 31  # DS_ABI_VERSION of include/diffsound_hip.h
+ABI_VERSION = 32  # DS_ABI_VERSION of include/diffsound_hip.h
 
 c_i32p = ctypes.POINTER(ctypes.c_int32)
 _P = ctypes.c_void_p
@@ -129,7 +129,7 @@ class LobpcgDesc(ctypes.Structure):
                 ("pa", _P), ("pb", _P), ("ldp", _I64), ("pr16", _P), ("gbuf", _P), ("cbuf", _P), ("nrm", _P), ("lam_dev", _P),
                 ("res_work", _P), ("res_work_bytes", _I64), ("gram_work", _P), ("gram_work_bytes", _I64), ("lam", ctypes.POINTER(_D)), ("rerr", ctypes.POINTER(_D)),
                 ("history", ctypes.POINTER(_D)), ("history_cap", _i32), ("iterations", _i32), ("result_in_s2", _i32),
-                ("wait_mode", _i32)]
+                ("wait_mode", _i32), ("ritz_tol", ctypes.c_double)]
 
 
 _lapack = None

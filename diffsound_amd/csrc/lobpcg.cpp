@@ -750,6 +750,8 @@ extern "C" int ds_lobpcg_iterate(ds_lobpcg_t* p, const ds_lapack_t* lapack, ds_s
     g_tm = Tm();
     const double t_begin = now_s();
     std::vector<double> lam(p->lam, p->lam + b), rel(b, std::numeric_limits<double>::infinity());
+    // Ritz values of the step before (p->ritz_tol > 0: a pair also has to have SETTLED to count as converged - see the header)
+    std::vector<double> lam_prev(b, std::numeric_limits<double>::infinity());
     Mat Gxp(b, b);
     for (int i = 0; i < b; ++i) Gxp(i, i) = lam[i];
     int ncl = 0, npc = 0, k0 = 0, since_refresh = 0, it = 0;
@@ -792,7 +794,10 @@ extern "C" int ds_lobpcg_iterate(ds_lobpcg_t* p, const ds_lapack_t* lapack, ds_s
         for (int j = 0; j < na; ++j)
             rel[ncl + j] = std::sqrt(nrm[j] / nrm[1024 + j]) / (p->A_norm + std::fabs(lam[ncl + j]) * p->B_norm);
         int nconv = 0;
-        while (nconv < k && rel[nconv] < p->tol) ++nconv;  // leading converged pairs only (reference _lobpcg.py:321-328)
+        // leading converged pairs only (reference _lobpcg.py:321-328)
+        while (nconv < k && rel[nconv] < p->tol &&
+               (p->ritz_tol <= 0.0 || std::fabs(lam[nconv] - lam_prev[nconv]) <= p->ritz_tol * std::fabs(lam[nconv])))
+            ++nconv;
         worst = 0.0;
         for (int j = 0; j < k; ++j) worst = std::max(worst, rel[j]);
         if (p->history && it < p->history_cap) p->history[it] = worst;
@@ -942,7 +947,7 @@ extern "C" int ds_lobpcg_iterate(ds_lobpcg_t* p, const ds_lapack_t* lapack, ds_s
                 ZZ(i, j) = Z1(i, j);
                 ZZ(i, na + j) = Zp(i, j);
             }
-        for (int j = 0; j < na; ++j) lam[ncl + j] = E[j];
+        for (int j = 0; j < na; ++j) { lam_prev[ncl + j] = lam[ncl + j]; lam[ncl + j] = E[j]; }
         if (Qraw.r != 0) {  // the new basis straight from the raw one: [X' P'] = [Y X P W] (Q [Z1 Zp]), Q = [E | Qw]
             Mat Zbot(na, 2 * na);
             for (int i = 0; i < na; ++i)

@@ -109,6 +109,17 @@ class SolverConfig:
     # ``precond_sweeps`` / ``nested_precond_sweeps`` - W = B R + B (R - K B R) per iteration on the fine / corner-node level: measured
     # and NOT adopted (one iteration less for twice the cycle: profiles/r06_start_sweeps.txt); Python loop only.
     start_sweeps: int = 0
+    # ``ritz_tol`` > 0: a pair counts as converged (and is locked) only when, besides its backward error < tol, its Ritz value moved by
+    # less than this (relative) in the last step; ``nested_ritz_tol`` is the corner-node phase's.  The backward error is relative to
+    # ||K|| + lambda ||M||, ~1e3 x the wanted eigenvalues: a SMOOTH vector passes the corner phase's loose 3e-3 whatever its Rayleigh
+    # quotient is.  A random start block never met that case (its error is high-frequency until the wanted pairs have settled); a swept
+    # one did - with 32 modes in a block of 40 the first 16 columns were locked at the first test with Ritz values 2 x off (1.1e10
+    # for 5.6e9), the corner phase ran to its iteration cap and the fine level took 10 iterations instead of 5
+    # (profiles/r06_start_sweeps.txt).  With the settled test the sweeps help at every block width measured there.
+    ritz_tol: float = 0.0
+    nested_ritz_tol: float = 0.05
+    start_sweeps_fp32: bool = False  # (experiment: the sweeps through the fp32 preconditioner kernels instead of the bf16 driver)
+    start_sweeps_qr: bool = False    # (experiment: M-orthonormalise the block after every sweep)
     precond_sweeps: int = 1
     nested_precond_sweeps: int = 1
     nested_tol: float = 0.0
@@ -687,6 +698,8 @@ class ModalSolver:
                             lmax_cap=min(cfg.lmax_cap, 4.0) if cfg.lmax_cap > 0 else 0.0, precond="chebyshev",
                             raw_rr=cfg.raw_rr, raw_start=cfg.raw_start, warm_power_iters=cfg.warm_power_iters,
                             warm_power_spread=cfg.warm_power_spread, start_sweeps=cfg.start_sweeps,
+                            start_sweeps_fp32=cfg.start_sweeps_fp32, start_sweeps_qr=cfg.start_sweeps_qr,
+                            ritz_tol=cfg.nested_ritz_tol,
                             precond_sweeps=getattr(cfg, "nested_precond_sweeps", 1), native=cfg.native)
         pre = self.precond.coarse if isinstance(self.precond, TwoLevelChebyshev) else None
         if pre is not None and (pre.degree != ccfg.cheb_degree
@@ -773,7 +786,7 @@ class ModalSolver:
             R.copy_(X)
             native_sweep = getattr(ops, "chebyshev_apply16", None)
             if not (native_sweep is not None and isinstance(self.precond, ChebyshevBlockJacobi) and cfg.precond_storage == "bf16"
-                    and dt == torch.float32 and native_sweep(self.precond, R, X)):
+                    and dt == torch.float32 and not getattr(cfg, "start_sweeps_fp32", False) and native_sweep(self.precond, R, X)):
                 self.precond_apply(R, X)
             # (every sweep scales the block by ~1 / ||K||: 1e-10 on the benchmark's stiffness - three of them would leave the range
             # the preconditioner's bf16 blocks can hold; back to unit size after each)
@@ -786,6 +799,8 @@ class ModalSolver:
             if Y is not None:
                 ops.apply_M(X, MW)
                 ops.mix(Y, ops.gram(Y, MW), X, alpha=-1.0, beta=1.0)
+            if getattr(cfg, "start_sweeps_qr", False):  # (experiment: M-orthonormalise between the sweeps - a true block inverse iteration)
+                self._orthonormalize(X, S[:, :ny] if ny else None, MW, VW=S[:, :ny + b] if ny else None)
         # operator norm estimates with a random block, as the reference does (_lobpcg.py:280-285)
         # (The probe block is the same every time - same seed, same number of columns drawn before it - and ||M G0|| depends on
         # the geometry only: operators that can name their geometry's generation keep the block, its norm and ||M G0|| / ||G0||
@@ -892,6 +907,7 @@ class ModalSolver:
         since_refresh = 0
         best_worst = float("inf")
         rel = torch.full((b,), float("inf"), dtype=torch.float64, device=dev)
+        lam_prev = None  # Ritz values of the step before (cfg.ritz_tol)
         # The iteration as ONE native call (ds_lobpcg_iterate) when the ops offer it and nothing needs the interpreter
         # between iterations (no tracker callback, the built-in preconditioners): same kernels, same dense steps, but
         # a hypothesis lane then runs its whole solve without the interpreter lock.
@@ -923,7 +939,10 @@ class ModalSolver:
                 rn2, xn2 = ops.residual(R[:, :na], MX[:, :na], Xa, lam[ncl:], src=KS[:, k0:k0 + na])
             rel[ncl:] = torch.sqrt(rn2 / xn2) / (A_norm + lam[ncl:].abs() * B_norm)
             relk = rel[:k]
-            conv = (relk < tol).to(torch.int32)
+            conv = relk < tol
+            if cfg.ritz_tol > 0.0:  # ... and settled: |theta - theta_before| <= ritz_tol |theta|  (never at the start block's own Ritz values)
+                conv = (conv & ((lam[:k] - lam_prev[:k]).abs() <= cfg.ritz_tol * lam[:k].abs())) if lam_prev is not None else torch.zeros_like(conv)
+            conv = conv.to(torch.int32)
             # leading converged pairs only, to keep strict ordering (reference _lobpcg.py:321-328)
             nconv = int(torch.cumprod(conv, 0).sum())
             history.append((it, float(relk.max())))
@@ -1016,6 +1035,8 @@ class ModalSolver:
                 Ea, ZZ, Gxp = ritz(GA)
                 if rawQ is not None:
                     ZZ = (rawQ[1] @ ZZ).contiguous()
+            if cfg.ritz_tol > 0.0:
+                lam_prev = lam.clone()
             lam[ncl:] = Ea
             if ncl:
                 S2[:, ny:ny + ncl].copy_(S[:, ny:ny + ncl])

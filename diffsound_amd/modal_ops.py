@@ -590,6 +590,7 @@ class _HipBlockOps:
         rerr_h = (ctypes.c_double * b)()
         hist_h = (ctypes.c_double * (cfg.maxit + 1))()
         d.lam, d.rerr, d.history, d.history_cap = lam_h, rerr_h, hist_h, cfg.maxit + 1
+        d.ritz_tol = float(getattr(cfg, "ritz_tol", 0.0))
         d.wait_mode = int(getattr(self, "host_wait_mode", -1))  # (this operator object's - i.e. this lane's - own setting; -1: the process default)
         with _hip.blas_one_thread():
             _hip.check(self._L.ds_lobpcg_iterate(ctypes.byref(d), ctypes.byref(_hip.lapack_table()), _hip.stream_ptr()),

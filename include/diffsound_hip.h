@@ -40,7 +40,7 @@ enum { DS_OK = 0, DS_ERR_ARG = 1, DS_ERR_HIP = 2, DS_ERR_NOMEM = 3 };
 /* Thread-local text of the last error returned on this thread ("" if none). */
 const char* ds_last_error(void);
 /* Library ABI version (bumped on any signature change); ds_abi_version() returns the value the library was built with. */
-#define DS_ABI_VERSION 31
+#define DS_ABI_VERSION 32
 int ds_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------------
@@ -459,6 +459,11 @@ typedef struct {
                                  then a sleep on a blocking event, -1: the process default (ds_host_wait_mode).  Per solve, so that
                                  the hypothesis lanes of one pipeline, another pipeline of the process and a single solve beside
                                  them each keep their own setting */
+    double ritz_tol;          /* ABI 32: > 0: a pair counts as converged (and is locked) only when, besides rel < tol, its Ritz value
+                                 moved by less than ritz_tol (relative) in the last step.  The backward error rel is relative to
+                                 ||K|| + lambda ||M||: a SMOOTH vector passes a loose tol (the corner-level phase of a nested start:
+                                 3e-3) whatever its Rayleigh quotient is - a start block that went through the preconditioner was
+                                 locked with Ritz values 2 x off (profiles/r06_start_sweeps.txt).  0: the reference's test alone */
 } ds_lobpcg_t;
 int ds_lobpcg_iterate(ds_lobpcg_t* p, const ds_lapack_t* lapack, ds_stream_t stream);
 /* ABI 31.  Self-check of the loop's host-side dense steps with the given LAPACK table - no device involved (the CPU test suite

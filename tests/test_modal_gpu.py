@@ -414,6 +414,37 @@ def test_start_block_in_coefficients_changes_nothing_but_rounding(dev, mesh, ord
     assert ref is None or float(((a.eigenvalues.cpu() - ref).abs() / ref).max()) < EIG_TOL
 
 
+def test_swept_start_block_is_not_locked_before_its_ritz_values_have_settled(dev):
+    """SolverConfig.nested_ritz_tol (round 6).  The corner-node phase of a nested start stops on a backward error of 3e-3 relative to
+    ||K|| + lambda ||M|| - a test a SMOOTH block passes whatever its Rayleigh quotients are.  A start block that went through the
+    preconditioner is smooth: with 32 modes in a block of 40 its first 16 columns were locked at the first test with Ritz values
+    2 x off, the phase ran to its iteration cap and the fine level took twice the iterations of a plain random start
+    (profiles/r06_start_sweeps.txt).  With the settled test the swept start costs no more fine-level iterations than the plain one
+    (one of slack), its corner phase ends before the cap, and the native loop and the Python loop agree on both counts."""
+    from diffsound_amd import meshgen
+    from diffsound_amd.diffelastic.mesh import TetMesh
+    import bench
+
+    v, t = meshgen.kuhn_box(26)
+    tm = TetMesh(torch.from_numpy(v).to(dev), torch.from_numpy(t).long().to(dev)).to_high_order(2)
+    run = {}
+    for name, over in (("plain", dict(start_sweeps=0)), ("swept", dict(start_sweeps=2)), ("swept, python loop", dict(start_sweeps=2, native=False)),
+                       ("swept, backward error alone", dict(start_sweeps=2, nested_ritz_tol=0.0))):
+        cfg = bench.solver_config(block=40)
+        for k_, v_ in over.items():
+            setattr(cfg, k_, v_)
+        assert cfg.nested_ritz_tol == (0.0 if "alone" in name else 0.05)
+        _, _, run[name] = _solve(tm.vertices, tm.tets, 2, 32, dev, **cfg.__dict__)
+        print(name, "corner", run[name].coarse_iterations, "fine", run[name].iterations)
+    plain, swept, py = run["plain"], run["swept"], run["swept, python loop"]
+    assert float(swept.rerr.max()) < 1e-5 and float(plain.rerr.max()) < 1e-5
+    assert swept.coarse_iterations < 8 and swept.iterations <= plain.iterations + 1
+    assert abs(py.coarse_iterations - swept.coarse_iterations) <= 1 and abs(py.iterations - swept.iterations) <= 1
+    assert float(((swept.eigenvalues - plain.eigenvalues).abs() / plain.eigenvalues).max()) < 1e-5
+    # (what the settled test repairs - not asserted as a failure, it is a property of this mesh: the old test's counts are printed)
+    assert run["swept, backward error alone"].iterations >= swept.iterations
+
+
 def test_native_solve_on_the_lapack_inside_libtorch(dev):
     """The native iteration with the MKL entry points of libtorch_cpu.so (dsyevd / dgemm, no stages) instead of SciPy's capsules -
     the fallback that keeps the product independent of SciPy's private table: the same eigenvalues to the solve's accuracy, the

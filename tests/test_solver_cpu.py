@@ -291,6 +291,21 @@ def test_basic_method_on_the_cpu(cube, dtype, tol_eig):
         ModalSolver(ops, SolverConfig(block=ops.n // 2)).solve_basic(8)
 
 
+def test_settled_ritz_values_are_part_of_the_convergence_test_when_asked(cube):
+    """SolverConfig.ritz_tol: a pair counts as converged only when its Ritz value has also stopped moving.  On a cold start it changes
+    nothing that matters (the same eigenvalues, at most one iteration more); a converged block handed back as the start - which the
+    backward error alone accepts at its first test, iteration 0 - has to take one step to show that its values stand still."""
+    mk = lambda: CpuModalOps(cube["Kl"], cube["Km"], cube["M3"], cube["v"], cube["lam"], cube["mu"], dtype=torch.float64)
+    a = ModalSolver(mk(), SolverConfig(block=24, lmax_cap=10.0, tol=5e-8)).solve(16)
+    b = ModalSolver(mk(), SolverConfig(block=24, lmax_cap=10.0, tol=5e-8, ritz_tol=1e-3)).solve(16)
+    assert a.iterations <= b.iterations <= a.iterations + 1
+    assert np.abs(b.eigenvalues.numpy() / cube["ref"] - 1).max() < 1e-7
+    w0 = ModalSolver(mk(), SolverConfig(block=24, lmax_cap=10.0, tol=5e-8)).solve(16, X0=a.block_vectors)
+    w1 = ModalSolver(mk(), SolverConfig(block=24, lmax_cap=10.0, tol=5e-8, ritz_tol=1e-3)).solve(16, X0=a.block_vectors)
+    assert w0.iterations == 0 and w1.iterations == 1
+    assert np.abs(w1.eigenvalues.numpy() / cube["ref"] - 1).max() < 1e-7
+
+
 def test_start_sweeps_are_ignored_without_a_nested_start(cube):
     """SolverConfig.start_sweeps (round 6) belongs to the corner-node phase of a nested start (the GPU suite runs it through the
     benchmark's configuration: tests/test_parity_gpu.py, tests/test_modal_gpu.py).  A solve that nothing follows ignores the
