@@ -119,7 +119,7 @@ def parse():
     ap.add_argument("--start-sweeps", type=int, default=2,
                     help="applications of the preconditioner to the random start block before its first Ritz step "
                          "(SolverConfig.start_sweeps; 0 = rounds 1-5)")
-    ap.add_argument("--nested-ritz-tol", type=float, default=0.05,
+    ap.add_argument("--nested-ritz-tol", type=float, default=0.2,
                     help="a pair of the corner-node phase counts as converged only when its Ritz value also moved by less than this "
                          "(relative) in the last step (SolverConfig.nested_ritz_tol; 0 = the backward error alone)")
     ap.add_argument("--warm-start", action="store_true", help="amortised variant: reuse the previous block")
@@ -212,7 +212,7 @@ def solver_config(a=None, **over):
     if getattr(a, "ortho_passes", -1) > 0:
         cfg.ortho_passes = a.ortho_passes
     cfg.start_sweeps = getattr(a, "start_sweeps", 0)
-    cfg.nested_ritz_tol = getattr(a, "nested_ritz_tol", 0.05)
+    cfg.nested_ritz_tol = getattr(a, "nested_ritz_tol", 0.2)
     cfg.nested_tol, cfg.nested_maxit = a.nested_tol, a.nested_maxit
     cfg.nested_cheb_degree, cfg.nested_cheb_ratio = a.coarse_degree, a.coarse_ratio
     return cfg

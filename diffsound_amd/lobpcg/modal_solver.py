@@ -115,9 +115,11 @@ class SolverConfig:
     # quotient is.  A random start block never met that case (its error is high-frequency until the wanted pairs have settled); a swept
     # one did - with 32 modes in a block of 40 the first 16 columns were locked at the first test with Ritz values 2 x off (1.1e10
     # for 5.6e9), the corner phase ran to its iteration cap and the fine level took 10 iterations instead of 5
-    # (profiles/r06_start_sweeps.txt).  With the settled test the sweeps help at every block width measured there.
+    # (profiles/r06_start_sweeps.txt).  With the settled test the sweeps help at every block width measured there; any value forbids a
+    # lock at the FIRST test, which is what went wrong - 0.05 .. 0.4 measure alike, 0.2 keeps the benchmark's block of 80 at the
+    # time it had without the test (0.05 locks one step later there: +1 ms on one hypothesis).
     ritz_tol: float = 0.0
-    nested_ritz_tol: float = 0.05
+    nested_ritz_tol: float = 0.2
     start_sweeps_fp32: bool = False  # (experiment: the sweeps through the fp32 preconditioner kernels instead of the bf16 driver)
     start_sweeps_qr: bool = False    # (experiment: M-orthonormalise the block after every sweep)
     precond_sweeps: int = 1

@@ -433,7 +433,7 @@ def test_swept_start_block_is_not_locked_before_its_ritz_values_have_settled(dev
         cfg = bench.solver_config(block=40)
         for k_, v_ in over.items():
             setattr(cfg, k_, v_)
-        assert cfg.nested_ritz_tol == (0.0 if "alone" in name else 0.05)
+        assert cfg.nested_ritz_tol == (0.0 if "alone" in name else 0.2)
         _, _, run[name] = _solve(tm.vertices, tm.tets, 2, 32, dev, **cfg.__dict__)
         print(name, "corner", run[name].coarse_iterations, "fine", run[name].iterations)
     plain, swept, py = run["plain"], run["swept"], run["swept, python loop"]
