@@ -562,6 +562,30 @@ class TwoLevelChebyshev:
                 self._buf = (mk(R.shape[0]), mk(nc), mk(nc), mk(R.shape[0]))
             Rr, Rc, Ec, Wc = self._buf
             native = getattr(ops, "twolevel_apply", None)
+            form = getattr(self, "cycle_form", "symmetric")
+            if form != "symmetric":  # (experiment, Python path only: tools/experiments/cycle_forms.py)
+                if form == "post":        # W = C' R, then post-smoothing from that guess
+                    ops.restrict(Rs, Rc)
+                    self.coarse.apply(Rc, Ec)
+                    Ws.zero_()
+                    ops.prolong_add(Ec, Ws)
+                    self.smooth.apply(Rs, Ws, from_guess=True)
+                elif form == "pre":       # pre-smoothing, then the corner-level correction of its residual
+                    Rr.copy_(Rs)
+                    self.smooth.apply(Rr, Ws)
+                    ops.spmm_residual(Ws, Rs, Rr)
+                    ops.restrict(Rr, Rc)
+                    self.coarse.apply(Rc, Ec)
+                    ops.prolong_add(Ec, Ws)
+                elif form == "additive":  # W = S R + P C P^T R
+                    ops.restrict(Rs, Rc)
+                    self.coarse.apply(Rc, Ec)
+                    Rr.copy_(Rs)
+                    self.smooth.apply(Rr, Ws)
+                    ops.prolong_add(Ec, Ws)
+                else:
+                    raise ValueError(form)
+                continue
             if native is not None and self.use_native and self.storage == "bf16" and R.is_cuda:
                 if self._buf16 is None or self._buf16[0].shape[2] != w:
                     mk = lambda cnt, rows: torch.empty((cnt, rows, w), dtype=torch.bfloat16, device=R.device)
