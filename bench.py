@@ -136,6 +136,12 @@ def parse():
     ap.add_argument("--mfma-groups", default="8,8",
                     help="nodes per wavefront of the MFMA form of the preconditioner's bf16 terms on the fine and on the "
                          "corner-node level (8, or 0 = the VALU kernel on that level)")
+    ap.add_argument("--group-jacobi", type=int, default=8, choices=[0, 8],
+                    help="the corner-node level's polynomial on the group-block Jacobi (inverse of the 24 x 24 diagonal block of every "
+                         "8-node group of the matrix-core tables; degree / ratio: --group-degree / --group-ratio) or, 0, on the "
+                         "3 x 3 node blocks (--coarse-degree / --coarse-ratio; rounds 2-5)")
+    ap.add_argument("--group-degree", type=int, default=14)
+    ap.add_argument("--group-ratio", type=float, default=150.0)
     ap.add_argument("--loss", default="mse", choices=["mse", "mss"],
                     help="scalar loss head: mse = the headline metric's; mss = the reference experiments' multi-scale "
                          "spectral loss (MSSLoss [1024..64], 'l1_loss', material_sync_train.py:124) on the STFT kernels")
@@ -213,6 +219,7 @@ def solver_config(a=None, **over):
         cfg.ortho_passes = a.ortho_passes
     cfg.start_sweeps = getattr(a, "start_sweeps", 0)
     cfg.nested_ritz_tol = getattr(a, "nested_ritz_tol", 0.2)
+    cfg.group_degree, cfg.group_ratio = getattr(a, "group_degree", 14), getattr(a, "group_ratio", 150.0)
     cfg.nested_tol, cfg.nested_maxit = a.nested_tol, a.nested_maxit
     cfg.nested_cheb_degree, cfg.nested_cheb_ratio = a.coarse_degree, a.coarse_ratio
     return cfg
@@ -415,7 +422,7 @@ def main_c5(a):
     mesh = TetMesh(torch.from_numpy(v).to(dev), torch.from_numpy(t).long().to(dev)).to_high_order(2)
     sysd = TetSystem(mesh.vertices, mesh.tets, 2, MAT[0])
     lam, mu = (float(x) for x in _lame(MAT[1], MAT[2]))
-    ops = HipModalOps(sysd, lam, mu)
+    ops = HipModalOps(sysd, lam, mu, coarse_group_jacobi=a.group_jacobi)
     torch.cuda.synchronize()
     t_setup = time.time() - t0
     n, nv, nnzb = sysd.n, sysd.nv, sysd.nnzb
@@ -494,7 +501,7 @@ def main_c5(a):
     t0 = time.time()
     nest = dict(nested_tol=a.nested_tol, nested_maxit=a.nested_maxit, nested_cheb_degree=a.coarse_degree,
                 nested_cheb_ratio=a.coarse_ratio, nested_ritz_tol=a.nested_ritz_tol,
-                start_sweeps=a.start_sweeps)  # the nested start of the headline benchmark
+                start_sweeps=a.start_sweeps, group_degree=a.group_degree, group_ratio=a.group_ratio)  # the nested start of the headline benchmark
     # every solve is run twice and the second is reported: the first one allocates its multi-GB blocks (hipMalloc of
     # 7 GB pieces costs hundreds of ms and varies from run to run); a user's second eigendecomposition pays none of it
     for rep in range(2):
@@ -1034,7 +1041,8 @@ def main():
 
         loss_fn = MSSLoss([1024, 512, 256, 128, 64], 32000, type="l1_loss")
     pipe = ModalPipeline(mesh.vertices, mesh.tets, a.order, a.modes, MAT, solver_config=cfg, loss_fn=loss_fn,
-                         mfma_groups=tuple(int(x) for x in a.mfma_groups.split(",")), host_wait=a.host_wait)
+                         mfma_groups=tuple(int(x) for x in a.mfma_groups.split(",")), host_wait=a.host_wait,
+                         coarse_group_jacobi=a.group_jacobi)
     torch.cuda.synchronize()
     t_sym = time.time() - t_sym
     nhyp = a.hyp_per_gpu * world

@@ -13,7 +13,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DS_EXP_LIB") or os.path.join(_HERE, "csrc", "libdiffsound_hip.so")  # (DS_EXP_LIB: A/B builds, experiments)
-ABI_VERSION = 32  # DS_ABI_VERSION of include/diffsound_hip.h
+ABI_VERSION = 33  # DS_ABI_VERSION of include/diffsound_hip.h
 
 c_i32p = ctypes.POINTER(ctypes.c_int32)
 _P = ctypes.c_void_p
@@ -100,7 +100,8 @@ class LevelDesc(ctypes.Structure):
                 ("mf_max_batch_blocks", ctypes.c_int32), ("level_tag", ctypes.c_int32),
                 ("mf_gptr", _P), ("mf_gcol", _P), ("mf_gmeta", _P), ("mf_gbase", _P), ("mf_ghead", _P), ("mf_kc", _P),
                 ("m32_max_entries", ctypes.c_int32), ("m32_max_batch_blocks", ctypes.c_int32),
-                ("m32_gptr", _P), ("m32_gcol", _P), ("m32_gmeta", _P), ("m32_gbase", _P), ("m32_k", _P), ("m32_m", _P)]
+                ("m32_gptr", _P), ("m32_gcol", _P), ("m32_gmeta", _P), ("m32_gbase", _P), ("m32_k", _P), ("m32_m", _P),
+                ("tgrp", _P), ("mf_nblocks", _I64)]
 
 
 class TwoLevelDesc(ctypes.Structure):
@@ -245,6 +246,9 @@ _SIGNATURES["ds_chebyshev_apply"] = (_I, [ctypes.POINTER(LevelDesc), _P, _I64, _
 _SIGNATURES["ds_chebyshev_apply16"] = (_I, [ctypes.POINTER(LevelDesc), _P, _I64, _P, _I64, _P, _P, _P, _I64, _I, _P])
 _SIGNATURES["ds_spmm_union16"] = (_I, [_I, _P, _P, _I64, _I, _P, _P, _I64, _I64, _P, _I64, _P, _I64, _I, _P, _I64, _P, _I, _F,
                                       _F, _I, _P, _I64, _P])
+_SIGNATURES["ds_group_inverse"] = (_I, [_P, _P, _P, _I64, _I, _P, _P])
+_SIGNATURES["ds_group_pack_kc"] = (_I, [_P, _P, _P, _P, _P, _P, _I, _I64, _P, _P])
+_SIGNATURES["ds_group_apply16"] = (_I, [_P, _I, _P, _I, _I64, _P, _I, _I64, _I64, _I, _P])
 _SIGNATURES["ds_cheb_init16"] = (_I, [_P, _I, _I64, _P, _I64, _P, _I64, _P, _I64, _I, _F, _P])
 _SIGNATURES["ds_scalar_csr_spmm16"] = (_I, [_P, _P, _P, _I64, _P, _I64, _P, _I64, _I, _F, _P])
 _SIGNATURES["ds_lobpcg_iterate"] = (_I, [ctypes.POINTER(LobpcgDesc), ctypes.POINTER(LapackTable), _P])

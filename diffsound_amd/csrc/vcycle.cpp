@@ -26,6 +26,10 @@ int chebyshev(const ds_level_t& L, const float* R, int64_t ldr, float* Wout, int
     double rho = 1.0 / sigma1;
     const int terms = from_guess ? L.degree : L.degree - 1;
     float *cur = A, *oth = B;
+    if (L.tgrp) {
+        ds::set_error("chebyshev: the group-block Jacobi lives on the bf16 cycle's matrix-core tables only");
+        return DS_ERR_ARG;
+    }
     if (!from_guess) {  // W_1 = T R / theta (straight into Wout when no term follows)
         int rc = ds_cheb_init(R, ldr, B, lds, terms == 0 ? Wout : cur, terms == 0 ? ldw : lds, L.dinv, L.nv, ncols,
                               (float)(1.0 / theta), stream);
@@ -57,7 +61,8 @@ int union16(const ds_level_t& L, int epilogue, const void* X, int64_t ldx, void*
             int64_t ldr, const float* dinv, int ncols, float c1, float c2, int first, const void* Wprev, int64_t ldp,
             ds_stream_t stream) {
     if (L.mf_group_nodes)
-        return ds_spmm_union16m(epilogue, L.mf_group_nodes, L.level_tag, L.mf_gptr, L.mf_gcol, L.mf_gmeta, L.mf_gbase, L.mf_ghead, L.mf_kc, L.nnzb,
+        return ds_spmm_union16m(epilogue, L.mf_group_nodes, L.level_tag, L.mf_gptr, L.mf_gcol, L.mf_gmeta, L.mf_gbase, L.mf_ghead, L.mf_kc,
+                                L.mf_nblocks > 0 ? L.mf_nblocks : L.nnzb,
                                 (L.nv + L.mf_group_nodes - 1) / L.mf_group_nodes, L.mf_max_entries, L.mf_max_batch_blocks, L.nv, X, ldx, Y,
                                 ldy, y_f32,
                                 R0, ldr, dinv, ncols, c1, c2, first, Wprev, ldp, stream);
@@ -80,6 +85,15 @@ int chebyshev16(const ds_level_t& L, const void* Rinit, int rinit_f32, int64_t l
         return DS_ERR_ARG;
     }
     void *cur = A, *oth = B;
+    if (L.tgrp) {  // group-block Jacobi: the right-hand side of every term is T_g R (bf16, in R16); L.dinv is an identity
+        if (from_guess || !L.mf_group_nodes) {
+            ds::set_error("chebyshev16: the group-block Jacobi serves the polynomial from a zero guess on the matrix-core tables");
+            return DS_ERR_ARG;
+        }
+        int rc = ds_group_apply16(L.tgrp, L.mf_group_nodes, Rinit, rinit_f32, ldri, R16, 0, ldr, L.nv, ncols, stream);
+        if (rc != DS_OK) return rc;
+        Rinit = R16, rinit_f32 = 0, ldri = ldr;
+    }
     if (!from_guess) {
         int rc = ds_cheb_init16(Rinit, rinit_f32, ldri, terms == 0 ? Wout : cur, terms == 0 ? ldw : lds,
                                 rinit_f32 ? R16 : nullptr, ldr, L.dinv, L.nv, ncols, (float)(1.0 / theta), stream);
@@ -106,6 +120,10 @@ int chebyshev16(const ds_level_t& L, const void* Rinit, int rinit_f32, int64_t l
 
 int twolevel16(const ds_twolevel_t* p, ds_stream_t stream) {
     const int c = p->ncols;
+    if (p->fine.tgrp) {  // (its residual launch and its post-smoothing from a guess need K itself)
+        ds::set_error("ds_twolevel_apply16: the group-block Jacobi is the corner-node level's");
+        return DS_ERR_ARG;
+    }
     // W1 = S R (bf16 iterates in Wc / D / AD; R16 = bf16 copy of R, written by the first step)
     int rc = chebyshev16(p->fine, p->R, 1, p->ldr, p->R16, p->ldr16, p->Wc, p->ldwc, 0, p->D, p->AD, p->ldd, c, false, stream);
     if (rc != DS_OK) return rc;

@@ -124,6 +124,13 @@ class SolverConfig:
     start_sweeps_qr: bool = False    # (experiment: M-orthonormalise the block after every sweep)
     precond_sweeps: int = 1
     nested_precond_sweeps: int = 1
+    # Corner-node levels whose operator object runs the GROUP-block Jacobi (HipModalOps.group_jacobi = 8: T = the inverse of the
+    # 24 x 24 diagonal block of every 8-node group of the matrix-core tables): degree and interval ratio of that level's polynomial -
+    # in the V-cycle and in the nested start's corner phase - in the place of coarse_degree / coarse_ratio and nested_cheb_*.
+    # Chebyshev(14, 150) in T_g K follows Chebyshev(22, 350) in the node blocks' T K iteration for iteration
+    # (profiles/r06_group_block_jacobi_gpu.txt).
+    group_degree: int = 14
+    group_ratio: float = 150.0
     nested_tol: float = 0.0
     nested_maxit: int = 8
     nested_cheb_degree: int = 28
@@ -394,6 +401,9 @@ class ChebyshevBlockJacobi:
         attributes, which two pipelines in one process would have fought over)."""
         self.ops = ops
         self.degree = max(1, int(degree))
+        # T of this polynomial: the operator object's group-block Jacobi (HipModalOps.group_jacobi, the corner-node level) or its
+        # 3 x 3 node blocks.  The native bf16 cycle reads it off the level descriptor; here: the power iteration and the Python path.
+        self.group = int(getattr(ops, "group_jacobi", 0) or 0)
         warm_iters = ChebyshevBlockJacobi.warm_power_iters if warm_iters is None else int(warm_iters)
         warm_spread = ChebyshevBlockJacobi.warm_spread if warm_spread is None else float(warm_spread)
         if power_iters <= 0:  # no estimate: the rigorous bound lambda_max(T K) <= nodes per element is the interval's end
@@ -420,7 +430,10 @@ class ChebyshevBlockJacobi:
         lm = prev = None
         for i in range(power_iters):  # largest eigenvalue of T K by block power iteration
             ops.apply_K(x, y)
-            ops.cheb_init(y, z, x, 1.0)  # x = T y
+            if self.group:
+                x = ops.group_T(y)
+            else:
+                ops.cheb_init(y, z, x, 1.0)  # x = T y
             nrm = torch.linalg.vector_norm(x.double(), dim=0)
             lm = nrm.max()
             x = (x / nrm.to(dt)[None, :]).contiguous()
@@ -474,6 +487,8 @@ class ChebyshevBlockJacobi:
         number of terms of the Chebyshev ITERATION for K W = R is run from it (W <- W_0 + p(T K) T (R - K W_0));
         this is the post-smoother of the two-level cycle and needs the fused-term op."""
         ops = self.ops
+        if self.group:
+            return self._apply_group(R, W, from_guess)
         if hasattr(ops, "cheb_spmm") and (self.degree > 1 or from_guess):
             for c0 in range(0, R.shape[1], self._CHUNK):  # columns are independent: wide blocks go in chunks
                 c1 = min(R.shape[1], c0 + self._CHUNK)
@@ -492,6 +507,27 @@ class ChebyshevBlockJacobi:
             rho_new = 1.0 / (2.0 * sigma1 - rho)
             ops.cheb_step(AD, R, D, W, rho_new * rho, 2.0 * rho_new / delta)  # R-=AD; D=c1 D+c2 T R; W+=D
             rho = rho_new
+
+    def _apply_group(self, R, W, from_guess):
+        """The polynomial in T_g K in torch on the level's fp32 product - the Python path of the group-block Jacobi (a tracker
+        callback, fp32 storage, the tests' comparisons); the product path is the native bf16 cycle."""
+        if from_guess:
+            raise RuntimeError("the group-block Jacobi serves the polynomial from a zero guess (the corner-node level)")
+        ops = self.ops
+        theta, delta = 0.5 * (self.lmax + self.lmin), 0.5 * (self.lmax - self.lmin)
+        z = ops.group_T(R.contiguous())
+        x = z / theta
+        d = x.clone()
+        sigma1 = theta / delta
+        rho = 1.0 / sigma1
+        kx = torch.empty_like(x)
+        for _ in range(self.degree - 1):
+            ops.apply_K(x, kx)
+            rho_new = 1.0 / (2.0 * sigma1 - rho)
+            d = (rho_new * rho) * d + (2.0 * rho_new / delta) * (z - ops.group_T(kx))
+            x = x + d
+            rho = rho_new
+        W.copy_(x)
 
     def _buffers(self, R):
         if self._D is None or self._D.shape != R.shape:
@@ -545,7 +581,9 @@ class TwoLevelChebyshev:
         args = (cfg.power_iters, cfg.seed, cfg.lmax_safety)
         warm = dict(warm_iters=getattr(cfg, "warm_power_iters", None), warm_spread=getattr(cfg, "warm_power_spread", None))
         self.smooth = ChebyshevBlockJacobi(ops, cfg.smooth_degree, cfg.smooth_ratio, *args, cap=cfg.lmax_cap, **warm)
-        self.coarse = ChebyshevBlockJacobi(ops.coarse, cfg.coarse_degree, cfg.coarse_ratio, *args,
+        grp = bool(getattr(ops.coarse, "group_jacobi", 0))
+        self.coarse = ChebyshevBlockJacobi(ops.coarse, cfg.group_degree if grp else cfg.coarse_degree,
+                                           cfg.group_ratio if grp else cfg.coarse_ratio, *args,
                                            cap=min(cfg.lmax_cap, 4.0) if cfg.lmax_cap > 0 else 0.0, **warm)
         self.lmax = self.smooth.lmax
         self._buf = None
@@ -595,7 +633,7 @@ class TwoLevelChebyshev:
                           (self.coarse.degree, self.coarse.lmax, self.coarse.lmin), Rs, Ws, f16[1], f16[2], f16[3], c16[0],
                           c16[1], c16[2], c16[3], f16[0], R16=f16[4]):
                     continue
-            if native is not None and self.use_native:
+            if native is not None and self.use_native and not self.coarse.group:  # (the fp32 cycle knows the node blocks only)
                 D, AD = self.smooth._buffers(Rs)
                 Dc, ADc = self.coarse._buffers(Rc)
                 if native((self.smooth.degree, self.smooth.lmax, self.smooth.lmin),
@@ -718,8 +756,10 @@ class ModalSolver:
         co = ops.coarse
         if co.rigid is None:
             co.rigid = co._rigid_basis()
+        grp = bool(getattr(co, "group_jacobi", 0))
         ccfg = SolverConfig(block=b, guard=cfg.guard, tol=cfg.nested_tol, maxit=cfg.nested_maxit, seed=cfg.seed,
-                            cheb_degree=cfg.nested_cheb_degree, cheb_ratio=cfg.nested_cheb_ratio,
+                            cheb_degree=cfg.group_degree if grp else cfg.nested_cheb_degree,
+                            cheb_ratio=cfg.group_ratio if grp else cfg.nested_cheb_ratio,
                             power_iters=cfg.power_iters, lmax_safety=cfg.lmax_safety,
                             lmax_cap=min(cfg.lmax_cap, 4.0) if cfg.lmax_cap > 0 else 0.0, precond="chebyshev",
                             raw_rr=cfg.raw_rr, raw_start=cfg.raw_start, warm_power_iters=cfg.warm_power_iters,

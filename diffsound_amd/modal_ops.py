@@ -200,6 +200,36 @@ class TetSystem:
                     gptr=gptr.to(torch.int32), gcol=gcol, gmeta=gmeta, gbase=gbase.to(torch.int32).contiguous(), ghead=ghead,
                     kperm=order.to(torch.int32).contiguous())
 
+    def mfma_tables_dense(self, group_nodes=8):
+        """The tables of ``mfma_tables`` with EVERY (node of the group, entry of its union) position present: what the term kernel
+        is handed when the level's blocks are those of T_g K (group-block Jacobi, ds_group_pack_kc).  Same gptr / gcol; gmeta = all
+        presence bits of the group's real nodes | (8 x entry) << 8; gbase = 8 x the group's first entry; plain batches of MF_BATCH
+        entries (128 blocks: the kernel's form without the tail)."""
+        cache = self.__dict__.setdefault("_mfma_tables", {})
+        mt = self.mfma_tables(group_nodes)
+        with _MFMA_TABLES_LOCK:
+            key_ = ("dense", int(group_nodes))
+            if key_ not in cache:
+                G, nv, dev = int(group_nodes), self.nv, self.device
+                gptr = mt["gptr"].long()
+                ne_g = gptr[1:] - gptr[:-1]
+                ng = ne_g.numel()
+                grp = torch.repeat_interleave(torch.arange(ng, device=dev), ne_g)
+                ewithin = torch.arange(int(gptr[-1]), device=dev) - gptr[:-1][grp]
+                nreal = (nv - G * torch.arange(ng, device=dev)).clamp(max=G)
+                mask = ((1 << nreal) - 1)[grp]
+                gmeta = (mask | ((G * ewithin) << 8)).to(torch.int32).contiguous()
+                ghead = torch.zeros((ng, 128), dtype=torch.int32, device=dev)
+                sel = ewithin < 64
+                ghead[grp[sel], ewithin[sel]] = mt["gcol"][sel]
+                ghead[grp[sel], 64 + ewithin[sel]] = gmeta[sel]
+                cache[key_] = dict(G=G, batch=mt["batch"], ngroups=ng, max_entries=mt["max_entries"],
+                                   max_batch_blocks=G * min(mt["batch"], mt["max_entries"]), gptr=mt["gptr"], gcol=mt["gcol"],
+                                   gmeta=gmeta, gbase=(G * gptr[:-1]).to(torch.int32).contiguous(), ghead=ghead,
+                                   nblocks=G * int(gptr[-1]))
+                torch.cuda.current_stream(self.device).synchronize()
+        return cache[key_]
+
     def with_own_values(self):
         """A view of this system that shares the mesh, pattern and tables but OWNS its assembled values
         (K_lambda, K_mu, M_s, per-tet geometry; 0.7 GB on the benchmark mesh): concurrent hypothesis lanes each
@@ -408,7 +438,15 @@ class _HipBlockOps:
         d.degree, d.lmax, d.lmin = int(degree), float(lmax), float(lmin)
         d.level_tag = self._level_tag
         mt = self._mfma
-        if mt is not None and self.kc is not None:  # the level's bf16 terms run on the matrix cores (ds_spmm_union16m)
+        d.tgrp, d.mf_nblocks = None, 0
+        if self.group_jacobi and self.tgrp is not None:
+            # group-block Jacobi: the blocks of T_g K on the dense tables, an identity for dinv, T_g for the right-hand side
+            md = self._mfma_dense
+            d.mf_group_nodes, d.mf_max_entries, d.mf_max_batch_blocks = md["G"], md["max_entries"], md["max_batch_blocks"]
+            d.mf_gptr, d.mf_gcol, d.mf_gmeta, d.mf_gbase, d.mf_ghead = (md[k].data_ptr() for k in ("gptr", "gcol", "gmeta", "gbase", "ghead"))
+            d.mf_kc, d.mf_nblocks = self.kc_dense.data_ptr(), md["nblocks"]
+            d.tgrp, d.dinv = self.tgrp.data_ptr(), self.dinv_id.data_ptr()
+        elif mt is not None and self.kc is not None:  # the level's bf16 terms run on the matrix cores (ds_spmm_union16m)
             d.mf_group_nodes, d.mf_max_entries, d.mf_max_batch_blocks = mt["G"], mt["max_entries"], mt["max_batch_blocks"]
             d.mf_gptr, d.mf_gcol, d.mf_gmeta, d.mf_gbase, d.mf_ghead = (mt[k].data_ptr() for k in ("gptr", "gcol", "gmeta", "gbase", "ghead"))
             d.mf_kc = self.kc.data_ptr()
@@ -425,6 +463,11 @@ class _HipBlockOps:
         return d
 
     _mfma = None  # tables of the MFMA form of the bf16 terms (TetSystem.mfma_tables), None: the VALU kernel
+    # GROUP-block Jacobi of the level's bf16 polynomial (round 6; the corner-node level only): 8 = T is the inverse of the 24 x 24
+    # diagonal block of every group of 8 nodes of the matrix-core tables, 0 = the 3 x 3 node blocks (dinv).  tgrp (ng, 24, 24) fp32,
+    # kc_dense the blocks of T_g K on TetSystem.mfma_tables_dense, dinv_id an identity per node - all per material (set_material).
+    group_jacobi = 0
+    tgrp = kc_dense = dinv_id = _mfma_dense = None
     kc = None     # (nnzb, 3, 4) bf16: the 3x3 blocks in the order of those tables (ds_pack_kc)
     _mfma32 = None  # tables of the fp32 MFMA form of the level's own products K X / M X (groups of 4 nodes), None: VALU
     k4 = None     # (nnzb * 9 + 4,) fp32: the 3x3 blocks (row-major) in the order of those tables, 16 bytes of slack
@@ -529,6 +572,8 @@ class _HipBlockOps:
                     or co.level_desc(tl.coarse, cs.degree, cs.lmax, cs.lmin) is None):
                 return None
             bf = cfg.precond_storage == "bf16"
+            if cs.group and not bf:
+                return None  # (the group-block Jacobi lives on the bf16 cycle: an fp32 cycle goes through the Python loop)
             sdt = torch.bfloat16 if bf else torch.float32
             scr = self._scratch("native_tl_fine", (5, self.n, b), sdt)
             scc = co._scratch("native_tl_coarse", (4, co.n, b), sdt)
@@ -546,6 +591,8 @@ class _HipBlockOps:
             if precond.ops is not self or self.level_desc(d.level, precond.degree, precond.lmax, precond.lmin) is None:
                 return None
             bf = cfg.precond_storage == "bf16" and precond.degree >= 2
+            if precond.group and not bf:
+                return None
             scr = self._scratch("native_cheb", (3, self.n, b), torch.bfloat16 if bf else torch.float32)
             d.pa, d.pb, d.ldp = scr[0].data_ptr(), scr[1].data_ptr(), b
             d.pr16 = scr[2].data_ptr() if bf else None
@@ -1081,10 +1128,17 @@ class HipModalOps(_HipBlockOps):
     # LDS staging the form requires (profiles/r04_mfma32_*.txt)
     mfma32 = False
 
-    def __init__(self, system: TetSystem, lam, mu, two_level=None, _level=0, mfma_groups=None, mfma32=None):
+    # the corner-node level's polynomial on the group-block Jacobi (``group_jacobi`` of that level's operator object): 8 or 0
+    coarse_group_jacobi = 8
+
+    def __init__(self, system: TetSystem, lam, mu, two_level=None, _level=0, mfma_groups=None, mfma32=None, coarse_group_jacobi=None):
         """two_level: build the corner-node level for the two-level preconditioner (ord-2 meshes; default on)."""
         self.sys = system
         self._level_tag = min(int(_level), 1)
+        if coarse_group_jacobi is not None:
+            self.coarse_group_jacobi = int(coarse_group_jacobi)
+        if self.coarse_group_jacobi not in (0, 8):
+            raise ValueError("coarse_group_jacobi: groups of 8 nodes, or 0 for the node blocks")
         if mfma_groups is not None:
             self.mfma_groups = tuple(mfma_groups)
         if mfma32 is not None:
@@ -1102,7 +1156,7 @@ class HipModalOps(_HipBlockOps):
             if lvl is not None:
                 self._xfer = lvl
                 self.coarse = HipModalOps(lvl["sys"], lam, mu, two_level=False, _level=1, mfma_groups=self.mfma_groups,
-                                          mfma32=self.mfma32)
+                                          mfma32=self.mfma32, coarse_group_jacobi=self.coarse_group_jacobi)
         G = self.mfma_groups[min(_level, 1)]
         if G not in (0, 8):
             raise ValueError("mfma_groups: 8 nodes per wavefront, or 0 for the VALU kernel")
@@ -1110,6 +1164,10 @@ class HipModalOps(_HipBlockOps):
             mt = system.mfma_tables(G)
             if mt["max_entries"] <= 256 and mt["max_batch_blocks"] <= MF_BATCH * G:  # what ds_spmm_union16m serves
                 self._mfma = mt
+                if _level == 1 and self.coarse_group_jacobi == G and system.nv >= 4 * G:
+                    md = system.mfma_tables_dense(G)
+                    if md["nblocks"] * 24 < 0x7F000000:
+                        self._mfma_dense, self.group_jacobi = md, G
         if self.mfma32 and system.groups is not None and system.nnzb * 36 + 16 < 0x7F000000:
             m4 = system.mfma_tables(MF32_G, MF32_BATCH)
             if m4["max_entries"] <= 256 and m4["max_batch_blocks"] <= MF32_BATCH * MF32_G:  # what ds_spmm_union32m serves
@@ -1117,6 +1175,18 @@ class HipModalOps(_HipBlockOps):
         self.set_material(lam, mu)
         self.rigid = self._rigid_basis() if _level == 0 else None
         self._rigid_generation = getattr(system, "geometry_generation", 0)
+
+    def group_T(self, X):
+        """T_g X with the group-block Jacobi's blocks, fp32 in and out (ds_group_apply16): the power iteration's 8 columns and the
+        Python path of the polynomial; the bf16 cycle applies T_g to its right-hand side inside the native driver."""
+        X = X if (X.stride(1) == 1 and (X.data_ptr() | (X.stride(0) * 4)) % 16 == 0) else X.contiguous()
+        Y = torch.empty((X.shape[0], X.shape[1]), dtype=torch.float32, device=X.device)
+        for c0 in range(0, X.shape[1], 256):
+            c1 = min(X.shape[1], c0 + 256)
+            _hip.check(self._L.ds_group_apply16(_hip.ptr(self.tgrp), self.group_jacobi, X[:, c0:c1].data_ptr(), 1, _ld(X),
+                                                Y[:, c0:c1].data_ptr(), 1, _ld(Y), self.nv, c1 - c0, _hip.stream_ptr()),
+                       "ds_group_apply16")
+        return Y
 
     def probe_products(self, G0):
         """(K_lambda G0, K_mu G0, M G0) in fp64 for an fp32 probe block G0 of a multiple of 4 columns - ONE walk of the pattern
@@ -1165,6 +1235,19 @@ class HipModalOps(_HipBlockOps):
                     self.kc = torch.empty((s.nnzb, 3, 4), dtype=torch.bfloat16, device=self.device)
                 _hip.check(self._L.ds_pack_kc(p(self.k32), p(self._mfma["kperm"]), s.nnzb, p(self.kc), _hip.stream_ptr()),
                            "ds_pack_kc")
+            if self.group_jacobi and self._mfma is not None:
+                md = self._mfma_dense
+                if self.tgrp is None:
+                    ng = md["ngroups"]
+                    self.tgrp = torch.empty((ng, 3 * self.group_jacobi, 3 * self.group_jacobi), dtype=torch.float32, device=self.device)
+                    self.kc_dense = torch.zeros((md["nblocks"], 3, 4), dtype=torch.bfloat16, device=self.device)
+                    self.dinv_id = torch.eye(3, dtype=torch.float32, device=self.device).reshape(1, 9).repeat(s.nv, 1).contiguous()
+                _hip.check(self._L.ds_group_inverse(p(s.rowptr), p(s.colidx), p(self.k32), s.nv, self.group_jacobi, p(self.tgrp),
+                                                    _hip.stream_ptr()), "ds_group_inverse")
+                mt_ = self._mfma
+                _hip.check(self._L.ds_group_pack_kc(p(self.k32), p(self.tgrp), p(mt_["gptr"]), p(mt_["gmeta"]), p(mt_["gbase"]),
+                                                    p(mt_["kperm"]), self.group_jacobi, s.nv, p(self.kc_dense), _hip.stream_ptr()),
+                           "ds_group_pack_kc")
             if self._mfma32 is not None:
                 if self.k4 is None:  # (zeros: the 16 bytes of slack behind the last block are read and must be finite)
                     self.k4 = torch.zeros((s.nnzb * 9 + 4,), dtype=torch.float32, device=self.device)

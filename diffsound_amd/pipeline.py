@@ -71,13 +71,16 @@ class ModalPipeline:
     oscillator, target audio."""
 
     def __init__(self, vertices, tets, order, modes, mat, sample_num=8000, sr=32000, force_frames=150,
-                 solver_config=None, target_freqs=None, loss_fn=None, mfma_groups=None, host_wait="sleep"):
+                 solver_config=None, target_freqs=None, loss_fn=None, mfma_groups=None, host_wait="sleep",
+                 coarse_group_jacobi=None):
         """``mfma_groups``: nodes per wavefront of the MFMA form of the preconditioner's bf16 terms on (fine, corner-node) level,
         handed to every operator object THIS pipeline builds (None: the library default).  ``host_wait``: how this pipeline's
         lanes wait for their streams when several are in flight ("sleep" | "spin").  Both are per pipeline (round 6): two
         pipelines in one process - or ranks run as threads - do not share a knob."""
         self.device = vertices.device
         self.mfma_groups = None if mfma_groups is None else tuple(mfma_groups)
+        # (group-block Jacobi of the corner-node level's polynomial: 8 / 0, None = HipModalOps' default; per pipeline)
+        self.coarse_group_jacobi = coarse_group_jacobi
         self.host_wait = host_wait
         # scalar loss head (audio, target) -> 0-dim tensor; None = the MSE of the headline metric.  The reference's
         # experiments put MSSLoss here (experiments/material_sync_train.py:124,159): pass that module.
@@ -123,7 +126,8 @@ class ModalPipeline:
             holder.system.assemble()
         lam_f, mu_f = float(lam.detach()), float(mu.detach())
         if holder.ops is None:
-            holder.ops = HipModalOps(holder.system, lam_f, mu_f, mfma_groups=self.mfma_groups)
+            holder.ops = HipModalOps(holder.system, lam_f, mu_f, mfma_groups=self.mfma_groups,
+                                     coarse_group_jacobi=self.coarse_group_jacobi)
             set_wait_mode(holder.ops, getattr(holder, "host_wait_mode", 0))  # (the native solve's waits: this lane's own setting)
         else:
             holder.ops.set_material(lam_f, mu_f)

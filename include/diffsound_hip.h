@@ -40,7 +40,7 @@ enum { DS_OK = 0, DS_ERR_ARG = 1, DS_ERR_HIP = 2, DS_ERR_NOMEM = 3 };
 /* Thread-local text of the last error returned on this thread ("" if none). */
 const char* ds_last_error(void);
 /* Library ABI version (bumped on any signature change); ds_abi_version() returns the value the library was built with. */
-#define DS_ABI_VERSION 32
+#define DS_ABI_VERSION 33
 int ds_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------------
@@ -303,6 +303,13 @@ typedef struct {
     const int32_t *m32_gptr, *m32_gcol, *m32_gmeta, *m32_gbase;
     const float* m32_k;
     const float* m32_m;
+    /* ABI 33, bf16 cycles on the matrix-core tables only: GROUP-block Jacobi.  tgrp != NULL: (ceil(nv / 8) x 24 x 24) f32, the
+     * inverses T_g of the 24 x 24 diagonal blocks of the level's groups of 8 nodes (ds_group_inverse).  The level's polynomial is
+     * then p(T_g K) T_g: its right-hand side goes through ds_group_apply16 first, mf_kc holds the blocks of T_g K (ds_group_pack_kc:
+     * DENSE over node x entry, mf_gmeta / mf_gbase / mf_ghead with every presence bit set, mf_nblocks = 8 x the number of union
+     * entries of the level) and dinv an identity per node.  NULL / 0: the node blocks (dinv) as before. */
+    const float* tgrp;
+    int64_t mf_nblocks;
 } ds_level_t;
 typedef struct {
     ds_level_t fine, coarse;
@@ -362,6 +369,20 @@ int ds_spmm_union16(int epilogue, const int32_t* utab, const int32_t* ctab, int6
 #define DS_MF_BATCH 16
 #define DS_MF_TAIL 2
 int ds_pack_kc(const float* k32, const int32_t* kperm, int64_t nnzb, void* kc, ds_stream_t stream);
+/* ABI 33: the group-block Jacobi of the bf16 polynomial (ds_level_t.tgrp; reference: the preconditioner is the caller's opaque
+ * callable, src/lobpcg/_lobpcg.py:441).  Groups of group_nodes = 8 consecutive nodes, ng = ceil(nv / 8).
+ * ds_group_inverse: T (ng x 24 x 24 f32) = the inverses of the diagonal blocks K_gg of the BSR-3 matrix (rowptr, colidx, k32:
+ *   nnzb x 9 f32), nodes behind the last one as identity rows; once per material.
+ * ds_group_pack_kc: kc (8 x entries x 3 x 4 bf16) = the blocks of T_g K, dense: position (gptr[g] + e) * 8 + s' = sum_s
+ *   T_g[s', s] K(s, e); gptr / gmeta / gbase / kperm are the COMPACT tables of ds_spmm_union16m on the same topology.
+ * ds_group_apply16: Y = T_g X on (3 nv x ncols) blocks, ncols <= 256, X and Y each f32 (x_f32 / y_f32) or bf16; Y may be X when
+ *   both have one element type. */
+int ds_group_inverse(const int32_t* rowptr, const int32_t* colidx, const float* k32, int64_t nv, int group_nodes, float* T,
+                     ds_stream_t stream);
+int ds_group_pack_kc(const float* k32, const float* T, const int32_t* gptr, const int32_t* gmeta, const int32_t* gbase,
+                     const int32_t* kperm, int group_nodes, int64_t nv, void* kc, ds_stream_t stream);
+int ds_group_apply16(const float* T, int group_nodes, const void* X, int x_f32, int64_t ldx, void* Y, int y_f32, int64_t ldy,
+                     int64_t nv, int ncols, ds_stream_t stream);
 int ds_spmm_union16m(int epilogue, int group_nodes, int level_tag, const int32_t* gptr, const int32_t* gcol,
                      const int32_t* gmeta, const int32_t* gbase, const int32_t* ghead, const void* kc, int64_t nnzb, int64_t ngroups, int max_entries,
                      int max_batch_blocks, int64_t nv, const void* X, int64_t ldx, void* Y, int64_t ldy, int y_f32,

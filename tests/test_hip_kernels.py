@@ -51,7 +51,9 @@ def case(request, dev):
     M3, Ms = fem.assemble_mass(v, t, order, MAT[0])
     lam, mu = fem.lame(MAT[1], MAT[2])
     sysd = TetSystem(v.to(dev), t.to(dev), order, MAT[0], reorder=False)  # kernel parity in the caller's numbering
-    hops = HipModalOps(sysd, lam, mu)
+    # (kernel parity against the oracle's operators: the corner-node level on the 3 x 3 node blocks, as the oracle's polynomial is;
+    # the group-block Jacobi has its own tests - test_group_block_jacobi_*)
+    hops = HipModalOps(sysd, lam, mu, coarse_group_jacobi=0)
     cops = CpuModalOps(Kl, Km, M3, v.numpy(), lam, mu, tets=t.numpy() if order == 2 else None)
     return dict(v=v, t=t, order=order, Kl=Kl, Km=Km, M3=M3, Ms=Ms, sys=sysd, hops=hops, cops=cops, lam=lam, mu=mu)
 

@@ -147,7 +147,9 @@ def test_native_iteration_driver_matches_python_loop(dev, mesh, order, k, block,
     v, t = fem.to_high_order(torch.from_numpy(v), torch.from_numpy(t).long(), order)
     sysd = TetSystem(v.to(dev), t.to(dev), order, MAT[0])
     lam, mu = fem.lame(MAT[1], MAT[2])
-    ops = HipModalOps(sysd, lam, mu)
+    # (fp32 preconditioner blocks: the corner-node level on its node blocks - the group-block Jacobi lives on the bf16 cycle and
+    # an fp32 cycle would leave the native driver for the Python loop)
+    ops = HipModalOps(sysd, lam, mu, coarse_group_jacobi=0 if storage == "fp32" else None)
     out = {}
     for native in (True, False):
         cfg = SolverConfig(block=block, lmax_cap=float({1: 4, 2: 10}[order]), tol=1e-5, nested_tol=nested, native=native,
@@ -412,6 +414,97 @@ def test_start_block_in_coefficients_changes_nothing_but_rounding(dev, mesh, ord
     assert abs(a.iterations - b.iterations) <= 1
     ref = modal.reference_eigs(ops, k) if hasattr(modal, "reference_eigs") else None
     assert ref is None or float(((a.eigenvalues.cpu() - ref).abs() / ref).max()) < EIG_TOL
+
+
+def test_group_block_jacobi_pieces_and_polynomial(dev):
+    """The group-block Jacobi of the corner-node level's polynomial (round 6; ds_group_inverse / ds_group_pack_kc / ds_group_apply16,
+    ds_level_t.tgrp): T_g against torch's inverse of the 24 x 24 diagonal blocks gathered from the BSR values; T_g X against
+    torch.bmm; and the polynomial p(T_g K) T_g R of the native bf16 driver - the term kernel on the DENSE blocks of T_g K, an identity
+    for dinv, the right-hand side through T_g first - against the same polynomial in torch on the level's fp32 product, to the
+    rounding of bf16 iterates, every column, deterministic.  On a mesh whose corner level ends in a group of fewer than 8 nodes."""
+    from diffsound_amd import meshgen
+    from diffsound_amd.lobpcg.modal_solver import ChebyshevBlockJacobi
+    from diffsound_amd.modal_ops import HipModalOps, TetSystem
+
+    v, t = meshgen.kuhn_box(10)
+    v, t = fem.to_high_order(torch.from_numpy(v), torch.from_numpy(t).long(), 2)
+    sysd = TetSystem(v.to(dev), t.to(dev), 2, MAT[0])
+    lam, mu = fem.lame(MAT[1], MAT[2])
+    ops = HipModalOps(sysd, lam, mu)
+    co = ops.coarse
+    assert co.group_jacobi == 8 and ops.group_jacobi == 0 and co.nv % 8 != 0
+    s, G = co.sys, 8
+    ng = (s.nv + G - 1) // G
+    rows = torch.repeat_interleave(torch.arange(s.nv, device=dev), (s.rowptr[1:] - s.rowptr[:-1]).long())
+    cols = s.colidx.long()
+    sel = (rows // G) == (cols // G)
+    Kgg = torch.zeros((ng, 24, 24), dtype=torch.float64, device=dev)
+    blk = co.k32[sel].double().reshape(-1, 3, 3)
+    g, a, b = rows[sel] // G, rows[sel] % G, cols[sel] % G
+    for i in range(3):
+        for j in range(3):
+            Kgg[g, 3 * a + i, 3 * b + j] = blk[:, i, j]
+    idx = torch.arange(3 * (s.nv - G * (ng - 1)), 24, device=dev)
+    Kgg[-1, idx, idx] = 1.0
+    Tref = torch.linalg.inv(Kgg)
+    err = (co.tgrp.double() - Tref).abs().amax(dim=(1, 2)) / Tref.abs().amax(dim=(1, 2))
+    assert float(err.max()) < 1e-6  # (fp64 Gauss-Jordan, stored in fp32)
+    assert torch.equal(co.tgrp, co.tgrp.transpose(1, 2))
+    X = torch.randn((co.n, 12), device=dev)
+    Xp = torch.cat([X, X.new_zeros((ng * 24 - co.n, 12))], 0)
+    ref = torch.bmm(co.tgrp, Xp.reshape(ng, 24, 12)).reshape(-1, 12)[:co.n]
+    assert float((co.group_T(X) - ref).abs().max() / ref.abs().max()) < 1e-6
+    pre = ChebyshevBlockJacobi(co, 14, 150.0, 20, 0, 1.2, cap=4.0)
+    assert pre.group == 8 and 1.5 < pre.lmax <= 4.0
+    for ncols in (80, 40):
+        R = torch.randn((co.n, ncols), device=dev) * 1e9
+        Wn = torch.full_like(R, float("nan"))
+        assert co.chebyshev_apply16(pre, R.clone(), Wn)  # the native bf16 driver
+        Wp = torch.empty_like(R)
+        pre.apply(R.clone(), Wp)  # torch, fp32
+        cols_err = (Wn - Wp).norm(dim=0) / Wp.norm(dim=0)
+        assert bool(torch.isfinite(Wn).all()) and float(cols_err.max()) < 3e-2, float(cols_err.max())
+        Wn2 = torch.empty_like(R)
+        co.chebyshev_apply16(pre, R.clone(), Wn2)
+        assert torch.equal(Wn, Wn2)
+    # a new material: T_g and the blocks of T_g K follow (the polynomial of the OLD material on the new blocks would not match)
+    co.set_material(2.0 * lam, 0.7 * mu)
+    pre2 = ChebyshevBlockJacobi(co, 14, 150.0, 20, 0, 1.2, cap=4.0)
+    R = torch.randn((co.n, 80), device=dev) * 1e9
+    Wn, Wp = torch.empty_like(R), torch.empty_like(R)
+    assert co.chebyshev_apply16(pre2, R.clone(), Wn)
+    pre2.apply(R.clone(), Wp)
+    assert float(((Wn - Wp).norm(dim=0) / Wp.norm(dim=0)).max()) < 3e-2
+
+
+def test_group_block_jacobi_keeps_the_iteration_counts_with_a_shorter_polynomial(dev):
+    """The corner-node level's polynomial on the group-block Jacobi, Chebyshev(14, ratio 150) in T_g K, against the node blocks'
+    Chebyshev(22, ratio 350) at the benchmark's settings: the same eigenpairs to the solve's accuracy, no more iterations on either
+    level (one of slack), through the native loop and through the Python loop (whose polynomial is the torch form on fp32)."""
+    from diffsound_amd import meshgen
+    from diffsound_amd.lobpcg.modal_solver import ModalSolver
+    from diffsound_amd.modal_ops import HipModalOps, TetSystem
+    import bench
+
+    v, t = meshgen.kuhn_box(16)
+    v, t = fem.to_high_order(torch.from_numpy(v), torch.from_numpy(t).long(), 2)
+    sysd = TetSystem(v.to(dev), t.to(dev), 2, MAT[0])
+    lam, mu = fem.lame(MAT[1], MAT[2])
+    res = {}
+    for gj in (0, 8):
+        ops = HipModalOps(sysd, lam, mu, coarse_group_jacobi=gj)
+        assert ops.coarse.group_jacobi == gj
+        for native in (True, False):
+            cfg = bench.solver_config()
+            cfg.native = native
+            assert (cfg.group_degree, cfg.group_ratio, cfg.coarse_degree, cfg.coarse_ratio) == (14, 150.0, 22, 350.0)
+            res[gj, native] = ModalSolver(ops, cfg).solve(64)
+            print("group", gj, "native", native, "corner", res[gj, native].coarse_iterations, "fine", res[gj, native].iterations)
+    ref = res[0, True]
+    for key, r in res.items():
+        assert float(r.rerr.max()) < 1e-5
+        assert float(((r.eigenvalues - ref.eigenvalues).abs() / ref.eigenvalues).max()) < 1e-5
+        assert r.iterations <= ref.iterations + 1 and r.coarse_iterations <= ref.coarse_iterations + 1, key
 
 
 def test_swept_start_block_is_not_locked_before_its_ritz_values_have_settled(dev):
