@@ -110,12 +110,16 @@ __global__ void __launch_bounds__(64)
     __shared__ double A[GJ_N][2 * GJ_N + 1];
     __shared__ double prow[2 * GJ_N];
     __shared__ double fcol[GJ_N];
+    __shared__ double Dg[GJ_G][9];  // the nodes' own 3 x 3 blocks: what a group whose elimination breaks down falls back to
+    __shared__ int bad;
     const int64_t g = blockIdx.x;
     const int tid = threadIdx.x;
+    if (tid == 0) bad = 0;
     for (int i = tid; i < GJ_N * 2 * GJ_N; i += 64) {
         const int r = i / (2 * GJ_N), c = i - r * 2 * GJ_N;
         A[r][c] = (c == GJ_N + r) ? 1.0 : 0.0;
     }
+    for (int i = tid; i < GJ_G * 9; i += 64) Dg[i / 9][i % 9] = (i % 9) % 4 == 0 ? 1.0 : 0.0;
     __syncthreads();
     {   // 8 lanes per node of the group walk that node's row
         const int s = tid >> 3, l = tid & 7;
@@ -127,7 +131,10 @@ __global__ void __launch_bounds__(64)
                 const int cs = (int)(c - g * GJ_G);
                 const float* b = k32 + (int64_t)j * 9;
                 for (int i = 0; i < 3; ++i)
-                    for (int k = 0; k < 3; ++k) A[3 * s + i][3 * cs + k] = (double)b[3 * i + k];
+                    for (int k = 0; k < 3; ++k) {
+                        A[3 * s + i][3 * cs + k] = (double)b[3 * i + k];
+                        if (cs == s) Dg[s][3 * i + k] = (double)b[3 * i + k];
+                    }
             }
         } else if (l < 3) {
             A[3 * s + l][3 * s + l] = 1.0;
@@ -135,7 +142,9 @@ __global__ void __launch_bounds__(64)
     }
     __syncthreads();
     for (int p = 0; p < GJ_N; ++p) {
-        const double piv = 1.0 / A[p][p];
+        const double app = A[p][p];
+        if (tid == 0 && !(app > 0.0)) bad = 1;  // (not positive, or not a number: K_gg is not positive definite in fp64)
+        const double piv = 1.0 / app;
         for (int c = tid; c < 2 * GJ_N; c += 64) prow[c] = A[p][c] * piv;
         if (tid < GJ_N) fcol[tid] = A[tid][p];
         __syncthreads();
@@ -144,6 +153,22 @@ __global__ void __launch_bounds__(64)
             A[r][c] = (r == p) ? prow[c] : A[r][c] - fcol[r] * prow[c];
         }
         __syncthreads();
+    }
+    if (bad) {  // the node blocks' inverses for this group (the polynomial's interval bound holds for them as well)
+        for (int i = tid; i < GJ_N * GJ_N; i += 64) T[g * GJ_N * GJ_N + i] = 0.f;
+        __syncthreads();
+        if (tid < GJ_G) {
+            const double* d = Dg[tid];
+            const double c00 = d[4] * d[8] - d[5] * d[7], c01 = d[5] * d[6] - d[3] * d[8], c02 = d[3] * d[7] - d[4] * d[6];
+            const double det = d[0] * c00 + d[1] * c01 + d[2] * c02, id = 1.0 / det;
+            const double inv[9] = {c00 * id, (d[2] * d[7] - d[1] * d[8]) * id, (d[1] * d[5] - d[2] * d[4]) * id,
+                                   c01 * id, (d[0] * d[8] - d[2] * d[6]) * id, (d[2] * d[3] - d[0] * d[5]) * id,
+                                   c02 * id, (d[1] * d[6] - d[0] * d[7]) * id, (d[0] * d[4] - d[1] * d[3]) * id};
+            for (int i = 0; i < 3; ++i)
+                for (int k = 0; k < 3; ++k)
+                    T[g * GJ_N * GJ_N + (3 * tid + i) * GJ_N + 3 * tid + k] = (float)(0.5 * (inv[3 * i + k] + inv[3 * k + i]));
+        }
+        return;
     }
     for (int i = tid; i < GJ_N * GJ_N; i += 64) {
         const int r = i / GJ_N, c = i - r * GJ_N;

@@ -467,6 +467,25 @@ def test_group_block_jacobi_pieces_and_polynomial(dev):
         Wn2 = torch.empty_like(R)
         co.chebyshev_apply16(pre, R.clone(), Wn2)
         assert torch.equal(Wn, Wn2)
+    # a group whose diagonal block is not positive definite (here: one node's own block negated) falls back to the inverses of its
+    # nodes' 3 x 3 blocks; the other groups are untouched
+    from diffsound_amd import _hip
+    kbad = co.k32.clone()
+    node = 8 * 5 + 2
+    j = int(s.rowptr[node]) + int((s.colidx[int(s.rowptr[node]):int(s.rowptr[node + 1])] == node).nonzero()[0])
+    kbad[j] = -kbad[j]
+    Tb = torch.empty_like(co.tgrp)
+    _hip.check(_hip.lib().ds_group_inverse(_hip.ptr(s.rowptr), _hip.ptr(s.colidx), _hip.ptr(kbad), s.nv, 8, _hip.ptr(Tb),
+                                           _hip.stream_ptr()), "ds_group_inverse")
+    keep = torch.ones(ng, dtype=torch.bool, device=dev)
+    keep[5] = False
+    assert torch.equal(Tb[keep], co.tgrp[keep])
+    want = torch.zeros((24, 24), dtype=torch.float64, device=dev)
+    for a_ in range(8):
+        nd = 8 * 5 + a_
+        jj = int(s.rowptr[nd]) + int((s.colidx[int(s.rowptr[nd]):int(s.rowptr[nd + 1])] == nd).nonzero()[0])
+        want[3 * a_:3 * a_ + 3, 3 * a_:3 * a_ + 3] = torch.linalg.inv(kbad[jj].double().reshape(3, 3))
+    assert float((Tb[5].double() - want).abs().max() / want.abs().max()) < 1e-6
     # a new material: T_g and the blocks of T_g K follow (the polynomial of the OLD material on the new blocks would not match)
     co.set_material(2.0 * lam, 0.7 * mu)
     pre2 = ChebyshevBlockJacobi(co, 14, 150.0, 20, 0, 1.2, cap=4.0)
