@@ -140,6 +140,11 @@ def parse():
                     help="the corner-node level's polynomial on the group-block Jacobi (inverse of the 24 x 24 diagonal block of every "
                          "8-node group of the matrix-core tables; degree / ratio: --group-degree / --group-ratio) or, 0, on the "
                          "3 x 3 node blocks (--coarse-degree / --coarse-ratio; rounds 2-5)")
+    ap.add_argument("--one-level-group", type=int, default=-1, choices=[-1, 0, 8],
+                    help="--workload geom: the one-level polynomial of the ord-1 meshes on the group-block Jacobi (8) or on the node blocks "
+                         "(0); -1 = the library's default; its degree / ratio: --cheb-group-degree / --cheb-group-ratio")
+    ap.add_argument("--cheb-group-degree", type=int, default=0)
+    ap.add_argument("--cheb-group-ratio", type=float, default=0.0)
     ap.add_argument("--group-degree", type=int, default=14)
     ap.add_argument("--group-ratio", type=float, default=150.0)
     ap.add_argument("--loss", default="mse", choices=["mse", "mss"],
@@ -563,7 +568,11 @@ def main_geom(a):
         meshes.append((torch.from_numpy(v).to(dev), torch.from_numpy(t).long().to(dev)))
     mat = MatSet.Ceramic
     geom_cfg = None  # (None: DiffSoundObj's own default, lobpcg.modal_solver.tuned_config(order))
-    if any(f in sys.argv for f in ("--cheb-degree", "--cheb-ratio", "--block", "--start-sweeps", "--nested-ritz-tol")):
+    if a.one_level_group >= 0:  # (a process-wide default of the library, set here for the A/B: DiffSoundObj builds the operator objects)
+        from diffsound_amd.modal_ops import HipModalOps
+
+        HipModalOps.one_level_group_jacobi = a.one_level_group
+    if any(f in sys.argv for f in ("--cheb-degree", "--cheb-ratio", "--block", "--start-sweeps", "--nested-ritz-tol", "--cheb-group-degree", "--cheb-group-ratio")):
         from diffsound_amd.lobpcg.modal_solver import tuned_config
 
         geom_cfg = tuned_config(order)
@@ -573,6 +582,10 @@ def main_geom(a):
             geom_cfg.block = a.block
         if "--start-sweeps" in sys.argv:
             geom_cfg.start_sweeps = a.start_sweeps
+        if a.cheb_group_degree > 0:
+            geom_cfg.cheb_group_degree = a.cheb_group_degree
+        if a.cheb_group_ratio > 0:
+            geom_cfg.cheb_group_ratio = a.cheb_group_ratio
     theta = torch.nn.Parameter(torch.tensor(1.0, device=dev))
     opt = torch.optim.Adam([theta], lr=2e-3)
     zscale = lambda: torch.stack([torch.ones((), device=dev), torch.ones((), device=dev), theta])

@@ -131,6 +131,10 @@ class SolverConfig:
     # (profiles/r06_group_block_jacobi_gpu.txt).
     group_degree: int = 14
     group_ratio: float = 150.0
+    # ... and of the ONE-level polynomial of an operator object that runs the group blocks itself (HipModalOps.one_level_group_jacobi,
+    # ord-1 meshes), in the place of cheb_degree / cheb_ratio
+    cheb_group_degree: int = 16
+    cheb_group_ratio: float = 300.0
     nested_tol: float = 0.0
     nested_maxit: int = 8
     nested_cheb_degree: int = 28
@@ -688,7 +692,9 @@ class ModalSolver:
             if two:
                 self.precond = TwoLevelChebyshev(ops, self.cfg)
             else:
-                self.precond = ChebyshevBlockJacobi(ops, self.cfg.cheb_degree, self.cfg.cheb_ratio,
+                grp = bool(getattr(ops, "group_jacobi", 0))
+                self.precond = ChebyshevBlockJacobi(ops, self.cfg.cheb_group_degree if grp else self.cfg.cheb_degree,
+                                                    self.cfg.cheb_group_ratio if grp else self.cfg.cheb_ratio,
                                                     self.cfg.power_iters, self.cfg.seed, self.cfg.lmax_safety,
                                                     self.cfg.lmax_cap, warm_iters=self.cfg.warm_power_iters,
                                                     warm_spread=self.cfg.warm_power_spread)
@@ -760,6 +766,7 @@ class ModalSolver:
         ccfg = SolverConfig(block=b, guard=cfg.guard, tol=cfg.nested_tol, maxit=cfg.nested_maxit, seed=cfg.seed,
                             cheb_degree=cfg.group_degree if grp else cfg.nested_cheb_degree,
                             cheb_ratio=cfg.group_ratio if grp else cfg.nested_cheb_ratio,
+                            cheb_group_degree=cfg.group_degree, cheb_group_ratio=cfg.group_ratio,
                             power_iters=cfg.power_iters, lmax_safety=cfg.lmax_safety,
                             lmax_cap=min(cfg.lmax_cap, 4.0) if cfg.lmax_cap > 0 else 0.0, precond="chebyshev",
                             raw_rr=cfg.raw_rr, raw_start=cfg.raw_start, warm_power_iters=cfg.warm_power_iters,

@@ -1130,15 +1130,20 @@ class HipModalOps(_HipBlockOps):
 
     # the corner-node level's polynomial on the group-block Jacobi (``group_jacobi`` of that level's operator object): 8 or 0
     coarse_group_jacobi = 8
+    # the same for the ONE-level polynomial of an ord-1 mesh's operator object (no corner-node level): 8 or 0
+    one_level_group_jacobi = 0
 
-    def __init__(self, system: TetSystem, lam, mu, two_level=None, _level=0, mfma_groups=None, mfma32=None, coarse_group_jacobi=None):
+    def __init__(self, system: TetSystem, lam, mu, two_level=None, _level=0, mfma_groups=None, mfma32=None, coarse_group_jacobi=None,
+                 one_level_group_jacobi=None):
         """two_level: build the corner-node level for the two-level preconditioner (ord-2 meshes; default on)."""
         self.sys = system
         self._level_tag = min(int(_level), 1)
         if coarse_group_jacobi is not None:
             self.coarse_group_jacobi = int(coarse_group_jacobi)
-        if self.coarse_group_jacobi not in (0, 8):
-            raise ValueError("coarse_group_jacobi: groups of 8 nodes, or 0 for the node blocks")
+        if one_level_group_jacobi is not None:
+            self.one_level_group_jacobi = int(one_level_group_jacobi)
+        if self.coarse_group_jacobi not in (0, 8) or self.one_level_group_jacobi not in (0, 8):
+            raise ValueError("coarse_group_jacobi / one_level_group_jacobi: groups of 8 nodes, or 0 for the node blocks")
         if mfma_groups is not None:
             self.mfma_groups = tuple(mfma_groups)
         if mfma32 is not None:
@@ -1164,7 +1169,8 @@ class HipModalOps(_HipBlockOps):
             mt = system.mfma_tables(G)
             if mt["max_entries"] <= 256 and mt["max_batch_blocks"] <= MF_BATCH * G:  # what ds_spmm_union16m serves
                 self._mfma = mt
-                if _level == 1 and self.coarse_group_jacobi == G and system.nv >= 4 * G:
+                if (((_level == 1 and self.coarse_group_jacobi == G) or
+                     (_level == 0 and system.order == 1 and self.one_level_group_jacobi == G)) and system.nv >= 4 * G):
                     md = system.mfma_tables_dense(G)
                     if md["nblocks"] * 24 < 0x7F000000:
                         self._mfma_dense, self.group_jacobi = md, G

@@ -526,6 +526,31 @@ def test_group_block_jacobi_keeps_the_iteration_counts_with_a_shorter_polynomial
         assert r.iterations <= ref.iterations + 1 and r.coarse_iterations <= ref.coarse_iterations + 1, key
 
 
+def test_one_level_polynomial_on_the_group_blocks(dev):
+    """HipModalOps(one_level_group_jacobi=8): the ONE-level polynomial of an ord-1 mesh's operator object on the group-block Jacobi
+    (off by default - the shape loop's fresh objects pay more for the blocks than the shorter polynomial saves,
+    profiles/r06_geom_one_level_group.txt): the same eigenpairs as on the node blocks, no more iterations at two thirds of the terms."""
+    from diffsound_amd import meshgen
+    from diffsound_amd.lobpcg.modal_solver import ModalSolver, tuned_config
+    from diffsound_amd.modal_ops import HipModalOps, TetSystem
+
+    v, t = meshgen.kuhn_box(20)
+    sysd = TetSystem(torch.from_numpy(v).to(dev), torch.from_numpy(t).long().to(dev), 1, MAT[0])
+    lam, mu = fem.lame(MAT[1], MAT[2])
+    res = {}
+    for gj in (0, 8):
+        ops = HipModalOps(sysd, lam, mu, one_level_group_jacobi=gj)
+        assert ops.group_jacobi == gj and ops.coarse is None
+        cfg = tuned_config(1, tol=1e-5)
+        assert (cfg.cheb_degree, cfg.cheb_group_degree) == (24, 16)
+        s = ModalSolver(ops, cfg)
+        assert s.precond.degree == (16 if gj else 24) and s.precond.group == gj
+        res[gj] = s.solve(32)
+    a, b = res[0], res[8]
+    assert float(b.rerr.max()) < 1e-5 and float(((a.eigenvalues - b.eigenvalues).abs() / a.eigenvalues).max()) < 1e-5
+    assert b.iterations <= a.iterations + 1
+
+
 def test_swept_start_block_is_not_locked_before_its_ritz_values_have_settled(dev):
     """SolverConfig.nested_ritz_tol (round 6).  The corner-node phase of a nested start stops on a backward error of 3e-3 relative to
     ||K|| + lambda ||M|| - a test a SMOOTH block passes whatever its Rayleigh quotients are.  A start block that went through the
