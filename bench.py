@@ -37,6 +37,49 @@ PROF_KINDS = {0: "term", 1: "kx", 2: "mx", 3: "resid", 4: "gram", 5: "mix", 6: "
 SPMM_SOURCES = ("spmm.hip", "spmm_union.inc", "spmm_mfma.inc", "spmm_mfma32.inc", "ds_common.h", "ds_diag.h", "../modal_ops.py")
 
 
+_LOAD_AT_START = None
+try:
+    _LOAD_AT_START = os.getloadavg()
+except OSError:
+    pass
+
+
+def host_load_record():
+    """What else runs on the GPU box's host (a box is one GPU of a shared 8-GPU host): the 1 / 5 / 15-minute load averages when this
+    process started and now (this run itself adds about its lane threads), and the time of one 240 x 240 dsyevd on one thread - the
+    Ritz step's size - as a probe of the host's speed.  The eight-lane rate and the API legs move with these."""
+    import time as _t
+
+    rec = {"loadavg_at_start": None if _LOAD_AT_START is None else [round(x, 2) for x in _LOAD_AT_START]}
+    try:
+        rec["loadavg_now"] = [round(x, 2) for x in os.getloadavg()]
+    except OSError:
+        rec["loadavg_now"] = None
+    try:
+        import numpy as _np
+        from scipy.linalg import lapack as _la
+
+        a_ = _np.random.default_rng(0).standard_normal((240, 240))
+        a_ = a_ + a_.T
+        ts = []
+        try:
+            from threadpoolctl import threadpool_limits as _lim
+        except Exception:
+            import contextlib as _cl
+
+            _lim = lambda n: _cl.nullcontext()
+        with _lim(1):
+            for _ in range(7):
+                t0 = _t.perf_counter()
+                _la.dsyevd(a_)
+                ts.append(_t.perf_counter() - t0)
+        rec["dsyevd_240_ms_median_of_7"] = round(1e3 * sorted(ts)[3], 3)
+    except Exception as e:  # (a diagnostic: never the reason a run fails)
+        rec["dsyevd_240_ms_median_of_7"] = None
+        rec["probe_error"] = str(e)[:80]
+    return rec
+
+
 def spmm_source_hash():
     """sha256 (16 hex digits) over the sources of the SpMM kernels: the key that ties a PMC traffic figure under
     profiles/ to the kernel it was measured on (tools/pmc_bytes.py records it; a figure with another key is stale)."""
@@ -1514,6 +1557,7 @@ def main():
             "collective": (f"{a.dist_backend} all-reduce of the scalar loss over {world} ranks" if world > 1 else "none (1 rank)"),
             "process_group": ({"backend": dist.get_backend(), "world_size": dist.get_world_size(),
                                "is_rccl": dist.get_backend() == "nccl"} if world > 1 else None),
+            "host_load": host_load_record(),
             "host_threads": {"hardware_threads": hw_threads, "ranks_on_node": local_world, "lanes_per_rank": min(a.lanes, a.hyp_per_gpu),
                              "lane_threads_on_node": local_world * min(a.lanes, a.hyp_per_gpu), "lapack_threads_per_lane": 1,
                              "within_half_of_hardware_threads": local_world * min(a.lanes, a.hyp_per_gpu) <= hw_threads // 2},

@@ -69,6 +69,9 @@ def test_bench_line_contract(one_rank):
         assert api[key]["ms_per_epoch"] > 0 and api[key]["eigen_decompositions"] >= 1 and np.isfinite(api[key]["loss_first_last"]).all()
     assert api["cycle_15"]["ms_per_epoch"] < api["cycle_1_cold_start"]["ms_per_epoch"] and api["cycle_15"]["eigen_decompositions"] == 2
     assert "moves" in d["materials"] and d["ranks"][0]["cpu_affinity"]["bound"] in (True, False)
+    # (what else runs on the box's host: load averages at start and now, one dsyevd of the Ritz step's size on one thread)
+    hl = d["host_load"]
+    assert len(hl["loadavg_at_start"]) == 3 and len(hl["loadavg_now"]) == 3 and 0 < hl["dsyevd_240_ms_median_of_7"] < 100
     # the amortised variant (eigendecomposition every 15 passes) beside the headline, and the per-rank view of the step
     am = d["amortised"]
     assert am["eigen_decompose_cycle"] == 15 and am["unit"] == "passes/s" and am["value"] > d["value"]
