@@ -44,6 +44,41 @@ except OSError:
     pass
 
 
+def _cgroup_cpu_stat():
+    """nr_periods / nr_throttled / throttled time of this process's CPU cgroup (v2: cpu.stat with throttled_usec; v1: throttled_time
+    in ns) and its quota - a GPU box gives an ordinary user a share of the host's CPUs, and a process that asks for more is paused."""
+    out = {}
+    for path in ("/sys/fs/cgroup/cpu.stat", "/sys/fs/cgroup/cpu/cpu.stat", "/sys/fs/cgroup/cpu,cpuacct/cpu.stat"):
+        try:
+            with open(path) as f:
+                for line in f:
+                    k, _, v = line.partition(" ")
+                    if k in ("nr_periods", "nr_throttled", "throttled_usec", "throttled_time", "usage_usec"):
+                        out[k] = int(v)
+            out["source"] = path
+            break
+        except OSError:
+            continue
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                out["quota"] = f.read().strip()
+            break
+        except OSError:
+            continue
+    return out
+
+
+_CGROUP_AT_START = _cgroup_cpu_stat()
+_CGROUP_TIMED = None
+_CGROUP_MARKS = [("process start", _CGROUP_AT_START)]
+
+
+def _cg_mark(label):
+    """A named point of the run for the per-leg view of the CPU cgroup's counters (host_load.cgroup_cpu.legs)."""
+    _CGROUP_MARKS.append((label, _cgroup_cpu_stat()))
+
+
 def host_load_record():
     """What else runs on the GPU box's host (a box is one GPU of a shared 8-GPU host): the 1 / 5 / 15-minute load averages when this
     process started and now (this run itself adds about its lane threads), and the time of one 240 x 240 dsyevd on one thread - the
@@ -51,6 +86,13 @@ def host_load_record():
     import time as _t
 
     rec = {"loadavg_at_start": None if _LOAD_AT_START is None else [round(x, 2) for x in _LOAD_AT_START]}
+    now = _cgroup_cpu_stat()
+    rec["cgroup_cpu"] = {"quota": now.get("quota"), "source": now.get("source"),
+                         "during_this_process": {k: now[k] - _CGROUP_AT_START.get(k, 0) for k in now if isinstance(now[k], int)},
+                         "during_the_timed_region": _CGROUP_TIMED, "torch_threads": __import__("torch").get_num_threads(),
+                         "legs": [{"until": lb, **{k: st[k] - prev.get(k, 0) for k in ("usage_usec", "nr_throttled", "throttled_usec", "throttled_time")
+                                                   if k in st}}
+                                  for (_, prev), (lb, st) in zip(_CGROUP_MARKS[:-1], _CGROUP_MARKS[1:])]}
     try:
         rec["loadavg_now"] = [round(x, 2) for x in os.getloadavg()]
     except OSError:
@@ -1023,8 +1065,26 @@ def api_path_leg(a, verts, tets, dev, cfg):
     return out
 
 
+def cap_torch_threads_at_the_cpu_quota():
+    """torch sizes its CPU thread team by the CPUs it may run on (128 on a GPU box once the rank is bound to its NUMA node); the box's
+    cgroup gives 16 CPUs' worth of time per 100 ms, and a team larger than that is paused the moment it all runs (cpu.stat:
+    nr_throttled).  The product's hot path is one BLAS thread per lane either way; this keeps torch's own CPU ops inside the quota."""
+    q = str(_CGROUP_AT_START.get("quota", "")).split()
+    try:
+        cpus = int(q[0]) // int(q[1]) if len(q) == 2 and q[0] != "max" else 0
+    except (ValueError, ZeroDivisionError):
+        cpus = 0
+    if cpus > 0:
+        import torch
+
+        if torch.get_num_threads() > cpus:
+            torch.set_num_threads(max(1, cpus))
+
+
 def main():
     a = parse()
+    if not a.cpu_baseline_child and not a.geom_cpu_child:  # (the CPU oracle's children size their own pools)
+        cap_torch_threads_at_the_cpu_quota()
     if a.geom_cpu_child:
         return geom_cpu_child(a)
     if a.workload == "c5":
@@ -1165,7 +1225,9 @@ def main():
                               warm_init=warm if a.warm_start else None, material_at=lambda s, i, E, nu: moved(s0 + s, E, nu))
         return [res.block_vectors for _, res, _ in outs[-1]] if a.warm_start else None
 
+    _cg_mark("setup (mesh, tables, pipeline)")
     warm = run_steps(max(a.warmup, 0), None)
+    _cg_mark("warm-up steps")
     if a.warmup <= 0 and a.lanes > 1 and len(mine) > 1:
         # --warmup 0: the lanes' streams, operators and value arrays are set-up, not part of a step
         pipe.run_batch([(MAT[1], MAT[2])] * min(a.lanes, len(mine)), lanes=a.lanes, backward=False)
@@ -1181,12 +1243,16 @@ def main():
         _hip.check(_hip.lib().ds_profile_stream(prof_stream, PROF_CAP), "ds_profile_stream")
     barrier()
     torch.cuda.synchronize()
+    cg0 = _cgroup_cpu_stat()
     t0 = time.time()
     del its_all[:]
     run_steps(a.steps, warm)
     iters, total = list(its_all), on_step.total
     torch.cuda.synchronize()
     own_dt = time.time() - t0  # this rank's own work, before it waits for the slowest one
+    cg1 = _cgroup_cpu_stat()
+    global _CGROUP_TIMED
+    _CGROUP_TIMED = {k: cg1[k] - cg0.get(k, 0) for k in cg1 if isinstance(cg1[k], int)}  # (CPU time used / periods throttled inside the timed region)
     barrier()
     dt = time.time() - t0
     cdev = dev if (world > 1 and a.dist_backend == "nccl") else torch.device("cpu")
@@ -1241,11 +1307,15 @@ def main():
     # ---- the path a user of the reference runs: one hypothesis at a time, its kernel time and launch
     #      count, and the literal loop of experiments/material_sync_train.py through the drop-in API - rank 0 of a 1-rank job
     one_hyp = kstats = api = None
+    _cg_mark("timed steps + amortised variant")
     if world == 1 and not a.no_api_path:
         one_hyp = one_hypothesis_leg(pipe, hyps, dev, passes=12, steps_done=steps_done[0])
+        _cg_mark("one hypothesis at a time")
         kstats = kernel_stats_leg(pipe, hyps, dev)
+        _cg_mark("kernel statistics (torch profiler)")
         v0, t0_ = meshgen.kuhn_box(a.cells)
         api = api_path_leg(a, torch.from_numpy(v0).to(dev), torch.from_numpy(t0_).long().to(dev), dev, cfg)
+        _cg_mark("API loop")
         del v0, t0_
         torch.cuda.empty_cache()
 

@@ -72,6 +72,8 @@ def test_bench_line_contract(one_rank):
     # (what else runs on the box's host: load averages at start and now, one dsyevd of the Ritz step's size on one thread)
     hl = d["host_load"]
     assert len(hl["loadavg_at_start"]) == 3 and len(hl["loadavg_now"]) == 3 and 0 < hl["dsyevd_240_ms_median_of_7"] < 100
+    cg = hl["cgroup_cpu"]  # (the CPU cgroup's quota and throttling counters: whole process, timed region, per leg)
+    assert cg["torch_threads"] >= 1 and isinstance(cg["legs"], list) and isinstance(cg["during_the_timed_region"], dict)
     # the amortised variant (eigendecomposition every 15 passes) beside the headline, and the per-rank view of the step
     am = d["amortised"]
     assert am["eigen_decompose_cycle"] == 15 and am["unit"] == "passes/s" and am["value"] > d["value"]
